@@ -1,0 +1,213 @@
+/*
+ * cvo_hip.h -- C-ABI of the MI355X (gfx950) backend for unified_cvo's pairwise
+ * CvoGPU::align() / inner_product_gpu() / function_angle() hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  The C++
+ * classes in include/UnifiedCvo/ (cvo::CvoGPU, cvo::CvoPointCloud, cvo::CvoParams) are a
+ * thin veneer over these entry points, and a maintainer of the reference binds them as
+ * shown in INTEGRATION.md.  Each entry point cites the reference interface it replaces
+ * (file:line relative to the upstream repository).
+ *
+ * Conventions
+ *   * 4x4 transforms are 16 floats, COLUMN-major (the memory layout of Eigen::Matrix4f).
+ *   * `init_T` is the reference's T_target_frame_to_source_frame argument; it is taken as
+ *     the running (R, T) directly (CvoGPU.cu:1363-1364).  `out_T` is the returned
+ *     `transform` = [R^T | -R^T T] (CvoGPU.cu:94-112, 1562).
+ *   * Return codes: 0 = ok, -1 = "flow vanished" exactly as the reference (CvoGPU.cu:1454-1458),
+ *     <= -2 = argument / HIP errors (CVO_E_*); never exit().  cvo_last_error() gives text.
+ *   * A context is bound to one HIP device and owns one stream; it is not thread-safe,
+ *     distinct contexts are independent.
+ */
+#ifndef CVO_HIP_H
+#define CVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVO_FEATURE_DIMENSIONS 5 /* CMakeLists.txt:498 (cvo_gpu_img_lib) */
+#define CVO_NUM_CLASSES 19       /* CMakeLists.txt:498 */
+
+#define CVO_OK 0
+#define CVO_RET_FLOW_VANISHED (-1)
+#define CVO_E_INVALID (-2)
+#define CVO_E_HIP (-3)
+#define CVO_E_NOMEM (-4)
+#define CVO_E_UNSUPPORTED (-5)
+
+/* Layout-identical to cvo::CvoParams (include/UnifiedCvo/cvo/CvoParams.hpp:12-73): same
+ * members, same order, same types, so a reference build can pass &params unchanged. */
+typedef struct cvo_params_t {
+  float ell_init_first_frame;
+  float ell_init;
+  float ell_min;
+  int min_ell_iter_limit;
+  float ell_max;
+  double dl;
+  double dl_step;
+  float sigma;
+  float sp_thres;
+  float c;
+  float d;
+  float c_ell;
+  float c_sigma;
+  float s_ell;
+  float s_sigma;
+  int MAX_ITER;
+  float eps;
+  float eps_2;
+  float min_step;
+  float max_step;
+  float step;
+  int nearest_neighbors_max;
+  float ell_decay_rate;
+  float ell_decay_rate_first_frame;
+  int ell_decay_start;
+  int ell_decay_start_first_frame;
+  int indicator_window_size;
+  float indicator_stable_threshold;
+  int is_pcl_visualization_on;
+  int is_using_least_square;
+  int is_ell_adaptive;
+  int is_full_ip_matrix;
+  int is_using_geometry;
+  int is_using_intensity;
+  int is_using_semantics;
+  int is_using_range_ell;
+  int is_using_kdtree;
+  int is_exporting_association;
+  int is_using_geometric_type;
+  int multiframe_using_cpu;
+  int multiframe_max_iters;
+  float multiframe_ell_init;
+  float multiframe_ell_min;
+  int multiframe_iter_per_ell;
+  float multiframe_ell_decay_rate;
+  int multiframe_iterations_per_ell;
+  int multiframe_iterations_per_solve;
+  int multiframe_expected_points;
+  float multiframe_downsample_voxel_size;
+  int multiframe_num_neighbors;
+  int multiframe_least_squares_num_threads;
+  int multiframe_min_nonzeros;
+} cvo_params_t;
+
+/* Fills *p with the defaults of CvoParams::CvoParams() (CvoParams.hpp:75-126).  max_step and
+ * step, which the reference leaves uninitialised, are set to 0.8 and 0 (documented in DESIGN.md). */
+void cvo_params_default(cvo_params_t* p);
+
+typedef struct cvo_ctx cvo_ctx;     /* device + stream + cached scratch */
+typedef struct cvo_cloud cvo_cloud; /* a point cloud resident in HBM */
+
+/* One record per optimiser iteration, written by the device when tracing is requested. */
+typedef struct cvo_trace_t {
+  int k;
+  int K;
+  float ell;
+  float step;
+  unsigned int nnz;
+  unsigned int max_nnz;
+  float omega[3];
+  float v[3];
+  double B, C, D, E;
+  double dist;
+  float R[9]; /* running R after the update, row-major */
+  float T[3];
+} cvo_trace_t;
+
+/* Per-call outputs beyond the transform. */
+typedef struct cvo_align_info_t {
+  int iterations;        /* value of k when the loop ended ("cvo # of iterations", CvoGPU.cu:1545) */
+  int ret;               /* 0 or -1, as CvoGPU::align returns */
+  float final_ell;
+  int final_num_neighbors;
+  double seconds;        /* registration_seconds: hipEvent time of the loop (CvoGPU.cu:1534-1560) */
+} cvo_align_info_t;
+
+/* Optional controls for cvo_align_ex / cvo_align_batch_ex (all zero = reference behaviour). */
+typedef struct cvo_align_opts_t {
+  int max_iterations;    /* >0: stop after this many iterations (parity tests, benchmarks) */
+  int override_state;    /* 1: start from ell0 / K0 below instead of ell_init / nearest_neighbors_max */
+  float ell0;
+  int K0;
+  cvo_trace_t* trace;    /* host array, or NULL */
+  int trace_capacity;    /* rows available per pair */
+  int trace_dense;       /* record every iteration k < trace_dense ... */
+  int trace_every;       /* ... and every k % trace_every == 0 (0 = none) */
+  int* n_trace;          /* out: rows written (per pair) */
+  int iters_per_launch;  /* iterations enqueued per host check (0 = default) */
+  int use_graph;         /* 0 = default (on), 1 = force plain launches, 2 = force graph */
+} cvo_align_opts_t;
+
+/* ---- context ------------------------------------------------------------------------ */
+int cvo_ctx_create(int device, cvo_ctx** out);
+void cvo_ctx_destroy(cvo_ctx* ctx);
+const char* cvo_last_error(const cvo_ctx* ctx);
+/* HIP stream of the context as an opaque pointer (hipStream_t). */
+void* cvo_ctx_stream(cvo_ctx* ctx);
+int cvo_ctx_synchronize(cvo_ctx* ctx);
+
+/* ---- clouds: replaces CvoPointCloud_to_gpu (CvoGPU_impl.cu:206-285) ------------------
+ * xyz: n x 3.  feat: n x 5 row-major or NULL.  label: n x 19 row-major or NULL.
+ * geotype: n x 2 or NULL.  Missing arrays are stored as zeros, as the reference leaves the
+ * default-constructed CvoPoint fields (PointSegmentedDistribution.hpp:40-56). */
+int cvo_cloud_upload(cvo_ctx* ctx, int n, const float* xyz, const float* feat, const float* label,
+                     const float* geotype, cvo_cloud** out);
+/* Replaces pcl_PointCloud_to_gpu (CvoGPU_impl.cu:287-362): n records of the 192-byte AoS
+ * CvoPoint = pcl::PointSegmentedDistribution<5,19> (PointSegmentedDistribution.hpp:17-99). */
+int cvo_cloud_upload_aos192(cvo_ctx* ctx, int n, const void* cvo_points, cvo_cloud** out);
+int cvo_cloud_size(const cvo_cloud* c);
+void cvo_cloud_free(cvo_cloud* c);
+
+/* ---- CvoGPU::align (CvoGPU.cu:1574-1632) --------------------------------------------- */
+int cvo_align(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source, const cvo_cloud* target,
+              const float init_T[16], float out_T[16], cvo_align_info_t* info);
+int cvo_align_ex(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source, const cvo_cloud* target,
+                 const float init_T[16], float out_T[16], cvo_align_info_t* info,
+                 const cvo_align_opts_t* opts);
+
+/* New (not in the reference): n independent frame pairs solved concurrently on the
+ * context's device.  init_T / out_T: n x 16.  infos: n entries or NULL.  Returns CVO_OK or
+ * a CVO_E_* code; the per-pair 0 / -1 results are in infos[i].ret. */
+int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo_cloud* const* sources,
+                    const cvo_cloud* const* targets, const float* init_T, float* out_T,
+                    cvo_align_info_t* infos, const cvo_align_opts_t* opts);
+/* Copies the n x 16 result transforms of the last cvo_align_batch to DEVICE memory `dst`
+ * on the context's stream (so a caller can hand them to an RCCL all-gather without a host
+ * round trip). */
+int cvo_batch_poses_to_device(cvo_ctx* ctx, void* dst_device, int n_pairs);
+
+/* ---- inner_product_gpu / function_angle (CvoGPU.cu:1780-1873) ------------------------ */
+int cvo_inner_product(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source,
+                      const cvo_cloud* target, const float T[16], float ell, float* out);
+int cvo_function_angle(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source,
+                       const cvo_cloud* target, const float T[16], float ell, int is_approximate,
+                       float* out);
+
+/* ---- compute_association_gpu(float lengthscale) (CvoGPU.cu:1876-1911) -----------------
+ * CSR of Association::pairs (row = source index, col = target index, ascending).
+ * row_ptr: n_source + 1 ints.  col/val: capacity entries.  *nnz_out = pairs found (may
+ * exceed capacity, in which case only row_ptr is complete and CVO_E_NOMEM is returned). */
+int cvo_association(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source,
+                    const cvo_cloud* target, const float T[16], float ell, int* row_ptr, int* col,
+                    float* val, size_t capacity, size_t* nnz_out);
+
+/* ---- test / profiling hooks ---------------------------------------------------------- */
+/* Dumps the ELL kernel matrix of the LAST iteration executed by cvo_align_ex (row stride K):
+ * mat/ind sized n_source*K, nonzeros sized n_source; K = the num_neighbors of that iteration. */
+int cvo_debug_last_ell(cvo_ctx* ctx, int K, float* mat, int* ind, unsigned int* nonzeros);
+/* Runs only the N x M candidate scan `reps` times on the current state of the last pair
+ * (used by bench.py to time the dominant kernel with HIP events on the context's stream).
+ * Returns the average milliseconds per launch in *ms. */
+int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms);
+/* Number of candidate pairs the scan of the last iteration produced (superset of nnz). */
+int cvo_debug_last_candidates(cvo_ctx* ctx, unsigned long long* out);
+const char* cvo_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,979 @@
+/*
+ * cvo_oracle.cpp -- CPU restatement of unified_cvo's pairwise CvoGPU::align() path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see cvo_oracle.h).  PARITY UNPINNED: no reference golden
+ * vectors exist and the reference cannot be built here; pins are tests/test_oracle_*.py.
+ *
+ * Every function cites the reference file:line (relative to the upstream repository root)
+ * it follows.  The restatement follows the reference's CUDA path (src/cvo/CvoGPU.cu), not
+ * its two CPU variants, which differ by design.
+ *
+ * Floating-point conventions (the reference's exact rounding is compiler dependent and
+ * unknowable here, so they are fixed explicitly and mirrored by the HIP kernels):
+ *   * code that the reference runs ON THE DEVICE (kernels, thrust functors) is compiled by
+ *     nvcc with its default -fmad=true: "a*b + c" patterns are written as explicit fmaf();
+ *     Eigen's fixed-size 3-term reductions are a0 + (a1 + a2) (redux_novec_unroller).
+ *   * code that the reference runs ON THE HOST (LieGroup.cpp, align_impl scalar maths) is
+ *     written with plain, unfused arithmetic in source order.
+ *   * this file must be compiled with -ffp-contract=off so that only the explicit fmaf()
+ *     calls fuse.
+ *   * float/double promotion follows the C++ expression types of the reference exactly
+ *     (e.g. exp() is evaluated in double because of the 2.0 literal, CvoGPU.cu:551).
+ */
+#include "cvo_oracle.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <queue>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+constexpr int FD = ORACLE_FEATURE_DIMENSIONS;
+constexpr int NC = ORACLE_NUM_CLASSES;
+
+// ---- small helpers encoding the conventions above ------------------------------------
+
+// Eigen fixed-size 3-term dot product compiled for the device: a0*b0 + (a1*b1 + a2*b2).
+inline float dot3_dev(float a0, float a1, float a2, float b0, float b1, float b2) {
+  return std::fmaf(a0, b0, std::fmaf(a1, b1, a2 * b2));
+}
+// a*b - c*d on the device.
+inline float dop_dev(float a, float b, float c, float d) { return std::fmaf(a, b, -(c * d)); }
+
+struct V3 {
+  float x, y, z;
+};
+inline V3 cross_dev(const V3& a, const V3& b) {  // Eigen cross(), OrthoMethods.h
+  return {dop_dev(a.y, b.z, a.z, b.y), dop_dev(a.z, b.x, a.x, b.z), dop_dev(a.x, b.y, a.y, b.x)};
+}
+struct M3 {
+  float m[3][3];
+};
+inline M3 skew(const V3& v) {  // gpu_utils.cuh:9-15
+  M3 r;
+  r.m[0][0] = 0;    r.m[0][1] = -v.z; r.m[0][2] = v.y;
+  r.m[1][0] = v.z;  r.m[1][1] = 0;    r.m[1][2] = -v.x;
+  r.m[2][0] = -v.y; r.m[2][1] = v.x;  r.m[2][2] = 0;
+  return r;
+}
+inline M3 matmul_dev(const M3& a, const M3& b) {
+  M3 r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      r.m[i][j] = dot3_dev(a.m[i][0], a.m[i][1], a.m[i][2], b.m[0][j], b.m[1][j], b.m[2][j]);
+  return r;
+}
+inline V3 matvec_dev(const M3& a, const V3& v) {
+  return {dot3_dev(a.m[0][0], a.m[0][1], a.m[0][2], v.x, v.y, v.z),
+          dot3_dev(a.m[1][0], a.m[1][1], a.m[1][2], v.x, v.y, v.z),
+          dot3_dev(a.m[2][0], a.m[2][1], a.m[2][2], v.x, v.y, v.z)};
+}
+
+// squared_dist(const T&, const T&), gpu_utils.cuh:72-78 (device)
+inline float squared_dist_xyz(const float* a, const float* b) {
+  float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  return std::fmaf(dz, dz, std::fmaf(dy, dy, dx * dx));
+}
+// squared_dist(const T*, const T*, int), gpu_utils.cuh:33-41 (device)
+inline float squared_dist_n(const float* a, const float* b, int dim) {
+  float result = 0;
+  for (int i = 0; i < dim; i++) {
+    float tmp = a[i] - b[i];
+    result = std::fmaf(tmp, tmp, result);
+  }
+  return result;
+}
+inline float square_norm_n(const float* a, int dim) {  // gpu_utils.cuh:96-104
+  float result = 0;
+  for (int j = 0; j < dim; j++) result = std::fmaf(a[j], a[j], result);
+  return result;
+}
+inline float dot_n(const float* a, const float* b, int dim) {  // gpu_utils.cuh:23-30
+  float result = 0;
+  for (int i = 0; i < dim; i++) result = std::fmaf(a[i], b[i], result);
+  return result;
+}
+// compute_geometric_type_ip, CvoGPU.cu:203-215
+inline float geometric_type_ip(const float* ga, const float* gb) {
+  float norm2_a = square_norm_n(ga, 2);
+  float norm2_b = square_norm_n(gb, 2);
+  float dot_ab = dot_n(ga, gb, 2);
+  return dot_ab * dot_ab / (norm2_a * norm2_b);
+}
+// compute_range_ell, CvoGPU.cu:86-90: ((dist)/500.0 + 1.0) * ell evaluated in double
+inline float compute_range_ell(float curr_ell, float curr_dist_to_sensor) {
+  return (float)(((double)curr_dist_to_sensor / 500.0 + 1.0) * (double)curr_ell);
+}
+
+const float kZeros[32] = {0};
+
+struct CloudView {
+  int n;
+  const float *xyz, *feat, *label, *geo;
+  const float* p(int i) const { return xyz + 3 * i; }
+  const float* f(int i) const { return feat ? feat + FD * i : kZeros; }
+  const float* l(int i) const { return label ? label + NC * i : kZeros; }
+  const float* g(int i) const { return geo ? geo + 2 * i : kZeros; }
+};
+inline CloudView view(const OracleCloud* c) { return {c->n, c->xyz, c->feat, c->label, c->geo}; }
+
+struct RowConsts {
+  float sp_thres, sigma2, c2, c_sigma2, s_ell, s_sigma2;
+  float l, d2_thres, d2_c_thres, d2_s_thres;
+};
+
+// Prologue of fill_in_A_mat_gpu, CvoGPU.cu:494-515
+inline RowConsts row_consts(const OracleParams& P, const float* pa, float ell) {
+  RowConsts r;
+  r.sp_thres = P.sp_thres;
+  r.sigma2 = P.sigma * P.sigma;
+  r.c2 = P.c_ell * P.c_ell;
+  r.c_sigma2 = P.c_sigma * P.c_sigma;
+  r.s_ell = P.s_ell;
+  r.s_sigma2 = P.s_sigma * P.s_sigma;
+  float a_to_sensor = std::sqrt(std::fmaf(pa[2], pa[2], std::fmaf(pa[1], pa[1], pa[0] * pa[0])));
+  r.l = compute_range_ell(ell, a_to_sensor);
+  r.d2_thres = 1;
+  r.d2_c_thres = 1;
+  r.d2_s_thres = 1;
+  if (P.is_using_geometry)
+    r.d2_thres = (float)(-2.0 * r.l * r.l * (double)std::log(P.sp_thres / r.sigma2));
+  if (P.is_using_intensity)
+    r.d2_c_thres = (float)(-2.0 * r.c2 * (double)std::log(P.sp_thres / r.c_sigma2));
+  if (P.is_using_semantics)
+    r.d2_s_thres = (float)(-2.0 * r.s_ell * r.s_ell * (double)std::log(P.sp_thres / r.s_sigma2));
+  return r;
+}
+
+// Body of the j-loop of fill_in_A_mat_gpu for one (i, j), CvoGPU.cu:528-573.
+// Returns true and sets a if the pair survives all `continue`s (the a > sp_thres test is
+// done by the caller, CvoGPU.cu:576).
+inline bool pair_value(const OracleParams& P, const RowConsts& rc, const CloudView& X, int i,
+                       const CloudView& Y, int j, float* a_out) {
+  float a = 1, sk = 1, ck = 1, k = 1, geo_sim = 1;
+  if (P.is_using_geometric_type) {
+    geo_sim = geometric_type_ip(X.g(i), Y.g(j));
+    if (geo_sim < 0.01) return false;
+  }
+  if (P.is_using_geometry) {
+    float d2 = squared_dist_xyz(Y.p(j), X.p(i));
+    if (d2 < rc.d2_thres)
+      k = (float)((double)rc.sigma2 * std::exp((double)(-d2) / (2.0 * rc.l * rc.l)));
+    else
+      return false;
+  }
+  if (P.is_using_intensity) {
+    float d2_color = squared_dist_n(X.f(i), Y.f(j), FD);
+    if (d2_color < rc.d2_c_thres)
+      ck = (float)((double)rc.c_sigma2 * std::exp((double)(-d2_color) / (2.0 * rc.c2)));
+    else
+      return false;
+  }
+  if (P.is_using_semantics) {
+    float d2_semantic = squared_dist_n(X.l(i), Y.l(j), NC);
+    if (d2_semantic < rc.d2_s_thres)
+      sk = (float)((double)(P.s_sigma * P.s_sigma) *
+                   std::exp((double)(-d2_semantic) / (2.0 * rc.s_ell * rc.s_ell)));
+    else
+      return false;
+  }
+  a = ck * k * sk * geo_sim;
+  *a_out = a;
+  return true;
+}
+
+// fill_in_A_mat_gpu for one row, literal form: CvoGPU.cu:477-593
+inline unsigned se_row_literal(const OracleParams& P, const CloudView& X, int i, const CloudView& Y,
+                               int K, float ell, float* mat_row, int* ind_row) {
+  RowConsts rc = row_consts(P, X.p(i), ell);
+  unsigned num_inds = 0;
+  for (int j = 0; j < Y.n; j++) {
+    if (num_inds == (unsigned)K) break;
+    float a;
+    if (!pair_value(P, rc, X, i, Y, j, &a)) continue;
+    if (a > P.sp_thres) {
+      mat_row[num_inds] = a;
+      ind_row[num_inds] = j;
+      num_inds++;
+    }
+  }
+  return num_inds;
+}
+
+// Same result as se_row_literal, but the geometric cut-off (the only O(N*M) work) is
+// evaluated blockwise so the compiler can vectorise it; survivors go through pair_value()
+// in ascending j.  Valid because a pair failing `d2 < d2_thres` has no side effect.
+// yx/yy/yz: SoA copies of the transformed target coordinates.
+inline unsigned se_row_blocked(const OracleParams& P, const CloudView& X, int i, const CloudView& Y,
+                               const float* yx, const float* yy, const float* yz, int K, float ell,
+                               float* mat_row, int* ind_row) {
+  RowConsts rc = row_consts(P, X.p(i), ell);
+  unsigned num_inds = 0;
+  const float ax = X.p(i)[0], ay = X.p(i)[1], az = X.p(i)[2];
+  const float thr = rc.d2_thres;
+  constexpr int BLK = 64;
+  const int m = Y.n;
+  for (int j0 = 0; j0 < m; j0 += BLK) {
+    if (num_inds == (unsigned)K) break;
+    const int jn = std::min(BLK, m - j0);
+    unsigned char hit[BLK];
+    int any = 0;
+    for (int t = 0; t < jn; t++) {
+      float dx = yx[j0 + t] - ax, dy = yy[j0 + t] - ay, dz = yz[j0 + t] - az;
+      float d2 = std::fmaf(dz, dz, std::fmaf(dy, dy, dx * dx));
+      unsigned char h = d2 < thr;
+      hit[t] = h;
+      any |= h;
+    }
+    if (!any) continue;
+    for (int t = 0; t < jn; t++) {
+      if (!hit[t]) continue;
+      if (num_inds == (unsigned)K) break;
+      float a;
+      if (!pair_value(P, rc, X, i, Y, j0 + t, &a)) continue;
+      if (a > P.sp_thres) {
+        mat_row[num_inds] = a;
+        ind_row[num_inds] = j0 + t;
+        num_inds++;
+      }
+    }
+  }
+  return num_inds;
+}
+
+// se_kernel (CvoGPU.cu:648-683) + reset_state_at_new_iter (CvoState.cu:143-157): rows are
+// written from slot 0; slot nnz holds ind = -1, mat = 0 when nnz < K (what memset leaves).
+void se_kernel_impl(const OracleParams& P, const CloudView& X, const CloudView& Y, int K, float ell,
+                    float* mat, int* ind, unsigned* nonzeros, bool literal) {
+  const int n = X.n, m = Y.n;
+  std::vector<float> yx, yy, yz;
+  const bool blocked = !literal && P.is_using_geometry;
+  if (blocked) {
+    yx.resize(m);
+    yy.resize(m);
+    yz.resize(m);
+    for (int j = 0; j < m; j++) {
+      yx[j] = Y.p(j)[0];
+      yy[j] = Y.p(j)[1];
+      yz[j] = Y.p(j)[2];
+    }
+  }
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int i = 0; i < n; i++) {
+    float* mr = mat + (size_t)i * K;
+    int* ir = ind + (size_t)i * K;
+    unsigned nn = blocked ? se_row_blocked(P, X, i, Y, yx.data(), yy.data(), yz.data(), K, ell, mr, ir)
+                          : se_row_literal(P, X, i, Y, K, ell, mr, ir);
+    if ((int)nn < K) {
+      ir[nn] = -1;
+      mr[nn] = 0;
+    }
+    nonzeros[i] = nn;
+  }
+}
+
+// update_tf, CvoGPU.cu:94-126 (host; R row-major here)
+void update_tf_impl(const float R[9], const float T[3], float Ri[9], float Ti[3]) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Ri[3 * i + j] = R[3 * j + i];
+  for (int i = 0; i < 3; i++) {
+    // (-R_inv) * T, Eigen 3-term product a0 + (a1 + a2) on the host (unfused)
+    float a0 = (-Ri[3 * i + 0]) * T[0], a1 = (-Ri[3 * i + 1]) * T[1], a2 = (-Ri[3 * i + 2]) * T[2];
+    Ti[i] = a0 + (a1 + a2);
+  }
+}
+
+// transform_point_R_T::operator(), CvoGPU_impl.cu:31-82 (device functor, xyz only:
+// update_normal_and_cov is false on the path, CvoGPU.cu:1408)
+inline void transform_point(const float Ri[9], const float Ti[3], const float* in, float* out) {
+  for (int i = 0; i < 3; i++)
+    out[i] = dot3_dev(Ri[3 * i + 0], Ri[3 * i + 1], Ri[3 * i + 2], in[0], in[1], in[2]) + Ti[i];
+}
+
+struct FlowOut {
+  float omega[3], v[3];
+};
+
+// compute_flow_gpu_no_eigen (CvoGPU.cu:729-790) + compute_flow host half (793-848)
+FlowOut compute_flow_impl(const OracleParams& P, const CloudView& X, const CloudView& Y, int K,
+                          const float* mat, const int* ind) {
+  const int n = X.n;
+  std::vector<double> om(3 * (size_t)n), vv(3 * (size_t)n);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) {
+    const float* px = X.p(i);
+    V3 pxe{px[0], px[1], px[2]};
+    float o0 = 0, o1 = 0, o2 = 0, v0 = 0, v1 = 0, v2 = 0;
+    for (int j = 0; j < K; j++) {
+      int idx = ind[(size_t)i * K + j];
+      if (idx == -1) break;
+      const float* py = Y.p(idx);
+      V3 pye{py[0], py[1], py[2]};
+      V3 cr = cross_dev(pxe, pye);
+      float dx = pye.x - pxe.x, dy = pye.y - pxe.y, dz = pye.z - pxe.z;
+      float a = mat[(size_t)i * K + j];
+      o0 = std::fmaf(cr.x, a, o0);
+      o1 = std::fmaf(cr.y, a, o1);
+      o2 = std::fmaf(cr.z, a, o2);
+      v0 = std::fmaf(dx, a, v0);
+      v1 = std::fmaf(dy, a, v1);
+      v2 = std::fmaf(dz, a, v2);
+    }
+    om[3 * (size_t)i + 0] = (double)(o0 / P.c);
+    om[3 * (size_t)i + 1] = (double)(o1 / P.c);
+    om[3 * (size_t)i + 2] = (double)(o2 / P.c);
+    vv[3 * (size_t)i + 0] = (double)(v0 / P.d);
+    vv[3 * (size_t)i + 1] = (double)(v1 / P.d);
+    vv[3 * (size_t)i + 2] = (double)(v2 / P.d);
+  }
+  // thrust::reduce in double (order unspecified upstream; sequential here), CvoGPU.cu:824-825
+  double so[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
+  for (int i = 0; i < n; i++)
+    for (int c = 0; c < 3; c++) {
+      so[c] += om[3 * (size_t)i + c];
+      sv[c] += vv[3 * (size_t)i + c];
+    }
+  float ov[6] = {(float)so[0], (float)so[1], (float)so[2], (float)sv[0], (float)sv[1], (float)sv[2]};
+  // Eigen::MatrixBase::normalize(): z = squaredNorm(); if (z > 0) *this /= sqrt(z);  (827-832)
+  float z = 0;
+  for (int c = 0; c < 6; c++) z = z + ov[c] * ov[c];
+  if (z > 0) {
+    float s = std::sqrt(z);
+    for (int c = 0; c < 6; c++) ov[c] = ov[c] / s;
+  }
+  FlowOut f;
+  for (int c = 0; c < 3; c++) {
+    f.omega[c] = ov[c];
+    f.v[c] = ov[3 + c];
+  }
+  return f;
+}
+
+struct XiMats {
+  M3 oh, m2, m3, m4;
+  V3 ohv, m2v, m3v;
+};
+inline XiMats xi_mats(const float omega[3], const float v[3]) {
+  XiMats x;
+  V3 w{omega[0], omega[1], omega[2]}, vv{v[0], v[1], v[2]};
+  x.oh = skew(w);
+  x.m2 = matmul_dev(x.oh, x.oh);  // (omega_hat*omega_hat) evaluated into a temporary
+  x.m3 = matmul_dev(x.m2, x.oh);
+  x.m4 = matmul_dev(x.m3, x.oh);
+  x.ohv = matvec_dev(x.oh, vv);
+  x.m2v = matvec_dev(x.m2, vv);
+  x.m3v = matvec_dev(x.m3, vv);
+  return x;
+}
+struct XiZ {
+  V3 xiz, xi2z, xi3z, xi4z;
+  float normxiz2, xiz_dot_xi2z, epsil_const;
+};
+// compute_step_size_xi for one target, CvoGPU.cu:953-998
+inline XiZ xi_point(const XiMats& M, const float omega[3], const float v[3], const float* y) {
+  XiZ r;
+  V3 w{omega[0], omega[1], omega[2]}, yy{y[0], y[1], y[2]};
+  V3 c = cross_dev(w, yy);
+  r.xiz = {c.x + v[0], c.y + v[1], c.z + v[2]};
+  V3 a = matvec_dev(M.m2, yy);
+  r.xi2z = {a.x + M.ohv.x, a.y + M.ohv.y, a.z + M.ohv.z};
+  a = matvec_dev(M.m3, yy);
+  r.xi3z = {a.x + M.m2v.x, a.y + M.m2v.y, a.z + M.m2v.z};
+  a = matvec_dev(M.m4, yy);
+  r.xi4z = {a.x + M.m3v.x, a.y + M.m3v.y, a.z + M.m3v.z};
+  r.normxiz2 = dot3_dev(r.xiz.x, r.xiz.y, r.xiz.z, r.xiz.x, r.xiz.y, r.xiz.z);
+  r.xiz_dot_xi2z = -dot3_dev(r.xiz.x, r.xiz.y, r.xiz.z, r.xi2z.x, r.xi2z.y, r.xi2z.z);
+  r.epsil_const = std::fmaf(2.0f, dot3_dev(r.xiz.x, r.xiz.y, r.xiz.z, r.xi3z.x, r.xi3z.y, r.xi3z.z),
+                            dot3_dev(r.xi2z.x, r.xi2z.y, r.xi2z.z, r.xi2z.x, r.xi2z.y, r.xi2z.z));
+  return r;
+}
+
+struct Coefs {
+  double B, C, D, E;
+};
+// compute_step_size_poly_coeff (CvoGPU.cu:1001-1082) + the four thrust::reduce (1118-1121)
+Coefs poly_coeff_impl(const OracleParams& P, const CloudView& X, const CloudView& Y, int K, float ell,
+                      const float* mat, const int* ind, const float omega[3], const float v[3]) {
+  const int n = X.n, m = Y.n;
+  XiMats M = xi_mats(omega, v);
+  std::vector<XiZ> xz(m);
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < m; j++) xz[j] = xi_point(M, omega, v, Y.p(j));
+  std::vector<double> Bv(n), Cv(n), Dv(n), Ev(n);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) {
+    double Bi = 0, Ci = 0, Di = 0, Ei = 0;
+    const float* px = X.p(i);
+    float d2_sqrt = std::sqrt(dot3_dev(px[0], px[1], px[2], px[0], px[1], px[2]));  // px.norm()
+    float temp_ell = ell;
+    if (P.is_using_range_ell) temp_ell = compute_range_ell(ell, d2_sqrt);
+    for (int j = 0; j < K; j++) {
+      int idx = ind[(size_t)i * K + j];
+      if (idx == -1) break;
+      float temp_coef = (float)(1 / (2.0 * temp_ell * temp_ell));
+      const float* py = Y.p(idx);
+      float dfx = px[0] - py[0], dfy = px[1] - py[1], dfz = px[2] - py[2];
+      const XiZ& z = xz[idx];
+      float beta_ij = (float)(-2.0 * temp_coef * (double)dot3_dev(z.xiz.x, z.xiz.y, z.xiz.z, dfx, dfy, dfz));
+      float gamma_ij =
+          (-temp_coef) * (z.normxiz2 + dot3_dev(2.0f * z.xi2z.x, 2.0f * z.xi2z.y, 2.0f * z.xi2z.z, dfx, dfy, dfz));
+      float delta_ij = (float)(2.0 * temp_coef *
+                               (double)(z.xiz_dot_xi2z + dot3_dev(-z.xi3z.x, -z.xi3z.y, -z.xi3z.z, dfx, dfy, dfz)));
+      float epsil_ij =
+          (-temp_coef) * (z.epsil_const + dot3_dev(2.0f * z.xi4z.x, 2.0f * z.xi4z.y, 2.0f * z.xi4z.z, dfx, dfy, dfz));
+      float A_ij = mat[(size_t)i * K + j];
+      double bi = (double)(A_ij * beta_ij);
+      Bi += bi;
+      double ci = (double)A_ij * ((double)gamma_ij + (double)(beta_ij * beta_ij) / 2.0);
+      Ci += ci;
+      double di = (double)A_ij * ((double)std::fmaf(beta_ij, gamma_ij, delta_ij) +
+                                  (double)(beta_ij * beta_ij * beta_ij) / 6.0);
+      Di += di;
+      double ei = (double)A_ij * ((double)std::fmaf(beta_ij, delta_ij, epsil_ij) +
+                                  1 / 2.0 * beta_ij * beta_ij * gamma_ij + 1 / 2.0 * gamma_ij * gamma_ij +
+                                  1 / 24.0 * beta_ij * beta_ij * beta_ij * beta_ij);
+      Ei += ei;
+    }
+    Bv[i] = Bi;
+    Cv[i] = Ci;
+    Dv[i] = Di;
+    Ev[i] = Ei;
+  }
+  Coefs c{0, 0, 0, 0};
+  for (int i = 0; i < n; i++) {
+    c.B += Bv[i];
+    c.C += Cv[i];
+    c.D += Dv[i];
+    c.E += Ev[i];
+  }
+  return c;
+}
+
+// Roots of p0 x^3 + p1 x^2 + p2 x + p3.  The reference takes the eigenvalues of the
+// companion matrix with Eigen 3.3.9's EigenSolver (LieGroup.cpp:309-325; Eigen is not in
+// the repository).  Restated as Cardano/trigonometric roots + Newton polish + deflation;
+// pinned against numpy.roots in tests/test_oracle_math.py.
+void cubic_roots_impl(const double coef[4], double re[3], double im[3]) {
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  double a = coef[1] / coef[0], b = coef[2] / coef[0], c = coef[3] / coef[0];
+  if (!std::isfinite(a) || !std::isfinite(b) || !std::isfinite(c)) {
+    for (int i = 0; i < 3; i++) re[i] = im[i] = nan;
+    return;
+  }
+  auto f = [&](double x) { return ((x + a) * x + b) * x + c; };
+  auto df = [&](double x) { return (3 * x + 2 * a) * x + b; };
+  auto polish = [&](double x) {
+    for (int it = 0; it < 4; it++) {
+      double d = df(x);
+      if (d == 0 || !std::isfinite(d)) break;
+      double nx = x - f(x) / d;
+      if (!std::isfinite(nx)) break;
+      x = nx;
+    }
+    return x;
+  };
+  double p = b - a * a / 3.0;
+  double q = 2.0 * a * a * a / 27.0 - a * b / 3.0 + c;
+  double disc = q * q / 4.0 + p * p * p / 27.0;
+  double r0;
+  if (disc > 0) {
+    double s = std::sqrt(disc);
+    double u = (-q / 2.0 >= 0) ? std::cbrt(-q / 2.0 + s) : std::cbrt(-q / 2.0 - s);
+    double vv = (u != 0) ? -p / (3.0 * u) : 0.0;
+    r0 = u + vv - a / 3.0;
+  } else {
+    double mm = 2.0 * std::sqrt(std::max(0.0, -p / 3.0));
+    double arg = (p != 0) ? (3.0 * q) / (p * mm) : 0.0;
+    arg = std::max(-1.0, std::min(1.0, arg));
+    double th = std::acos(arg) / 3.0;
+    // pick the root that is best separated (largest magnitude of t) for a stable deflation
+    double t0 = mm * std::cos(th), t2 = mm * std::cos(th - 4.0 * M_PI / 3.0);
+    r0 = ((std::fabs(t0) >= std::fabs(t2)) ? t0 : t2) - a / 3.0;
+  }
+  r0 = polish(r0);
+  // deflate: x^2 + (a + r0) x + (b + r0 (a + r0))
+  double qa = a + r0, qb = b + r0 * qa;
+  double D = qa * qa - 4.0 * qb;
+  re[0] = r0;
+  im[0] = 0;
+  if (D >= 0) {
+    double s = std::sqrt(D);
+    double t = -0.5 * (qa + (qa >= 0 ? s : -s));
+    double x1 = t, x2 = (t != 0) ? qb / t : 0.0;
+    re[1] = polish(x1);
+    im[1] = 0;
+    re[2] = polish(x2);
+    im[2] = 0;
+  } else {
+    re[1] = re[2] = -0.5 * qa;
+    im[1] = 0.5 * std::sqrt(-D);
+    im[2] = -im[1];
+  }
+}
+
+// compute_step_size host half, CvoGPU.cu:1122-1158 (including the overwrite quirk: when no
+// root is admissible temp_step stays DBL_MAX and the `> max_step` branch wins).
+float select_step_impl(double B, double C, double D, double E, float min_step, float max_step) {
+  double p_coef[4] = {4.0 * E, 3.0 * D, 2.0 * C, B};
+  double re[3], im[3];
+  cubic_roots_impl(p_coef, re, im);
+  double temp_step = std::numeric_limits<double>::max();
+  for (int i = 0; i < 3; i++)
+    if (re[i] > 0 && re[i] < temp_step && std::fabs(im[i]) < 1e-5) temp_step = re[i];
+  float step = temp_step == std::numeric_limits<double>::max() ? min_step : (float)temp_step;
+  if (temp_step > max_step)
+    step = max_step;
+  else if (temp_step < min_step)
+    step = min_step;
+  else
+    step = (float)temp_step;
+  return step;
+}
+
+// Exp_SEK3(Matrix<float,6,1>, float dt), LieGroup.cpp:244-274 (host, float, unfused).
+// out: 3x4 row-major [R | Jl*v].
+void exp_sek3_impl(const float xi[6], float dt, float out[12]) {
+  const float TOLERANCE = 1e-6f;  // LieGroup.cpp:9
+  float w0 = xi[0], w1 = xi[1], w2 = xi[2];
+  float theta = std::sqrt(w0 * w0 + (w1 * w1 + w2 * w2));
+  float R[3][3], Jl[3][3];
+  const float I[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  if (theta < TOLERANCE) {
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) R[i][j] = Jl[i][j] = I[i][j];
+  } else {
+    float A[3][3] = {{0, -w2, w1}, {w2, 0, -w0}, {-w1, w0, 0}};
+    float theta2 = theta * theta;
+    float stheta = std::sin(dt * theta);
+    float ctheta = std::cos(dt * theta);
+    float oneMinusCosTheta2 = (1 - ctheta) / (theta2);
+    float A2[3][3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) A2[i][j] = A[i][0] * A[0][j] + (A[i][1] * A[1][j] + A[i][2] * A[2][j]);
+    float s1 = stheta / theta;
+    float s3 = (dt * theta - stheta) / (theta2 * theta);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        R[i][j] = (I[i][j] + s1 * A[i][j]) + oneMinusCosTheta2 * A2[i][j];
+        Jl[i][j] = (dt * I[i][j] + oneMinusCosTheta2 * A[i][j]) + s3 * A2[i][j];
+      }
+  }
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) out[4 * i + j] = R[i][j];
+    out[4 * i + 3] = Jl[i][0] * xi[3] + (Jl[i][1] * xi[4] + Jl[i][2] * xi[5]);
+  }
+}
+
+// ||Sophus::SE3d(dRT).log()||, CvoGPU.cu:1473-1476.  Sophus 1.0.0 is not in the repository;
+// restated from its published algorithm: SO3(R) = Eigen::Quaterniond(R) (no normalisation),
+// SO3::logAndTheta via 2*atan(n/w)/n, SE3::log via V^-1.  Pinned against scipy logm.
+double se3_log_norm_impl(const double R[9], const double t[3]) {
+  const double eps = 1e-10;  // Sophus::Constants<double>::epsilon()
+  double q[4];               // x y z w
+  auto m = [&](int i, int j) { return R[3 * i + j]; };
+  double tr = m(0, 0) + m(1, 1) + m(2, 2);
+  if (tr > 0) {
+    double s = std::sqrt(tr + 1.0);
+    q[3] = 0.5 * s;
+    s = 0.5 / s;
+    q[0] = (m(2, 1) - m(1, 2)) * s;
+    q[1] = (m(0, 2) - m(2, 0)) * s;
+    q[2] = (m(1, 0) - m(0, 1)) * s;
+  } else {
+    int i = 0;
+    if (m(1, 1) > m(0, 0)) i = 1;
+    if (m(2, 2) > m(i, i)) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    double s = std::sqrt(m(i, i) - m(j, j) - m(k, k) + 1.0);
+    q[i] = 0.5 * s;
+    s = 0.5 / s;
+    q[3] = (m(k, j) - m(j, k)) * s;
+    q[j] = (m(j, i) + m(i, j)) * s;
+    q[k] = (m(k, i) + m(i, k)) * s;
+  }
+  double squared_n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+  double n = std::sqrt(squared_n);
+  double w = q[3];
+  double two_atan_nbyw_by_n;
+  if (n < eps) {
+    double squared_w = w * w;
+    two_atan_nbyw_by_n = 2.0 / w - 2.0 * squared_n / (w * squared_w);
+  } else {
+    if (std::fabs(w) < eps) {
+      two_atan_nbyw_by_n = (w > 0 ? M_PI : -M_PI) / n;
+    } else {
+      two_atan_nbyw_by_n = 2.0 * std::atan(n / w) / n;
+    }
+  }
+  double theta = two_atan_nbyw_by_n * n;
+  double om[3] = {two_atan_nbyw_by_n * q[0], two_atan_nbyw_by_n * q[1], two_atan_nbyw_by_n * q[2]};
+  double O[3][3] = {{0, -om[2], om[1]}, {om[2], 0, -om[0]}, {-om[1], om[0], 0}};
+  double O2[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) O2[i][j] = O[i][0] * O[0][j] + O[i][1] * O[1][j] + O[i][2] * O[2][j];
+  double coef;
+  if (std::fabs(theta) < eps) {
+    coef = 1.0 / 12.0;
+  } else {
+    double half_theta = 0.5 * theta;
+    coef = (1.0 - theta * std::cos(half_theta) / (2.0 * std::sin(half_theta))) / (theta * theta);
+  }
+  double u[3];
+  for (int i = 0; i < 3; i++) {
+    u[i] = 0;
+    for (int j = 0; j < 3; j++) {
+      double Vinv = (i == j ? 1.0 : 0.0) - 0.5 * O[i][j] + coef * O2[i][j];
+      u[i] += Vinv * t[j];
+    }
+  }
+  double s = 0;
+  for (int i = 0; i < 3; i++) s += u[i] * u[i];
+  for (int i = 0; i < 3; i++) s += om[i] * om[i];
+  return std::sqrt(s);
+}
+
+// A_sparsity_indicator_ell_update, CvoGPU.cu:1167-1285 (literal control flow: the three
+// `if`s are sequential, not else-if).
+struct Indicator {
+  std::queue<float> start_q, end_q;
+  float start_sum = 0, end_sum = 0;
+  bool update(float indicator, int queue_len, float thr) {
+    bool decrease = false;
+    if ((int)start_q.size() < queue_len) {
+      start_q.push(indicator);
+      start_sum += indicator;
+    }
+    if ((int)start_q.size() >= queue_len && (int)end_q.size() < queue_len) {
+      end_q.push(indicator);
+      end_sum += indicator;
+    }
+    if ((int)start_q.size() >= queue_len && (int)end_q.size() >= queue_len) {
+      if (end_sum / start_sum > 1 - thr && end_sum / start_sum < 1 + thr) {
+        decrease = true;
+        std::queue<float> e1, e2;
+        std::swap(start_q, e1);
+        std::swap(end_q, e2);
+        start_sum = 0;
+        end_sum = 0;
+      } else {
+        end_sum -= end_q.front();
+        start_sum += end_q.front();
+        start_q.push(end_q.front());
+        end_q.pop();
+        start_sum -= start_q.front();
+        start_q.pop();
+        end_q.push(indicator);
+        end_sum += indicator;
+      }
+    }
+    return decrease;
+  }
+};
+
+struct IterResult {
+  int status;  // 0 continue, 1 break (eps), 2 break (eps_2)
+  int ret;
+};
+
+struct Workspace {
+  std::vector<float> yt;  // transformed target xyz
+  std::vector<float> mat;
+  std::vector<int> ind;
+  std::vector<unsigned> nonzeros;
+};
+
+// One pass of the loop body of align_impl, CvoGPU.cu:1387-1531, up to (not including) the
+// indicator / ell / K bookkeeping, which the caller does.
+IterResult iterate(const OracleParams& P, const CloudView& X, const CloudView& Y0, float R[9], float T[3],
+                   float ell, int K, Workspace& ws, OracleTrace* tr) {
+  const int n = X.n, m = Y0.n;
+  float Ri[9], Ti[3];
+  update_tf_impl(R, T, Ri, Ti);  // CvoGPU.cu:1393
+  ws.yt.resize(3 * (size_t)m);
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < m; j++) transform_point(Ri, Ti, Y0.p(j), &ws.yt[3 * (size_t)j]);  // 1404
+  CloudView Y = Y0;
+  Y.xyz = ws.yt.data();
+  if (ws.mat.size() < (size_t)n * K) {
+    ws.mat.resize((size_t)n * K);
+    ws.ind.resize((size_t)n * K);
+  }
+  ws.nonzeros.resize(n);
+  se_kernel_impl(P, X, Y, K, ell, ws.mat.data(), ws.ind.data(), ws.nonzeros.data(), false);  // 1419
+  unsigned nnz = 0, mx = 0;  // compute_nonzeros SparseKernelMat.cu:37-46; max_element CvoGPU.cu:1518
+  for (int i = 0; i < n; i++) {
+    nnz += ws.nonzeros[i];
+    mx = std::max(mx, ws.nonzeros[i]);
+  }
+  FlowOut f = compute_flow_impl(P, X, Y, K, ws.mat.data(), ws.ind.data());  // 1443
+  Coefs c = poly_coeff_impl(P, X, Y, K, ell, ws.mat.data(), ws.ind.data(), f.omega, f.v);
+  float step = select_step_impl(c.B, c.C, c.D, c.E, P.min_step, P.max_step);  // 1451
+  if (tr) {
+    tr->K = K;
+    tr->ell = ell;
+    tr->step = step;
+    tr->nnz = nnz;
+    tr->max_nnz = mx;
+    for (int k = 0; k < 3; k++) {
+      tr->omega[k] = f.omega[k];
+      tr->v[k] = f.v[k];
+    }
+    tr->B = c.B;
+    tr->C = c.C;
+    tr->D = c.D;
+    tr->E = c.E;
+    tr->dist = 0;
+  }
+  auto norm3d = [](const float* a) {
+    double x = a[0], y = a[1], z = a[2];
+    return std::sqrt(x * x + (y * y + z * z));
+  };
+  IterResult res{0, 0};
+  if (norm3d(f.omega) < P.eps && norm3d(f.v) < P.eps) {  // 1454-1458
+    auto norm3f = [](const float* a) { return std::sqrt(a[0] * a[0] + (a[1] * a[1] + a[2] * a[2])); };
+    if (norm3f(f.omega) < 1e-8 && norm3f(f.v) < 1e-8) res.ret = -1;
+    res.status = 1;
+    if (tr) {
+      std::memcpy(tr->R, R, sizeof(float) * 9);
+      std::memcpy(tr->T, T, sizeof(float) * 3);
+    }
+    return res;
+  }
+  float xi[6] = {f.omega[0], f.omega[1], f.omega[2], f.v[0], f.v[1], f.v[2]};
+  float dtrans[12];
+  exp_sek3_impl(xi, step, dtrans);  // 1462
+  double dR[9], dT[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) dR[3 * i + j] = (double)dtrans[4 * i + j];
+    dT[i] = (double)dtrans[4 * i + 3];
+  }
+  // T = (R.cast<double>() * dT + T.cast<double>()).cast<float>();  R = (R.cast<double>() * dR).cast<float>()
+  float Tn[3], Rn[9];
+  for (int i = 0; i < 3; i++) {
+    double r0 = R[3 * i + 0], r1 = R[3 * i + 1], r2 = R[3 * i + 2];
+    Tn[i] = (float)((r0 * dT[0] + (r1 * dT[1] + r2 * dT[2])) + (double)T[i]);
+    for (int j = 0; j < 3; j++) Rn[3 * i + j] = (float)(r0 * dR[0 + j] + (r1 * dR[3 + j] + r2 * dR[6 + j]));
+  }
+  std::memcpy(R, Rn, sizeof(Rn));
+  std::memcpy(T, Tn, sizeof(Tn));
+  double dist = se3_log_norm_impl(dR, dT);  // 1473-1476
+  if (tr) {
+    tr->dist = dist;
+    std::memcpy(tr->R, R, sizeof(float) * 9);
+    std::memcpy(tr->T, T, sizeof(float) * 3);
+  }
+  if (dist < P.eps_2) res.status = 2;  // 1505-1508 (checked by the caller after the indicator update)
+  return res;
+}
+
+void mat4_from_RT_inverse(const float R[9], const float T[3], float out_colmajor[16]) {
+  // final update_tf(R, T, &cvo_state, transform), CvoGPU.cu:1562
+  float Ri[9], Ti[3];
+  update_tf_impl(R, T, Ri, Ti);
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) out_colmajor[4 * j + i] = Ri[3 * i + j];
+    out_colmajor[12 + i] = Ti[i];
+  }
+  out_colmajor[3] = out_colmajor[7] = out_colmajor[11] = 0;
+  out_colmajor[15] = 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+void oracle_cubic_roots(const double coef[4], double re[3], double im[3]) { cubic_roots_impl(coef, re, im); }
+float oracle_select_step(double B, double C, double D, double E, float min_step, float max_step) {
+  return select_step_impl(B, C, D, E, min_step, max_step);
+}
+void oracle_exp_sek3(const float xi[6], float dt, float out[12]) { exp_sek3_impl(xi, dt, out); }
+double oracle_se3_log_norm(const double dR[9], const double dT[3]) { return se3_log_norm_impl(dR, dT); }
+void oracle_indicator_run(const float* indicators, int n, int window, float thr, unsigned char* decisions) {
+  Indicator ind;
+  for (int i = 0; i < n; i++) decisions[i] = ind.update(indicators[i], window, thr) ? 1 : 0;
+}
+void oracle_update_tf(const float R[9], const float T[3], float R_inv[9], float T_inv[3]) {
+  update_tf_impl(R, T, R_inv, T_inv);
+}
+void oracle_transform(const float R_inv[9], const float T_inv[3], int m, const float* y0, float* yt) {
+  for (int j = 0; j < m; j++) transform_point(R_inv, T_inv, y0 + 3 * j, yt + 3 * j);
+}
+void oracle_se_kernel(const OracleParams* p, const OracleCloud* x, const OracleCloud* y, int K, float ell,
+                      float* mat, int* ind, unsigned int* nonzeros, int literal) {
+  // reset_state_at_new_iter: mat = 0, ind = -1 over rows*K (CvoState.cu:143-157)
+  std::fill(mat, mat + (size_t)x->n * K, 0.0f);
+  std::fill(ind, ind + (size_t)x->n * K, -1);
+  se_kernel_impl(*p, view(x), view(y), K, ell, mat, ind, nonzeros, literal != 0);
+}
+
+int oracle_iteration(const OracleParams* p, const OracleCloud* x, const OracleCloud* y, float R[9], float T[3],
+                     float ell, int K, OracleTrace* out, int* ret_code, float* ell_mat_out, int* ell_ind_out,
+                     unsigned int* nonzeros_out) {
+  Workspace ws;
+  IterResult r = iterate(*p, view(x), view(y), R, T, ell, K, ws, out);
+  if (ret_code) *ret_code = r.ret;
+  size_t nk = (size_t)x->n * K;
+  if (ell_mat_out) {
+    std::fill(ell_mat_out, ell_mat_out + nk, 0.0f);
+    for (int i = 0; i < x->n; i++)
+      for (unsigned s = 0; s < ws.nonzeros[i]; s++) ell_mat_out[(size_t)i * K + s] = ws.mat[(size_t)i * K + s];
+  }
+  if (ell_ind_out) {
+    std::fill(ell_ind_out, ell_ind_out + nk, -1);
+    for (int i = 0; i < x->n; i++)
+      for (unsigned s = 0; s < ws.nonzeros[i]; s++) ell_ind_out[(size_t)i * K + s] = ws.ind[(size_t)i * K + s];
+  }
+  if (nonzeros_out) std::memcpy(nonzeros_out, ws.nonzeros.data(), sizeof(unsigned) * x->n);
+  return r.status;
+}
+
+// CvoGPU::align + align_impl, CvoGPU.cu:1338-1632
+int oracle_align(const OracleParams* p, const OracleCloud* x, const OracleCloud* y, const float init[16],
+                 float out[16], int* iterations, OracleTrace* trace, int max_trace, int trace_dense,
+                 int trace_every, int* n_trace, double* seconds, int max_iter_override) {
+  if (n_trace) *n_trace = 0;
+  if (iterations) *iterations = 0;
+  if (x->n == 0 || y->n == 0) return 0;  // CvoGPU.cu:1614-1617: transform untouched
+  const OracleParams& P = *p;
+  CloudView X = view(x), Y0 = view(y);
+  float R[9], T[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[3 * i + j] = init[4 * j + i];
+    T[i] = init[12 + i];
+  }
+  auto t0 = std::chrono::steady_clock::now();
+  int ret = 0;
+  Indicator indicator;
+  float ell = P.ell_init;  // CvoState ctor, CvoState.cu:30
+  int num_neighbors = P.nearest_neighbors_max;
+  int max_iter = max_iter_override > 0 ? std::min(max_iter_override, P.MAX_ITER) : P.MAX_ITER;
+  Workspace ws;
+  int k = 0;
+  int nt = 0;
+  for (; k < max_iter; k++) {
+    OracleTrace tr;
+    std::memset(&tr, 0, sizeof(tr));
+    tr.k = k;
+    IterResult r = iterate(P, X, Y0, R, T, ell, num_neighbors, ws, &tr);
+    bool rec = trace && nt < max_trace && (k < trace_dense || (trace_every > 0 && k % trace_every == 0));
+    if (rec) trace[nt++] = tr;
+    if (r.status == 1) {
+      ret = r.ret;
+      break;
+    }
+    float ip_curr = (float)((double)tr.nnz / std::sqrt((double)X.n * (double)Y0.n));  // 1486
+    bool need_decay_ell = indicator.update(ip_curr, P.indicator_window_size, P.indicator_stable_threshold);
+    if (r.status == 2) break;  // 1505-1508
+    if (k > P.ell_decay_start && need_decay_ell) {  // 1509-1513
+      ell = ell * P.ell_decay_rate;
+      if (ell < P.ell_min) ell = P.ell_min;
+    }
+    num_neighbors = std::min(P.nearest_neighbors_max, (int)(tr.max_nnz * 1.2));  // 1529
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+  if (iterations) *iterations = k;
+  if (n_trace) *n_trace = nt;
+  mat4_from_RT_inverse(R, T, out);
+  return ret;
+}
+
+// inner_product_impl + A_sum, CvoGPU.cu:1719-1778, SparseKernelMat.cu:62-68.  The float
+// thrust::reduce over all rows*cols slots has unspecified order; restated as the float
+// cast of the double sum of the stored entries.
+static double inner_product_sum(const OracleParams& P, const CloudView& X, const CloudView& Y0,
+                                const float Tm[16], float ell, std::vector<float>* mat_out,
+                                std::vector<int>* ind_out, std::vector<unsigned>* nz_out) {
+  float R[9], T[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Tm[4 * j + i];
+    T[i] = Tm[12 + i];
+  }
+  float Ri[9], Ti[3];
+  update_tf_impl(R, T, Ri, Ti);
+  std::vector<float> yt(3 * (size_t)Y0.n);
+  for (int j = 0; j < Y0.n; j++) transform_point(Ri, Ti, Y0.p(j), &yt[3 * (size_t)j]);
+  CloudView Y = Y0;
+  Y.xyz = yt.data();
+  int K = P.nearest_neighbors_max;
+  std::vector<float> mat((size_t)X.n * K, 0.0f);
+  std::vector<int> ind((size_t)X.n * K, -1);
+  std::vector<unsigned> nz(X.n);
+  se_kernel_impl(P, X, Y, K, ell, mat.data(), ind.data(), nz.data(), false);
+  double s = 0;
+  for (int i = 0; i < X.n; i++)
+    for (unsigned t = 0; t < nz[i]; t++) s += (double)mat[(size_t)i * K + t];
+  if (mat_out) mat_out->swap(mat);
+  if (ind_out) ind_out->swap(ind);
+  if (nz_out) nz_out->swap(nz);
+  return s;
+}
+
+float oracle_inner_product(const OracleParams* p, const OracleCloud* x, const OracleCloud* y, const float Tm[16],
+                           float ell) {
+  return (float)inner_product_sum(*p, view(x), view(y), Tm, ell, nullptr, nullptr, nullptr);
+}
+
+// function_angle, CvoGPU.cu:1814-1846 (is_gpu = true branch)
+float oracle_function_angle(const OracleParams* p, const OracleCloud* x, const OracleCloud* y, const float Tm[16],
+                            float ell, int is_approximate) {
+  if (x->n == 0 || y->n == 0) return 0;
+  const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  float fxfz = oracle_inner_product(p, x, y, Tm, ell);
+  float fx_norm, fz_norm;
+  if (is_approximate) {
+    fx_norm = (float)std::sqrt((double)x->n);
+    fz_norm = (float)std::sqrt((double)y->n);
+  } else {
+    fx_norm = std::sqrt(oracle_inner_product(p, x, x, identity, ell));
+    fz_norm = std::sqrt(oracle_inner_product(p, y, y, identity, ell));
+  }
+  return fxfz / (fx_norm * fz_norm);
+}
+
+// compute_association_gpu(float lengthscale) -> gpu_association_to_cpu, CvoGPU.cu:1876-1911,
+// CvoGPU_impl.cu:366-427, as CSR (row-major sparse, columns in stored = ascending order).
+int oracle_association(const OracleParams* p, const OracleCloud* x, const OracleCloud* y, const float Tm[16],
+                       float ell, int* row_ptr, int* col, float* val) {
+  std::vector<float> mat;
+  std::vector<int> ind;
+  std::vector<unsigned> nz;
+  inner_product_sum(*p, view(x), view(y), Tm, ell, &mat, &ind, &nz);
+  int K = p->nearest_neighbors_max, cnt = 0;
+  for (int i = 0; i < x->n; i++) {
+    row_ptr[i] = cnt;
+    for (unsigned t = 0; t < nz[i]; t++) {
+      col[cnt] = ind[(size_t)i * K + t];
+      val[cnt] = mat[(size_t)i * K + t];
+      cnt++;
+    }
+  }
+  row_ptr[x->n] = cnt;
+  return cnt;
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
+}  // extern "C"

@@ -1,0 +1,378 @@
+"""Python mirror of the reference's operator interface for the path (cvo::CvoGPU, cvo::CvoPointCloud;
+include/UnifiedCvo/cvo/CvoGPU.hpp:49-229, utils/CvoPointCloud.hpp:126-188), over the C-ABI.
+
+This is the harness used by tests/ and bench.py; the C++ veneer with the same names lives in
+include/UnifiedCvo/.  All compute happens in libcvo_hip.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .params import CvoParams, read_cvo_params_yaml
+from .synth import FEATURE_DIMENSIONS, NUM_CLASSES
+
+
+class CvoError(RuntimeError):
+    pass
+
+
+def _fptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class CvoPointCloud:
+    """Host container: positions (n,3), features (n,F), labels (n,C), geometric_types (n,2)."""
+
+    def __init__(self, feature_dimensions=0, num_classes=0):
+        self.num_points_ = 0
+        self.feature_dimensions_ = feature_dimensions
+        self.num_classes_ = num_classes
+        self.positions_ = np.zeros((0, 3), np.float32)
+        self.features_ = np.zeros((0, feature_dimensions), np.float32)
+        self.labels_ = np.zeros((0, num_classes), np.float32)
+        self.geometric_types_ = np.zeros((0, 2), np.float32)
+        self._reserved = False
+
+    # -- constructors mirroring the pcl ones (CvoPointCloud.cpp:569-652) -------------------------
+    @classmethod
+    def from_xyz(cls, xyz):
+        """pcl::PointXYZ constructor: F = 0, geometric_type = (1, 0) (CvoPointCloud.cpp:633-652)."""
+        pc = cls(0, 0)
+        pc.positions_ = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        pc.num_points_ = pc.positions_.shape[0]
+        pc.geometric_types_ = np.tile(np.array([[1.0, 0.0]], np.float32), (pc.num_points_, 1))
+        pc._reserved = True
+        return pc
+
+    @classmethod
+    def from_xyzrgb(cls, xyz, rgb_u8):
+        """pcl::PointXYZRGB constructor: features (r,g,b)/255,0,0; type (0,1) (CvoPointCloud.cpp:569-594)."""
+        pc = cls(5, 0)
+        pc.positions_ = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        pc.num_points_ = pc.positions_.shape[0]
+        f = np.zeros((pc.num_points_, 5), np.float32)
+        f[:, :3] = (np.asarray(rgb_u8).astype(np.int32).astype(np.float32) / np.float32(255.0))
+        pc.features_ = f
+        pc.geometric_types_ = np.tile(np.array([[0.0, 1.0]], np.float32), (pc.num_points_, 1))
+        pc._reserved = True
+        return pc
+
+    @classmethod
+    def from_arrays(cls, xyz, features=None, labels=None, geometric_types=None):
+        n = np.asarray(xyz).reshape(-1, 3).shape[0]
+        F = 0 if features is None else np.asarray(features).shape[1]
+        Cn = 0 if labels is None else np.asarray(labels).shape[1]
+        pc = cls(F, Cn)
+        pc.reserve(n, F, Cn)
+        pc.positions_[:] = np.asarray(xyz, np.float32).reshape(-1, 3)
+        if F:
+            pc.features_[:] = features
+        if Cn:
+            pc.labels_[:] = labels
+        if geometric_types is not None:
+            pc.geometric_types_[:] = geometric_types
+        return pc
+
+    # -- reserve / add_point (CvoPointCloud.cpp:1384-1420) ----------------------------------------
+    def reserve(self, num_points, feature_dims, num_classes):
+        self.num_points_ = num_points
+        self.feature_dimensions_ = feature_dims
+        self.num_classes_ = num_classes
+        self.positions_ = np.zeros((num_points, 3), np.float32)
+        self.features_ = np.zeros((num_points, feature_dims), np.float32)
+        self.labels_ = np.zeros((num_points, num_classes), np.float32)
+        self.geometric_types_ = np.zeros((num_points, 2), np.float32)
+        self._reserved = True
+
+    def add_point(self, index, xyz, feature, label, geometric_type):
+        if index >= self.num_points_:
+            return -1
+        if (not self._reserved or self.features_.shape[0] < self.num_points_
+                or self.features_.shape[1] != self.feature_dimensions_ or len(geometric_type) != 2):
+            return -1
+        self.positions_[index] = xyz
+        if self.feature_dimensions_:
+            self.features_[index] = feature
+        if self.num_classes_:
+            self.labels_[index] = label
+        self.geometric_types_[index] = geometric_type
+        return 0
+
+    # -- getters (CvoPointCloud.hpp:140-154) ------------------------------------------------------
+    def num_points(self):
+        return self.num_points_
+
+    size = num_points
+
+    def num_classes(self):
+        return self.num_classes_
+
+    def num_features(self):
+        return self.feature_dimensions_
+
+    feature_dimensions = num_features
+
+    def positions(self):
+        return self.positions_
+
+    def features(self):
+        return self.features_
+
+    def labels(self):
+        return self.labels_
+
+    semantics = labels
+
+    def geometric_types(self):
+        return self.geometric_types_.reshape(-1)
+
+    @staticmethod
+    def transform(pose, inp, out):
+        """static CvoPointCloud::transform (CvoPointCloud.cpp:1366-1382); feature_dimensions_ is not copied."""
+        P = np.asarray(pose, np.float32).reshape(4, 4)
+        out.num_points_ = inp.num_points_
+        out.num_classes_ = inp.num_classes_
+        out.features_ = inp.features_.copy()
+        out.labels_ = inp.labels_.copy()
+        out.positions_ = (inp.positions_ @ P[:3, :3].T + P[:3, 3]).astype(np.float32)
+        out.geometric_types_ = inp.geometric_types_.copy()
+        out._reserved = True
+
+    def __add__(self, other):
+        """operator+ concatenation (CvoPointCloud.cpp:1139-1151)."""
+        r = CvoPointCloud(self.feature_dimensions_, self.num_classes_)
+        r.num_points_ = self.num_points_ + other.num_points_
+        r.positions_ = np.concatenate([self.positions_, other.positions_])
+        r.features_ = np.concatenate([self.features_, other.features_]) if self.feature_dimensions_ else self.features_
+        r.labels_ = np.concatenate([self.labels_, other.labels_]) if self.num_classes_ else self.labels_
+        r.geometric_types_ = np.concatenate([self.geometric_types_, other.geometric_types_])
+        r._reserved = True
+        return r
+
+    # -- what CvoPointCloud_to_gpu builds per point (CvoGPU_impl.cu:206-263) ----------------------
+    def device_arrays(self):
+        n = self.num_points_
+        xyz = np.ascontiguousarray(self.positions_, np.float32)
+        feat = None
+        if self.features_.shape[0] == n and self.features_.shape[1] > 0:
+            feat = np.zeros((n, FEATURE_DIMENSIONS), np.float32)
+            k = min(FEATURE_DIMENSIONS, self.features_.shape[1])
+            feat[:, :k] = self.features_[:, :k]
+        label = None
+        if self.num_classes_ > 0:
+            label = np.zeros((n, NUM_CLASSES), np.float32)
+            k = min(NUM_CLASSES, self.labels_.shape[1])
+            label[:, :k] = self.labels_[:, :k]
+        geo = np.ascontiguousarray(self.geometric_types_, np.float32).reshape(n, 2)
+        return xyz, feat, label, geo
+
+
+class DeviceCloud:
+    """A cloud resident in HBM (cvo_cloud*)."""
+
+    def __init__(self, gpu, pc):
+        self.gpu = gpu
+        self.n = pc.num_points()
+        xyz, feat, label, geo = pc.device_arrays()
+        self._keep = (xyz, feat, label, geo)
+        h = C.c_void_p()
+        rc = gpu.L.cvo_cloud_upload(gpu.ctx, self.n, _fptr(xyz), _fptr(feat), _fptr(label), _fptr(geo), C.byref(h))
+        gpu._check(rc)
+        self.handle = h
+
+    def free(self):
+        if self.handle:
+            self.gpu.L.cvo_cloud_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _mat_to_c(T):
+    a = np.ascontiguousarray(np.asarray(T, np.float32).reshape(4, 4).T).reshape(16)
+    return a
+
+
+class AlignResult:
+    def __init__(self, ret, transform, info, trace=None):
+        self.ret = ret
+        self.transform = transform  # 4x4 float32 (row, col)
+        self.iterations = info.iterations
+        self.final_ell = info.final_ell
+        self.final_num_neighbors = info.final_num_neighbors
+        self.seconds = info.seconds
+        self.trace = trace
+
+
+class CvoGPU:
+    """cvo::CvoGPU(yaml) over the HIP backend."""
+
+    def __init__(self, param_file=None, params=None, device=0):
+        self.L = _capi.lib()
+        if params is not None:
+            self.params = params
+        elif param_file is not None:
+            self.params = read_cvo_params_yaml(param_file)
+        else:
+            self.params = CvoParams()
+        ctx = C.c_void_p()
+        rc = self.L.cvo_ctx_create(device, C.byref(ctx))
+        if rc != 0:
+            raise CvoError(f"cvo_ctx_create(device={device}) failed with {rc}: is a HIP GPU visible?")
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.cvo_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc <= _capi.CVO_E_INVALID:
+            raise CvoError(f"error {rc}: {self.L.cvo_last_error(self.ctx).decode()}")
+        return rc
+
+    def get_params(self):
+        return self.params
+
+    def write_params(self, p):
+        """CvoGPU::write_params (CvoGPU.cu:73-77): the device copy is refreshed per call here."""
+        self.params = p
+
+    def upload(self, pc):
+        return DeviceCloud(self, pc)
+
+    def _dev(self, pc):
+        return pc if isinstance(pc, DeviceCloud) else DeviceCloud(self, pc)
+
+    def _opts(self, max_iterations=0, ell0=None, K0=None, trace_capacity=0, trace_dense=0, trace_every=0,
+              n_pairs=1, iters_per_launch=0, use_graph=0):
+        o = _capi.cvo_align_opts_t()
+        o.max_iterations = max_iterations
+        keep = []
+        if ell0 is not None or K0 is not None:
+            o.override_state = 1
+            o.ell0 = self.params.ell_init if ell0 is None else ell0
+            o.K0 = self.params.nearest_neighbors_max if K0 is None else K0
+        if trace_capacity > 0:
+            tr = (_capi.cvo_trace_t * (trace_capacity * n_pairs))()
+            nt = (C.c_int * n_pairs)()
+            o.trace = tr
+            o.trace_capacity = trace_capacity
+            o.trace_dense = trace_dense
+            o.trace_every = trace_every
+            o.n_trace = nt
+            keep = [tr, nt]
+        o.iters_per_launch = iters_per_launch
+        o.use_graph = use_graph
+        return o, keep
+
+    def align(self, source, target, T_target_frame_to_source_frame, **kw):
+        """CvoGPU::align (CvoGPU.cu:1605-1632).  Returns AlignResult (ret = 0 / -1)."""
+        if source.num_points() == 0 or target.num_points() == 0 if not isinstance(source, DeviceCloud) else False:
+            info = _capi.cvo_align_info_t()
+            return AlignResult(0, None, info)  # transform untouched
+        src, tgt = self._dev(source), self._dev(target)
+        p = self.params.to_ctypes()
+        init = _mat_to_c(T_target_frame_to_source_frame)
+        out = np.zeros(16, np.float32)
+        info = _capi.cvo_align_info_t()
+        opts, keep = self._opts(**kw)
+        rc = self.L.cvo_align_ex(self.ctx, C.byref(p), src.handle, tgt.handle, _fptr(init), _fptr(out),
+                                 C.byref(info), C.byref(opts))
+        self._check(rc)
+        trace = None
+        if keep:
+            trace = [keep[0][i] for i in range(keep[1][0])]
+        self._keepalive = keep
+        return AlignResult(rc, out.reshape(4, 4).T.copy(), info, trace)
+
+    def align_batch(self, sources, targets, inits, **kw):
+        """n independent pairs solved concurrently on this context's GPU (cvo_align_batch)."""
+        n = len(sources)
+        src = [self._dev(s) for s in sources]
+        tgt = [self._dev(t) for t in targets]
+        sh = (C.c_void_p * n)(*[s.handle for s in src])
+        th = (C.c_void_p * n)(*[t.handle for t in tgt])
+        init = np.concatenate([_mat_to_c(T) for T in inits]).astype(np.float32)
+        out = np.zeros(16 * n, np.float32)
+        infos = (_capi.cvo_align_info_t * n)()
+        p = self.params.to_ctypes()
+        opts, keep = self._opts(n_pairs=n, **kw)
+        rc = self.L.cvo_align_batch(self.ctx, C.byref(p), n, sh, th, _fptr(init), _fptr(out), infos, C.byref(opts))
+        self._check(rc)
+        res = []
+        cap = opts.trace_capacity
+        for i in range(n):
+            trace = None
+            if keep:
+                trace = [keep[0][i * cap + t] for t in range(keep[1][i])]
+            res.append(AlignResult(infos[i].ret, out[16 * i:16 * i + 16].reshape(4, 4).T.copy(), infos[i], trace))
+        self._keepalive = keep
+        return res
+
+    def poses_to_device(self, dst_ptr, n):
+        self._check(self.L.cvo_batch_poses_to_device(self.ctx, C.c_void_p(dst_ptr), n))
+
+    def inner_product_gpu(self, source, target, T, ell):
+        src, tgt = self._dev(source), self._dev(target)
+        p = self.params.to_ctypes()
+        out = C.c_float()
+        Tm = _mat_to_c(T)
+        self._check(self.L.cvo_inner_product(self.ctx, C.byref(p), src.handle, tgt.handle, _fptr(Tm), ell,
+                                             C.byref(out)))
+        return out.value
+
+    def function_angle(self, source, target, T, ell, is_approximate=True):
+        src, tgt = self._dev(source), self._dev(target)
+        p = self.params.to_ctypes()
+        out = C.c_float()
+        Tm = _mat_to_c(T)
+        self._check(self.L.cvo_function_angle(self.ctx, C.byref(p), src.handle, tgt.handle, _fptr(Tm), ell,
+                                              1 if is_approximate else 0, C.byref(out)))
+        return out.value
+
+    def compute_association_gpu(self, source, target, T, lengthscale):
+        """Association::pairs as CSR (row_ptr, col, val) (CvoGPU.cu:1876-1911)."""
+        src, tgt = self._dev(source), self._dev(target)
+        n = src.n
+        p = self.params.to_ctypes()
+        cap = n * min(self.params.nearest_neighbors_max, tgt.n)
+        row_ptr = np.zeros(n + 1, np.int32)
+        col = np.zeros(max(cap, 1), np.int32)
+        val = np.zeros(max(cap, 1), np.float32)
+        nnz = C.c_size_t()
+        Tm = _mat_to_c(T)
+        self._check(self.L.cvo_association(self.ctx, C.byref(p), src.handle, tgt.handle, _fptr(Tm), lengthscale,
+                                           row_ptr.ctypes.data_as(C.POINTER(C.c_int)),
+                                           col.ctypes.data_as(C.POINTER(C.c_int)), _fptr(val), cap, C.byref(nnz)))
+        return row_ptr, col[:nnz.value], val[:nnz.value]
+
+    # -- test / profiling hooks --------------------------------------------------------------------
+    def debug_last_ell(self, n_rows, K):
+        mat = np.zeros((n_rows, K), np.float32)
+        ind = np.zeros((n_rows, K), np.int32)
+        nz = np.zeros(n_rows, np.uint32)
+        self._check(self.L.cvo_debug_last_ell(self.ctx, K, _fptr(mat), ind.ctypes.data_as(C.POINTER(C.c_int)),
+                                              nz.ctypes.data_as(C.POINTER(C.c_uint))))
+        return mat, ind, nz
+
+    def debug_time_scan(self, reps=20):
+        ms = C.c_float()
+        self._check(self.L.cvo_debug_time_scan(self.ctx, reps, C.byref(ms)))
+        return ms.value
+
+    def debug_last_candidates(self):
+        v = C.c_ulonglong()
+        self._check(self.L.cvo_debug_last_candidates(self.ctx, C.byref(v)))
+        return v.value

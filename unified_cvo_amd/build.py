@@ -1,0 +1,69 @@
+"""In-tree build of the gfx950 backend (libcvo_hip.so) with hipcc.
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only build container;
+the resulting shared object travels to the GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libcvo_hip.so")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-shared",
+    "-ffp-contract=off",  # only the explicit fmaf() calls fuse (DESIGN.md "Numerics")
+    "-Wall",
+    "-Wextra",
+    "-Wno-unused-parameter",
+    "-Wno-pass-failed",
+]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; the gfx950 backend cannot be built")
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in ("cvo_hip.hip",)]
+
+
+def headers():
+    hs = [os.path.join(CSRC, f) for f in ("cvo_device.h", "cvo_kernels.h")]
+    hs.append(os.path.join(ROOT, "include", "cvo_hip.h"))
+    return hs
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in sources() + headers())
+
+
+def build(force=False, verbose=True):
+    """Compile every HIP source for gfx950 into unified_cvo_amd/lib/libcvo_hip.so."""
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", os.path.join(ROOT, "include"), "-o", LIB] + sources()
+    if verbose:
+        print("[unified_cvo_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

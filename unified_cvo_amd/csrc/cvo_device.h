@@ -1,0 +1,387 @@
+// cvo_device.h -- device-side data structures and scalar maths for the gfx950 backend.
+//
+// The arithmetic conventions (which a*b+c patterns are fused, the association of 3-term
+// sums, where float is promoted to double) are the ones fixed in DESIGN.md "Numerics":
+// device-side code of the reference (nvcc, -fmad=true) uses explicit fmaf(); host-side code
+// of the reference (LieGroup.cpp, align_impl) uses plain unfused arithmetic.  This file is
+// compiled with -ffp-contract=off so nothing else fuses.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/cvo_hip.h"
+
+namespace cvo_dev {
+
+constexpr int FD = CVO_FEATURE_DIMENSIONS;  // 5 floats stored as 8 (two float4)
+constexpr int NC = CVO_NUM_CLASSES;         // 19 floats stored as 20 (five float4)
+constexpr int FD_PAD = 8;
+constexpr int NC_PAD = 20;
+constexpr int IND_CAP = 512;  // capacity of each indicator FIFO (window + 1 must fit)
+
+// Per-call constants (passed by value as a kernel argument).
+struct DevParams {
+  float sp_thres, sigma2, c2, c_sigma2, s_ell, s_sigma, c, d;
+  float log_geo;                 // logf(sp_thres / sigma2), evaluated on the host
+  float d2_c_thres, d2_s_thres;  // row independent cut-offs (CvoGPU.cu:512-515)
+  float ell_min, ell_decay_rate;
+  int ell_decay_start;
+  int max_iter;  // loop bound (MAX_ITER, or the caller's smaller max_iterations)
+  float eps, eps_2, min_step, max_step;
+  int K_max;
+  int window;
+  float stable_thr;
+  int use_geo, use_col, use_sem, use_range_ell, use_geotype;
+  int trace_dense, trace_every, trace_capacity;
+  int mode;  // 0 = align loop, 1 = single evaluation (inner product / association)
+  int T;     // target chunks (of 64) per scan wave: 1, 2 or 4
+  int rows_per_block;
+};
+
+// Running state of one frame pair; lives in HBM, only touched by one thread of k_step.
+struct PairState {
+  float R[9], T[3];        // running pose (row-major R), CvoGPU.cu:1363-1364
+  float Rinv[9], Tinv[3];  // transform applied to the target cloud this iteration
+  float ell;
+  int K;  // num_neighbors
+  int k;  // iteration counter
+  int status;  // 0 running, 1 finished
+  int ret;
+  int iterations;
+  float step;
+  float omega[3], v[3];
+  unsigned nnz, max_nnz;
+  double B, C, D, E;
+  double dist;
+  double asum;  // sum of kernel values (mode 1)
+  unsigned long long ncand;
+  int n_trace;
+  float out_T[16];  // column-major [R^T | -R^T T]
+  // A_sparsity_indicator_ell_update FIFOs (CvoGPU.cu:1167-1285)
+  float sq[IND_CAP], eq[IND_CAP];
+  int s_head, s_size, e_head, e_size;
+  float s_sum, e_sum;
+};
+
+// Everything a kernel needs to know about one frame pair.
+struct PairDesc {
+  int N, M, Mpad, nchunks, nslices, nsl_pad, nblk;
+  float cx, cy, cz;  // centre subtracted in the cull arithmetic only
+  const float4* x4;
+  const float4* xfeat;
+  const float4* xlabel;
+  const float2* xgeo;
+  const float4* y4;
+  const float4* yfeat;
+  const float4* ylabel;
+  const float2* ygeo;
+  float4* yt4;    // transformed targets, exact
+  float4* ycull;  // {y~x, y~y, y~z, |y~|^2}, y~ = yt - centre; pads are {0,0,0,+inf}
+  float4* xcull;  // {-2x~x, -2x~y, -2x~z, thres_i + margin_i - |x~|^2}
+  float2* rowc;   // {l_i, d2_thres_i}
+  unsigned long long* masks;  // [N][nchunks] candidate bit masks (valid where flagged)
+  unsigned short* flags;      // [N][nsl_pad] per (row, scan slice): which of its T chunks are non-empty
+  float* ell_a;               // ELL kernel matrix values, [K_max][N]
+  int* ell_j;                 // ELL column indices, [K_max][N]
+  unsigned* nnz_row;          // nonzeros[N]
+  double* flow_part;          // [nblk][8]: omega(3), v(3), sum a, pad
+  unsigned long long* cnt_part;  // [nblk][4]: nnz, max, candidates, pad
+  double* coef_part;          // [nblk][4]: B C D E
+  PairState* st;
+  cvo_trace_t* trace;
+  int* status_out;  // mirror of st->status for cheap host polling
+};
+
+// ---- conventions (see oracle/cvo_oracle.cpp, identical by construction, not by include) ----
+__device__ __forceinline__ float dot3_dev(float a0, float a1, float a2, float b0, float b1, float b2) {
+  return __builtin_fmaf(a0, b0, __builtin_fmaf(a1, b1, a2 * b2));
+}
+__device__ __forceinline__ float dop_dev(float a, float b, float c, float d) {
+  return __builtin_fmaf(a, b, -(c * d));
+}
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ V3 cross_dev(V3 a, V3 b) {
+  return {dop_dev(a.y, b.z, a.z, b.y), dop_dev(a.z, b.x, a.x, b.z), dop_dev(a.x, b.y, a.y, b.x)};
+}
+struct M3 {
+  float m[3][3];
+};
+__device__ __forceinline__ M3 matmul_dev(const M3& a, const M3& b) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      r.m[i][j] = dot3_dev(a.m[i][0], a.m[i][1], a.m[i][2], b.m[0][j], b.m[1][j], b.m[2][j]);
+  return r;
+}
+__device__ __forceinline__ V3 matvec_dev(const M3& a, V3 v) {
+  return {dot3_dev(a.m[0][0], a.m[0][1], a.m[0][2], v.x, v.y, v.z),
+          dot3_dev(a.m[1][0], a.m[1][1], a.m[1][2], v.x, v.y, v.z),
+          dot3_dev(a.m[2][0], a.m[2][1], a.m[2][2], v.x, v.y, v.z)};
+}
+
+// transform_point_R_T (CvoGPU_impl.cu:31-82): R*p + T, R row-major here.
+__device__ __forceinline__ V3 transform_point(const float* Ri, const float* Ti, float x, float y, float z) {
+  return {dot3_dev(Ri[0], Ri[1], Ri[2], x, y, z) + Ti[0], dot3_dev(Ri[3], Ri[4], Ri[5], x, y, z) + Ti[1],
+          dot3_dev(Ri[6], Ri[7], Ri[8], x, y, z) + Ti[2]};
+}
+
+// compute_range_ell (CvoGPU.cu:86-90)
+__device__ __forceinline__ float compute_range_ell(float ell, float dist) {
+  return (float)(((double)dist / 500.0 + 1.0) * (double)ell);
+}
+
+// The matrices of compute_step_size_xi (CvoGPU.cu:953-998), which depend only on (omega, v).
+struct XiMats {
+  M3 m2, m3, m4;
+  V3 ohv, m2v, m3v;
+  float omega[3], v[3];
+};
+__device__ inline void xi_mats(const float* omega, const float* v, XiMats& x) {
+  M3 oh;
+  oh.m[0][0] = 0;          oh.m[0][1] = -omega[2]; oh.m[0][2] = omega[1];
+  oh.m[1][0] = omega[2];   oh.m[1][1] = 0;         oh.m[1][2] = -omega[0];
+  oh.m[2][0] = -omega[1];  oh.m[2][1] = omega[0];  oh.m[2][2] = 0;
+  V3 vv{v[0], v[1], v[2]};
+  x.m2 = matmul_dev(oh, oh);
+  x.m3 = matmul_dev(x.m2, oh);
+  x.m4 = matmul_dev(x.m3, oh);
+  x.ohv = matvec_dev(oh, vv);
+  x.m2v = matvec_dev(x.m2, vv);
+  x.m3v = matvec_dev(x.m3, vv);
+  for (int i = 0; i < 3; i++) {
+    x.omega[i] = omega[i];
+    x.v[i] = v[i];
+  }
+}
+
+// ---- scalar host-side maths of the reference, run by one device thread ---------------------
+
+// Roots of p0 x^3 + p1 x^2 + p2 x + p3 (poly_solver_order3, LieGroup.cpp:309-325).
+__device__ inline void cubic_roots(const double coef[4], double re[3], double im[3]) {
+  const double nan = __builtin_nan("");
+  double a = coef[1] / coef[0], b = coef[2] / coef[0], c = coef[3] / coef[0];
+  if (!isfinite(a) || !isfinite(b) || !isfinite(c)) {
+    for (int i = 0; i < 3; i++) re[i] = im[i] = nan;
+    return;
+  }
+  auto f = [&](double x) { return ((x + a) * x + b) * x + c; };
+  auto df = [&](double x) { return (3 * x + 2 * a) * x + b; };
+  auto polish = [&](double x) {
+    for (int it = 0; it < 4; it++) {
+      double dd = df(x);
+      if (dd == 0 || !isfinite(dd)) break;
+      double nx = x - f(x) / dd;
+      if (!isfinite(nx)) break;
+      x = nx;
+    }
+    return x;
+  };
+  double p = b - a * a / 3.0;
+  double q = 2.0 * a * a * a / 27.0 - a * b / 3.0 + c;
+  double disc = q * q / 4.0 + p * p * p / 27.0;
+  double r0;
+  if (disc > 0) {
+    double s = sqrt(disc);
+    double u = (-q / 2.0 >= 0) ? cbrt(-q / 2.0 + s) : cbrt(-q / 2.0 - s);
+    double vv = (u != 0) ? -p / (3.0 * u) : 0.0;
+    r0 = u + vv - a / 3.0;
+  } else {
+    double mm = 2.0 * sqrt(fmax(0.0, -p / 3.0));
+    double arg = (p != 0) ? (3.0 * q) / (p * mm) : 0.0;
+    arg = fmax(-1.0, fmin(1.0, arg));
+    double th = acos(arg) / 3.0;
+    double t0 = mm * cos(th), t2 = mm * cos(th - 4.0 * 3.14159265358979323846 / 3.0);
+    r0 = ((fabs(t0) >= fabs(t2)) ? t0 : t2) - a / 3.0;
+  }
+  r0 = polish(r0);
+  double qa = a + r0, qb = b + r0 * qa;
+  double D = qa * qa - 4.0 * qb;
+  re[0] = r0;
+  im[0] = 0;
+  if (D >= 0) {
+    double s = sqrt(D);
+    double t = -0.5 * (qa + (qa >= 0 ? s : -s));
+    double x1 = t, x2 = (t != 0) ? qb / t : 0.0;
+    re[1] = polish(x1);
+    im[1] = 0;
+    re[2] = polish(x2);
+    im[2] = 0;
+  } else {
+    re[1] = re[2] = -0.5 * qa;
+    im[1] = 0.5 * sqrt(-D);
+    im[2] = -im[1];
+  }
+}
+
+// compute_step_size host half (CvoGPU.cu:1122-1158), overwrite quirk included.
+__device__ inline float select_step(double B, double C, double D, double E, float min_step, float max_step) {
+  const double DMAX = 1.7976931348623157e308;
+  double p_coef[4] = {4.0 * E, 3.0 * D, 2.0 * C, B};
+  double re[3], im[3];
+  cubic_roots(p_coef, re, im);
+  double temp_step = DMAX;
+  for (int i = 0; i < 3; i++)
+    if (re[i] > 0 && re[i] < temp_step && fabs(im[i]) < 1e-5) temp_step = re[i];
+  float step;
+  if (temp_step > (double)max_step)
+    step = max_step;
+  else if (temp_step < (double)min_step)
+    step = min_step;
+  else
+    step = (float)temp_step;
+  return step;
+}
+
+// Exp_SEK3 (LieGroup.cpp:244-274); out = 3x4 row-major [R | Jl v].
+__device__ inline void exp_sek3(const float xi[6], float dt, float out[12]) {
+  const float TOLERANCE = 1e-6f;
+  float w0 = xi[0], w1 = xi[1], w2 = xi[2];
+  float theta = sqrtf(w0 * w0 + (w1 * w1 + w2 * w2));
+  float R[3][3], Jl[3][3];
+  const float I[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  if (theta < TOLERANCE) {
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) R[i][j] = Jl[i][j] = I[i][j];
+  } else {
+    float A[3][3] = {{0, -w2, w1}, {w2, 0, -w0}, {-w1, w0, 0}};
+    float theta2 = theta * theta;
+    float stheta = sinf(dt * theta);
+    float ctheta = cosf(dt * theta);
+    float oneMinusCosTheta2 = (1 - ctheta) / (theta2);
+    float A2[3][3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) A2[i][j] = A[i][0] * A[0][j] + (A[i][1] * A[1][j] + A[i][2] * A[2][j]);
+    float s1 = stheta / theta;
+    float s3 = (dt * theta - stheta) / (theta2 * theta);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        R[i][j] = (I[i][j] + s1 * A[i][j]) + oneMinusCosTheta2 * A2[i][j];
+        Jl[i][j] = (dt * I[i][j] + oneMinusCosTheta2 * A[i][j]) + s3 * A2[i][j];
+      }
+  }
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) out[4 * i + j] = R[i][j];
+    out[4 * i + 3] = Jl[i][0] * xi[3] + (Jl[i][1] * xi[4] + Jl[i][2] * xi[5]);
+  }
+}
+
+// ||Sophus::SE3d(dRT).log()|| (CvoGPU.cu:1473-1476), Sophus 1.0.0 algorithm.
+__device__ inline double se3_log_norm(const double R[9], const double t[3]) {
+  const double eps = 1e-10;
+  const double PI = 3.14159265358979323846;
+  double q[4];
+  double tr = R[0] + R[4] + R[8];
+  if (tr > 0) {
+    double s = sqrt(tr + 1.0);
+    q[3] = 0.5 * s;
+    s = 0.5 / s;
+    q[0] = (R[7] - R[5]) * s;
+    q[1] = (R[2] - R[6]) * s;
+    q[2] = (R[3] - R[1]) * s;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[4 * i]) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    double s = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+    q[i] = 0.5 * s;
+    s = 0.5 / s;
+    q[3] = (R[3 * k + j] - R[3 * j + k]) * s;
+    q[j] = (R[3 * j + i] + R[3 * i + j]) * s;
+    q[k] = (R[3 * k + i] + R[3 * i + k]) * s;
+  }
+  double squared_n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+  double n = sqrt(squared_n);
+  double w = q[3];
+  double two_atan_nbyw_by_n;
+  if (n < eps) {
+    double squared_w = w * w;
+    two_atan_nbyw_by_n = 2.0 / w - 2.0 * squared_n / (w * squared_w);
+  } else {
+    if (fabs(w) < eps) {
+      two_atan_nbyw_by_n = (w > 0 ? PI : -PI) / n;
+    } else {
+      two_atan_nbyw_by_n = 2.0 * atan(n / w) / n;
+    }
+  }
+  double theta = two_atan_nbyw_by_n * n;
+  double om[3] = {two_atan_nbyw_by_n * q[0], two_atan_nbyw_by_n * q[1], two_atan_nbyw_by_n * q[2]};
+  double O[3][3] = {{0, -om[2], om[1]}, {om[2], 0, -om[0]}, {-om[1], om[0], 0}};
+  double O2[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) O2[i][j] = O[i][0] * O[0][j] + O[i][1] * O[1][j] + O[i][2] * O[2][j];
+  double coef;
+  if (fabs(theta) < eps) {
+    coef = 1.0 / 12.0;
+  } else {
+    double half_theta = 0.5 * theta;
+    coef = (1.0 - theta * cos(half_theta) / (2.0 * sin(half_theta))) / (theta * theta);
+  }
+  double s = 0;
+  for (int i = 0; i < 3; i++) {
+    double u = 0;
+    for (int j = 0; j < 3; j++) {
+      double Vinv = (i == j ? 1.0 : 0.0) - 0.5 * O[i][j] + coef * O2[i][j];
+      u += Vinv * t[j];
+    }
+    s += u * u;
+  }
+  for (int i = 0; i < 3; i++) s += om[i] * om[i];
+  return sqrt(s);
+}
+
+// A_sparsity_indicator_ell_update (CvoGPU.cu:1167-1285), FIFOs as ring buffers.
+__device__ inline bool indicator_update(PairState* st, float indicator, int queue_len, float thr) {
+  bool decrease = false;
+  auto s_push = [&](float x) {
+    st->sq[(st->s_head + st->s_size) % IND_CAP] = x;
+    st->s_size++;
+  };
+  auto e_push = [&](float x) {
+    st->eq[(st->e_head + st->e_size) % IND_CAP] = x;
+    st->e_size++;
+  };
+  if (st->s_size < queue_len) {
+    s_push(indicator);
+    st->s_sum += indicator;
+  }
+  if (st->s_size >= queue_len && st->e_size < queue_len) {
+    e_push(indicator);
+    st->e_sum += indicator;
+  }
+  if (st->s_size >= queue_len && st->e_size >= queue_len) {
+    if (st->e_sum / st->s_sum > 1 - thr && st->e_sum / st->s_sum < 1 + thr) {
+      decrease = true;
+      st->s_head = st->s_size = st->e_head = st->e_size = 0;
+      st->s_sum = 0;
+      st->e_sum = 0;
+    } else {
+      float ef = st->eq[st->e_head];
+      st->e_sum -= ef;
+      st->s_sum += ef;
+      s_push(ef);
+      st->e_head = (st->e_head + 1) % IND_CAP;
+      st->e_size--;
+      st->s_sum -= st->sq[st->s_head];
+      st->s_head = (st->s_head + 1) % IND_CAP;
+      st->s_size--;
+      e_push(indicator);
+      st->e_sum += indicator;
+    }
+  }
+  return decrease;
+}
+
+__device__ inline void update_tf(const float R[9], const float T[3], float Ri[9], float Ti[3]) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Ri[3 * i + j] = R[3 * j + i];
+  for (int i = 0; i < 3; i++) {
+    float a0 = (-Ri[3 * i + 0]) * T[0], a1 = (-Ri[3 * i + 1]) * T[1], a2 = (-Ri[3 * i + 2]) * T[2];
+    Ti[i] = a0 + (a1 + a2);
+  }
+}
+
+}  // namespace cvo_dev

@@ -1,0 +1,865 @@
+// cvo_hip.hip -- host side of the C-ABI declared in include/cvo_hip.h: contexts, HBM-resident
+// clouds, workspace layout, and the enqueue-only optimiser loop (hipGraph replays of
+// [k_scan, k_assoc, k_coeff, k_step] with a device-side status word; no host round trip per
+// iteration, unlike the ~15 blocking syncs per iteration of CvoGPU.cu:1387-1533).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cvo_kernels.h"
+
+using namespace cvo_dev;
+
+#define CVO_VERSION_STRING "unified_cvo_amd 0.1 (gfx950)"
+
+struct cvo_cloud {
+  cvo_ctx* ctx;
+  int n;
+  float4* x4;
+  float4* feat;   // 2 float4 per point
+  float4* label;  // 5 float4 per point
+  float2* geo;
+  float cx, cy, cz;  // centroid (used only as the cull centre)
+};
+
+namespace {
+
+struct PairLayout {  // byte offsets of one pair's workspace inside the arena
+  size_t yt4, ycull, xcull, rowc, masks, flags, ell_a, ell_j, nnz_row, flow_part, cnt_part, coef_part, trace,
+      total;
+};
+
+struct GraphKey {
+  int n_pairs, T, gx, gy, nblk, U;
+  bool operator==(const GraphKey& o) const {
+    return n_pairs == o.n_pairs && T == o.T && gx == o.gx && gy == o.gy && nblk == o.nblk && U == o.U;
+  }
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct cvo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // workspace
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  PairDesc* d_descs = nullptr;
+  PairState* d_states = nullptr;
+  int* d_status = nullptr;
+  DevParams* d_params = nullptr;
+  int cap_pairs = 0;
+  std::vector<PairDesc> h_descs;
+  std::vector<PairState> h_states;
+  int* h_status[2] = {nullptr, nullptr};  // pinned
+  hipEvent_t ev_chk[2] = {nullptr, nullptr};
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  // graph cache
+  hipGraphExec_t graph_exec = nullptr;
+  GraphKey graph_key{0, 0, 0, 0, 0, 0};
+  // last call (debug hooks)
+  int last_pairs = 0;
+  int last_N = 0, last_M = 0, last_Kmax = 0;
+  DevParams last_params{};
+  int last_gx = 0, last_gy = 0;
+  PairLayout last_layout{};
+};
+
+namespace {
+
+int fail(cvo_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                       \
+  do {                                                                                           \
+    hipError_t e__ = (expr);                                                                     \
+    if (e__ != hipSuccess)                                                                       \
+      return fail(ctx, CVO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));           \
+  } while (0)
+
+PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, int* Mpad_out, int* nchunks_out,
+                       int* nsl_pad_out, int* nblk_out) {
+  const int Mpad = (int)align_up((size_t)M, 256);
+  const int nchunks = Mpad / 64;
+  const int nsl_pad = (int)align_up((size_t)nchunks, 8);  // enough for T = 1
+  const int nblk = (N + 255) / 256;
+  PairLayout L{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  L.yt4 = take(sizeof(float4) * (size_t)Mpad);
+  L.ycull = take(sizeof(float4) * (size_t)Mpad);
+  L.xcull = take(sizeof(float4) * (size_t)(N + 4));
+  L.rowc = take(sizeof(float2) * (size_t)N);
+  L.masks = take(sizeof(unsigned long long) * (size_t)N * nchunks);
+  L.flags = take(sizeof(unsigned short) * (size_t)N * nsl_pad);
+  L.ell_a = take(sizeof(float) * (size_t)N * Kmax);
+  L.ell_j = take(sizeof(int) * (size_t)N * Kmax);
+  L.nnz_row = take(sizeof(unsigned) * (size_t)N);
+  L.flow_part = take(sizeof(double) * 8 * (size_t)nblk);
+  L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)nblk);
+  L.coef_part = take(sizeof(double) * 4 * (size_t)nblk);
+  L.trace = take(sizeof(cvo_trace_t) * (size_t)std::max(trace_capacity, 0));
+  L.total = off;
+  *Mpad_out = Mpad;
+  *nchunks_out = nchunks;
+  *nsl_pad_out = nsl_pad;
+  *nblk_out = nblk;
+  return L;
+}
+
+void free_workspace(cvo_ctx* c) {
+  if (c->arena) (void)hipFree(c->arena);
+  if (c->d_descs) (void)hipFree(c->d_descs);
+  if (c->d_states) (void)hipFree(c->d_states);
+  if (c->d_status) (void)hipFree(c->d_status);
+  for (int i = 0; i < 2; i++)
+    if (c->h_status[i]) (void)hipHostFree(c->h_status[i]);
+  c->arena = nullptr;
+  c->d_descs = nullptr;
+  c->d_states = nullptr;
+  c->d_status = nullptr;
+  c->h_status[0] = c->h_status[1] = nullptr;
+  c->arena_bytes = 0;
+  c->cap_pairs = 0;
+}
+
+int ensure_workspace(cvo_ctx* c, int n_pairs, size_t bytes_per_pair) {
+  if (n_pairs > c->cap_pairs) {
+    if (c->d_descs) (void)hipFree(c->d_descs);
+    if (c->d_states) (void)hipFree(c->d_states);
+    if (c->d_status) (void)hipFree(c->d_status);
+    for (int i = 0; i < 2; i++)
+      if (c->h_status[i]) (void)hipHostFree(c->h_status[i]);
+    c->d_descs = nullptr;
+    c->d_states = nullptr;
+    c->d_status = nullptr;
+    HIP_TRY(c, hipMalloc(&c->d_descs, sizeof(PairDesc) * (size_t)n_pairs));
+    HIP_TRY(c, hipMalloc(&c->d_states, sizeof(PairState) * (size_t)n_pairs));
+    HIP_TRY(c, hipMalloc(&c->d_status, sizeof(int) * (size_t)n_pairs));
+    for (int i = 0; i < 2; i++) HIP_TRY(c, hipHostMalloc(&c->h_status[i], sizeof(int) * (size_t)n_pairs));
+    c->cap_pairs = n_pairs;
+    if (c->graph_exec) {
+      (void)hipGraphExecDestroy(c->graph_exec);
+      c->graph_exec = nullptr;
+    }
+  }
+  const size_t need = bytes_per_pair * (size_t)n_pairs;
+  if (need > c->arena_bytes) {
+    if (c->arena) (void)hipFree(c->arena);
+    c->arena = nullptr;
+    c->arena_bytes = 0;
+    hipError_t e = hipMalloc(&c->arena, need);
+    if (e != hipSuccess) return fail(c, CVO_E_NOMEM, "workspace hipMalloc failed: " + std::string(hipGetErrorString(e)));
+    c->arena_bytes = need;
+    if (c->graph_exec) {
+      (void)hipGraphExecDestroy(c->graph_exec);
+      c->graph_exec = nullptr;
+    }
+  }
+  return CVO_OK;
+}
+
+DevParams make_dev_params(const cvo_params_t& p) {
+  DevParams d{};
+  d.sp_thres = p.sp_thres;
+  d.sigma2 = p.sigma * p.sigma;
+  d.c2 = p.c_ell * p.c_ell;
+  d.c_sigma2 = p.c_sigma * p.c_sigma;
+  d.s_ell = p.s_ell;
+  d.s_sigma = p.s_sigma;
+  d.c = p.c;
+  d.d = p.d;
+  const float s_sigma2 = p.s_sigma * p.s_sigma;
+  // log() on float arguments (CvoGPU.cu:509-515); evaluated with the host libm, once per call
+  d.log_geo = std::log(p.sp_thres / d.sigma2);
+  d.d2_c_thres = 1.f;
+  d.d2_s_thres = 1.f;
+  if (p.is_using_intensity) d.d2_c_thres = (float)(-2.0 * d.c2 * (double)std::log(p.sp_thres / d.c_sigma2));
+  if (p.is_using_semantics)
+    d.d2_s_thres = (float)(-2.0 * d.s_ell * d.s_ell * (double)std::log(p.sp_thres / s_sigma2));
+  d.ell_min = p.ell_min;
+  d.ell_decay_rate = p.ell_decay_rate;
+  d.ell_decay_start = p.ell_decay_start;
+  d.max_iter = p.MAX_ITER;
+  d.eps = p.eps;
+  d.eps_2 = p.eps_2;
+  d.min_step = p.min_step;
+  d.max_step = p.max_step;
+  d.K_max = p.nearest_neighbors_max;
+  d.window = p.indicator_window_size;
+  d.stable_thr = p.indicator_stable_threshold;
+  d.use_geo = p.is_using_geometry != 0;
+  d.use_col = p.is_using_intensity != 0;
+  d.use_sem = p.is_using_semantics != 0;
+  d.use_range_ell = p.is_using_range_ell != 0;
+  d.use_geotype = p.is_using_geometric_type != 0;
+  return d;
+}
+
+// Scan geometry: T chunks per wave and rows per block, chosen so a launch has a few thousand
+// waves (256 CUs x 4 SIMDs want >= 2..4 waves each) without making waves trivially short.
+void choose_scan_config(int n_pairs, int N, int Mpad, int* T_out, int* rpb_out) {
+  const long target_waves = 4096;
+  int T = 4;
+  while (T > 1) {
+    const long slices = Mpad / (64 * T);
+    const long waves = slices * ((N + 63) / 64) * n_pairs;
+    if (waves >= target_waves) break;
+    T >>= 1;
+  }
+  const long slices = Mpad / (64 * T);
+  int rpb = 256;
+  while (rpb > 16) {
+    const long waves = slices * ((N + rpb - 1) / rpb) * n_pairs;
+    if (waves >= target_waves) break;
+    rpb >>= 1;
+  }
+  const char* eT = getenv("CVO_SCAN_T");
+  const char* eR = getenv("CVO_SCAN_ROWS");
+  if (eT) {
+    int v = atoi(eT);
+    if (v == 1 || v == 2 || v == 4) T = v;
+  }
+  if (eR) {
+    int v = atoi(eR);
+    if (v >= 1) rpb = v;
+  }
+  *T_out = T;
+  *rpb_out = rpb;
+}
+
+void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const DevParams* dp, int force) {
+  switch (T) {
+    case 1: hipLaunchKernelGGL((k_scan<1, 4>), grid, dim3(256), 0, s, descs, dp, force); break;
+    case 2: hipLaunchKernelGGL((k_scan<2, 2>), grid, dim3(256), 0, s, descs, dp, force); break;
+    default: hipLaunchKernelGGL((k_scan<4, 2>), grid, dim3(256), 0, s, descs, dp, force); break;
+  }
+}
+
+void launch_iteration(cvo_ctx* c, int n_pairs, int T, int gx, int gy, int nblk) {
+  launch_scan(c->stream, T, dim3(gx, gy, n_pairs), c->d_descs, c->d_params, 0);
+  hipLaunchKernelGGL(k_assoc, dim3(nblk, n_pairs), dim3(256), 0, c->stream, c->d_descs, c->d_params);
+  hipLaunchKernelGGL(k_coeff, dim3(nblk, n_pairs), dim3(256), 0, c->stream, c->d_descs, c->d_params);
+  hipLaunchKernelGGL(k_step<false>, dim3(n_pairs), dim3(STEP_THREADS), 0, c->stream, c->d_descs, c->d_params);
+}
+
+struct BatchSetup {
+  int N, M, Mpad, nchunks, nsl_pad, nblk, T, rpb, gx, gy;
+  PairLayout L;
+};
+
+// Builds descriptors + initial states for a batch and uploads them.
+int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo_cloud* const* sources,
+                const cvo_cloud* const* targets, const float* init_T, const cvo_align_opts_t* opts, int mode,
+                float mode_ell, BatchSetup* S, DevParams* dp_out) {
+  if (!ctx) return CVO_E_INVALID;
+  if (!params || n_pairs <= 0 || !sources || !targets) return fail(ctx, CVO_E_INVALID, "null argument");
+  if (params->is_using_kdtree)
+    return fail(ctx, CVO_E_UNSUPPORTED, "is_using_kdtree=1 is out of scope (SURVEY.md section 2, row 11)");
+  if (params->nearest_neighbors_max <= 0) return fail(ctx, CVO_E_INVALID, "nearest_neighbors_max must be > 0");
+  if (params->indicator_window_size + 1 >= IND_CAP || params->indicator_window_size < 0)
+    return fail(ctx, CVO_E_INVALID, "indicator_window_size out of range");
+  int N = 0, M = 0;
+  for (int p = 0; p < n_pairs; p++) {
+    if (!sources[p] || !targets[p]) return fail(ctx, CVO_E_INVALID, "null cloud");
+    if (sources[p]->ctx != ctx || targets[p]->ctx != ctx)
+      return fail(ctx, CVO_E_INVALID, "cloud belongs to another context");
+    if (sources[p]->n <= 0 || targets[p]->n <= 0) return fail(ctx, CVO_E_INVALID, "empty cloud in batch");
+    N = std::max(N, sources[p]->n);
+    M = std::max(M, targets[p]->n);
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int trace_cap = (opts && opts->trace) ? opts->trace_capacity : 0;
+  const int Kmax = params->nearest_neighbors_max;
+  S->N = N;
+  S->M = M;
+  S->L = make_layout(N, M, Kmax, trace_cap, &S->Mpad, &S->nchunks, &S->nsl_pad, &S->nblk);
+  int rc = ensure_workspace(ctx, n_pairs, S->L.total);
+  if (rc != CVO_OK) return rc;
+  choose_scan_config(n_pairs, N, S->Mpad, &S->T, &S->rpb);
+
+  DevParams dp = make_dev_params(*params);
+  dp.mode = mode;
+  dp.T = S->T;
+  dp.rows_per_block = S->rpb;
+  if (opts && opts->max_iterations > 0) dp.max_iter = std::min(dp.max_iter, opts->max_iterations);
+  dp.trace_capacity = trace_cap;
+  dp.trace_dense = opts ? opts->trace_dense : 0;
+  dp.trace_every = opts ? opts->trace_every : 0;
+  *dp_out = dp;
+
+  ctx->h_descs.resize(n_pairs);
+  ctx->h_states.resize(n_pairs);
+  for (int p = 0; p < n_pairs; p++) {
+    const cvo_cloud* X = sources[p];
+    const cvo_cloud* Y = targets[p];
+    char* base = ctx->arena + S->L.total * (size_t)p;
+    PairDesc& D = ctx->h_descs[p];
+    std::memset(&D, 0, sizeof(D));
+    D.N = X->n;
+    D.M = Y->n;
+    // per-pair padding derived from the batch maxima so every pair shares one launch geometry
+    D.Mpad = S->Mpad;
+    D.nchunks = S->nchunks;
+    D.nslices = S->Mpad / (64 * S->T);
+    D.nsl_pad = S->nsl_pad;
+    D.nblk = S->nblk;
+    D.cx = X->cx;
+    D.cy = X->cy;
+    D.cz = X->cz;
+    D.x4 = X->x4;
+    D.xfeat = X->feat;
+    D.xlabel = X->label;
+    D.xgeo = X->geo;
+    D.y4 = Y->x4;
+    D.yfeat = Y->feat;
+    D.ylabel = Y->label;
+    D.ygeo = Y->geo;
+    D.yt4 = (float4*)(base + S->L.yt4);
+    D.ycull = (float4*)(base + S->L.ycull);
+    D.xcull = (float4*)(base + S->L.xcull);
+    D.rowc = (float2*)(base + S->L.rowc);
+    D.masks = (unsigned long long*)(base + S->L.masks);
+    D.flags = (unsigned short*)(base + S->L.flags);
+    D.ell_a = (float*)(base + S->L.ell_a);
+    D.ell_j = (int*)(base + S->L.ell_j);
+    D.nnz_row = (unsigned*)(base + S->L.nnz_row);
+    D.flow_part = (double*)(base + S->L.flow_part);
+    D.cnt_part = (unsigned long long*)(base + S->L.cnt_part);
+    D.coef_part = (double*)(base + S->L.coef_part);
+    D.st = ctx->d_states + p;
+    D.trace = trace_cap > 0 ? (cvo_trace_t*)(base + S->L.trace) : nullptr;
+    D.status_out = ctx->d_status + p;
+
+    PairState& st = ctx->h_states[p];
+    std::memset(&st, 0, sizeof(st));
+    const float* Tm = init_T + 16 * (size_t)p;
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) st.R[3 * i + j] = Tm[4 * j + i];  // CvoGPU.cu:1363-1364
+      st.T[i] = Tm[12 + i];
+    }
+    st.ell = mode == 0 ? params->ell_init : mode_ell;  // CvoState.cu:30
+    st.K = Kmax;                                        // CvoGPU.cu:1385
+    if (mode == 0 && opts && opts->override_state) {
+      st.ell = opts->ell0;
+      st.K = opts->K0;
+    }
+    // flags must start clean (they are self-cleaning afterwards)
+    HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, sizeof(unsigned short) * (size_t)S->N * S->nsl_pad, ctx->stream));
+  }
+  // the blocks of k_assoc beyond a smaller pair's N still write their (zero) partials, but the
+  // partial arrays of pairs whose N is smaller than the batch maximum are fully covered by nblk.
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_descs, ctx->h_descs.data(), sizeof(PairDesc) * (size_t)n_pairs,
+                              hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_states, ctx->h_states.data(), sizeof(PairState) * (size_t)n_pairs,
+                              hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int) * (size_t)n_pairs, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_params, &dp, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
+  S->gx = (S->Mpad / (64 * S->T) + 3) / 4;
+  S->gy = (N + S->rpb - 1) / S->rpb;
+  ctx->last_pairs = n_pairs;
+  ctx->last_N = N;
+  ctx->last_M = M;
+  ctx->last_Kmax = Kmax;
+  ctx->last_params = dp;
+  ctx->last_gx = S->gx;
+  ctx->last_gy = S->gy;
+  ctx->last_layout = S->L;
+  return CVO_OK;
+}
+
+int run_single_eval(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source, const cvo_cloud* target,
+                    const float Tm[16], float ell, BatchSetup* S) {
+  DevParams dp;
+  const cvo_cloud* src[1] = {source};
+  const cvo_cloud* tgt[1] = {target};
+  int rc = setup_batch(ctx, params, 1, src, tgt, Tm, nullptr, 1, ell, S, &dp);
+  if (rc != CVO_OK) return rc;
+  hipLaunchKernelGGL(k_step<true>, dim3(1), dim3(STEP_THREADS), 0, ctx->stream, ctx->d_descs, ctx->d_params);
+  launch_scan(ctx->stream, S->T, dim3(S->gx, S->gy, 1), ctx->d_descs, ctx->d_params, 0);
+  hipLaunchKernelGGL(k_assoc, dim3(S->nblk, 1), dim3(256), 0, ctx->stream, ctx->d_descs, ctx->d_params);
+  hipLaunchKernelGGL(k_step<false>, dim3(1), dim3(STEP_THREADS), 0, ctx->stream, ctx->d_descs, ctx->d_params);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_states.data(), ctx->d_states, sizeof(PairState), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CVO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cvo_version(void) { return CVO_VERSION_STRING; }
+
+void cvo_params_default(cvo_params_t* p) {
+  // CvoParams::CvoParams(), CvoParams.hpp:75-126
+  std::memset(p, 0, sizeof(*p));
+  p->ell_init_first_frame = 0.5f;
+  p->ell_init = 0.5f;
+  p->ell_min = 0.05f;
+  p->min_ell_iter_limit = 1;
+  p->ell_max = 1.2f;
+  p->dl = 0;
+  p->dl_step = 0.3;
+  p->sigma = 0.1f;
+  p->sp_thres = 0.0006f;
+  p->c = 7.0f;
+  p->d = 7.0f;
+  p->c_ell = 0.15f;
+  p->c_sigma = 0.6f;
+  p->s_ell = 0.1f;
+  p->s_sigma = 0.8f;
+  p->MAX_ITER = 10000;
+  p->min_step = 2e-5f;
+  p->eps = 0.00005f;
+  p->eps_2 = 0.000012f;
+  p->max_step = 0.8f;  // uninitialised upstream; see DESIGN.md
+  p->step = 0.f;       // uninitialised upstream, unused by the path
+  p->ell_decay_rate = 0.9f;
+  p->ell_decay_rate_first_frame = 0.99f;
+  p->ell_decay_start = 30;
+  p->ell_decay_start_first_frame = 300;
+  p->indicator_window_size = 15;
+  p->indicator_stable_threshold = 0.2f;
+  p->is_pcl_visualization_on = 0;
+  p->is_using_least_square = 0;
+  p->is_ell_adaptive = 0;
+  p->is_full_ip_matrix = 0;
+  p->is_using_geometry = 1;
+  p->is_using_intensity = 0;
+  p->is_using_semantics = 0;
+  p->is_using_range_ell = 0;
+  p->is_using_kdtree = 0;
+  p->is_using_geometric_type = 0;
+  p->is_exporting_association = 0;
+  p->multiframe_using_cpu = 1;
+  p->multiframe_max_iters = 200;
+  p->nearest_neighbors_max = 512;
+  p->multiframe_ell_init = 0.15f;
+  p->multiframe_ell_min = 0.05f;
+  p->multiframe_iter_per_ell = 10;
+  p->multiframe_ell_decay_rate = 0.7f;
+  p->multiframe_iterations_per_ell = 50;
+  p->multiframe_iterations_per_solve = 8;
+  p->multiframe_downsample_voxel_size = 0.5f;
+  p->multiframe_expected_points = 1000;
+  p->multiframe_num_neighbors = 128;
+  p->multiframe_min_nonzeros = 300;
+  p->multiframe_least_squares_num_threads = 24;
+}
+
+int cvo_ctx_create(int device, cvo_ctx** out) {
+  if (!out) return CVO_E_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CVO_E_HIP;
+  if (hipSetDevice(device) != hipSuccess) return CVO_E_HIP;
+  cvo_ctx* c = new cvo_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(&c->d_params, sizeof(DevParams)) != hipSuccess ||
+      hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_chk[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_chk[1], hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return CVO_E_HIP;
+  }
+  *out = c;
+  return CVO_OK;
+}
+
+void cvo_ctx_destroy(cvo_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  free_workspace(c);
+  if (c->d_params) (void)hipFree(c->d_params);
+  for (int i = 0; i < 2; i++)
+    if (c->ev_chk[i]) (void)hipEventDestroy(c->ev_chk[i]);
+  if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+  if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* cvo_last_error(const cvo_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+void* cvo_ctx_stream(cvo_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int cvo_ctx_synchronize(cvo_ctx* ctx) {
+  if (!ctx) return CVO_E_INVALID;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CVO_OK;
+}
+
+static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, const std::vector<float>& feat,
+                         const std::vector<float>& label, const std::vector<float>& geo, cvo_cloud** out) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  cvo_cloud* c = new cvo_cloud();
+  std::memset(c, 0, sizeof(*c));
+  c->ctx = ctx;
+  c->n = n;
+  double sx = 0, sy = 0, sz = 0;
+  for (int i = 0; i < n; i++) {
+    sx += x4[4 * (size_t)i];
+    sy += x4[4 * (size_t)i + 1];
+    sz += x4[4 * (size_t)i + 2];
+  }
+  if (n > 0) {
+    c->cx = (float)(sx / n);
+    c->cy = (float)(sy / n);
+    c->cz = (float)(sz / n);
+  }
+  if (!std::isfinite(c->cx) || !std::isfinite(c->cy) || !std::isfinite(c->cz)) c->cx = c->cy = c->cz = 0.f;
+  const size_t nn = (size_t)std::max(n, 1);
+  hipError_t e = hipMalloc(&c->x4, sizeof(float4) * nn);
+  if (e == hipSuccess) e = hipMalloc(&c->feat, sizeof(float4) * 2 * nn);
+  if (e == hipSuccess) e = hipMalloc(&c->label, sizeof(float4) * 5 * nn);
+  if (e == hipSuccess) e = hipMalloc(&c->geo, sizeof(float2) * nn);
+  if (e != hipSuccess) {
+    cvo_cloud_free(c);
+    return fail(ctx, CVO_E_NOMEM, std::string("cloud hipMalloc: ") + hipGetErrorString(e));
+  }
+  if (n > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(c->x4, x4.data(), sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(c->feat, feat.data(), sizeof(float) * FD_PAD * (size_t)n, hipMemcpyHostToDevice,
+                                ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(c->label, label.data(), sizeof(float) * NC_PAD * (size_t)n, hipMemcpyHostToDevice,
+                                ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(c->geo, geo.data(), sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the staging vectors die with the caller
+  }
+  *out = c;
+  return CVO_OK;
+}
+
+int cvo_cloud_upload(cvo_ctx* ctx, int n, const float* xyz, const float* feat, const float* label,
+                     const float* geotype, cvo_cloud** out) {
+  if (!ctx || !out || n < 0 || (n > 0 && !xyz)) return fail(ctx, CVO_E_INVALID, "cvo_cloud_upload: bad argument");
+  std::vector<float> x4(4 * (size_t)n, 0.f), f8(FD_PAD * (size_t)n, 0.f), l20(NC_PAD * (size_t)n, 0.f),
+      g2(2 * (size_t)n, 0.f);
+  for (int i = 0; i < n; i++) {
+    for (int c = 0; c < 3; c++) x4[4 * (size_t)i + c] = xyz[3 * (size_t)i + c];
+    if (feat)
+      for (int c = 0; c < FD; c++) f8[FD_PAD * (size_t)i + c] = feat[FD * (size_t)i + c];
+    if (label)
+      for (int c = 0; c < NC; c++) l20[NC_PAD * (size_t)i + c] = label[NC * (size_t)i + c];
+    if (geotype)
+      for (int c = 0; c < 2; c++) g2[2 * (size_t)i + c] = geotype[2 * (size_t)i + c];
+  }
+  return upload_packed(ctx, n, x4, f8, l20, g2, out);
+}
+
+int cvo_cloud_upload_aos192(cvo_ctx* ctx, int n, const void* pts, cvo_cloud** out) {
+  if (!ctx || !out || n < 0 || (n > 0 && !pts)) return fail(ctx, CVO_E_INVALID, "cvo_cloud_upload_aos192: bad argument");
+  // PointSegmentedDistribution<5,19> byte offsets: xyz@0, features@20,
+  // label_distribution@44, geometric_type@120, sizeof = 192.
+  std::vector<float> x4(4 * (size_t)n, 0.f), f8(FD_PAD * (size_t)n, 0.f), l20(NC_PAD * (size_t)n, 0.f),
+      g2(2 * (size_t)n, 0.f);
+  const char* b = (const char*)pts;
+  for (int i = 0; i < n; i++) {
+    const char* r = b + 192 * (size_t)i;
+    std::memcpy(&x4[4 * (size_t)i], r + 0, 12);
+    std::memcpy(&f8[FD_PAD * (size_t)i], r + 20, 4 * FD);
+    std::memcpy(&l20[NC_PAD * (size_t)i], r + 44, 4 * NC);
+    std::memcpy(&g2[2 * (size_t)i], r + 120, 8);
+  }
+  return upload_packed(ctx, n, x4, f8, l20, g2, out);
+}
+
+int cvo_cloud_size(const cvo_cloud* c) { return c ? c->n : 0; }
+
+void cvo_cloud_free(cvo_cloud* c) {
+  if (!c) return;
+  if (c->ctx) (void)hipSetDevice(c->ctx->device);
+  if (c->x4) (void)hipFree(c->x4);
+  if (c->feat) (void)hipFree(c->feat);
+  if (c->label) (void)hipFree(c->label);
+  if (c->geo) (void)hipFree(c->geo);
+  delete c;
+}
+
+int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo_cloud* const* sources,
+                    const cvo_cloud* const* targets, const float* init_T, float* out_T, cvo_align_info_t* infos,
+                    const cvo_align_opts_t* opts) {
+  if (!ctx) return CVO_E_INVALID;
+  if (!init_T || !out_T) return fail(ctx, CVO_E_INVALID, "null transform pointer");
+  BatchSetup S;
+  DevParams dp;
+  int rc = setup_batch(ctx, params, n_pairs, sources, targets, init_T, opts, 0, 0.f, &S, &dp);
+  if (rc != CVO_OK) return rc;
+
+  const int max_iter = dp.max_iter;
+  int U = (opts && opts->iters_per_launch > 0) ? opts->iters_per_launch : 16;
+  U = std::max(1, std::min(U, std::max(1, max_iter)));
+  const int graph_mode = opts ? opts->use_graph : 0;
+  const bool use_graph = graph_mode != 1;
+
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+  hipLaunchKernelGGL(k_step<true>, dim3(n_pairs), dim3(STEP_THREADS), 0, ctx->stream, ctx->d_descs, ctx->d_params);
+  HIP_TRY(ctx, hipGetLastError());
+
+  if (max_iter > 0) {
+    if (use_graph) {
+      GraphKey key{n_pairs, S.T, S.gx, S.gy, S.nblk, U};
+      if (!ctx->graph_exec || !(ctx->graph_key == key)) {
+        if (ctx->graph_exec) {
+          (void)hipGraphExecDestroy(ctx->graph_exec);
+          ctx->graph_exec = nullptr;
+        }
+        hipGraph_t g = nullptr;
+        HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        for (int u = 0; u < U; u++) launch_iteration(ctx, n_pairs, S.T, S.gx, S.gy, S.nblk);
+        HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &g));
+        hipError_t e = hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) return fail(ctx, CVO_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        ctx->graph_key = key;
+      }
+    }
+    const int n_chunks = (max_iter + U - 1) / U;
+    int waited = 0;  // chunks whose status has been inspected
+    bool all_done = false;
+    for (int ch = 0; ch < n_chunks && !all_done; ch++) {
+      if (use_graph) {
+        HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
+      } else {
+        for (int u = 0; u < U; u++) launch_iteration(ctx, n_pairs, S.T, S.gx, S.gy, S.nblk);
+        HIP_TRY(ctx, hipGetLastError());
+      }
+      const int slot = ch & 1;
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status[slot], ctx->d_status, sizeof(int) * (size_t)n_pairs,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_chk[slot], ctx->stream));
+      // keep one chunk of speculation in flight: inspect the chunk before this one
+      if (ch >= 1) {
+        const int ws = (ch - 1) & 1;
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_chk[ws]));
+        waited = ch;
+        all_done = true;
+        for (int p = 0; p < n_pairs; p++) all_done = all_done && ctx->h_status[ws][p] != 0;
+      }
+    }
+    (void)waited;
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_states.data(), ctx->d_states, sizeof(PairState) * (size_t)n_pairs,
+                              hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+  for (int p = 0; p < n_pairs; p++) {
+    const PairState& st = ctx->h_states[p];
+    std::memcpy(out_T + 16 * (size_t)p, st.out_T, sizeof(float) * 16);
+    if (infos) {
+      infos[p].iterations = st.status ? st.iterations : st.k;
+      infos[p].ret = st.ret;
+      infos[p].final_ell = st.ell;
+      infos[p].final_num_neighbors = st.K;
+      infos[p].seconds = (double)ms * 1e-3;
+    }
+    if (opts && opts->trace && opts->trace_capacity > 0) {
+      const int nt = std::min(st.n_trace, opts->trace_capacity);
+      if (nt > 0)
+        HIP_TRY(ctx, hipMemcpy(opts->trace + (size_t)p * opts->trace_capacity, ctx->h_descs[p].trace,
+                               sizeof(cvo_trace_t) * (size_t)nt, hipMemcpyDeviceToHost));
+      if (opts->n_trace) opts->n_trace[p] = nt;
+    }
+  }
+  return CVO_OK;
+}
+
+int cvo_align_ex(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source, const cvo_cloud* target,
+                 const float init_T[16], float out_T[16], cvo_align_info_t* info, const cvo_align_opts_t* opts) {
+  if (!ctx) return CVO_E_INVALID;
+  if (!source || !target) return fail(ctx, CVO_E_INVALID, "null cloud");
+  if (info) std::memset(info, 0, sizeof(*info));
+  // empty input: return 0 and leave `transform` untouched (CvoGPU.cu:1614-1617)
+  if (source->n == 0 || target->n == 0) return 0;
+  const cvo_cloud* src[1] = {source};
+  const cvo_cloud* tgt[1] = {target};
+  cvo_align_info_t local;
+  int rc = cvo_align_batch(ctx, params, 1, src, tgt, init_T, out_T, &local, opts);
+  if (rc != CVO_OK) return rc;
+  if (info) *info = local;
+  return local.ret;
+}
+
+int cvo_align(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source, const cvo_cloud* target,
+              const float init_T[16], float out_T[16], cvo_align_info_t* info) {
+  return cvo_align_ex(ctx, params, source, target, init_T, out_T, info, nullptr);
+}
+
+int cvo_batch_poses_to_device(cvo_ctx* ctx, void* dst_device, int n_pairs) {
+  if (!ctx || !dst_device || n_pairs <= 0 || n_pairs > ctx->last_pairs)
+    return fail(ctx, CVO_E_INVALID, "cvo_batch_poses_to_device: bad argument");
+  std::vector<float> poses(16 * (size_t)n_pairs);
+  for (int p = 0; p < n_pairs; p++) std::memcpy(&poses[16 * (size_t)p], ctx->h_states[p].out_T, sizeof(float) * 16);
+  HIP_TRY(ctx, hipMemcpyAsync(dst_device, poses.data(), sizeof(float) * poses.size(), hipMemcpyHostToDevice,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CVO_OK;
+}
+
+int cvo_inner_product(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source, const cvo_cloud* target,
+                      const float T[16], float ell, float* out) {
+  if (!ctx || !out || !T) return fail(ctx, CVO_E_INVALID, "cvo_inner_product: bad argument");
+  if (!source || !target) return fail(ctx, CVO_E_INVALID, "null cloud");
+  if (source->n == 0 || target->n == 0) {
+    *out = 0.f;
+    return CVO_OK;
+  }
+  BatchSetup S;
+  int rc = run_single_eval(ctx, params, source, target, T, ell, &S);
+  if (rc != CVO_OK) return rc;
+  *out = (float)ctx->h_states[0].asum;
+  return CVO_OK;
+}
+
+int cvo_function_angle(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source, const cvo_cloud* target,
+                       const float T[16], float ell, int is_approximate, float* out) {
+  // function_angle, CvoGPU.cu:1814-1846
+  if (!ctx || !out || !T) return fail(ctx, CVO_E_INVALID, "cvo_function_angle: bad argument");
+  if (!source || !target) return fail(ctx, CVO_E_INVALID, "null cloud");
+  if (source->n == 0 || target->n == 0) {
+    *out = 0.f;
+    return CVO_OK;
+  }
+  const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  float fxfz = 0, fx_norm = 0, fz_norm = 0;
+  int rc = cvo_inner_product(ctx, params, source, target, T, ell, &fxfz);
+  if (rc != CVO_OK) return rc;
+  if (is_approximate) {
+    fx_norm = (float)std::sqrt((double)source->n);
+    fz_norm = (float)std::sqrt((double)target->n);
+  } else {
+    float a = 0, b = 0;
+    rc = cvo_inner_product(ctx, params, source, source, identity, ell, &a);
+    if (rc != CVO_OK) return rc;
+    rc = cvo_inner_product(ctx, params, target, target, identity, ell, &b);
+    if (rc != CVO_OK) return rc;
+    fx_norm = std::sqrt(a);
+    fz_norm = std::sqrt(b);
+  }
+  *out = fxfz / (fx_norm * fz_norm);
+  return CVO_OK;
+}
+
+static int fetch_ell(cvo_ctx* ctx, int pair, std::vector<unsigned>& nz, std::vector<float>& a, std::vector<int>& j,
+                     unsigned* max_out) {
+  const PairDesc& D = ctx->h_descs[pair];
+  const int N = D.N;
+  nz.resize(N);
+  HIP_TRY(ctx, hipMemcpy(nz.data(), D.nnz_row, sizeof(unsigned) * (size_t)N, hipMemcpyDeviceToHost));
+  unsigned mx = 0;
+  for (int i = 0; i < N; i++) mx = std::max(mx, nz[i]);
+  a.resize((size_t)mx * N);
+  j.resize((size_t)mx * N);
+  if (mx) {
+    HIP_TRY(ctx, hipMemcpy(a.data(), D.ell_a, sizeof(float) * (size_t)mx * N, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(j.data(), D.ell_j, sizeof(int) * (size_t)mx * N, hipMemcpyDeviceToHost));
+  }
+  *max_out = mx;
+  return CVO_OK;
+}
+
+int cvo_association(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source, const cvo_cloud* target,
+                    const float T[16], float ell, int* row_ptr, int* col, float* val, size_t capacity,
+                    size_t* nnz_out) {
+  if (!ctx || !row_ptr || !T) return fail(ctx, CVO_E_INVALID, "cvo_association: bad argument");
+  if (!source || !target) return fail(ctx, CVO_E_INVALID, "null cloud");
+  if (nnz_out) *nnz_out = 0;
+  if (source->n == 0 || target->n == 0) return CVO_OK;  // CvoGPU.cu:1884-1885
+  BatchSetup S;
+  int rc = run_single_eval(ctx, params, source, target, T, ell, &S);
+  if (rc != CVO_OK) return rc;
+  std::vector<unsigned> nz;
+  std::vector<float> a;
+  std::vector<int> jj;
+  unsigned mx = 0;
+  rc = fetch_ell(ctx, 0, nz, a, jj, &mx);
+  if (rc != CVO_OK) return rc;
+  const int N = source->n;
+  size_t cnt = 0;
+  for (int i = 0; i < N; i++) {
+    row_ptr[i] = (int)cnt;
+    for (unsigned s = 0; s < nz[i]; s++) {
+      if (cnt < capacity && col && val) {
+        col[cnt] = jj[(size_t)s * N + i];
+        val[cnt] = a[(size_t)s * N + i];
+      }
+      cnt++;
+    }
+  }
+  row_ptr[N] = (int)cnt;
+  if (nnz_out) *nnz_out = cnt;
+  if (cnt > capacity) return fail(ctx, CVO_E_NOMEM, "association capacity too small");
+  return CVO_OK;
+}
+
+int cvo_debug_last_ell(cvo_ctx* ctx, int K, float* mat, int* ind, unsigned int* nonzeros) {
+  if (!ctx || ctx->last_pairs < 1 || K <= 0) return fail(ctx, CVO_E_INVALID, "cvo_debug_last_ell: bad argument");
+  std::vector<unsigned> nz;
+  std::vector<float> a;
+  std::vector<int> jj;
+  unsigned mx = 0;
+  int rc = fetch_ell(ctx, 0, nz, a, jj, &mx);
+  if (rc != CVO_OK) return rc;
+  const int N = ctx->h_descs[0].N;
+  for (int i = 0; i < N; i++) {
+    if (nonzeros) nonzeros[i] = nz[i];
+    for (int s = 0; s < K; s++) {
+      const bool ok = (unsigned)s < nz[i];
+      if (mat) mat[(size_t)i * K + s] = ok ? a[(size_t)s * N + i] : 0.f;
+      if (ind) ind[(size_t)i * K + s] = ok ? jj[(size_t)s * N + i] : -1;
+    }
+  }
+  return CVO_OK;
+}
+
+int cvo_debug_last_candidates(cvo_ctx* ctx, unsigned long long* out) {
+  if (!ctx || !out || ctx->last_pairs < 1) return fail(ctx, CVO_E_INVALID, "cvo_debug_last_candidates: bad argument");
+  *out = ctx->h_states[0].ncand;
+  return CVO_OK;
+}
+
+int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms) {
+  if (!ctx || !ms || reps <= 0 || ctx->last_pairs < 1)
+    return fail(ctx, CVO_E_INVALID, "cvo_debug_time_scan: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int n_pairs = ctx->last_pairs;
+  const DevParams& dp = ctx->last_params;
+  dim3 grid(ctx->last_gx, ctx->last_gy, n_pairs);
+  launch_scan(ctx->stream, dp.T, grid, ctx->d_descs, ctx->d_params, 1);  // warm-up
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+  for (int r = 0; r < reps; r++) launch_scan(ctx->stream, dp.T, grid, ctx->d_descs, ctx->d_params, 1);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  HIP_TRY(ctx, hipGetLastError());
+  // the extra scans leave flags behind; clean them so the workspace stays consistent
+  for (int p = 0; p < n_pairs; p++) {
+    const PairDesc& D = ctx->h_descs[p];
+    HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, sizeof(unsigned short) * (size_t)ctx->last_N * D.nsl_pad, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  float t = 0;
+  HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->ev_start, ctx->ev_stop));
+  *ms = t / reps;
+  return CVO_OK;
+}
+
+}  // extern "C"
