@@ -458,64 +458,114 @@ Coefs poly_coeff_impl(const OracleParams& P, const CloudView& X, const CloudView
   return c;
 }
 
-// Roots of p0 x^3 + p1 x^2 + p2 x + p3.  The reference takes the eigenvalues of the
-// companion matrix with Eigen 3.3.9's EigenSolver (LieGroup.cpp:309-325; Eigen is not in
-// the repository).  Restated as Cardano/trigonometric roots + Newton polish + deflation;
-// pinned against numpy.roots in tests/test_oracle_math.py.
-void cubic_roots_impl(const double coef[4], double re[3], double im[3]) {
-  const double nan = std::numeric_limits<double>::quiet_NaN();
-  double a = coef[1] / coef[0], b = coef[2] / coef[0], c = coef[3] / coef[0];
-  if (!std::isfinite(a) || !std::isfinite(b) || !std::isfinite(c)) {
+#define CUBIC_QUAL static
+#define CUBIC_NAME cubic_roots_impl
+#define CUBIC_FABS std::fabs
+#define CUBIC_SQRT std::sqrt
+#define CUBIC_ISFINITE std::isfinite
+#define CUBIC_NAN std::numeric_limits<double>::quiet_NaN()
+// Roots of p0 x^3 + p1 x^2 + p2 x + p3.  The reference takes the eigenvalues of the companion
+// matrix with Eigen 3.3.9's EigenSolver (LieGroup.cpp:309-325; Eigen is not in the repository).
+// Restated with a backward-stable scheme that uses only + - * / sqrt (so CPU and GPU agree
+// bitwise): the real roots are bracketed between the critical points of the monic cubic and
+// refined by safeguarded Newton (bisection fallback); a complex pair follows from Vieta.
+// Pinned against numpy.roots (LAPACK companion eigenvalues) in tests/test_oracle_math.py.
+CUBIC_QUAL double cubic_solve_bracket(double a, double b, double c, double lo, double hi) {
+  auto f = [&](double x) { return ((x + a) * x + b) * x + c; };
+  auto df = [&](double x) { return (3.0 * x + 2.0 * a) * x + b; };
+  double fl = f(lo), fh = f(hi);
+  if (fl == 0.0) return lo;
+  if (fh == 0.0) return hi;
+  double xl, xh;
+  if (fl < 0.0) {
+    xl = lo;
+    xh = hi;
+  } else {
+    xl = hi;
+    xh = lo;
+  }
+  double x = 0.5 * (lo + hi);
+  double dxold = CUBIC_FABS(hi - lo), dx = dxold;
+  double fx = f(x), dfx = df(x);
+  for (int it = 0; it < 300; it++) {
+    if ((((x - xh) * dfx - fx) * ((x - xl) * dfx - fx) > 0.0) || (CUBIC_FABS(2.0 * fx) > CUBIC_FABS(dxold * dfx))) {
+      dxold = dx;
+      dx = 0.5 * (xh - xl);
+      x = xl + dx;
+      if (xl == x) return x;
+    } else {
+      dxold = dx;
+      dx = fx / dfx;
+      const double tmp = x;
+      x -= dx;
+      if (tmp == x) return x;
+    }
+    fx = f(x);
+    dfx = df(x);
+    if (fx == 0.0) return x;
+    if (fx < 0.0)
+      xl = x;
+    else
+      xh = x;
+  }
+  return x;
+}
+
+CUBIC_QUAL void CUBIC_NAME(const double coef[4], double re[3], double im[3]) {
+  const double nan = CUBIC_NAN;
+  const double a = coef[1] / coef[0], b = coef[2] / coef[0], c = coef[3] / coef[0];
+  if (!CUBIC_ISFINITE(a) || !CUBIC_ISFINITE(b) || !CUBIC_ISFINITE(c)) {
     for (int i = 0; i < 3; i++) re[i] = im[i] = nan;
     return;
   }
   auto f = [&](double x) { return ((x + a) * x + b) * x + c; };
-  auto df = [&](double x) { return (3 * x + 2 * a) * x + b; };
-  auto polish = [&](double x) {
-    for (int it = 0; it < 4; it++) {
-      double d = df(x);
-      if (d == 0 || !std::isfinite(d)) break;
-      double nx = x - f(x) / d;
-      if (!std::isfinite(nx)) break;
-      x = nx;
-    }
-    return x;
-  };
-  double p = b - a * a / 3.0;
-  double q = 2.0 * a * a * a / 27.0 - a * b / 3.0 + c;
-  double disc = q * q / 4.0 + p * p * p / 27.0;
-  double r0;
-  if (disc > 0) {
-    double s = std::sqrt(disc);
-    double u = (-q / 2.0 >= 0) ? std::cbrt(-q / 2.0 + s) : std::cbrt(-q / 2.0 - s);
-    double vv = (u != 0) ? -p / (3.0 * u) : 0.0;
-    r0 = u + vv - a / 3.0;
+  double bound = CUBIC_FABS(a);
+  if (CUBIC_FABS(b) > bound) bound = CUBIC_FABS(b);
+  if (CUBIC_FABS(c) > bound) bound = CUBIC_FABS(c);
+  bound = 1.0 + bound;  // Cauchy bound on |root|
+  double r[3] = {0.0, 0.0, 0.0};
+  int nr = 0;
+  const double dq = a * a - 3.0 * b;
+  if (!(dq > 0.0)) {
+    r[nr++] = cubic_solve_bracket(a, b, c, -bound, bound);
   } else {
-    double mm = 2.0 * std::sqrt(std::max(0.0, -p / 3.0));
-    double arg = (p != 0) ? (3.0 * q) / (p * mm) : 0.0;
-    arg = std::max(-1.0, std::min(1.0, arg));
-    double th = std::acos(arg) / 3.0;
-    // pick the root that is best separated (largest magnitude of t) for a stable deflation
-    double t0 = mm * std::cos(th), t2 = mm * std::cos(th - 4.0 * M_PI / 3.0);
-    r0 = ((std::fabs(t0) >= std::fabs(t2)) ? t0 : t2) - a / 3.0;
+    const double s = CUBIC_SQRT(dq);
+    const double t = (a >= 0.0) ? (-a - s) : (-a + s);
+    const double xa = t / 3.0, xb = (t != 0.0) ? b / t : 0.0;
+    const double x1 = xa < xb ? xa : xb, x2 = xa < xb ? xb : xa;
+    const double f1 = f(x1), f2 = f(x2);
+    if (f1 >= 0.0) r[nr++] = (f1 == 0.0) ? x1 : cubic_solve_bracket(a, b, c, -bound, x1);
+    if (f1 > 0.0 && f2 < 0.0) r[nr++] = cubic_solve_bracket(a, b, c, x1, x2);
+    if (f2 <= 0.0) r[nr++] = (f2 == 0.0) ? x2 : cubic_solve_bracket(a, b, c, x2, bound);
   }
-  r0 = polish(r0);
-  // deflate: x^2 + (a + r0) x + (b + r0 (a + r0))
-  double qa = a + r0, qb = b + r0 * qa;
-  double D = qa * qa - 4.0 * qb;
-  re[0] = r0;
-  im[0] = 0;
-  if (D >= 0) {
-    double s = std::sqrt(D);
-    double t = -0.5 * (qa + (qa >= 0 ? s : -s));
-    double x1 = t, x2 = (t != 0) ? qb / t : 0.0;
-    re[1] = polish(x1);
-    im[1] = 0;
-    re[2] = polish(x2);
-    im[2] = 0;
+  if (nr == 3) {
+    for (int i = 0; i < 3; i++) {
+      re[i] = r[i];
+      im[i] = 0.0;
+    }
+  } else if (nr == 2) {  // an exact double root at a critical point
+    re[0] = r[0];
+    re[1] = r[1];
+    const double dbl = -a - r[0] - r[1];
+    re[2] = dbl;
+    im[0] = im[1] = im[2] = 0.0;
   } else {
-    re[1] = re[2] = -0.5 * qa;
-    im[1] = 0.5 * std::sqrt(-D);
+    const double r0 = r[0];
+    // complex pair z, conj(z) from Vieta: r0 + 2 Re z = -a, 2 r0 Re z + |z|^2 = b, r0 |z|^2 = -c;
+    // use the pair of relations that does not cancel for the size of r0
+    double rr, mod2;
+    if (CUBIC_FABS(r0) >= 0.5 * CUBIC_FABS(a) && r0 != 0.0) {
+      mod2 = -c / r0;
+      rr = (b - mod2) / (2.0 * r0);
+    } else {
+      rr = 0.5 * (-a - r0);
+      mod2 = b - 2.0 * r0 * rr;
+    }
+    const double ii = mod2 - rr * rr;
+    re[0] = r0;
+    im[0] = 0.0;
+    re[1] = re[2] = rr;
+    im[1] = ii > 0.0 ? CUBIC_SQRT(ii) : 0.0;
     im[2] = -im[1];
   }
 }

@@ -1,0 +1,316 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the oracle on the same seeded inputs.
+
+Layers (hard part 6):
+  (i)   single-iteration parity on shared state: integer/index work (ELL pattern, nnz, max_nnz, K) must be
+        bit-exact; floating point within the tolerances written next to each assert;
+  (ii)  trajectory-prefix parity at fixed iteration counts;
+  (iii) final-pose parity: 1e-4 (max-abs over the 4x4) where termination is well conditioned, 2e-4
+        (= 2 * min_step) for runs that end clamped at min_step (configs 2/3).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from unified_cvo_amd import CvoGPU, CvoPointCloud, CvoParams, CvoError, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_TWIST = 1e-5      # on the normalised twist (unit 6-vector)
+TOL_COEF_REL = 1e-9   # B, C, D, E are double sums of identical float terms; only the order differs
+TOL_POSE = 1e-4
+TOL_POSE_CLAMPED = 2e-4
+TOL_IP_REL = 1e-4
+
+
+def _ocloud(oracle, pc):
+    return oracle.Cloud.from_pointcloud(pc)
+
+
+def _cmp_trace(a, b):
+    assert (a.k, a.K, a.nnz, a.max_nnz) == (b.k, b.K, b.nnz, b.max_nnz), (a.k, a.K, b.K, a.nnz, b.nnz)
+    assert a.ell == b.ell
+    assert np.allclose(list(a.omega) + list(a.v), list(b.omega) + list(b.v), rtol=0, atol=TOL_TWIST), a.k
+    for n in "BCDE":
+        x, y = getattr(a, n), getattr(b, n)
+        assert abs(x - y) <= TOL_COEF_REL * max(abs(y), 1e-12) + 1e-15, (a.k, n, x, y)
+    assert a.step == pytest.approx(b.step, rel=1e-6)
+    assert a.dist == pytest.approx(b.dist, rel=1e-5, abs=1e-12)
+    assert np.allclose(list(a.R) + list(a.T), list(b.R) + list(b.T), rtol=0, atol=1e-6)
+
+
+def _single_iteration(oracle, P, src, tgt, init, ell=None, K=None):
+    gpu = CvoGPU(params=P)
+    ell = P.ell_init if ell is None else ell
+    K = P.nearest_neighbors_max if K is None else K
+    g = gpu.align(src, tgt, init, max_iterations=1, ell0=ell, K0=K, trace_capacity=2, trace_dense=2)
+    mat, ind, nz = gpu.debug_last_ell(src.num_points(), K)
+    o = oracle.iteration(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt), init[:3, :3],
+                         init[:3, 3], ell, K, want_ell=True)
+    assert np.array_equal(nz, o["nonzeros"])          # bit-exact: index work
+    assert np.array_equal(ind, o["ind"])              # bit-exact: ordered truncation included
+    assert np.allclose(mat, o["mat"], rtol=2e-7, atol=0)  # 1 float ulp: exp() of two libms
+    assert len(g.trace) == 1
+    _cmp_trace(g.trace[0], o["trace"])
+    assert gpu.debug_last_candidates() >= int(nz.sum())  # the scan is a superset of the association
+    return g, o, (mat, ind, nz)
+
+
+@pytest.mark.parametrize("n,m", [(1000, 1000), (777, 1234), (64, 5000), (3000, 65)])
+def test_single_iteration_geometric(oracle, n, m):
+    P, src, tgt, init = cases.config2(n=n, m=m)
+    _single_iteration(oracle, P, src, tgt, init)
+
+
+def test_single_iteration_nonidentity_state(oracle):
+    P, src, tgt, _ = cases.config2(n=1500)
+    init = synth.gt_motion().astype(np.float32)
+    _single_iteration(oracle, P, src, tgt, init, ell=0.12, K=9)
+
+
+def test_single_iteration_ordered_truncation(oracle):
+    """Rows over the cap keep the first K qualifying targets in ascending j."""
+    P, src, tgt, init = cases.config2(n=600)
+    g, o, (mat, ind, nz) = _single_iteration(oracle, P, src, tgt, init, ell=1.5, K=5)
+    assert (nz == 5).all() and np.all(np.diff(ind, axis=1) > 0)
+
+
+def test_single_iteration_colour(oracle):
+    P, src, tgt, init = cases.config3(n=1500)
+    _single_iteration(oracle, P, src, tgt, init)
+
+
+def test_single_iteration_semantic(oracle):
+    P, src, tgt, init = cases.config4(n=1500)
+    _single_iteration(oracle, P, src, tgt, init)
+    _single_iteration(oracle, P, src, tgt, init, ell=0.6, K=40)
+
+
+def test_single_iteration_geometric_type_and_range_ell(oracle):
+    P, src, tgt, init = cases.config2(n=900)
+    P.is_using_geometric_type = 1
+    P.is_using_range_ell = 1
+    rs = np.random.default_rng(5)
+    gx = np.where(rs.random((900, 1)) < 0.5, [[1.0, 0.0]], [[0.0, 1.0]]).astype(np.float32)
+    gy = np.where(rs.random((900, 1)) < 0.5, [[1.0, 0.0]], [[0.3, 0.9]]).astype(np.float32)
+    src = CvoPointCloud.from_arrays(src.positions(), None, None, gx)
+    tgt = CvoPointCloud.from_arrays(tgt.positions(), None, None, gy)
+    _single_iteration(oracle, P, src, tgt, init, ell=0.5)
+
+
+def test_no_geometry_kernel_is_dense(oracle):
+    """is_using_geometry = 0: k = 1 and no distance cut at all (every pair is a candidate)."""
+    P, src, tgt, init = cases.config3(n=150)
+    P.is_using_geometry = 0
+    _single_iteration(oracle, P, src, tgt, init, K=64)
+
+
+def test_full_size_single_iteration_10k(oracle):
+    """BASELINE.json's headline size, checked directly (the oracle needs milliseconds for one pass)."""
+    P, src, tgt, init = cases.config2(n=10000)
+    _single_iteration(oracle, P, src, tgt, init)
+
+
+def _prefix(oracle, P, src, tgt, init, n_it, gpu=None):
+    gpu = gpu or CvoGPU(params=P)
+    g = gpu.align(src, tgt, init, max_iterations=n_it, trace_capacity=n_it, trace_dense=n_it)
+    o = oracle.align(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt), init,
+                     trace_capacity=n_it, trace_dense=n_it, max_iterations=n_it)
+    assert g.iterations == o["iterations"] and g.ret == o["ret"]
+    assert len(g.trace) == len(o["trace"])
+    return g, o
+
+
+@pytest.mark.parametrize("builder,kw,n_it", [(cases.config2, dict(n=2000), 120), (cases.config3, dict(n=1500), 80),
+                                             (cases.config4, dict(n=2000), 80), (cases.config1, {}, 150)])
+def test_trajectory_prefix(oracle, builder, kw, n_it):
+    """Per-iteration state over a prefix of the optimisation (config 1 runs on the neighbour cap throughout)."""
+    P, src, tgt, init = builder(**kw)
+    g, o = _prefix(oracle, P, src, tgt, init, n_it)
+    for a, b in zip(g.trace, o["trace"]):
+        _cmp_trace(a, b)
+    assert cases.max_abs_diff(g.transform, o["transform"]) <= 1e-6
+
+
+def test_final_pose_config2_clamped(oracle):
+    P, src, tgt, init = cases.config2(n=2000)
+    gpu = CvoGPU(params=P)
+    g = gpu.align(src, tgt, init)
+    o = oracle.align(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt), init)
+    assert g.iterations == o["iterations"] == P.MAX_ITER and g.ret == o["ret"] == 0
+    assert cases.max_abs_diff(g.transform, o["transform"]) <= TOL_POSE_CLAMPED
+    assert cases.max_abs_diff(g.transform, np.linalg.inv(synth.gt_motion())) < 2e-3
+    assert g.seconds > 0
+
+
+def test_final_pose_config4_converges(oracle):
+    """Warm-start semantic tracking ends through dist < eps_2: well conditioned, 1e-4."""
+    P, src, tgt, init = cases.config4(n=2000)
+    gpu = CvoGPU(params=P)
+    g = gpu.align(src, tgt, init)
+    o = oracle.align(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt), init)
+    assert g.ret == o["ret"] == 0
+    assert abs(g.iterations - o["iterations"]) <= 2 and g.iterations < P.MAX_ITER
+    assert cases.max_abs_diff(g.transform, o["transform"]) <= TOL_POSE
+
+
+def test_config1_demo_fixed_iteration_pose(oracle):
+    """Config 1's own stop is an accidental small step: compare at k = 1000."""
+    P, src, tgt, init = cases.config1()
+    g, o = _prefix(oracle, P, src, tgt, init, 1000, gpu=CvoGPU(params=P))
+    assert g.trace[0].max_nnz == 256 == g.trace[0].K
+    assert cases.max_abs_diff(g.transform, o["transform"]) <= TOL_POSE
+
+
+def test_against_committed_golden_traces():
+    """HIP path vs tests/golden/oracle_traces.json (no oracle call at all)."""
+    with open(os.path.join(cases.GOLDEN, "oracle_traces.json")) as f:
+        gold = {c["name"]: c for c in json.load(f)["cases"]}
+    for name, builder in (("config2_n2000", cases.config2), ("config4_n2000", cases.config4)):
+        gc = gold[name]
+        P, src, tgt, init = builder(**gc["kwargs"])
+        gpu = CvoGPU(params=P)
+        g = gpu.align(src, tgt, init, trace_capacity=400, trace_dense=50, trace_every=100)
+        got = {t.k: t for t in g.trace}
+        for t in gc["trace"]:
+            if t["k"] >= 50:
+                continue  # beyond the dense prefix trajectories may differ in the last bits
+            a = got[t["k"]]
+            assert (a.K, a.nnz, a.max_nnz) == (t["K"], t["nnz"], t["max_nnz"]), (name, t["k"])
+            assert np.allclose(list(a.omega) + list(a.v), t["omega"] + t["v"], atol=TOL_TWIST)
+        tol = TOL_POSE if name == "config4_n2000" else TOL_POSE_CLAMPED
+        assert cases.max_abs_diff(g.transform, gc["transform"]) <= tol
+        ip = gpu.inner_product_gpu(src, tgt, init, P.ell_init)
+        assert ip == pytest.approx(gc["inner_product_init"], rel=TOL_IP_REL)
+        fa = gpu.function_angle(src, tgt, init, P.ell_init, True)
+        assert fa == pytest.approx(gc["function_angle_init"], rel=TOL_IP_REL)
+
+
+@pytest.mark.parametrize("builder,kw", [(cases.config2, dict(n=3000)), (cases.config4, dict(n=1500)),
+                                        (cases.config1, {})])
+def test_inner_product_and_function_angle(oracle, builder, kw):
+    P, src, tgt, init = builder(**kw)
+    gpu = CvoGPU(params=P)
+    op = oracle.params_from(P)
+    ox, oy = _ocloud(oracle, src), _ocloud(oracle, tgt)
+    for T, ell in ((init, P.ell_init), (synth.gt_motion().astype(np.float32), 0.25)):
+        ip_g = gpu.inner_product_gpu(src, tgt, T, ell)
+        ip_o = oracle.inner_product(op, ox, oy, T, ell)
+        assert ip_g == pytest.approx(ip_o, rel=TOL_IP_REL, abs=1e-12)
+        for approx in (True, False):
+            fa_g = gpu.function_angle(src, tgt, T, ell, approx)
+            fa_o = oracle.function_angle(op, ox, oy, T, ell, approx)
+            assert fa_g == pytest.approx(fa_o, rel=TOL_IP_REL, abs=1e-12)
+
+
+def test_function_angle_self_is_one():
+    P, src, _, _ = cases.config2(n=4000)
+    gpu = CvoGPU(params=P)
+    assert gpu.function_angle(src, src, np.eye(4), 0.2, False) == pytest.approx(1.0, abs=1e-6)
+
+
+def test_inner_product_is_additive_over_target_subsets():
+    """Linearity property at BASELINE size: <X, Y1 u Y2> = <X, Y1> + <X, Y2> while no row hits K_max."""
+    P, src, tgt, init = cases.config2(n=10000)
+    gpu = CvoGPU(params=P)
+    y = tgt.positions()
+    a = gpu.inner_product_gpu(src, CvoPointCloud.from_xyz(y[:6000]), init, 0.3)
+    b = gpu.inner_product_gpu(src, CvoPointCloud.from_xyz(y[6000:]), init, 0.3)
+    c = gpu.inner_product_gpu(src, tgt, init, 0.3)
+    assert c == pytest.approx(a + b, rel=1e-5)
+
+
+def test_association_matches_oracle(oracle):
+    P, src, tgt, init = cases.config2(n=1200)
+    gpu = CvoGPU(params=P)
+    rp, col, val = gpu.compute_association_gpu(src, tgt, init, 0.3)
+    orp, ocol, oval = oracle.association(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt), init, 0.3)
+    assert np.array_equal(rp, orp) and np.array_equal(col, ocol)
+    assert np.allclose(val, oval, rtol=2e-7, atol=0)
+
+
+def test_empty_cloud_returns_zero_and_leaves_transform():
+    gpu = CvoGPU(params=CvoParams())
+    empty = CvoPointCloud.from_xyz(np.zeros((0, 3), np.float32))
+    full = CvoPointCloud.from_xyz(np.ones((10, 3), np.float32))
+    r = gpu.align(empty, full, np.eye(4))
+    assert r.ret == 0 and r.transform is None
+    assert gpu.function_angle(gpu.upload(empty), gpu.upload(full), np.eye(4), 0.3) == 0.0
+
+
+def test_flow_vanishes_returns_minus_one(oracle):
+    """Clouds farther apart than the cut-off: empty A, ret = -1, pose untouched (CvoGPU.cu:1454-1458)."""
+    P, src, tgt, init = cases.config2(n=500)
+    far = CvoPointCloud.from_xyz(tgt.positions() + np.float32(100.0))
+    gpu = CvoGPU(params=P)
+    g = gpu.align(src, far, init)
+    assert g.ret == -1 and g.iterations == 0
+    assert np.allclose(g.transform, np.eye(4))
+    # NaN geometric types: every comparison false
+    P.is_using_geometric_type = 1
+    g = CvoGPU(params=P).align(CvoPointCloud.from_arrays(src.positions()), CvoPointCloud.from_arrays(tgt.positions()), init)
+    assert g.ret == -1
+
+
+def test_tiny_clouds(oracle):
+    P, _, _, init = cases.config2(n=100)
+    a = CvoPointCloud.from_xyz(np.array([[0.0, 0.0, 5.0]], np.float32))
+    b = CvoPointCloud.from_xyz(np.array([[0.05, 0.0, 5.0], [9.0, 9.0, 9.0]], np.float32))
+    gpu = CvoGPU(params=P)
+    g = gpu.align(a, b, init, max_iterations=20, trace_capacity=20, trace_dense=20)
+    o = oracle.align(oracle.params_from(P), _ocloud(oracle, a), _ocloud(oracle, b), init, trace_capacity=20,
+                     trace_dense=20, max_iterations=20)
+    assert g.iterations == o["iterations"] and g.ret == o["ret"]
+    assert cases.max_abs_diff(g.transform, o["transform"]) <= 1e-6
+
+
+def test_unsupported_and_invalid_arguments():
+    P, src, tgt, init = cases.config2(n=100)
+    P.is_using_kdtree = 1
+    with pytest.raises(CvoError):
+        CvoGPU(params=P).align(src, tgt, init)
+    P.is_using_kdtree = 0
+    P.nearest_neighbors_max = 0
+    with pytest.raises(CvoError):
+        CvoGPU(params=P).align(src, tgt, init)
+
+
+def test_graph_and_plain_launch_paths_agree():
+    P, src, tgt, init = cases.config2(n=1500)
+    gpu = CvoGPU(params=P)
+    a = gpu.align(src, tgt, init, max_iterations=333, use_graph=1)
+    b = gpu.align(src, tgt, init, max_iterations=333, use_graph=2, iters_per_launch=7)
+    assert a.iterations == b.iterations == 333
+    assert np.array_equal(a.transform, b.transform)
+
+
+def test_batch_equals_individual_aligns():
+    """cvo_align_batch: ragged pairs solved concurrently give bit-identical poses to one-at-a-time calls."""
+    pairs = [cases.config2(n=1500, pair_id=0), cases.config2(n=900, pair_id=1, m=1300), cases.config2(n=2000, pair_id=2)]
+    P = pairs[0][0]
+    gpu = CvoGPU(params=P)
+    res = gpu.align_batch([p[1] for p in pairs], [p[2] for p in pairs], [p[3] for p in pairs], max_iterations=400)
+    for (Pp, s, t, init), r in zip(pairs, res):
+        one = CvoGPU(params=P).align(s, t, init, max_iterations=400)
+        assert r.iterations == one.iterations == 400
+        assert np.array_equal(r.transform, one.transform)
+
+
+def test_determinism_full_size():
+    P, src, tgt, init = cases.config2(n=10000)
+    gpu = CvoGPU(params=P)
+    a = gpu.align(src, tgt, init, max_iterations=150)
+    b = gpu.align(src, tgt, init, max_iterations=150)
+    assert np.array_equal(a.transform, b.transform)
+
+
+def test_noise_free_alignment_recovers_motion_full_size():
+    """Size-independent property at 10k x 10k: with exact correspondences the returned transform is T_gt^-1."""
+    P = cases.load_params("geometric_gpu")
+    src, tgt, _ = synth.geometric_pair(10000, 7, noise=0.0)
+    gpu = CvoGPU(params=P)
+    g = gpu.align(CvoPointCloud.from_xyz(src), CvoPointCloud.from_xyz(tgt), np.eye(4))
+    assert g.ret == 0
+    assert cases.max_abs_diff(g.transform, np.linalg.inv(synth.gt_motion())) < 5e-4
