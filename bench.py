@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on MI355X: frame-pair align()/s (and ms/iteration) on 10k x 10k
+geometric clouds, `pairs_per_gpu` independent pairs per GPU (BASELINE.json configs[4]: 64 per GPU),
+one process per GPU, poses all-gathered with RCCL at the end of every step.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 2 --warmup 1
+
+A "step" = one pass of the hot path over one batch: every rank solves its `pairs_per_gpu` resident
+pairs to completion (cvo_align_batch) and the poses are gathered.  Inputs are resident in HBM before
+the timed region (the PCIe-inclusive number is printed to stderr and recorded in DESIGN.md, never in
+`value`).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
+C_CULL_FLOPS = 8               # flops per pair test
+
+
+def available_cpus():
+    """Logical CPUs this process may actually use (the GPU box has a cgroup quota below nproc)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=10000)
+    ap.add_argument("--pairs-per-gpu", type=int, default=64)
+    ap.add_argument("--max-iterations", type=int, default=0, help="debug only: cap the optimiser loop")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=400)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import cases
+    from unified_cvo_amd import CvoGPU, sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run for N>1")
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n = args.points
+    B = args.pairs_per_gpu
+    total_pairs = B * world
+    lo, hi = sharding.shard_range(total_pairs, world, rank)
+    P = cases.load_params("geometric_gpu")
+    gpu = CvoGPU(params=P, device=local_rank)
+    t_up = time.time()
+    pairs = [cases.config2(n=n, pair_id=p) for p in range(lo, hi)]
+    host_clouds = [(q[1], q[2]) for q in pairs]
+    t_gen = time.time() - t_up
+    t_up = time.time()
+    src = [gpu.upload(a) for a, _ in host_clouds]
+    tgt = [gpu.upload(b) for _, b in host_clouds]
+    t_h2d = time.time() - t_up
+    inits = [q[3] for q in pairs]
+    pose_buf = torch.zeros(hi - lo, 16, dtype=torch.float32, device=dev)
+    kw = dict(max_iterations=args.max_iterations) if args.max_iterations > 0 else {}
+
+    def step():
+        res = gpu.align_batch(src, tgt, inits, **kw)
+        gpu.poses_to_device(pose_buf.data_ptr(), hi - lo)
+        status = torch.tensor([r.ret for r in res], dtype=torch.int32, device=dev)
+        poses, stat = sharding.gather_poses(pose_buf, status, total_pairs, world, rank)
+        return res, poses, stat
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, poses, stat = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    elapsed = sharding.max_over_ranks(elapsed, dev)
+    iters = [r.iterations for r in res]
+    loop_s = res[0].seconds
+
+    out = None
+    if rank == 0:
+        aligns = total_pairs * args.steps
+        value = aligns / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
+        mean_iters = float(np.mean(iters))
+        # ms per optimiser iteration of one frame pair, with `B` pairs in flight on each GPU
+        ms_per_iter_pair = elapsed / args.steps / max(mean_iters, 1.0) / B * 1e3
+        # ---- roofline of the dominant kernel (k_scan), timed live with HIP events on the ctx stream
+        scan_ms = gpu.debug_time_scan(20)
+        pairs_per_launch = float(n) * float(n) * B
+        bytes_per_launch = (n * 12 + n * 12) * B          # SURVEY.md 8(d), one pass, geometric payload
+        achieved_gbs = bytes_per_launch / (scan_ms * 1e-3) / 1e9
+        pair_rate = pairs_per_launch / (scan_ms * 1e-3)
+        valu_peak_pairs = FP32_VALU_PEAK_TFLOPS * 1e12 / C_CULL_FLOPS
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("points") == n and tj.get("pairs") == B:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "kernel": "cvo_dev::k_scan", "bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(scan_ms, 5),
+            # the path is an all-pairs accumulation with O(N+M) compulsory bytes: the binding roof is FP32 VALU
+            "valu": {"achieved_pair_tests_per_s": pair_rate, "peak_pair_tests_per_s": valu_peak_pairs,
+                     "frac": round(pair_rate / valu_peak_pairs, 4), "flops_per_pair_test": C_CULL_FLOPS,
+                     "peak_tflops": FP32_VALU_PEAK_TFLOPS},
+        }
+        cpu_baseline = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import pyoracle as po
+            threads = available_cpus()
+            po.set_num_threads(threads)
+            op = po.params_from(P)
+            ox, oy = po.Cloud.from_pointcloud(host_clouds[0][0]), po.Cloud.from_pointcloud(host_clouds[0][1])
+            it = min(args.cpu_iters, P.MAX_ITER)
+            po.align(op, ox, oy, inits[0], max_iterations=5)  # warm-up (page-in, thread pool)
+            o = po.align(op, ox, oy, inits[0], max_iterations=it)
+            sec_per_iter = o["seconds"] / max(o["iterations"], 1)
+            cpu_value = 1.0 / (sec_per_iter * mean_iters)
+            cpu_baseline = {
+                "value": cpu_value, "unit": "align/s", "cores": threads, "kind": "port",
+                "ms_per_iter": sec_per_iter * 1e3,
+                "sample": f"first {o['iterations']} optimiser iterations of pair 0 ({n}x{n}) with the CPU oracle "
+                          f"(dense scan, OpenMP over rows), extrapolated to the {mean_iters:.0f} iterations of a full align()",
+            }
+            # cross-check of the measured batch against the oracle on the same sample
+            g = gpu.align(src[0], tgt[0], inits[0], max_iterations=it)
+            d = float(np.max(np.abs(g.transform - o["transform"])))
+            log(f"[bench] parity of the sample ({it} iterations): pose max|d| = {d:.2e}")
+            cpu_baseline["sample_parity_max_abs"] = d
+        out = {
+            "metric": "frame-pair align()/sec, 10k x 10k geometric clouds", "value": value, "unit": "align/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "ms_per_iter": ms_per_iter_pair, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[4] shape: {B} independent {n}x{n} xyz-only frame pairs per GPU "
+                                   f"(seeds 1000+p / 2000+p), cvo_geometric_params_gpu.yaml, identity init, "
+                                   f"{mean_iters:.0f} optimiser iterations per align()",
+                       "pairs_per_gpu": B, "points": n, "iterations_per_align": mean_iters,
+                       "parallelism": f"pairs sharded {B}/GPU over {world} GPU(s); one RCCL all-gather of poses per step"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        h2d_rate = (2 * n * 16 * 1.0) * B / max(t_h2d, 1e-9) / 1e9
+        log(f"[bench] inputs: generated in {t_gen:.2f}s, uploaded in {t_h2d:.3f}s ({h2d_rate:.2f} GB/s incl. host packing); "
+            f"PCIe-inclusive rate = {aligns / (elapsed + args.steps * t_h2d):.2f} align/s")
+        log(f"[bench] loop {loop_s:.3f}s/step on rank 0; scan kernel {scan_ms*1e3:.1f} us per launch of {B} pairs "
+            f"({pair_rate/1e12:.2f} T pair-tests/s = {100*pair_rate/valu_peak_pairs:.1f}% of FP32 VALU roof)")
+        assert int(stat.abs().sum().item()) == 0, "some align() returned -1"
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()
