@@ -1,0 +1,185 @@
+// cvo::CvoGPU over the C-ABI (see include/UnifiedCvo/cvo/CvoGPU.hpp).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+
+#include "cvo/CvoGPU.hpp"
+
+namespace cvo {
+namespace {
+
+struct DeviceCloud {
+  cvo_cloud* h = nullptr;
+  ~DeviceCloud() {
+    if (h) cvo_cloud_free(h);
+  }
+};
+
+void check(cvo_ctx* ctx, int rc, const char* what) {
+  if (rc <= CVO_E_INVALID) throw std::runtime_error(std::string(what) + ": " + cvo_last_error(ctx));
+}
+
+// What CvoPointCloud_to_gpu builds per point (upstream CvoGPU_impl.cu:206-263).
+void upload(cvo_ctx* ctx, const CvoPointCloud& pc, DeviceCloud& out) {
+  const int n = pc.num_points();
+  std::vector<float> xyz(3 * (size_t)n), feat, label, geo(2 * (size_t)n, 0.f);
+  for (int i = 0; i < n; i++)
+    for (int c = 0; c < 3; c++) xyz[3 * (size_t)i + c] = pc.positions()[i][c];
+  const MatXf& F = pc.features();
+  if (F.rows() == n && F.cols() > 0) {
+    feat.assign(CVO_FEATURE_DIMENSIONS * (size_t)n, 0.f);
+    for (int i = 0; i < n; i++)
+      for (int c = 0; c < CVO_FEATURE_DIMENSIONS && c < F.cols(); c++) feat[CVO_FEATURE_DIMENSIONS * (size_t)i + c] = F(i, c);
+  }
+  const MatXf& L = pc.labels();
+  if (pc.num_classes() > 0 && L.rows() == n) {
+    label.assign(CVO_NUM_CLASSES * (size_t)n, 0.f);
+    for (int i = 0; i < n; i++)
+      for (int c = 0; c < pc.num_classes() && c < CVO_NUM_CLASSES; c++) label[CVO_NUM_CLASSES * (size_t)i + c] = L(i, c);
+  }
+  const std::vector<float>& g = pc.geometric_types();
+  for (size_t i = 0; i < geo.size() && i < g.size(); i++) geo[i] = g[i];
+  check(ctx, cvo_cloud_upload(ctx, n, xyz.data(), feat.empty() ? nullptr : feat.data(),
+                              label.empty() ? nullptr : label.data(), geo.data(), &out.h),
+        "cvo_cloud_upload");
+}
+
+void fill_association(cvo_ctx* ctx, const cvo_params_t& p, cvo_cloud* s, cvo_cloud* t, const Mat4f& T, float ell,
+                      Association& a) {
+  const int n = cvo_cloud_size(s);
+  a.source_inliers.clear();
+  a.target_inliers.clear();
+  a.pairs.rows = n;
+  a.pairs.cols = cvo_cloud_size(t);
+  a.pairs.row_ptr.assign(n + 1, 0);
+  size_t nnz = 0;
+  int rc = cvo_association(ctx, &p, s, t, T.data(), ell, a.pairs.row_ptr.data(), nullptr, nullptr, 0, &nnz);
+  if (rc != CVO_E_NOMEM) check(ctx, rc, "cvo_association");
+  a.pairs.col.assign(nnz, 0);
+  a.pairs.val.assign(nnz, 0.f);
+  if (nnz)
+    check(ctx, cvo_association(ctx, &p, s, t, T.data(), ell, a.pairs.row_ptr.data(), a.pairs.col.data(),
+                               a.pairs.val.data(), nnz, &nnz),
+          "cvo_association");
+  for (int i = 0; i < n; i++)
+    if (a.pairs.row_ptr[i + 1] > a.pairs.row_ptr[i]) a.source_inliers.push_back(i);
+  a.target_inliers = a.pairs.col;
+}
+
+}  // namespace
+
+CvoGPU::CvoGPU(const std::string& f, int device) {
+  std::vector<std::string> warnings;
+  read_CvoParams_yaml(f.c_str(), &params, &warnings);
+  if (std::getenv("CVO_VERBOSE"))
+    for (const std::string& w : warnings) std::fprintf(stderr, "[cvo] %s: %s\n", f.c_str(), w.c_str());
+  int rc = cvo_ctx_create(device, &ctx);
+  if (rc != CVO_OK) throw std::runtime_error("cvo_ctx_create failed: no usable HIP device " + std::to_string(device));
+}
+
+CvoGPU::~CvoGPU() {
+  if (ctx) cvo_ctx_destroy(ctx);
+}
+
+void CvoGPU::write_params(const CvoParams* p_cpu) {
+  if (p_cpu != &params) params = *p_cpu;
+}
+
+int CvoGPU::align(const CvoPointCloud& source_points, const CvoPointCloud& target_points, const Mat4f& init,
+                  Mat4f& transform, Association* association, double* registration_seconds) const {
+  if (source_points.num_points() == 0 || target_points.num_points() == 0) return 0;
+  DeviceCloud s, t;
+  upload(ctx, source_points, s);
+  upload(ctx, target_points, t);
+  cvo_align_info_t info;
+  Mat4f out = transform;
+  int rc = cvo_align(ctx, &params, s.h, t.h, init.data(), out.data(), &info);
+  check(ctx, rc, "cvo_align");
+  transform = out;
+  if (registration_seconds) *registration_seconds = info.seconds;
+  if (params.is_exporting_association && association)  // upstream CvoGPU.cu:1552-1556
+    fill_association(ctx, params, s.h, t.h, out.inverse_rigid(), info.final_ell, *association);
+  return rc;
+}
+
+int CvoGPU::align(const void* src_pts, int n_source, const void* tgt_pts, int n_target, const Mat4f& init,
+                  Mat4f& transform, Association* association, double* registration_seconds) const {
+  if (n_source == 0 || n_target == 0) return 0;
+  DeviceCloud s, t;
+  check(ctx, cvo_cloud_upload_aos192(ctx, n_source, src_pts, &s.h), "cvo_cloud_upload_aos192");
+  check(ctx, cvo_cloud_upload_aos192(ctx, n_target, tgt_pts, &t.h), "cvo_cloud_upload_aos192");
+  cvo_align_info_t info;
+  Mat4f out = transform;
+  int rc = cvo_align(ctx, &params, s.h, t.h, init.data(), out.data(), &info);
+  check(ctx, rc, "cvo_align");
+  transform = out;
+  if (registration_seconds) *registration_seconds = info.seconds;
+  if (params.is_exporting_association && association)
+    fill_association(ctx, params, s.h, t.h, out.inverse_rigid(), info.final_ell, *association);
+  return rc;
+}
+
+std::vector<int> CvoGPU::align_batch(const std::vector<const CvoPointCloud*>& sources,
+                                     const std::vector<const CvoPointCloud*>& targets,
+                                     const std::vector<Mat4f>& inits, std::vector<Mat4f>& transforms,
+                                     double* seconds) const {
+  const int n = (int)sources.size();
+  if ((int)targets.size() != n || (int)inits.size() != n) throw std::runtime_error("align_batch: size mismatch");
+  std::vector<DeviceCloud> s(n), t(n);
+  std::vector<const cvo_cloud*> sh(n), th(n);
+  std::vector<float> init(16 * (size_t)n), out(16 * (size_t)n);
+  for (int i = 0; i < n; i++) {
+    upload(ctx, *sources[i], s[i]);
+    upload(ctx, *targets[i], t[i]);
+    sh[i] = s[i].h;
+    th[i] = t[i].h;
+    std::copy(inits[i].data(), inits[i].data() + 16, &init[16 * (size_t)i]);
+  }
+  std::vector<cvo_align_info_t> infos(n);
+  check(ctx, cvo_align_batch(ctx, &params, n, sh.data(), th.data(), init.data(), out.data(), infos.data(), nullptr),
+        "cvo_align_batch");
+  transforms.resize(n);
+  std::vector<int> rets(n);
+  for (int i = 0; i < n; i++) {
+    std::copy(&out[16 * (size_t)i], &out[16 * (size_t)i] + 16, transforms[i].data());
+    rets[i] = infos[i].ret;
+  }
+  if (seconds && n) *seconds = infos[0].seconds;
+  return rets;
+}
+
+float CvoGPU::inner_product_gpu(const CvoPointCloud& a, const CvoPointCloud& b, const Mat4f& T, float ell) const {
+  if (a.num_points() == 0 || b.num_points() == 0) return 0.f;
+  DeviceCloud s, t;
+  upload(ctx, a, s);
+  upload(ctx, b, t);
+  float v = 0;
+  check(ctx, cvo_inner_product(ctx, &params, s.h, t.h, T.data(), ell, &v), "cvo_inner_product");
+  return v;
+}
+
+float CvoGPU::function_angle(const CvoPointCloud& a, const CvoPointCloud& b, const Mat4f& T, float ell,
+                             bool is_approximate, bool is_gpu) const {
+  if (a.num_points() == 0 || b.num_points() == 0) return 0.f;
+  if (!is_gpu)  // upstream's is_gpu=false routes to inner_product_cpu (kd-tree, different semantics): out of scope
+    throw std::runtime_error("function_angle(is_gpu=false) is out of scope; see DESIGN.md");
+  DeviceCloud s, t;
+  upload(ctx, a, s);
+  upload(ctx, b, t);
+  float v = 0;
+  check(ctx, cvo_function_angle(ctx, &params, s.h, t.h, T.data(), ell, is_approximate ? 1 : 0, &v),
+        "cvo_function_angle");
+  return v;
+}
+
+void CvoGPU::compute_association_gpu(const CvoPointCloud& a, const CvoPointCloud& b, const Mat4f& T, float ell,
+                                     Association& association) const {
+  if (a.num_points() == 0 || b.num_points() == 0) return;
+  DeviceCloud s, t;
+  upload(ctx, a, s);
+  upload(ctx, b, t);
+  fill_association(ctx, params, s.h, t.h, T, ell, association);
+}
+
+}  // namespace cvo

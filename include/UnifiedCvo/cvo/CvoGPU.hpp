@@ -1,0 +1,57 @@
+// cvo::CvoGPU for MI355X: the public API of upstream include/UnifiedCvo/cvo/CvoGPU.hpp:49-229 (pairwise
+// overloads) over the C-ABI of cvo_hip.h.  Differences forced by the missing dependencies: Mat4f instead
+// of Eigen::Matrix4f (same 16-float column-major layout), the 192-byte CvoPoint array instead of
+// pcl::PointCloud<CvoPoint>.  The multi-frame overloads (Ceres IRLS) are out of scope.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "cvo/Association.hpp"
+#include "cvo/CvoParams.hpp"
+#include "utils/CvoPointCloud.hpp"
+#include "utils/data_type.hpp"
+
+namespace cvo {
+
+class CvoGPU {
+ public:
+  explicit CvoGPU(const std::string& yaml_param_file, int device = 0);
+  ~CvoGPU();
+  CvoGPU(const CvoGPU&) = delete;
+  CvoGPU& operator=(const CvoGPU&) = delete;
+
+  CvoParams& get_params() { return params; }
+  // Upstream re-uploads *p_cpu to the device copy only (CvoGPU.cu:73-77); here the backend reads the
+  // host struct at every call, so this stores *p_cpu as the parameters the next calls use.
+  void write_params(const CvoParams* p_cpu);
+
+  // 0 = success, -1 = the flow vanished (CvoGPU.cu:1454-1458).  Empty input: returns 0 and leaves
+  // `transform` untouched (CvoGPU.cu:1614-1617).  Backend failures throw std::runtime_error.
+  int align(const CvoPointCloud& source_points, const CvoPointCloud& target_points,
+            const Mat4f& T_target_frame_to_source_frame, Mat4f& transform, Association* association = nullptr,
+            double* registration_seconds = nullptr) const;
+  // pcl overload: n records of the 192-byte AoS CvoPoint (PointSegmentedDistribution<5,19>).
+  int align(const void* source_cvo_points, int n_source, const void* target_cvo_points, int n_target,
+            const Mat4f& T_target_frame_to_source_frame, Mat4f& transform, Association* association = nullptr,
+            double* registration_seconds = nullptr) const;
+
+  // New: independent frame pairs solved concurrently on this object's GPU.  Returns per-pair 0 / -1.
+  std::vector<int> align_batch(const std::vector<const CvoPointCloud*>& sources,
+                               const std::vector<const CvoPointCloud*>& targets, const std::vector<Mat4f>& inits,
+                               std::vector<Mat4f>& transforms, double* seconds = nullptr) const;
+
+  float function_angle(const CvoPointCloud& source_points, const CvoPointCloud& target_points,
+                       const Mat4f& T_target_frame_to_source_frame, float ell, bool is_approximate = true,
+                       bool is_gpu = true) const;
+  float inner_product_gpu(const CvoPointCloud& source_points, const CvoPointCloud& target_points,
+                          const Mat4f& T_target_frame_to_source_frame, float ell) const;
+  void compute_association_gpu(const CvoPointCloud& source_points, const CvoPointCloud& target_points,
+                               const Mat4f& T_target_frame_to_source_frame, float lengthscale,
+                               Association& association) const;
+
+ private:
+  CvoParams params;
+  cvo_ctx* ctx = nullptr;
+};
+
+}  // namespace cvo

@@ -33,7 +33,7 @@ struct DevParams {
   int use_geo, use_col, use_sem, use_range_ell, use_geotype;
   int trace_dense, trace_every, trace_capacity;
   int mode;  // 0 = align loop, 1 = single evaluation (inner product / association)
-  int T;     // target chunks (of 64) per scan wave: 1, 2 or 4
+  int T;     // target chunks (of 64) per scan wave: 1, 2, 4 or 8
   int rows_per_block;
 };
 

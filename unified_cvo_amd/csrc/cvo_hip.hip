@@ -90,7 +90,7 @@ int fail(cvo_ctx* ctx, int code, const std::string& msg) {
 
 PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, int* Mpad_out, int* nchunks_out,
                        int* nsl_pad_out, int* nblk_out) {
-  const int Mpad = (int)align_up((size_t)M, 256);
+  const int Mpad = (int)align_up((size_t)M, 512);
   const int nchunks = Mpad / 64;
   const int nsl_pad = (int)align_up((size_t)nchunks, 8);  // enough for T = 1
   const int nblk = (N + 255) / 256;
@@ -103,7 +103,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, int* Mpad_out
   };
   L.yt4 = take(sizeof(float4) * (size_t)Mpad);
   L.ycull = take(sizeof(float4) * (size_t)Mpad);
-  L.xcull = take(sizeof(float4) * (size_t)(N + 4));
+  L.xcull = take(sizeof(float4) * (size_t)(N + XCULL_PAD));
   L.rowc = take(sizeof(float2) * (size_t)N);
   L.masks = take(sizeof(unsigned long long) * (size_t)N * nchunks);
   L.flags = take(sizeof(unsigned short) * (size_t)N * nsl_pad);
@@ -215,7 +215,7 @@ DevParams make_dev_params(const cvo_params_t& p) {
 // waves (256 CUs x 4 SIMDs want >= 2..4 waves each) without making waves trivially short.
 void choose_scan_config(int n_pairs, int N, int Mpad, int* T_out, int* rpb_out) {
   const long target_waves = 4096;
-  int T = 4;
+  int T = 8;
   while (T > 1) {
     const long slices = Mpad / (64 * T);
     const long waves = slices * ((N + 63) / 64) * n_pairs;
@@ -233,11 +233,11 @@ void choose_scan_config(int n_pairs, int N, int Mpad, int* T_out, int* rpb_out) 
   const char* eR = getenv("CVO_SCAN_ROWS");
   if (eT) {
     int v = atoi(eT);
-    if (v == 1 || v == 2 || v == 4) T = v;
+    if (v == 1 || v == 2 || v == 4 || v == 8) T = v;
   }
   if (eR) {
     int v = atoi(eR);
-    if (v >= 1) rpb = v;
+    if (v >= 8 && v % 8 == 0) rpb = v;
   }
   *T_out = T;
   *rpb_out = rpb;
@@ -245,9 +245,10 @@ void choose_scan_config(int n_pairs, int N, int Mpad, int* T_out, int* rpb_out) 
 
 void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const DevParams* dp, int force) {
   switch (T) {
-    case 1: hipLaunchKernelGGL((k_scan<1, 4>), grid, dim3(256), 0, s, descs, dp, force); break;
-    case 2: hipLaunchKernelGGL((k_scan<2, 2>), grid, dim3(256), 0, s, descs, dp, force); break;
-    default: hipLaunchKernelGGL((k_scan<4, 2>), grid, dim3(256), 0, s, descs, dp, force); break;
+    case 1: hipLaunchKernelGGL((k_scan<1, 8>), grid, dim3(256), 0, s, descs, dp, force); break;
+    case 2: hipLaunchKernelGGL((k_scan<2, 4>), grid, dim3(256), 0, s, descs, dp, force); break;
+    case 4: hipLaunchKernelGGL((k_scan<4, 4>), grid, dim3(256), 0, s, descs, dp, force); break;
+    default: hipLaunchKernelGGL((k_scan<8, 2>), grid, dim3(256), 0, s, descs, dp, force); break;
   }
 }
 

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
   const int slice = blockIdx.x * 4 + wave;
   const int nslices = D->nslices;
   if (slice >= nslices) return;
-  const int rpb = Pp->rows_per_block;
+  const int rpb = Pp->rows_per_block;  // a multiple of RU
   const int N = D->N;
   const int r0 = blockIdx.y * rpb;
   if (r0 >= N) return;
@@ -86,47 +86,53 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
     y3[t] = q.z;
     yy[t] = q.w;
   }
-  const CVO_CONST f32x4* xc = (const CVO_CONST f32x4*)D->xcull;
+  // xcull is padded with never-passing rows (w = -inf) up to N + XCULL_PAD, so neither the last
+  // row group nor the prefetch of the group after it needs clamping.
+  const CVO_CONST f32x4* xr = (const CVO_CONST f32x4*)D->xcull + r0;
   CVO_GLOBAL unsigned long long* masks = (CVO_GLOBAL unsigned long long*)D->masks;
   CVO_GLOBAL unsigned short* flags = (CVO_GLOBAL unsigned short*)D->flags;
   const int nchunks = D->nchunks;
   const int nsl_pad = D->nsl_pad;
-  const int last = r1 - 1;
 
   f32x4 cur[RU], nxt[RU];
 #pragma unroll
-  for (int u = 0; u < RU; u++) cur[u] = xc[min(r0 + u, last)];
+  for (int u = 0; u < RU; u++) cur[u] = xr[u];
   for (int r = r0; r < r1; r += RU) {
+    xr += RU;
 #pragma unroll
-    for (int u = 0; u < RU; u++) nxt[u] = xc[min(r + RU + u, last)];  // prefetch the next row group
-    unsigned long long m[RU][T];
+    for (int u = 0; u < RU; u++) nxt[u] = xr[u];  // prefetch the next row group (scalar loads)
+    float acc[RU][T];
+    unsigned long long mu[RU];
     unsigned long long any = 0;
 #pragma unroll
     for (int u = 0; u < RU; u++) {
 #pragma unroll
       for (int t = 0; t < T; t++) {
-        float acc = __builtin_fmaf(y1[t], cur[u].x, yy[t]);
-        acc = __builtin_fmaf(y2[t], cur[u].y, acc);
-        acc = __builtin_fmaf(y3[t], cur[u].z, acc);
-        m[u][t] = __ballot(acc < cur[u].w);
-        any |= m[u][t];
+        float a = __builtin_fmaf(y1[t], cur[u].x, yy[t]);
+        a = __builtin_fmaf(y2[t], cur[u].y, a);
+        acc[u][t] = __builtin_fmaf(y3[t], cur[u].z, a);
       }
+      // one compare per row: min over the wave's T chunks (v_min3_f32) against the row threshold
+      float mn = acc[u][0];
+#pragma unroll
+      for (int t = 1; t < T; t++) mn = __builtin_fminf(mn, acc[u][t]);
+      mu[u] = __ballot(mn < cur[u].w);
+      any |= mu[u];
     }
-    if (any) {  // rare: a few % of row groups have a candidate in this slice
+    if (any) {  // rare: some row of the group has a candidate among this wave's 64*T targets
 #pragma unroll
       for (int u = 0; u < RU; u++) {
-        if (r + u < r1) {
+        if (mu[u]) {
           unsigned long long mine = 0;
           unsigned fl = 0;
 #pragma unroll
           for (int t = 0; t < T; t++) {
-            if (lane == t) mine = m[u][t];
-            fl |= (m[u][t] != 0 ? 1u : 0u) << t;
+            const unsigned long long m = __ballot(acc[u][t] < cur[u].w);
+            if (lane == t) mine = m;
+            fl |= (m != 0 ? 1u : 0u) << t;
           }
-          if (fl) {
-            if (lane < T && mine) masks[(size_t)(r + u) * nchunks + slice * T + lane] = mine;
-            if (lane == 0) flags[(size_t)(r + u) * nsl_pad + slice] = (unsigned short)fl;
-          }
+          if (lane < T && mine) masks[(size_t)(r + u) * nchunks + slice * T + lane] = mine;
+          if (lane == 0) flags[(size_t)(r + u) * nsl_pad + slice] = (unsigned short)fl;
         }
       }
     }
@@ -401,6 +407,7 @@ __global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ desc
 // launch before the first iteration (no bookkeeping, state comes from the host).
 // ------------------------------------------------------------------------------------------
 constexpr int STEP_THREADS = 1024;
+constexpr int XCULL_PAD = 32;  // >= 2 * the largest RU of k_scan
 
 template <bool INIT>
 __global__ __launch_bounds__(STEP_THREADS) void k_step(const PairDesc* __restrict__ descs,
@@ -598,6 +605,8 @@ __global__ __launch_bounds__(STEP_THREADS) void k_step(const PairDesc* __restric
     if (!P.use_geo) cw = __builtin_inff();
     D->xcull[i] = make_float4(-2.f * ux, -2.f * uy, -2.f * uz, cw);
   }
+  // never-passing pad rows so k_scan can run whole row groups and prefetch past the end
+  for (int i = N + tid; i < N + XCULL_PAD; i += STEP_THREADS) D->xcull[i] = make_float4(0.f, 0.f, 0.f, -__builtin_inff());
 }
 
 }  // namespace cvo_dev
