@@ -34,7 +34,7 @@ struct DevParams {
   int trace_dense, trace_every, trace_capacity;
   int mode;  // 0 = align loop, 1 = single evaluation (inner product / association)
   int T;     // target chunks (of 64) per scan wave: 1, 2, 4 or 8
-  int rows_per_block;
+  int groups_per_block;  // row groups per k_scan block (a multiple of 64)
 };
 
 // Running state of one frame pair; lives in HBM, only touched by one thread of k_step.
@@ -54,6 +54,7 @@ struct PairState {
   double dist;
   double asum;  // sum of kernel values (mode 1)
   unsigned long long ncand;
+  unsigned long long noverflow;  // rows that took k_assoc's literal path
   int n_trace;
   float out_T[16];  // column-major [R^T | -R^T T]
   // A_sparsity_indicator_ell_update FIFOs (CvoGPU.cu:1167-1285)
@@ -63,33 +64,48 @@ struct PairState {
 };
 
 // Everything a kernel needs to know about one frame pair.
+//
+// Index spaces: "original" = the caller's point order (what the reference's ordered truncation and
+// float accumulation order are defined on); "sorted" = spatial (k-d) order computed once per cloud at
+// upload (xorder / yorder map sorted position -> original index).  k_scan works entirely in sorted
+// space so that 4-row groups and 64-target chunks are spatially compact and whole tiles can be
+// rejected by a bounding-box test; k_assoc maps candidates back and restores ascending original j.
 struct PairDesc {
-  int N, M, Mpad, nchunks, nslices, nsl_pad, nblk;
+  int N, M, Mpad, nchunks, nslices, nsl_pad, nblk_assoc, nblk_coeff;
+  int NG;     // row groups of ROWS_PER_GROUP sorted rows
+  int NGpad;  // NG rounded up for the coarse test (pad groups have empty boxes)
   float cx, cy, cz;  // centre subtracted in the cull arithmetic only
   const float4* x4;
   const float4* xfeat;
   const float4* xlabel;
   const float2* xgeo;
+  const int* xorder;
   const float4* y4;
   const float4* yfeat;
   const float4* ylabel;
   const float2* ygeo;
-  float4* yt4;    // transformed targets, exact
-  float4* ycull;  // {y~x, y~y, y~z, |y~|^2}, y~ = yt - centre; pads are {0,0,0,+inf}
-  float4* xcull;  // {-2x~x, -2x~y, -2x~z, thres_i + margin_i - |x~|^2}
-  float2* rowc;   // {l_i, d2_thres_i}
-  unsigned long long* masks;  // [N][nchunks] candidate bit masks (valid where flagged)
-  unsigned short* flags;      // [N][nsl_pad] per (row, scan slice): which of its T chunks are non-empty
-  float* ell_a;               // ELL kernel matrix values, [K_max][N]
-  int* ell_j;                 // ELL column indices, [K_max][N]
-  unsigned* nnz_row;          // nonzeros[N]
-  double* flow_part;          // [nblk][8]: omega(3), v(3), sum a, pad
-  unsigned long long* cnt_part;  // [nblk][4]: nnz, max, candidates, pad
-  double* coef_part;          // [nblk][4]: B C D E
+  const int* yorder;
+  float4* yt4;    // transformed targets, exact, ORIGINAL index
+  float4* ycull;  // SORTED: {y~x, y~y, y~z, |y~|^2}, y~ = yt - centre; pads are {0,0,0,+inf}
+  float4* xcull;  // SORTED: {-2x~x, -2x~y, -2x~z, thres_i + margin_i - |x~|^2}
+  float2* rowc;   // ORIGINAL index: {l_i, d2_thres_i}
+  float4* gbox;   // [NGpad][2]: AABB of each sorted row group, grown by the group's cut-off radius
+  float4* cbox;   // [nchunks][2]: AABB of each 64-target sorted chunk
+  float4* sbox;   // [nslices][2]: AABB of each scan slice (T chunks)
+  unsigned long long* masks;  // [N sorted rows][nchunks] candidate bit masks (valid where flagged)
+  unsigned short* flags;      // [N sorted rows][nsl_pad]: which of a slice's T chunks are non-empty
+  float* ell_a;               // ELL kernel matrix values, [K_max][N], ORIGINAL row index
+  int* ell_j;                 // ELL column indices (original j), [K_max][N]
+  unsigned* nnz_row;          // nonzeros[N], ORIGINAL row index
+  double* flow_part;          // [nblk_assoc][8]: omega(3), v(3), sum a, pad
+  unsigned long long* cnt_part;  // [nblk_assoc][4]: nnz, max, candidates, overflow rows
+  double* coef_part;          // [nblk_coeff][4]: B C D E
   PairState* st;
   cvo_trace_t* trace;
   int* status_out;  // mirror of st->status for cheap host polling
 };
+
+constexpr int ROWS_PER_GROUP = 4;
 
 // ---- arithmetic conventions (DESIGN.md "Numerics") ------------------------------------------
 __device__ __forceinline__ float dot3_dev(float a0, float a1, float a2, float b0, float b1, float b2) {

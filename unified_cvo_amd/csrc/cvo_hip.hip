@@ -1,6 +1,6 @@
 // cvo_hip.hip -- host side of the C-ABI declared in include/cvo_hip.h: contexts, HBM-resident
 // clouds, workspace layout, and the enqueue-only optimiser loop (hipGraph replays of
-// [k_scan, k_assoc, k_coeff, k_step] with a device-side status word; no host round trip per
+// [k_scan, k_assoc, k_coeff, k_update, k_prep] with a device-side status word; no host round trip per
 // iteration, unlike the ~15 blocking syncs per iteration of CvoGPU.cu:1387-1533).
 #include <hip/hip_runtime.h>
 
@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,20 +26,22 @@ struct cvo_cloud {
   float4* feat;   // 2 float4 per point
   float4* label;  // 5 float4 per point
   float2* geo;
+  int* order;        // spatial (k-d) order: sorted position -> original index
   float cx, cy, cz;  // centroid (used only as the cull centre)
 };
 
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t yt4, ycull, xcull, rowc, masks, flags, ell_a, ell_j, nnz_row, flow_part, cnt_part, coef_part, trace,
-      total;
+  size_t yt4, ycull, xcull, rowc, gbox, cbox, sbox, masks, flags, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+      coef_part, trace, total;
 };
 
 struct GraphKey {
-  int n_pairs, T, gx, gy, nblk, U;
+  int n_pairs, T, gx, gy, nba, nbc, npb, idx16, U;
   bool operator==(const GraphKey& o) const {
-    return n_pairs == o.n_pairs && T == o.T && gx == o.gx && gy == o.gy && nblk == o.nblk && U == o.U;
+    return n_pairs == o.n_pairs && T == o.T && gx == o.gx && gy == o.gy && nba == o.nba && nbc == o.nbc &&
+           npb == o.npb && idx16 == o.idx16 && U == o.U;
   }
 };
 
@@ -65,7 +68,7 @@ struct cvo_ctx {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   // graph cache
   hipGraphExec_t graph_exec = nullptr;
-  GraphKey graph_key{0, 0, 0, 0, 0, 0};
+  GraphKey graph_key{0, 0, 0, 0, 0, 0, 0, 0, 0};
   // last call (debug hooks)
   int last_pairs = 0;
   int last_N = 0, last_M = 0, last_Kmax = 0;
@@ -88,12 +91,18 @@ int fail(cvo_ctx* ctx, int code, const std::string& msg) {
       return fail(ctx, CVO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));           \
   } while (0)
 
-PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, int* Mpad_out, int* nchunks_out,
-                       int* nsl_pad_out, int* nblk_out) {
+struct Dims {
+  int Mpad, nchunks, nsl_pad, nblk_assoc, nblk_coeff, NG, NGpad;
+};
+
+PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   const int Mpad = (int)align_up((size_t)M, 512);
   const int nchunks = Mpad / 64;
   const int nsl_pad = (int)align_up((size_t)nchunks, 8);  // enough for T = 1
-  const int nblk = (N + 255) / 256;
+  const int nba = (N + ASSOC_THREADS - 1) / ASSOC_THREADS;
+  const int nbc = (N + 255) / 256;
+  const int NG = (N + ROWS_PER_GROUP - 1) / ROWS_PER_GROUP;
+  const int NGpad = (int)align_up((size_t)NG, 64) + 64;
   PairLayout L{};
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -105,20 +114,26 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, int* Mpad_out
   L.ycull = take(sizeof(float4) * (size_t)Mpad);
   L.xcull = take(sizeof(float4) * (size_t)(N + XCULL_PAD));
   L.rowc = take(sizeof(float2) * (size_t)N);
+  L.gbox = take(sizeof(float4) * 2 * (size_t)NGpad);
+  L.cbox = take(sizeof(float4) * 2 * (size_t)nchunks);
+  L.sbox = take(sizeof(float4) * 2 * (size_t)nchunks);
   L.masks = take(sizeof(unsigned long long) * (size_t)N * nchunks);
   L.flags = take(sizeof(unsigned short) * (size_t)N * nsl_pad);
   L.ell_a = take(sizeof(float) * (size_t)N * Kmax);
   L.ell_j = take(sizeof(int) * (size_t)N * Kmax);
   L.nnz_row = take(sizeof(unsigned) * (size_t)N);
-  L.flow_part = take(sizeof(double) * 8 * (size_t)nblk);
-  L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)nblk);
-  L.coef_part = take(sizeof(double) * 4 * (size_t)nblk);
+  L.flow_part = take(sizeof(double) * 8 * (size_t)nba);
+  L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)nba);
+  L.coef_part = take(sizeof(double) * 4 * (size_t)nbc);
   L.trace = take(sizeof(cvo_trace_t) * (size_t)std::max(trace_capacity, 0));
   L.total = off;
-  *Mpad_out = Mpad;
-  *nchunks_out = nchunks;
-  *nsl_pad_out = nsl_pad;
-  *nblk_out = nblk;
+  d->Mpad = Mpad;
+  d->nchunks = nchunks;
+  d->nsl_pad = nsl_pad;
+  d->nblk_assoc = nba;
+  d->nblk_coeff = nbc;
+  d->NG = NG;
+  d->NGpad = NGpad;
   return L;
 }
 
@@ -211,57 +226,68 @@ DevParams make_dev_params(const cvo_params_t& p) {
   return d;
 }
 
-// Scan geometry: T chunks per wave and rows per block, chosen so a launch has a few thousand
-// waves (256 CUs x 4 SIMDs want >= 2..4 waves each) without making waves trivially short.
-void choose_scan_config(int n_pairs, int N, int Mpad, int* T_out, int* rpb_out) {
-  const long target_waves = 4096;
-  int T = 8;
-  while (T > 1) {
-    const long slices = Mpad / (64 * T);
-    const long waves = slices * ((N + 63) / 64) * n_pairs;
-    if (waves >= target_waves) break;
-    T >>= 1;
-  }
-  const long slices = Mpad / (64 * T);
-  int rpb = 256;
-  while (rpb > 16) {
-    const long waves = slices * ((N + rpb - 1) / rpb) * n_pairs;
-    if (waves >= target_waves) break;
-    rpb >>= 1;
-  }
+// Scan geometry: T chunks of 64 sorted targets per wave (smaller slices cull better, larger ones
+// amortise the row operands) and the number of row groups per block, chosen so that a launch has a
+// few thousand waves (256 CUs x 4 SIMDs want several waves each).
+void choose_scan_config(int n_pairs, int NG, int Mpad, int* T_out, int* gpb_out) {
+  int T = 2;
   const char* eT = getenv("CVO_SCAN_T");
-  const char* eR = getenv("CVO_SCAN_ROWS");
   if (eT) {
     int v = atoi(eT);
     if (v == 1 || v == 2 || v == 4 || v == 8) T = v;
   }
-  if (eR) {
-    int v = atoi(eR);
-    if (v >= 8 && v % 8 == 0) rpb = v;
+  // Measured on MI355X (64 x 10k x 10k): 128-group blocks beat larger ones by 1.6x; work per wave is
+  // very uneven after culling, so many short waves balance better than few long ones.
+  (void)n_pairs;
+  (void)Mpad;
+  int gpb = std::min(128, (int)align_up((size_t)NG, 64));
+  const char* eG = getenv("CVO_SCAN_GROUPS");
+  if (eG) {
+    int v = atoi(eG);
+    if (v >= 64 && v % 64 == 0) gpb = v;
   }
   *T_out = T;
-  *rpb_out = rpb;
+  *gpb_out = gpb;
 }
 
 void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const DevParams* dp, int force) {
   switch (T) {
-    case 1: hipLaunchKernelGGL((k_scan<1, 8>), grid, dim3(256), 0, s, descs, dp, force); break;
-    case 2: hipLaunchKernelGGL((k_scan<2, 4>), grid, dim3(256), 0, s, descs, dp, force); break;
-    case 4: hipLaunchKernelGGL((k_scan<4, 4>), grid, dim3(256), 0, s, descs, dp, force); break;
-    default: hipLaunchKernelGGL((k_scan<8, 2>), grid, dim3(256), 0, s, descs, dp, force); break;
+    case 1: hipLaunchKernelGGL(k_scan<1>, grid, dim3(256), 0, s, descs, dp, force); break;
+    case 2: hipLaunchKernelGGL(k_scan<2>, grid, dim3(256), 0, s, descs, dp, force); break;
+    case 4: hipLaunchKernelGGL(k_scan<4>, grid, dim3(256), 0, s, descs, dp, force); break;
+    default: hipLaunchKernelGGL(k_scan<8>, grid, dim3(256), 0, s, descs, dp, force); break;
   }
 }
 
-void launch_iteration(cvo_ctx* c, int n_pairs, int T, int gx, int gy, int nblk) {
-  launch_scan(c->stream, T, dim3(gx, gy, n_pairs), c->d_descs, c->d_params, 0);
-  hipLaunchKernelGGL(k_assoc, dim3(nblk, n_pairs), dim3(256), 0, c->stream, c->d_descs, c->d_params);
-  hipLaunchKernelGGL(k_coeff, dim3(nblk, n_pairs), dim3(256), 0, c->stream, c->d_descs, c->d_params);
-  hipLaunchKernelGGL(k_step<false>, dim3(n_pairs), dim3(STEP_THREADS), 0, c->stream, c->d_descs, c->d_params);
+void launch_assoc(hipStream_t s, bool idx16, dim3 grid, const PairDesc* descs, const DevParams* dp) {
+  if (idx16)
+    hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16>), grid, dim3(ASSOC_THREADS), 0, s, descs, dp);
+  else
+    hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32>), grid, dim3(ASSOC_THREADS), 0, s, descs, dp);
+}
+
+struct LaunchGeom {
+  int n_pairs, T, gx, gy, nba, nbc, npb;
+  bool idx16;
+};
+
+void launch_prep(cvo_ctx* c, const LaunchGeom& g) {
+  hipLaunchKernelGGL(k_prep, dim3(g.npb, g.n_pairs), dim3(PREP_THREADS), 0, c->stream, c->d_descs, c->d_params);
+}
+
+void launch_iteration(cvo_ctx* c, const LaunchGeom& g) {
+  launch_scan(c->stream, g.T, dim3(g.gx, g.gy, g.n_pairs), c->d_descs, c->d_params, 0);
+  launch_assoc(c->stream, g.idx16, dim3(g.nba, g.n_pairs), c->d_descs, c->d_params);
+  hipLaunchKernelGGL(k_coeff, dim3(g.nbc, g.n_pairs), dim3(256), 0, c->stream, c->d_descs, c->d_params);
+  hipLaunchKernelGGL(k_update<false>, dim3(g.n_pairs), dim3(64), 0, c->stream, c->d_descs, c->d_params);
+  launch_prep(c, g);
 }
 
 struct BatchSetup {
-  int N, M, Mpad, nchunks, nsl_pad, nblk, T, rpb, gx, gy;
+  int N, M, T, gpb, gx, gy;
+  Dims d;
   PairLayout L;
+  LaunchGeom geom;
 };
 
 // Builds descriptors + initial states for a batch and uploads them.
@@ -289,15 +315,15 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   const int Kmax = params->nearest_neighbors_max;
   S->N = N;
   S->M = M;
-  S->L = make_layout(N, M, Kmax, trace_cap, &S->Mpad, &S->nchunks, &S->nsl_pad, &S->nblk);
+  S->L = make_layout(N, M, Kmax, trace_cap, &S->d);
   int rc = ensure_workspace(ctx, n_pairs, S->L.total);
   if (rc != CVO_OK) return rc;
-  choose_scan_config(n_pairs, N, S->Mpad, &S->T, &S->rpb);
+  choose_scan_config(n_pairs, S->d.NG, S->d.Mpad, &S->T, &S->gpb);
 
   DevParams dp = make_dev_params(*params);
   dp.mode = mode;
   dp.T = S->T;
-  dp.rows_per_block = S->rpb;
+  dp.groups_per_block = S->gpb;
   if (opts && opts->max_iterations > 0) dp.max_iter = std::min(dp.max_iter, opts->max_iterations);
   dp.trace_capacity = trace_cap;
   dp.trace_dense = opts ? opts->trace_dense : 0;
@@ -314,12 +340,15 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     std::memset(&D, 0, sizeof(D));
     D.N = X->n;
     D.M = Y->n;
-    // per-pair padding derived from the batch maxima so every pair shares one launch geometry
-    D.Mpad = S->Mpad;
-    D.nchunks = S->nchunks;
-    D.nslices = S->Mpad / (64 * S->T);
-    D.nsl_pad = S->nsl_pad;
-    D.nblk = S->nblk;
+    // paddings are derived from the batch maxima so every pair shares one launch geometry
+    D.Mpad = S->d.Mpad;
+    D.nchunks = S->d.nchunks;
+    D.nslices = S->d.Mpad / (64 * S->T);
+    D.nsl_pad = S->d.nsl_pad;
+    D.nblk_assoc = S->d.nblk_assoc;
+    D.nblk_coeff = S->d.nblk_coeff;
+    D.NG = (X->n + ROWS_PER_GROUP - 1) / ROWS_PER_GROUP;
+    D.NGpad = S->d.NGpad;
     D.cx = X->cx;
     D.cy = X->cy;
     D.cz = X->cz;
@@ -327,14 +356,19 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.xfeat = X->feat;
     D.xlabel = X->label;
     D.xgeo = X->geo;
+    D.xorder = X->order;
     D.y4 = Y->x4;
     D.yfeat = Y->feat;
     D.ylabel = Y->label;
     D.ygeo = Y->geo;
+    D.yorder = Y->order;
     D.yt4 = (float4*)(base + S->L.yt4);
     D.ycull = (float4*)(base + S->L.ycull);
     D.xcull = (float4*)(base + S->L.xcull);
     D.rowc = (float2*)(base + S->L.rowc);
+    D.gbox = (float4*)(base + S->L.gbox);
+    D.cbox = (float4*)(base + S->L.cbox);
+    D.sbox = (float4*)(base + S->L.sbox);
     D.masks = (unsigned long long*)(base + S->L.masks);
     D.flags = (unsigned short*)(base + S->L.flags);
     D.ell_a = (float*)(base + S->L.ell_a);
@@ -361,7 +395,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
       st.K = opts->K0;
     }
     // flags must start clean (they are self-cleaning afterwards)
-    HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, sizeof(unsigned short) * (size_t)S->N * S->nsl_pad, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, sizeof(unsigned short) * (size_t)S->N * S->d.nsl_pad, ctx->stream));
   }
   // the blocks of k_assoc beyond a smaller pair's N still write their (zero) partials, but the
   // partial arrays of pairs whose N is smaller than the batch maximum are fully covered by nblk.
@@ -371,8 +405,16 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
                               hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int) * (size_t)n_pairs, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_params, &dp, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
-  S->gx = (S->Mpad / (64 * S->T) + 3) / 4;
-  S->gy = (N + S->rpb - 1) / S->rpb;
+  S->gx = (S->d.Mpad / (64 * S->T) + 3) / 4;
+  S->gy = ((int)align_up((size_t)S->d.NG, 64) + S->gpb - 1) / S->gpb;
+  S->geom.n_pairs = n_pairs;
+  S->geom.T = S->T;
+  S->geom.gx = S->gx;
+  S->geom.gy = S->gy;
+  S->geom.nba = S->d.nblk_assoc;
+  S->geom.nbc = S->d.nblk_coeff;
+  S->geom.npb = S->d.Mpad / PREP_THREADS + (S->d.NGpad * ROWS_PER_GROUP + PREP_THREADS - 1) / PREP_THREADS;
+  S->geom.idx16 = M < 65536;
   ctx->last_pairs = n_pairs;
   ctx->last_N = N;
   ctx->last_M = M;
@@ -391,10 +433,11 @@ int run_single_eval(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
   const cvo_cloud* tgt[1] = {target};
   int rc = setup_batch(ctx, params, 1, src, tgt, Tm, nullptr, 1, ell, S, &dp);
   if (rc != CVO_OK) return rc;
-  hipLaunchKernelGGL(k_step<true>, dim3(1), dim3(STEP_THREADS), 0, ctx->stream, ctx->d_descs, ctx->d_params);
+  hipLaunchKernelGGL(k_update<true>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params);
+  launch_prep(ctx, S->geom);
   launch_scan(ctx->stream, S->T, dim3(S->gx, S->gy, 1), ctx->d_descs, ctx->d_params, 0);
-  hipLaunchKernelGGL(k_assoc, dim3(S->nblk, 1), dim3(256), 0, ctx->stream, ctx->d_descs, ctx->d_params);
-  hipLaunchKernelGGL(k_step<false>, dim3(1), dim3(STEP_THREADS), 0, ctx->stream, ctx->d_descs, ctx->d_params);
+  launch_assoc(ctx->stream, S->geom.idx16, dim3(S->d.nblk_assoc, 1), ctx->d_descs, ctx->d_params);
+  hipLaunchKernelGGL(k_update<false>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_states.data(), ctx->d_states, sizeof(PairState), hipMemcpyDeviceToHost,
                               ctx->stream));
@@ -508,6 +551,45 @@ int cvo_ctx_synchronize(cvo_ctx* ctx) {
   return CVO_OK;
 }
 
+// Spatial permutation of a cloud (sorted position -> original index): a balanced k-d ordering whose
+// splits fall on multiples of 512 / 64 / 4 points, so that every aligned run of 512, 64 (a k_scan
+// chunk) or 4 (a k_scan row group) consecutive sorted points is a compact box.  Only the speed of
+// k_scan's tile culling depends on it, never a result (CVO_NO_SORT=1 keeps the identity order).
+static void kd_split(std::vector<int>& idx, int lo, int hi, const std::vector<float>& x4) {
+  const int n = hi - lo;
+  if (n <= 4) return;
+  const int unit = n > 512 ? 512 : (n > 64 ? 64 : 4);
+  int left = ((n / 2 + unit - 1) / unit) * unit;
+  if (left >= n) left -= unit;
+  if (left <= 0) return;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = lo; k < hi; k++)
+    for (int c = 0; c < 3; c++) {
+      const float v = x4[4 * (size_t)idx[k] + c];
+      mn[c] = std::min(mn[c], v);
+      mx[c] = std::max(mx[c], v);
+    }
+  int axis = 0;
+  for (int c = 1; c < 3; c++)
+    if (mx[c] - mn[c] > mx[axis] - mn[axis]) axis = c;
+  std::nth_element(idx.begin() + lo, idx.begin() + lo + left, idx.begin() + hi, [&](int a, int b) {
+    const float va = x4[4 * (size_t)a + axis], vb = x4[4 * (size_t)b + axis];
+    return va < vb || (va == vb && a < b);
+  });
+  kd_split(idx, lo, lo + left, x4);
+  kd_split(idx, lo + left, hi, x4);
+}
+
+static void spatial_order(const std::vector<float>& x4, int n, std::vector<int>& order) {
+  order.resize(n);
+  for (int i = 0; i < n; i++) order[i] = i;
+  if (n < 8 || getenv("CVO_NO_SORT")) return;
+  for (int i = 0; i < n; i++)
+    for (int c = 0; c < 3; c++)
+      if (!std::isfinite(x4[4 * (size_t)i + c])) return;  // keep the identity order for odd inputs
+  kd_split(order, 0, n, x4);
+}
+
 static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, const std::vector<float>& feat,
                          const std::vector<float>& label, const std::vector<float>& geo, cvo_cloud** out) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -532,6 +614,7 @@ static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, cons
   if (e == hipSuccess) e = hipMalloc(&c->feat, sizeof(float4) * 2 * nn);
   if (e == hipSuccess) e = hipMalloc(&c->label, sizeof(float4) * 5 * nn);
   if (e == hipSuccess) e = hipMalloc(&c->geo, sizeof(float2) * nn);
+  if (e == hipSuccess) e = hipMalloc(&c->order, sizeof(int) * nn);
   if (e != hipSuccess) {
     cvo_cloud_free(c);
     return fail(ctx, CVO_E_NOMEM, std::string("cloud hipMalloc: ") + hipGetErrorString(e));
@@ -543,6 +626,9 @@ static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, cons
     HIP_TRY(ctx, hipMemcpyAsync(c->label, label.data(), sizeof(float) * NC_PAD * (size_t)n, hipMemcpyHostToDevice,
                                 ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(c->geo, geo.data(), sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<int> order;
+    spatial_order(x4, n, order);
+    HIP_TRY(ctx, hipMemcpyAsync(c->order, order.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the staging vectors die with the caller
   }
   *out = c;
@@ -592,6 +678,7 @@ void cvo_cloud_free(cvo_cloud* c) {
   if (c->feat) (void)hipFree(c->feat);
   if (c->label) (void)hipFree(c->label);
   if (c->geo) (void)hipFree(c->geo);
+  if (c->order) (void)hipFree(c->order);
   delete c;
 }
 
@@ -612,12 +699,13 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   const bool use_graph = graph_mode != 1;
 
   HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-  hipLaunchKernelGGL(k_step<true>, dim3(n_pairs), dim3(STEP_THREADS), 0, ctx->stream, ctx->d_descs, ctx->d_params);
+  hipLaunchKernelGGL(k_update<true>, dim3(n_pairs), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params);
+  launch_prep(ctx, S.geom);
   HIP_TRY(ctx, hipGetLastError());
 
   if (max_iter > 0) {
     if (use_graph) {
-      GraphKey key{n_pairs, S.T, S.gx, S.gy, S.nblk, U};
+      GraphKey key{n_pairs, S.T, S.gx, S.gy, S.d.nblk_assoc, S.d.nblk_coeff, S.geom.npb, S.geom.idx16 ? 1 : 0, U};
       if (!ctx->graph_exec || !(ctx->graph_key == key)) {
         if (ctx->graph_exec) {
           (void)hipGraphExecDestroy(ctx->graph_exec);
@@ -625,7 +713,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
         }
         hipGraph_t g = nullptr;
         HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        for (int u = 0; u < U; u++) launch_iteration(ctx, n_pairs, S.T, S.gx, S.gy, S.nblk);
+        for (int u = 0; u < U; u++) launch_iteration(ctx, S.geom);
         HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &g));
         hipError_t e = hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
@@ -640,7 +728,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       if (use_graph) {
         HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
       } else {
-        for (int u = 0; u < U; u++) launch_iteration(ctx, n_pairs, S.T, S.gx, S.gy, S.nblk);
+        for (int u = 0; u < U; u++) launch_iteration(ctx, S.geom);
         HIP_TRY(ctx, hipGetLastError());
       }
       const int slot = ch & 1;

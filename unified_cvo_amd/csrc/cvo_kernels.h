@@ -1,22 +1,26 @@
 // cvo_kernels.h -- the hand-written gfx950 kernels of the pairwise align() hot path.
 //
-// One optimiser iteration of every in-flight frame pair is four launches (blockIdx.z/y = pair):
+// One optimiser iteration of every in-flight frame pair is five launches (blockIdx.z/y = pair):
 //
-//   k_scan   N x M candidate scan.  Replaces the O(N*M) part of fill_in_A_mat_gpu
-//            (CvoGPU.cu:477-593).  Lanes hold targets (coalesced float4 loads of the SoA
-//            `ycull`), source rows are wave-uniform (scalar loads of `xcull`): per 64 pairs it
-//            issues 3 v_fma_f32 + 1 v_cmp_lt_f32 whose 64-bit lane mask IS the row-major
-//            candidate bitmap word.  Non-empty words (a few %) are stored with a flag.
-//   k_assoc  one thread per source row walks its flagged mask words in ascending j and runs the
-//            reference's exact per-pair arithmetic (double exp, colour / semantic kernels,
-//            a > sp_thres, first-K truncation), writes the ELL matrix and accumulates the
-//            per-row flow (compute_flow_gpu_no_eigen, CvoGPU.cu:729-790).
+//   k_scan   N x M candidate scan in spatially sorted index space.  Replaces the O(N*M) part of
+//            fill_in_A_mat_gpu (CvoGPU.cu:477-593).  Lanes hold targets (coalesced float4 loads of
+//            the SoA `ycull`), source rows are wave-uniform (scalar loads of `xcull`).  Coarse
+//            level: 64 four-row groups at a time are tested box-against-box with the wave's target
+//            slice; only overlapping tiles get the fine test of 3 v_fma_f32 per 64 pairs, a
+//            v_min3 tree and one v_cmp whose lane mask IS the candidate bitmap word.
+//   k_assoc  one thread per source row gathers its candidates, restores ascending ORIGINAL j
+//            (insertion sort in LDS) and runs the reference's exact per-pair arithmetic (double
+//            exp, colour / semantic kernels, a > sp_thres, first-K truncation), writes the ELL
+//            matrix and accumulates the per-row flow (compute_flow_gpu_no_eigen,
+//            CvoGPU.cu:729-790).  Rows with more candidates than the LDS list holds run the
+//            reference's literal ordered scan over all targets.
 //   k_coeff  reduces the flow partials to the normalised twist, then one thread per row
 //            accumulates B,C,D,E (compute_step_size_xi + _poly_coeff, CvoGPU.cu:953-1082).
-//   k_step   one block per pair: reduces B..E, runs the reference's host-side scalar code on
-//            one thread (cubic, Exp, pose update, SE(3) log, indicator, ell decay, K update;
-//            CvoGPU.cu:1122-1158, 1452-1531) and then prepares the next iteration
-//            (update_tf + transform_pointcloud_thrust + per-row cut-offs + cull operands).
+//   k_update one wave per pair: reduces B..E and runs the reference's host-side scalar code on one
+//            lane (cubic, Exp, pose update, SE(3) log, indicator, ell decay, K update;
+//            CvoGPU.cu:1122-1158, 1452-1531).
+//   k_prep   wide: prepares the next iteration (update_tf + transform_pointcloud_thrust + per-row
+//            cut-offs + cull operands + bounding boxes).
 //
 // No host round trip happens inside the loop; finished pairs early-exit on their status word.
 #pragma once
@@ -55,14 +59,16 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // Address-space qualified views: pointers read out of a PairDesc are generic ("flat") to the
 // compiler; the scan's hot pointers are re-qualified so that the target tile uses global_load,
 // and the wave-uniform row operands use s_load (constant address space => scalar cache; xcull is
-// written by the previous kernel, k_step, so it is read-only for the lifetime of k_scan).
+// written by the previous kernel, k_prep, so it is read-only for the lifetime of k_scan).
+constexpr int XCULL_PAD = 32;  // rows k_scan may read past N (whole groups + prefetch)
 #define CVO_GLOBAL __attribute__((address_space(1)))
 #define CVO_CONST __attribute__((address_space(4)))
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // plain vector: loadable from any address space
 
-template <int T, int RU>
+template <int T>
 __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
                                               int force) {
+  constexpr int RG = ROWS_PER_GROUP;
   const PairDesc* __restrict__ D = descs + blockIdx.z;
   if (!force && D->st->status != 0) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -70,11 +76,11 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
   const int slice = blockIdx.x * 4 + wave;
   const int nslices = D->nslices;
   if (slice >= nslices) return;
-  const int rpb = Pp->rows_per_block;  // a multiple of RU
-  const int N = D->N;
-  const int r0 = blockIdx.y * rpb;
-  if (r0 >= N) return;
-  const int r1 = min(r0 + rpb, N);
+  const int gpb = Pp->groups_per_block;  // a multiple of 64
+  const int NG = D->NG;
+  const int g_begin = blockIdx.y * gpb;
+  if (g_begin >= NG) return;
+  const int g_end = min(g_begin + gpb, NG);
 
   const CVO_GLOBAL f32x4* yc = (const CVO_GLOBAL f32x4*)D->ycull;
   float y1[T], y2[T], y3[T], yy[T];
@@ -86,58 +92,82 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
     y3[t] = q.z;
     yy[t] = q.w;
   }
-  // xcull is padded with never-passing rows (w = -inf) up to N + XCULL_PAD, so neither the last
-  // row group nor the prefetch of the group after it needs clamping.
-  const CVO_CONST f32x4* xr = (const CVO_CONST f32x4*)D->xcull + r0;
+  // bounding box of this wave's 64*T targets (wave-uniform -> scalar loads)
+  const CVO_CONST f32x4* sb = (const CVO_CONST f32x4*)D->sbox + 2 * slice;
+  const f32x4 smin = sb[0], smax = sb[1];
+  const CVO_GLOBAL f32x4* gbox = (const CVO_GLOBAL f32x4*)D->gbox;
+  const CVO_CONST f32x4* xc = (const CVO_CONST f32x4*)D->xcull;
   CVO_GLOBAL unsigned long long* masks = (CVO_GLOBAL unsigned long long*)D->masks;
   CVO_GLOBAL unsigned short* flags = (CVO_GLOBAL unsigned short*)D->flags;
   const int nchunks = D->nchunks;
   const int nsl_pad = D->nsl_pad;
 
-  f32x4 cur[RU], nxt[RU];
+  for (int gb = g_begin; gb < g_end; gb += 64) {
+    // ---- coarse level: lane l tests row group gb + l (boxes are already grown by the cut-off radius;
+    // pad groups carry empty boxes) against the slice box
+    const int g = gb + lane;
+    const f32x4 bmin = gbox[2 * (size_t)g], bmax = gbox[2 * (size_t)g + 1];
+    const bool overlap = (bmin.x <= smax.x) & (bmax.x >= smin.x) & (bmin.y <= smax.y) & (bmax.y >= smin.y) &
+                         (bmin.z <= smax.z) & (bmax.z >= smin.z) & (g < g_end);
+    unsigned long long todo = __ballot(overlap);
+    if (!todo) continue;
+    // ---- fine level over the overlapping groups, rows of the next group prefetched (scalar loads)
+    int b = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    f32x4 cur[RG], nxt[RG];
+    {
+      const CVO_CONST f32x4* xr = xc + (size_t)(gb + b) * RG;
 #pragma unroll
-  for (int u = 0; u < RU; u++) cur[u] = xr[u];
-  for (int r = r0; r < r1; r += RU) {
-    xr += RU;
-#pragma unroll
-    for (int u = 0; u < RU; u++) nxt[u] = xr[u];  // prefetch the next row group (scalar loads)
-    float acc[RU][T];
-    unsigned long long mu[RU];
-    unsigned long long any = 0;
-#pragma unroll
-    for (int u = 0; u < RU; u++) {
-#pragma unroll
-      for (int t = 0; t < T; t++) {
-        float a = __builtin_fmaf(y1[t], cur[u].x, yy[t]);
-        a = __builtin_fmaf(y2[t], cur[u].y, a);
-        acc[u][t] = __builtin_fmaf(y3[t], cur[u].z, a);
-      }
-      // one compare per row: min over the wave's T chunks (v_min3_f32) against the row threshold
-      float mn = acc[u][0];
-#pragma unroll
-      for (int t = 1; t < T; t++) mn = __builtin_fminf(mn, acc[u][t]);
-      mu[u] = __ballot(mn < cur[u].w);
-      any |= mu[u];
+      for (int u = 0; u < RG; u++) cur[u] = xr[u];
     }
-    if (any) {  // rare: some row of the group has a candidate among this wave's 64*T targets
+    for (;;) {
+      const int nb = todo ? __builtin_ctzll(todo) : b;
+      {
+        const CVO_CONST f32x4* xr = xc + (size_t)(gb + nb) * RG;
 #pragma unroll
-      for (int u = 0; u < RU; u++) {
-        if (mu[u]) {
-          unsigned long long mine = 0;
-          unsigned fl = 0;
+        for (int u = 0; u < RG; u++) nxt[u] = xr[u];
+      }
+      float acc[RG][T];
+      unsigned long long mu[RG];
+      unsigned long long any = 0;
 #pragma unroll
-          for (int t = 0; t < T; t++) {
-            const unsigned long long m = __ballot(acc[u][t] < cur[u].w);
-            if (lane == t) mine = m;
-            fl |= (m != 0 ? 1u : 0u) << t;
+      for (int u = 0; u < RG; u++) {
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+          float a = __builtin_fmaf(y1[t], cur[u].x, yy[t]);
+          a = __builtin_fmaf(y2[t], cur[u].y, a);
+          acc[u][t] = __builtin_fmaf(y3[t], cur[u].z, a);
+        }
+        float mn = acc[u][0];
+#pragma unroll
+        for (int t = 1; t < T; t++) mn = __builtin_fminf(mn, acc[u][t]);
+        mu[u] = __ballot(mn < cur[u].w);
+        any |= mu[u];
+      }
+      if (any) {  // some row of the group has a candidate among this wave's 64*T targets
+        const int r = (gb + b) * RG;
+#pragma unroll
+        for (int u = 0; u < RG; u++) {
+          if (mu[u]) {
+            unsigned long long mine = 0;
+            unsigned fl = 0;
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+              const unsigned long long m = __ballot(acc[u][t] < cur[u].w);
+              if (lane == t) mine = m;
+              fl |= (m != 0 ? 1u : 0u) << t;
+            }
+            if (lane < T && mine) masks[(size_t)(r + u) * nchunks + slice * T + lane] = mine;
+            if (lane == 0) flags[(size_t)(r + u) * nsl_pad + slice] = (unsigned short)fl;
           }
-          if (lane < T && mine) masks[(size_t)(r + u) * nchunks + slice * T + lane] = mine;
-          if (lane == 0) flags[(size_t)(r + u) * nsl_pad + slice] = (unsigned short)fl;
         }
       }
-    }
+      if (!todo) break;
+      b = nb;
+      todo &= todo - 1;
 #pragma unroll
-    for (int u = 0; u < RU; u++) cur[u] = nxt[u];
+      for (int u = 0; u < RG; u++) cur[u] = nxt[u];
+    }
   }
 }
 
@@ -206,29 +236,72 @@ __device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __
 }
 
 // ------------------------------------------------------------------------------------------
-// k_assoc: ordered association + flow, one thread per source row.
+// k_assoc: ordered association + flow, one thread per (sorted) source row.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_assoc(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp) {
+constexpr int ASSOC_THREADS = 128;
+// candidates per row the sorted per-thread LDS list holds: 64 with 16-bit indices (M < 65536, 16.6 KB
+// per block so ~9 blocks share a CU), 32 with 32-bit indices
+constexpr int ASSOC_CAP16 = 64;
+constexpr int ASSOC_CAP32 = 32;
+
+struct RowAcc {
+  float o0 = 0, o1 = 0, o2 = 0, v0 = 0, v1 = 0, v2 = 0;
+  double asum = 0;
+  unsigned nnz = 0;
+};
+
+// One accepted/rejected pair (i, j): CvoGPU.cu:528-589 + the flow terms of 758-782.
+__device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* __restrict__ D, int i, int N,
+                                           const RowData& r, const V3& pxe, int j, RowAcc& A) {
+  float a;
+  float4 yt;
+  if (!eval_pair(P, D, i, r, j, a, yt)) return;
+  if (a > P.sp_thres) {
+    D->ell_a[(size_t)A.nnz * N + i] = a;
+    D->ell_j[(size_t)A.nnz * N + i] = j;
+    A.nnz++;
+    const V3 pye{yt.x, yt.y, yt.z};
+    const V3 cr = cross_dev(pxe, pye);
+    const float dx = pye.x - pxe.x, dy = pye.y - pxe.y, dz = pye.z - pxe.z;
+    A.o0 = __builtin_fmaf(cr.x, a, A.o0);
+    A.o1 = __builtin_fmaf(cr.y, a, A.o1);
+    A.o2 = __builtin_fmaf(cr.z, a, A.o2);
+    A.v0 = __builtin_fmaf(dx, a, A.v0);
+    A.v1 = __builtin_fmaf(dy, a, A.v1);
+    A.v2 = __builtin_fmaf(dz, a, A.v2);
+    A.asum += (double)a;
+  }
+}
+
+template <typename IdxT, int ASSOC_CAP>
+__global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restrict__ descs,
+                                                          const DevParams* __restrict__ Pp) {
+  constexpr int ASSOC_STRIDE = ASSOC_CAP + 1;  // odd stride: conflict-free per-thread lists
   const PairDesc* __restrict__ D = descs + blockIdx.y;
   PairState* st = D->st;
   if (st->status != 0) return;
   const DevParams P = *Pp;
-  const int N = D->N;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int N = D->N, M = D->M;
+  const int r_sorted = blockIdx.x * ASSOC_THREADS + threadIdx.x;
   const int K = st->K;
   const int T = P.T;
-  float o0 = 0, o1 = 0, o2 = 0, v0 = 0, v1 = 0, v2 = 0;
-  double asum = 0;
-  unsigned nnz = 0;
+  __shared__ IdxT s_list[ASSOC_THREADS * ASSOC_STRIDE];
+  IdxT* list = s_list + threadIdx.x * ASSOC_STRIDE;
+  RowAcc A;
   unsigned long long ncand = 0;
-  if (i < N) {
+  unsigned overflowed = 0;
+  if (r_sorted < N) {
+    const int i = D->xorder[r_sorted];
     const float4 x = D->x4[i];
     const float2 rc = D->rowc[i];
     const RowData r{x.x, x.y, x.z, rc.x, rc.y};
     const V3 pxe{x.x, x.y, x.z};
-    unsigned short* frow = D->flags + (size_t)i * D->nsl_pad;
-    const unsigned long long* mrow = D->masks + (size_t)i * D->nchunks;
+    // ---- gather this row's candidates (sorted-space bitmap) and restore ascending original j
+    unsigned short* frow = D->flags + (size_t)r_sorted * D->nsl_pad;
+    const unsigned long long* mrow = D->masks + (size_t)r_sorted * D->nchunks;
+    const int* yorder = D->yorder;
     const int nsl = D->nslices;
+    int cnt = 0;
     for (int s0 = 0; s0 < nsl; s0 += 8) {
       uint4 w = *reinterpret_cast<const uint4*>(frow + s0);
       if ((w.x | w.y | w.z | w.w) == 0) continue;
@@ -243,61 +316,75 @@ __global__ __launch_bounds__(256) void k_assoc(const PairDesc* __restrict__ desc
           const int chunk = (s0 + h) * T + t;
           unsigned long long m = mrow[chunk];
           ncand += (unsigned long long)__builtin_popcountll(m);
-          while (m && nnz < (unsigned)K) {  // `if (num_inds == num_neighbors) break;` CvoGPU.cu:526
+          while (m && !overflowed) {
             const int b = __builtin_ctzll(m);
             m &= m - 1;
-            const int j = chunk * 64 + b;
-            float a;
-            float4 yt;
-            if (!eval_pair(P, D, i, r, j, a, yt)) continue;
-            if (a > P.sp_thres) {  // CvoGPU.cu:576-589
-              D->ell_a[(size_t)nnz * N + i] = a;
-              D->ell_j[(size_t)nnz * N + i] = j;
-              nnz++;
-              // compute_flow_gpu_no_eigen, CvoGPU.cu:758-782 (float accumulation in j order)
-              const V3 pye{yt.x, yt.y, yt.z};
-              const V3 cr = cross_dev(pxe, pye);
-              const float dx = pye.x - pxe.x, dy = pye.y - pxe.y, dz = pye.z - pxe.z;
-              o0 = __builtin_fmaf(cr.x, a, o0);
-              o1 = __builtin_fmaf(cr.y, a, o1);
-              o2 = __builtin_fmaf(cr.z, a, o2);
-              v0 = __builtin_fmaf(dx, a, v0);
-              v1 = __builtin_fmaf(dy, a, v1);
-              v2 = __builtin_fmaf(dz, a, v2);
-              asum += (double)a;
+            const int j = yorder[chunk * 64 + b];
+            if (cnt == ASSOC_CAP) {
+              overflowed = 1;
+              break;
             }
+            int k = cnt++;  // insertion sort, ascending j
+            while (k > 0 && (int)list[k - 1] > j) {
+              list[k] = list[k - 1];
+              k--;
+            }
+            list[k] = (IdxT)j;
           }
         }
       }
     }
-    D->nnz_row[i] = nnz;
+    if (!overflowed) {
+      for (int k = 0; k < cnt && A.nnz < (unsigned)K; k++) visit_pair(P, D, i, N, r, pxe, (int)list[k], A);
+    } else {
+      // more candidates than the list holds (dense regime): the reference's literal ordered scan,
+      // `if (num_inds == num_neighbors) break;` included (CvoGPU.cu:524-527)
+      for (int j = 0; j < M && A.nnz < (unsigned)K; j++) visit_pair(P, D, i, N, r, pxe, j, A);
+    }
+    D->nnz_row[i] = A.nnz;
   }
   // per-row (omega_i / c, v_i / d) cast to double, then reduced in double (CvoGPU.cu:784-787, 824-825)
-  double red[7] = {(double)(o0 / P.c), (double)(o1 / P.c), (double)(o2 / P.c), (double)(v0 / P.d),
-                   (double)(v1 / P.d), (double)(v2 / P.d), asum};
-  __shared__ double s_red[4][8];
-  __shared__ unsigned long long s_cnt[4][3];
+  double red[7] = {(double)(A.o0 / P.c), (double)(A.o1 / P.c), (double)(A.o2 / P.c), (double)(A.v0 / P.d),
+                   (double)(A.v1 / P.d), (double)(A.v2 / P.d), A.asum};
+  constexpr int NW = ASSOC_THREADS / 64;
+  __shared__ double s_red[NW][8];
+  __shared__ unsigned long long s_cnt[NW][4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int c = 0; c < 7; c++) red[c] = wave_sum(red[c]);
-  unsigned long long nn = wave_sum_u64(nnz);
-  unsigned mx = wave_max_u32(nnz);
-  unsigned long long nc = wave_sum_u64(ncand);
+  const unsigned long long nn = wave_sum_u64(A.nnz);
+  const unsigned mx = wave_max_u32(A.nnz);
+  const unsigned long long nc = wave_sum_u64(ncand);
+  const unsigned long long nov = wave_sum_u64(overflowed);
   if (lane == 0) {
 #pragma unroll
     for (int c = 0; c < 7; c++) s_red[wave][c] = red[c];
     s_cnt[wave][0] = nn;
     s_cnt[wave][1] = mx;
     s_cnt[wave][2] = nc;
+    s_cnt[wave][3] = nov;
   }
   __syncthreads();
   if (threadIdx.x < 7) {
     const int c = threadIdx.x;
-    D->flow_part[(size_t)blockIdx.x * 8 + c] = ((s_red[0][c] + s_red[1][c]) + s_red[2][c]) + s_red[3][c];
+    double t = s_red[0][c];
+#pragma unroll
+    for (int w = 1; w < NW; w++) t += s_red[w][c];
+    D->flow_part[(size_t)blockIdx.x * 8 + c] = t;
   } else if (threadIdx.x == 8) {
-    D->cnt_part[(size_t)blockIdx.x * 4 + 0] = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
-    D->cnt_part[(size_t)blockIdx.x * 4 + 1] = max(max(s_cnt[0][1], s_cnt[1][1]), max(s_cnt[2][1], s_cnt[3][1]));
-    D->cnt_part[(size_t)blockIdx.x * 4 + 2] = s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2];
+    unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      a0 += s_cnt[w][0];
+      a1 = max(a1, s_cnt[w][1]);
+      a2 += s_cnt[w][2];
+      a3 += s_cnt[w][3];
+    }
+    unsigned long long* cp = D->cnt_part + (size_t)blockIdx.x * 4;
+    cp[0] = a0;
+    cp[1] = a1;
+    cp[2] = a2;
+    cp[3] = a3;
   }
 }
 
@@ -313,7 +400,7 @@ __global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ desc
   __shared__ double s_ov[6];
   __shared__ XiMats s_M;
   __shared__ double s_red[4][4];
-  const int nblk = D->nblk;
+  const int nblk = D->nblk_assoc;
   if (threadIdx.x < 6) {  // sequential double sum over the row blocks (fixed order)
     double s = 0;
     for (int b = 0; b < nblk; b++) s += D->flow_part[(size_t)b * 8 + threadIdx.x];
@@ -403,40 +490,31 @@ __global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ desc
 }
 
 // ------------------------------------------------------------------------------------------
-// k_step: per-pair scalar bookkeeping + preparation of the next iteration.  INIT = true is the
-// launch before the first iteration (no bookkeeping, state comes from the host).
+// k_update: per-pair scalar bookkeeping, one wave per pair.  INIT = true is the launch before the first
+// iteration (no bookkeeping, state comes from the host).
 // ------------------------------------------------------------------------------------------
-constexpr int STEP_THREADS = 1024;
-constexpr int XCULL_PAD = 32;  // >= 2 * the largest RU of k_scan
-
 template <bool INIT>
-__global__ __launch_bounds__(STEP_THREADS) void k_step(const PairDesc* __restrict__ descs,
-                                                       const DevParams* __restrict__ Pp) {
+__global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp) {
   const PairDesc* __restrict__ D = descs + blockIdx.x;
   PairState* st = D->st;
-  __shared__ float s_Ri[9], s_Ti[3];
-  __shared__ float s_ell;
-  __shared__ int s_done;
   __shared__ double s_c[4];
-  __shared__ unsigned long long s_n[3];
-  __shared__ float s_wmax[STEP_THREADS / 64];
+  __shared__ unsigned long long s_n[4];
   const DevParams P = *Pp;
   const int tid = threadIdx.x;
   if (!INIT) {
     if (st->status != 0) return;
-    const int nblk = D->nblk;
+    const int nba = D->nblk_assoc, nbc = D->nblk_coeff;
     if (tid < 4) {  // the four thrust::reduce of compute_step_size (CvoGPU.cu:1118-1121)
       double s = 0;
-      const int slot = P.mode == 0 ? tid : 0;
       if (P.mode == 0)
-        for (int b = 0; b < nblk; b++) s += D->coef_part[(size_t)b * 4 + slot];
+        for (int b = 0; b < nbc; b++) s += D->coef_part[(size_t)b * 4 + tid];
       else if (tid == 0)
-        for (int b = 0; b < nblk; b++) s += D->flow_part[(size_t)b * 8 + 6];
+        for (int b = 0; b < nba; b++) s += D->flow_part[(size_t)b * 8 + 6];
       s_c[tid] = s;
-    } else if (tid >= 64 && tid < 67) {
-      const int c = tid - 64;
+    } else if (tid >= 8 && tid < 12) {
+      const int c = tid - 8;
       unsigned long long s = 0;
-      for (int b = 0; b < nblk; b++) {
+      for (int b = 0; b < nba; b++) {
         const unsigned long long q = D->cnt_part[(size_t)b * 4 + c];
         s = (c == 1) ? max(s, q) : s + q;
       }
@@ -451,6 +529,7 @@ __global__ __launch_bounds__(STEP_THREADS) void k_step(const PairDesc* __restric
       st->nnz = nnz;
       st->max_nnz = max_nnz;
       st->ncand = s_n[2];
+      st->noverflow = s_n[3];
       if (P.mode != 0) {  // single evaluation: A_sum (SparseKernelMat.cu:62-68)
         st->asum = s_c[0];
         done = 1;
@@ -547,8 +626,8 @@ __global__ __launch_bounds__(STEP_THREADS) void k_step(const PairDesc* __restric
     // update_tf (CvoGPU.cu:94-112): the transform applied next, and the returned matrix when done
     float Ri[9], Ti[3];
     update_tf(st->R, st->T, Ri, Ti);
-    for (int q = 0; q < 9; q++) st->Rinv[q] = s_Ri[q] = Ri[q];
-    for (int q = 0; q < 3; q++) st->Tinv[q] = s_Ti[q] = Ti[q];
+    for (int q = 0; q < 9; q++) st->Rinv[q] = Ri[q];
+    for (int q = 0; q < 3; q++) st->Tinv[q] = Ti[q];
     for (int i = 0; i < 3; i++) {
       for (int j = 0; j < 3; j++) st->out_T[4 * j + i] = Ri[3 * i + j];
       st->out_T[12 + i] = Ti[i];
@@ -559,54 +638,142 @@ __global__ __launch_bounds__(STEP_THREADS) void k_step(const PairDesc* __restric
       st->status = 1;
       *D->status_out = 1;
     }
-    s_done = done;
-    s_ell = st->ell;
   }
-  __syncthreads();
-  if (s_done) return;
+}
 
-  // ---- prepare the next iteration -----------------------------------------------------------
-  // transform_pointcloud_thrust (CvoGPU_impl.cu:164-173) from the INITIAL cloud, plus the cull form
-  const int M = D->M, Mpad = D->Mpad, N = D->N;
+// ------------------------------------------------------------------------------------------
+// k_prep: everything the next iteration's kernels read.  Blocks [0, Mpad/512) handle the targets:
+// transform_pointcloud_thrust (CvoGPU_impl.cu:164-173) from the INITIAL cloud (exact, original index),
+// the cull form in sorted order and chunk / slice bounding boxes (one wave = one 64-target chunk).
+// The remaining blocks handle the rows: per-row constants of fill_in_A_mat_gpu (CvoGPU.cu:504-510), the
+// conservative cull operand (sorted order) and the bounding box of every group of ROWS_PER_GROUP rows,
+// grown by the group's largest cut-off radius ("boxes disjoint" => no pair of the tile is a hit).
+//
+// Cull arithmetic: pair (i, j) is a candidate iff
+//     |y~|^2 (1 - 4e-6) - 2 x~.y~  <  thr_i + 4e-6 |x~|^2 + 1e-5 thr_i - |x~|^2
+// i.e. the exact test d2 < thr_i with a slack of 4e-6 (|x~|^2 + |y~|^2) + 1e-5 thr_i, > 5x the
+// worst-case rounding of the expanded form plus the centring error.
+// ------------------------------------------------------------------------------------------
+constexpr int PREP_THREADS = 512;
+
+__global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restrict__ descs,
+                                                        const DevParams* __restrict__ Pp) {
+  const PairDesc* __restrict__ D = descs + blockIdx.y;
+  const PairState* st = D->st;
+  if (st->status != 0) return;
+  const DevParams P = *Pp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float INF = __builtin_inff();
   const float cx = D->cx, cy = D->cy, cz = D->cz;
-  float lmax = 0;
-  for (int j = tid; j < Mpad; j += STEP_THREADS) {
-    if (j < M) {
-      const float4 p = D->y4[j];
-      const V3 q = transform_point(s_Ri, s_Ti, p.x, p.y, p.z);
-      D->yt4[j] = make_float4(q.x, q.y, q.z, 0.f);
-      const float ux = q.x - cx, uy = q.y - cy, uz = q.z - cz;
-      const float nn = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-      D->ycull[j] = make_float4(ux, uy, uz, nn);
-      lmax = fmaxf(lmax, nn);
-    } else {
-      D->ycull[j] = make_float4(0.f, 0.f, 0.f, __builtin_inff());
-    }
-  }
-  lmax = wave_max_f32(lmax);
-  if ((tid & 63) == 0) s_wmax[tid >> 6] = lmax;
-  __syncthreads();
-  float ymax2 = 0;
+  const int ntb = D->Mpad / PREP_THREADS;
+  if ((int)blockIdx.x < ntb) {
+    __shared__ float s_box[PREP_THREADS / 64][6];
+    float Ri[9], Ti[3];
 #pragma unroll
-  for (int w = 0; w < STEP_THREADS / 64; w++) ymax2 = fmaxf(ymax2, s_wmax[w]);
-  // per-row constants of fill_in_A_mat_gpu (CvoGPU.cu:504-510) and the conservative cull operand
-  const float ell = s_ell;
-  for (int i = tid; i < N; i += STEP_THREADS) {
+    for (int q = 0; q < 9; q++) Ri[q] = st->Rinv[q];
+#pragma unroll
+    for (int q = 0; q < 3; q++) Ti[q] = st->Tinv[q];
+    const int M = D->M;
+    const int sidx = blockIdx.x * PREP_THREADS + tid;
+    float ux = 0, uy = 0, uz = 0, nn = INF;
+    float lox = INF, loy = INF, loz = INF, hix = -INF, hiy = -INF, hiz = -INF;
+    if (sidx < M) {
+      const int j = D->yorder[sidx];
+      const float4 p = D->y4[j];
+      const V3 q = transform_point(Ri, Ti, p.x, p.y, p.z);
+      D->yt4[j] = make_float4(q.x, q.y, q.z, 0.f);
+      ux = q.x - cx;
+      uy = q.y - cy;
+      uz = q.z - cz;
+      nn = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+      nn = __builtin_fmaf(-4e-6f, nn, nn);
+      lox = hix = ux;
+      loy = hiy = uy;
+      loz = hiz = uz;
+    }
+    D->ycull[sidx] = make_float4(ux, uy, uz, nn);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lox = fminf(lox, __shfl_xor(lox, o));
+      loy = fminf(loy, __shfl_xor(loy, o));
+      loz = fminf(loz, __shfl_xor(loz, o));
+      hix = fmaxf(hix, __shfl_xor(hix, o));
+      hiy = fmaxf(hiy, __shfl_xor(hiy, o));
+      hiz = fmaxf(hiz, __shfl_xor(hiz, o));
+    }
+    if (lane == 0) {
+      s_box[wave][0] = lox;
+      s_box[wave][1] = loy;
+      s_box[wave][2] = loz;
+      s_box[wave][3] = hix;
+      s_box[wave][4] = hiy;
+      s_box[wave][5] = hiz;
+    }
+    __syncthreads();
+    const int T = P.T;  // 1, 2, 4 or 8: slices never straddle a 512-target block
+    if (tid < (PREP_THREADS / 64) / T) {
+      float4 lo = make_float4(INF, INF, INF, 0.f), hi = make_float4(-INF, -INF, -INF, 0.f);
+      for (int t = 0; t < T; t++) {
+        const float* b = s_box[tid * T + t];
+        lo.x = fminf(lo.x, b[0]);
+        lo.y = fminf(lo.y, b[1]);
+        lo.z = fminf(lo.z, b[2]);
+        hi.x = fmaxf(hi.x, b[3]);
+        hi.y = fmaxf(hi.y, b[4]);
+        hi.z = fmaxf(hi.z, b[5]);
+      }
+      const int sl = blockIdx.x * ((PREP_THREADS / 64) / T) + tid;
+      D->sbox[2 * (size_t)sl] = lo;
+      D->sbox[2 * (size_t)sl + 1] = hi;
+    }
+    return;
+  }
+  // ---- rows
+  const int N = D->N;
+  const int rs = (blockIdx.x - ntb) * PREP_THREADS + tid;
+  if (rs >= D->NGpad * ROWS_PER_GROUP) return;  // whole waves drop out together (NGpad*4 is a multiple of 256)
+  const float ell = st->ell;
+  float ux = 0, uy = 0, uz = 0, cw = -INF, rad = 0;
+  float lox = INF, loy = INF, loz = INF, hix = -INF, hiy = -INF, hiz = -INF;
+  if (rs < N) {
+    const int i = D->xorder[rs];
     const float4 x = D->x4[i];
     const float a_to_sensor = sqrtf(__builtin_fmaf(x.z, x.z, __builtin_fmaf(x.y, x.y, x.x * x.x)));
     const float l = compute_range_ell(ell, a_to_sensor);
     float thr = 1.f;
     if (P.use_geo) thr = (float)(-2.0 * l * l * (double)P.log_geo);
     D->rowc[i] = make_float2(l, thr);
-    const float ux = x.x - cx, uy = x.y - cy, uz = x.z - cz;
+    ux = x.x - cx;
+    uy = x.y - cy;
+    uz = x.z - cz;
     const float nx = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-    const float margin = 4e-6f * (nx + ymax2) + 1e-5f * fabsf(thr);
-    float cw = (thr + margin) - nx;
-    if (!P.use_geo) cw = __builtin_inff();
-    D->xcull[i] = make_float4(-2.f * ux, -2.f * uy, -2.f * uz, cw);
+    const float margin = 4e-6f * nx + 1e-5f * fabsf(thr);
+    cw = (thr + margin) - nx;
+    rad = sqrtf(fmaxf(thr + margin, 0.f)) * 1.00001f + 1e-30f;
+    if (!P.use_geo || !(thr == thr)) {  // no geometric cut-off (or NaN): every pair is a candidate
+      cw = INF;
+      rad = INF;
+    }
+    lox = hix = ux;
+    loy = hiy = uy;
+    loz = hiz = uz;
   }
-  // never-passing pad rows so k_scan can run whole row groups and prefetch past the end
-  for (int i = N + tid; i < N + XCULL_PAD; i += STEP_THREADS) D->xcull[i] = make_float4(0.f, 0.f, 0.f, -__builtin_inff());
+  if (rs < N + XCULL_PAD) D->xcull[rs] = make_float4(-2.f * ux, -2.f * uy, -2.f * uz, cw);
+#pragma unroll
+  for (int o = 1; o < ROWS_PER_GROUP; o <<= 1) {
+    lox = fminf(lox, __shfl_xor(lox, o));
+    loy = fminf(loy, __shfl_xor(loy, o));
+    loz = fminf(loz, __shfl_xor(loz, o));
+    hix = fmaxf(hix, __shfl_xor(hix, o));
+    hiy = fmaxf(hiy, __shfl_xor(hiy, o));
+    hiz = fmaxf(hiz, __shfl_xor(hiz, o));
+    rad = fmaxf(rad, __shfl_xor(rad, o));
+  }
+  if ((rs & (ROWS_PER_GROUP - 1)) == 0) {
+    const int g = rs / ROWS_PER_GROUP;
+    D->gbox[2 * (size_t)g] = make_float4(lox - rad, loy - rad, loz - rad, 0.f);
+    D->gbox[2 * (size_t)g + 1] = make_float4(hix + rad, hiy + rad, hiz + rad, 0.f);
+  }
 }
 
 }  // namespace cvo_dev
