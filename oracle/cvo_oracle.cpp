@@ -467,9 +467,10 @@ Coefs poly_coeff_impl(const OracleParams& P, const CloudView& X, const CloudView
 // Roots of p0 x^3 + p1 x^2 + p2 x + p3.  The reference takes the eigenvalues of the companion
 // matrix with Eigen 3.3.9's EigenSolver (LieGroup.cpp:309-325; Eigen is not in the repository).
 // Restated with a backward-stable scheme that uses only + - * / sqrt (so CPU and GPU agree
-// bitwise): the real roots are bracketed between the critical points of the monic cubic and
-// refined by safeguarded Newton (bisection fallback); a complex pair follows from Vieta.
-// Pinned against numpy.roots (LAPACK companion eigenvalues) in tests/test_oracle_math.py.
+// bitwise): each real root is bracketed next to a critical point of the monic cubic (the outer
+// brackets grow by doubling) and refined by safeguarded Newton (bisection fallback); a complex
+// pair follows from Vieta.  Pinned against numpy.roots (LAPACK companion eigenvalues) in
+// tests/test_oracle_math.py.
 CUBIC_QUAL double cubic_solve_bracket(double a, double b, double c, double lo, double hi) {
   auto f = [&](double x) { return ((x + a) * x + b) * x + c; };
   auto df = [&](double x) { return (3.0 * x + 2.0 * a) * x + b; };
@@ -487,7 +488,7 @@ CUBIC_QUAL double cubic_solve_bracket(double a, double b, double c, double lo, d
   double x = 0.5 * (lo + hi);
   double dxold = CUBIC_FABS(hi - lo), dx = dxold;
   double fx = f(x), dfx = df(x);
-  for (int it = 0; it < 300; it++) {
+  for (int it = 0; it < 200; it++) {
     if ((((x - xh) * dfx - fx) * ((x - xl) * dfx - fx) > 0.0) || (CUBIC_FABS(2.0 * fx) > CUBIC_FABS(dxold * dfx))) {
       dxold = dx;
       dx = 0.5 * (xh - xl);
@@ -500,6 +501,7 @@ CUBIC_QUAL double cubic_solve_bracket(double a, double b, double c, double lo, d
       x -= dx;
       if (tmp == x) return x;
     }
+    if (CUBIC_FABS(dx) <= 4.5e-16 * CUBIC_FABS(x)) return x;  // converged to ~2 ulp (Newton can ping-pong there)
     fx = f(x);
     dfx = df(x);
     if (fx == 0.0) return x;
@@ -509,6 +511,26 @@ CUBIC_QUAL double cubic_solve_bracket(double a, double b, double c, double lo, d
       xh = x;
   }
   return x;
+}
+
+// Root of the monic cubic on the unbounded side of x0 (dir = +1: right of x0 where f(x0) <= 0 and f
+// increases to +inf; dir = -1: left of x0 where f(x0) >= 0 and f decreases to -inf).  The bracket is
+// grown by doubling so that Newton starts within a factor ~2 of the root.
+CUBIC_QUAL double cubic_solve_outward(double a, double b, double c, double x0, double dir, double bound) {
+  auto f = [&](double x) { return ((x + a) * x + b) * x + c; };
+  double h = CUBIC_FABS(x0) * 0.5;
+  if (h < 1e-3) h = 1e-3;
+  double prev = x0;
+  for (int it = 0; it < 1100; it++) {
+    double x = x0 + dir * h;
+    if (CUBIC_FABS(x) > bound) x = dir * bound;
+    const double fx = f(x);
+    if ((dir > 0.0) ? (fx >= 0.0) : (fx <= 0.0)) return dir > 0.0 ? cubic_solve_bracket(a, b, c, prev, x) : cubic_solve_bracket(a, b, c, x, prev);
+    if (CUBIC_FABS(x) >= bound) return x;  // cannot happen for a finite cubic (Cauchy bound)
+    prev = x;
+    h *= 2.0;
+  }
+  return prev;
 }
 
 CUBIC_QUAL void CUBIC_NAME(const double coef[4], double re[3], double im[3]) {
@@ -526,17 +548,20 @@ CUBIC_QUAL void CUBIC_NAME(const double coef[4], double re[3], double im[3]) {
   double r[3] = {0.0, 0.0, 0.0};
   int nr = 0;
   const double dq = a * a - 3.0 * b;
-  if (!(dq > 0.0)) {
-    r[nr++] = cubic_solve_bracket(a, b, c, -bound, bound);
+  if (!(dq > 0.0)) {  // monotone: one real root, on the side of the inflection point the sign says
+    const double xi = -a / 3.0;
+    const double fi = f(xi);
+    r[nr++] = (fi == 0.0) ? xi : (fi < 0.0 ? cubic_solve_outward(a, b, c, xi, 1.0, bound)
+                                           : cubic_solve_outward(a, b, c, xi, -1.0, bound));
   } else {
     const double s = CUBIC_SQRT(dq);
     const double t = (a >= 0.0) ? (-a - s) : (-a + s);
     const double xa = t / 3.0, xb = (t != 0.0) ? b / t : 0.0;
     const double x1 = xa < xb ? xa : xb, x2 = xa < xb ? xb : xa;
     const double f1 = f(x1), f2 = f(x2);
-    if (f1 >= 0.0) r[nr++] = (f1 == 0.0) ? x1 : cubic_solve_bracket(a, b, c, -bound, x1);
+    if (f1 >= 0.0) r[nr++] = (f1 == 0.0) ? x1 : cubic_solve_outward(a, b, c, x1, -1.0, bound);
     if (f1 > 0.0 && f2 < 0.0) r[nr++] = cubic_solve_bracket(a, b, c, x1, x2);
-    if (f2 <= 0.0) r[nr++] = (f2 == 0.0) ? x2 : cubic_solve_bracket(a, b, c, x2, bound);
+    if (f2 <= 0.0) r[nr++] = (f2 == 0.0) ? x2 : cubic_solve_outward(a, b, c, x2, 1.0, bound);
   }
   if (nr == 3) {
     for (int i = 0; i < 3; i++) {

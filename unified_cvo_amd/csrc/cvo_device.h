@@ -57,10 +57,11 @@ struct PairState {
   unsigned long long noverflow;  // rows that took k_assoc's literal path
   int n_trace;
   float out_T[16];  // column-major [R^T | -R^T T]
-  // A_sparsity_indicator_ell_update FIFOs (CvoGPU.cu:1167-1285)
-  float sq[IND_CAP], eq[IND_CAP];
+  // A_sparsity_indicator_ell_update FIFOs (CvoGPU.cu:1167-1285): bookkeeping here, storage below
   int s_head, s_size, e_head, e_size;
   float s_sum, e_sum;
+  // ---- everything above is the "hot" prefix k_update stages through LDS ----
+  float sq[IND_CAP], eq[IND_CAP];
 };
 
 // Everything a kernel needs to know about one frame pair.
@@ -75,7 +76,8 @@ struct PairDesc {
   int NG;     // row groups of ROWS_PER_GROUP sorted rows
   int NGpad;  // NG rounded up for the coarse test (pad groups have empty boxes)
   float cx, cy, cz;  // centre subtracted in the cull arithmetic only
-  const float4* x4;
+  const float4* x4;   // source xyz, ORIGINAL index
+  const float4* xs4;  // source xyz, SORTED order (coalesced row reads)
   const float4* xfeat;
   const float4* xlabel;
   const float2* xgeo;
@@ -85,18 +87,18 @@ struct PairDesc {
   const float4* ylabel;
   const float2* ygeo;
   const int* yorder;
-  float4* yt4;    // transformed targets, exact, ORIGINAL index
   float4* ycull;  // SORTED: {y~x, y~y, y~z, |y~|^2}, y~ = yt - centre; pads are {0,0,0,+inf}
   float4* xcull;  // SORTED: {-2x~x, -2x~y, -2x~z, thres_i + margin_i - |x~|^2}
-  float2* rowc;   // ORIGINAL index: {l_i, d2_thres_i}
+  float2* rowc;   // SORTED row: {l_i, d2_thres_i}
   float4* gbox;   // [NGpad][2]: AABB of each sorted row group, grown by the group's cut-off radius
   float4* cbox;   // [nchunks][2]: AABB of each 64-target sorted chunk
   float4* sbox;   // [nslices][2]: AABB of each scan slice (T chunks)
   unsigned long long* masks;  // [N sorted rows][nchunks] candidate bit masks (valid where flagged)
   unsigned short* flags;      // [N sorted rows][nsl_pad]: which of a slice's T chunks are non-empty
-  float* ell_a;               // ELL kernel matrix values, [K_max][N], ORIGINAL row index
-  int* ell_j;                 // ELL column indices (original j), [K_max][N]
-  unsigned* nnz_row;          // nonzeros[N], ORIGINAL row index
+  unsigned* rowsum;           // [N sorted rows]: bit (g % 32) set <=> flags[row][8g .. 8g+7] may be non-zero
+  float* ell_a;               // ELL kernel matrix values, [K_max][N], SORTED row index
+  int* ell_j;                 // ELL column indices (ORIGINAL j, ascending), [K_max][N]
+  unsigned* nnz_row;          // nonzeros[N], SORTED row index
   double* flow_part;          // [nblk_assoc][8]: omega(3), v(3), sum a, pad
   unsigned long long* cnt_part;  // [nblk_assoc][4]: nnz, max, candidates, overflow rows
   double* coef_part;          // [nblk_coeff][4]: B C D E
@@ -184,9 +186,10 @@ __device__ inline void xi_mats(const float* omega, const float* v, XiMats& x) {
 // Roots of p0 x^3 + p1 x^2 + p2 x + p3.  The reference takes the eigenvalues of the companion
 // matrix with Eigen 3.3.9's EigenSolver (LieGroup.cpp:309-325; Eigen is not in the repository).
 // Restated with a backward-stable scheme that uses only + - * / sqrt (so CPU and GPU agree
-// bitwise): the real roots are bracketed between the critical points of the monic cubic and
-// refined by safeguarded Newton (bisection fallback); a complex pair follows from Vieta.
-// Pinned against numpy.roots (LAPACK companion eigenvalues) in tests/test_oracle_math.py.
+// bitwise): each real root is bracketed next to a critical point of the monic cubic (the outer
+// brackets grow by doubling) and refined by safeguarded Newton (bisection fallback); a complex
+// pair follows from Vieta.  Pinned against numpy.roots (LAPACK companion eigenvalues) in
+// tests/test_oracle_math.py.
 CUBIC_QUAL double cubic_solve_bracket(double a, double b, double c, double lo, double hi) {
   auto f = [&](double x) { return ((x + a) * x + b) * x + c; };
   auto df = [&](double x) { return (3.0 * x + 2.0 * a) * x + b; };
@@ -204,7 +207,7 @@ CUBIC_QUAL double cubic_solve_bracket(double a, double b, double c, double lo, d
   double x = 0.5 * (lo + hi);
   double dxold = CUBIC_FABS(hi - lo), dx = dxold;
   double fx = f(x), dfx = df(x);
-  for (int it = 0; it < 300; it++) {
+  for (int it = 0; it < 200; it++) {
     if ((((x - xh) * dfx - fx) * ((x - xl) * dfx - fx) > 0.0) || (CUBIC_FABS(2.0 * fx) > CUBIC_FABS(dxold * dfx))) {
       dxold = dx;
       dx = 0.5 * (xh - xl);
@@ -217,6 +220,7 @@ CUBIC_QUAL double cubic_solve_bracket(double a, double b, double c, double lo, d
       x -= dx;
       if (tmp == x) return x;
     }
+    if (CUBIC_FABS(dx) <= 4.5e-16 * CUBIC_FABS(x)) return x;  // converged to ~2 ulp (Newton can ping-pong there)
     fx = f(x);
     dfx = df(x);
     if (fx == 0.0) return x;
@@ -226,6 +230,26 @@ CUBIC_QUAL double cubic_solve_bracket(double a, double b, double c, double lo, d
       xh = x;
   }
   return x;
+}
+
+// Root of the monic cubic on the unbounded side of x0 (dir = +1: right of x0 where f(x0) <= 0 and f
+// increases to +inf; dir = -1: left of x0 where f(x0) >= 0 and f decreases to -inf).  The bracket is
+// grown by doubling so that Newton starts within a factor ~2 of the root.
+CUBIC_QUAL double cubic_solve_outward(double a, double b, double c, double x0, double dir, double bound) {
+  auto f = [&](double x) { return ((x + a) * x + b) * x + c; };
+  double h = CUBIC_FABS(x0) * 0.5;
+  if (h < 1e-3) h = 1e-3;
+  double prev = x0;
+  for (int it = 0; it < 1100; it++) {
+    double x = x0 + dir * h;
+    if (CUBIC_FABS(x) > bound) x = dir * bound;
+    const double fx = f(x);
+    if ((dir > 0.0) ? (fx >= 0.0) : (fx <= 0.0)) return dir > 0.0 ? cubic_solve_bracket(a, b, c, prev, x) : cubic_solve_bracket(a, b, c, x, prev);
+    if (CUBIC_FABS(x) >= bound) return x;  // cannot happen for a finite cubic (Cauchy bound)
+    prev = x;
+    h *= 2.0;
+  }
+  return prev;
 }
 
 CUBIC_QUAL void CUBIC_NAME(const double coef[4], double re[3], double im[3]) {
@@ -243,17 +267,20 @@ CUBIC_QUAL void CUBIC_NAME(const double coef[4], double re[3], double im[3]) {
   double r[3] = {0.0, 0.0, 0.0};
   int nr = 0;
   const double dq = a * a - 3.0 * b;
-  if (!(dq > 0.0)) {
-    r[nr++] = cubic_solve_bracket(a, b, c, -bound, bound);
+  if (!(dq > 0.0)) {  // monotone: one real root, on the side of the inflection point the sign says
+    const double xi = -a / 3.0;
+    const double fi = f(xi);
+    r[nr++] = (fi == 0.0) ? xi : (fi < 0.0 ? cubic_solve_outward(a, b, c, xi, 1.0, bound)
+                                           : cubic_solve_outward(a, b, c, xi, -1.0, bound));
   } else {
     const double s = CUBIC_SQRT(dq);
     const double t = (a >= 0.0) ? (-a - s) : (-a + s);
     const double xa = t / 3.0, xb = (t != 0.0) ? b / t : 0.0;
     const double x1 = xa < xb ? xa : xb, x2 = xa < xb ? xb : xa;
     const double f1 = f(x1), f2 = f(x2);
-    if (f1 >= 0.0) r[nr++] = (f1 == 0.0) ? x1 : cubic_solve_bracket(a, b, c, -bound, x1);
+    if (f1 >= 0.0) r[nr++] = (f1 == 0.0) ? x1 : cubic_solve_outward(a, b, c, x1, -1.0, bound);
     if (f1 > 0.0 && f2 < 0.0) r[nr++] = cubic_solve_bracket(a, b, c, x1, x2);
-    if (f2 <= 0.0) r[nr++] = (f2 == 0.0) ? x2 : cubic_solve_bracket(a, b, c, x2, bound);
+    if (f2 <= 0.0) r[nr++] = (f2 == 0.0) ? x2 : cubic_solve_outward(a, b, c, x2, 1.0, bound);
   }
   if (nr == 3) {
     for (int i = 0; i < 3; i++) {
@@ -405,14 +432,15 @@ __device__ inline double se3_log_norm(const double R[9], const double t[3]) {
 }
 
 // A_sparsity_indicator_ell_update (CvoGPU.cu:1167-1285), FIFOs as ring buffers.
-__device__ inline bool indicator_update(PairState* st, float indicator, int queue_len, float thr) {
+__device__ inline bool indicator_update(PairState* st, float* sq, float* eq, float indicator, int queue_len,
+                                        float thr) {
   bool decrease = false;
   auto s_push = [&](float x) {
-    st->sq[(st->s_head + st->s_size) % IND_CAP] = x;
+    sq[(st->s_head + st->s_size) % IND_CAP] = x;
     st->s_size++;
   };
   auto e_push = [&](float x) {
-    st->eq[(st->e_head + st->e_size) % IND_CAP] = x;
+    eq[(st->e_head + st->e_size) % IND_CAP] = x;
     st->e_size++;
   };
   if (st->s_size < queue_len) {
@@ -430,13 +458,13 @@ __device__ inline bool indicator_update(PairState* st, float indicator, int queu
       st->s_sum = 0;
       st->e_sum = 0;
     } else {
-      float ef = st->eq[st->e_head];
+      float ef = eq[st->e_head];
       st->e_sum -= ef;
       st->s_sum += ef;
       s_push(ef);
       st->e_head = (st->e_head + 1) % IND_CAP;
       st->e_size--;
-      st->s_sum -= st->sq[st->s_head];
+      st->s_sum -= sq[st->s_head];
       st->s_head = (st->s_head + 1) % IND_CAP;
       st->s_size--;
       e_push(indicator);

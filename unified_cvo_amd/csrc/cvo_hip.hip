@@ -20,20 +20,22 @@ using namespace cvo_dev;
 #define CVO_VERSION_STRING "unified_cvo_amd 0.1 (gfx950)"
 
 struct cvo_cloud {
-  cvo_ctx* ctx;
-  int n;
-  float4* x4;
-  float4* feat;   // 2 float4 per point
-  float4* label;  // 5 float4 per point
-  float2* geo;
-  int* order;        // spatial (k-d) order: sorted position -> original index
-  float cx, cy, cz;  // centroid (used only as the cull centre)
+  cvo_ctx* ctx = nullptr;
+  int n = 0;
+  float4* x4 = nullptr;
+  float4* xs4 = nullptr;    // x4 permuted into the spatial order
+  float4* feat = nullptr;   // 2 float4 per point
+  float4* label = nullptr;  // 5 float4 per point
+  float2* geo = nullptr;
+  int* order = nullptr;        // spatial (k-d) order: sorted position -> original index
+  std::vector<int> h_order;  // host copy (the ELL is stored by sorted row; exports map it back)
+  float cx = 0, cy = 0, cz = 0;  // centroid (used only as the cull centre)
 };
 
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t yt4, ycull, xcull, rowc, gbox, cbox, sbox, masks, flags, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, rowc, gbox, cbox, sbox, masks, flags, rowsum, ell_a, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -74,6 +76,7 @@ struct cvo_ctx {
   int last_N = 0, last_M = 0, last_Kmax = 0;
   DevParams last_params{};
   int last_gx = 0, last_gy = 0;
+  std::vector<int> last_xorder;  // pair 0's source order: sorted row -> original row
   PairLayout last_layout{};
 };
 
@@ -110,7 +113,6 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
     off = align_up(off + bytes, 256);
     return o;
   };
-  L.yt4 = take(sizeof(float4) * (size_t)Mpad);
   L.ycull = take(sizeof(float4) * (size_t)Mpad);
   L.xcull = take(sizeof(float4) * (size_t)(N + XCULL_PAD));
   L.rowc = take(sizeof(float2) * (size_t)N);
@@ -119,6 +121,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.sbox = take(sizeof(float4) * 2 * (size_t)nchunks);
   L.masks = take(sizeof(unsigned long long) * (size_t)N * nchunks);
   L.flags = take(sizeof(unsigned short) * (size_t)N * nsl_pad);
+  L.rowsum = take(sizeof(unsigned) * (size_t)N);
   L.ell_a = take(sizeof(float) * (size_t)N * Kmax);
   L.ell_j = take(sizeof(int) * (size_t)N * Kmax);
   L.nnz_row = take(sizeof(unsigned) * (size_t)N);
@@ -250,20 +253,20 @@ void choose_scan_config(int n_pairs, int NG, int Mpad, int* T_out, int* gpb_out)
   *gpb_out = gpb;
 }
 
-void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const DevParams* dp, int force) {
+void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const DevParams* dp, const int* st, int force) {
   switch (T) {
-    case 1: hipLaunchKernelGGL(k_scan<1>, grid, dim3(256), 0, s, descs, dp, force); break;
-    case 2: hipLaunchKernelGGL(k_scan<2>, grid, dim3(256), 0, s, descs, dp, force); break;
-    case 4: hipLaunchKernelGGL(k_scan<4>, grid, dim3(256), 0, s, descs, dp, force); break;
-    default: hipLaunchKernelGGL(k_scan<8>, grid, dim3(256), 0, s, descs, dp, force); break;
+    case 1: hipLaunchKernelGGL(k_scan<1>, grid, dim3(256), 0, s, descs, dp, st, force); break;
+    case 2: hipLaunchKernelGGL(k_scan<2>, grid, dim3(256), 0, s, descs, dp, st, force); break;
+    case 4: hipLaunchKernelGGL(k_scan<4>, grid, dim3(256), 0, s, descs, dp, st, force); break;
+    default: hipLaunchKernelGGL(k_scan<8>, grid, dim3(256), 0, s, descs, dp, st, force); break;
   }
 }
 
-void launch_assoc(hipStream_t s, bool idx16, dim3 grid, const PairDesc* descs, const DevParams* dp) {
+void launch_assoc(hipStream_t s, bool idx16, dim3 grid, const PairDesc* descs, const DevParams* dp, const int* st) {
   if (idx16)
-    hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16>), grid, dim3(ASSOC_THREADS), 0, s, descs, dp);
+    hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16>), grid, dim3(ASSOC_THREADS), 0, s, descs, dp, st);
   else
-    hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32>), grid, dim3(ASSOC_THREADS), 0, s, descs, dp);
+    hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32>), grid, dim3(ASSOC_THREADS), 0, s, descs, dp, st);
 }
 
 struct LaunchGeom {
@@ -272,14 +275,15 @@ struct LaunchGeom {
 };
 
 void launch_prep(cvo_ctx* c, const LaunchGeom& g) {
-  hipLaunchKernelGGL(k_prep, dim3(g.npb, g.n_pairs), dim3(PREP_THREADS), 0, c->stream, c->d_descs, c->d_params);
+  hipLaunchKernelGGL(k_prep, dim3(g.npb, g.n_pairs), dim3(PREP_THREADS), 0, c->stream, c->d_descs, c->d_params,
+                     c->d_status);
 }
 
 void launch_iteration(cvo_ctx* c, const LaunchGeom& g) {
-  launch_scan(c->stream, g.T, dim3(g.gx, g.gy, g.n_pairs), c->d_descs, c->d_params, 0);
-  launch_assoc(c->stream, g.idx16, dim3(g.nba, g.n_pairs), c->d_descs, c->d_params);
-  hipLaunchKernelGGL(k_coeff, dim3(g.nbc, g.n_pairs), dim3(256), 0, c->stream, c->d_descs, c->d_params);
-  hipLaunchKernelGGL(k_update<false>, dim3(g.n_pairs), dim3(64), 0, c->stream, c->d_descs, c->d_params);
+  launch_scan(c->stream, g.T, dim3(g.gx, g.gy, g.n_pairs), c->d_descs, c->d_params, c->d_status, 0);
+  launch_assoc(c->stream, g.idx16, dim3(g.nba, g.n_pairs), c->d_descs, c->d_params, c->d_status);
+  hipLaunchKernelGGL(k_coeff, dim3(g.nbc, g.n_pairs), dim3(256), 0, c->stream, c->d_descs, c->d_params, c->d_status);
+  hipLaunchKernelGGL(k_update<false>, dim3(g.n_pairs), dim3(64), 0, c->stream, c->d_descs, c->d_params, c->d_status);
   launch_prep(c, g);
 }
 
@@ -353,6 +357,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.cy = X->cy;
     D.cz = X->cz;
     D.x4 = X->x4;
+    D.xs4 = X->xs4;
     D.xfeat = X->feat;
     D.xlabel = X->label;
     D.xgeo = X->geo;
@@ -362,7 +367,6 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.ylabel = Y->label;
     D.ygeo = Y->geo;
     D.yorder = Y->order;
-    D.yt4 = (float4*)(base + S->L.yt4);
     D.ycull = (float4*)(base + S->L.ycull);
     D.xcull = (float4*)(base + S->L.xcull);
     D.rowc = (float2*)(base + S->L.rowc);
@@ -371,6 +375,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.sbox = (float4*)(base + S->L.sbox);
     D.masks = (unsigned long long*)(base + S->L.masks);
     D.flags = (unsigned short*)(base + S->L.flags);
+    D.rowsum = (unsigned*)(base + S->L.rowsum);
     D.ell_a = (float*)(base + S->L.ell_a);
     D.ell_j = (int*)(base + S->L.ell_j);
     D.nnz_row = (unsigned*)(base + S->L.nnz_row);
@@ -396,6 +401,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     }
     // flags must start clean (they are self-cleaning afterwards)
     HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, sizeof(unsigned short) * (size_t)S->N * S->d.nsl_pad, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(D.rowsum, 0, sizeof(unsigned) * (size_t)S->N, ctx->stream));
   }
   // the blocks of k_assoc beyond a smaller pair's N still write their (zero) partials, but the
   // partial arrays of pairs whose N is smaller than the batch maximum are fully covered by nblk.
@@ -415,6 +421,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.nbc = S->d.nblk_coeff;
   S->geom.npb = S->d.Mpad / PREP_THREADS + (S->d.NGpad * ROWS_PER_GROUP + PREP_THREADS - 1) / PREP_THREADS;
   S->geom.idx16 = M < 65536;
+  ctx->last_xorder = sources[0]->h_order;
   ctx->last_pairs = n_pairs;
   ctx->last_N = N;
   ctx->last_M = M;
@@ -433,11 +440,11 @@ int run_single_eval(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
   const cvo_cloud* tgt[1] = {target};
   int rc = setup_batch(ctx, params, 1, src, tgt, Tm, nullptr, 1, ell, S, &dp);
   if (rc != CVO_OK) return rc;
-  hipLaunchKernelGGL(k_update<true>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params);
+  hipLaunchKernelGGL(k_update<true>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params, ctx->d_status);
   launch_prep(ctx, S->geom);
-  launch_scan(ctx->stream, S->T, dim3(S->gx, S->gy, 1), ctx->d_descs, ctx->d_params, 0);
-  launch_assoc(ctx->stream, S->geom.idx16, dim3(S->d.nblk_assoc, 1), ctx->d_descs, ctx->d_params);
-  hipLaunchKernelGGL(k_update<false>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params);
+  launch_scan(ctx->stream, S->T, dim3(S->gx, S->gy, 1), ctx->d_descs, ctx->d_params, ctx->d_status, 0);
+  launch_assoc(ctx->stream, S->geom.idx16, dim3(S->d.nblk_assoc, 1), ctx->d_descs, ctx->d_params, ctx->d_status);
+  hipLaunchKernelGGL(k_update<false>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params, ctx->d_status);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_states.data(), ctx->d_states, sizeof(PairState), hipMemcpyDeviceToHost,
                               ctx->stream));
@@ -594,7 +601,6 @@ static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, cons
                          const std::vector<float>& label, const std::vector<float>& geo, cvo_cloud** out) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   cvo_cloud* c = new cvo_cloud();
-  std::memset(c, 0, sizeof(*c));
   c->ctx = ctx;
   c->n = n;
   double sx = 0, sy = 0, sz = 0;
@@ -611,6 +617,7 @@ static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, cons
   if (!std::isfinite(c->cx) || !std::isfinite(c->cy) || !std::isfinite(c->cz)) c->cx = c->cy = c->cz = 0.f;
   const size_t nn = (size_t)std::max(n, 1);
   hipError_t e = hipMalloc(&c->x4, sizeof(float4) * nn);
+  if (e == hipSuccess) e = hipMalloc(&c->xs4, sizeof(float4) * nn);
   if (e == hipSuccess) e = hipMalloc(&c->feat, sizeof(float4) * 2 * nn);
   if (e == hipSuccess) e = hipMalloc(&c->label, sizeof(float4) * 5 * nn);
   if (e == hipSuccess) e = hipMalloc(&c->geo, sizeof(float2) * nn);
@@ -628,7 +635,11 @@ static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, cons
     HIP_TRY(ctx, hipMemcpyAsync(c->geo, geo.data(), sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     std::vector<int> order;
     spatial_order(x4, n, order);
+    std::vector<float> xs(4 * (size_t)n);
+    for (int r = 0; r < n; r++) std::memcpy(&xs[4 * (size_t)r], &x4[4 * (size_t)order[r]], 16);
     HIP_TRY(ctx, hipMemcpyAsync(c->order, order.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(c->xs4, xs.data(), sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    c->h_order = order;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the staging vectors die with the caller
   }
   *out = c;
@@ -675,6 +686,7 @@ void cvo_cloud_free(cvo_cloud* c) {
   if (!c) return;
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
   if (c->x4) (void)hipFree(c->x4);
+  if (c->xs4) (void)hipFree(c->xs4);
   if (c->feat) (void)hipFree(c->feat);
   if (c->label) (void)hipFree(c->label);
   if (c->geo) (void)hipFree(c->geo);
@@ -699,7 +711,8 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   const bool use_graph = graph_mode != 1;
 
   HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-  hipLaunchKernelGGL(k_update<true>, dim3(n_pairs), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params);
+  hipLaunchKernelGGL(k_update<true>, dim3(n_pairs), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params,
+                     ctx->d_status);
   launch_prep(ctx, S.geom);
   HIP_TRY(ctx, hipGetLastError());
 
@@ -884,13 +897,16 @@ int cvo_association(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
   rc = fetch_ell(ctx, 0, nz, a, jj, &mx);
   if (rc != CVO_OK) return rc;
   const int N = source->n;
+  std::vector<int> sorted_of(N);  // original row -> sorted row (the ELL is stored by sorted row)
+  for (int r = 0; r < N; r++) sorted_of[ctx->last_xorder[r]] = r;
   size_t cnt = 0;
   for (int i = 0; i < N; i++) {
     row_ptr[i] = (int)cnt;
-    for (unsigned s = 0; s < nz[i]; s++) {
+    const int r = sorted_of[i];
+    for (unsigned s = 0; s < nz[r]; s++) {
       if (cnt < capacity && col && val) {
-        col[cnt] = jj[(size_t)s * N + i];
-        val[cnt] = a[(size_t)s * N + i];
+        col[cnt] = jj[(size_t)s * N + r];
+        val[cnt] = a[(size_t)s * N + r];
       }
       cnt++;
     }
@@ -910,12 +926,13 @@ int cvo_debug_last_ell(cvo_ctx* ctx, int K, float* mat, int* ind, unsigned int* 
   int rc = fetch_ell(ctx, 0, nz, a, jj, &mx);
   if (rc != CVO_OK) return rc;
   const int N = ctx->h_descs[0].N;
-  for (int i = 0; i < N; i++) {
-    if (nonzeros) nonzeros[i] = nz[i];
+  for (int r = 0; r < N; r++) {
+    const int i = ctx->last_xorder[r];  // sorted row r holds original row i
+    if (nonzeros) nonzeros[i] = nz[r];
     for (int s = 0; s < K; s++) {
-      const bool ok = (unsigned)s < nz[i];
-      if (mat) mat[(size_t)i * K + s] = ok ? a[(size_t)s * N + i] : 0.f;
-      if (ind) ind[(size_t)i * K + s] = ok ? jj[(size_t)s * N + i] : -1;
+      const bool ok = (unsigned)s < nz[r];
+      if (mat) mat[(size_t)i * K + s] = ok ? a[(size_t)s * N + r] : 0.f;
+      if (ind) ind[(size_t)i * K + s] = ok ? jj[(size_t)s * N + r] : -1;
     }
   }
   return CVO_OK;
@@ -934,15 +951,16 @@ int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms) {
   const int n_pairs = ctx->last_pairs;
   const DevParams& dp = ctx->last_params;
   dim3 grid(ctx->last_gx, ctx->last_gy, n_pairs);
-  launch_scan(ctx->stream, dp.T, grid, ctx->d_descs, ctx->d_params, 1);  // warm-up
+  launch_scan(ctx->stream, dp.T, grid, ctx->d_descs, ctx->d_params, ctx->d_status, 1);  // warm-up
   HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-  for (int r = 0; r < reps; r++) launch_scan(ctx->stream, dp.T, grid, ctx->d_descs, ctx->d_params, 1);
+  for (int r = 0; r < reps; r++) launch_scan(ctx->stream, dp.T, grid, ctx->d_descs, ctx->d_params, ctx->d_status, 1);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
   // the extra scans leave flags behind; clean them so the workspace stays consistent
   for (int p = 0; p < n_pairs; p++) {
     const PairDesc& D = ctx->h_descs[p];
     HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, sizeof(unsigned short) * (size_t)ctx->last_N * D.nsl_pad, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(D.rowsum, 0, sizeof(unsigned) * (size_t)ctx->last_N, ctx->stream));
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   float t = 0;

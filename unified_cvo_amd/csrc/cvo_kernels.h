@@ -67,10 +67,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // plain vector: loada
 
 template <int T>
 __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
-                                              int force) {
+                                              const int* __restrict__ status, int force) {
   constexpr int RG = ROWS_PER_GROUP;
+  if (!force && status[blockIdx.z] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.z;
-  if (!force && D->st->status != 0) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int slice = blockIdx.x * 4 + wave;
@@ -99,6 +99,8 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
   const CVO_CONST f32x4* xc = (const CVO_CONST f32x4*)D->xcull;
   CVO_GLOBAL unsigned long long* masks = (CVO_GLOBAL unsigned long long*)D->masks;
   CVO_GLOBAL unsigned short* flags = (CVO_GLOBAL unsigned short*)D->flags;
+  CVO_GLOBAL unsigned* rowsum = (CVO_GLOBAL unsigned*)D->rowsum;
+  const unsigned rs_bit = 1u << ((slice >> 3) & 31);
   const int nchunks = D->nchunks;
   const int nsl_pad = D->nsl_pad;
 
@@ -158,7 +160,11 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
               fl |= (m != 0 ? 1u : 0u) << t;
             }
             if (lane < T && mine) masks[(size_t)(r + u) * nchunks + slice * T + lane] = mine;
-            if (lane == 0) flags[(size_t)(r + u) * nsl_pad + slice] = (unsigned short)fl;
+            if (lane == 0) {
+              flags[(size_t)(r + u) * nsl_pad + slice] = (unsigned short)fl;
+              // returnless atomic: tells k_assoc which 16-byte flag groups of this row to look at
+              __hip_atomic_fetch_or(rowsum + (r + u), rs_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
         }
       }
@@ -177,8 +183,19 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
 struct RowData {
   float x, y, z, l, d2_thres;
 };
+struct Pose {  // the transform applied to the target cloud this iteration (update_tf, CvoGPU.cu:94-112)
+  float Ri[9], Ti[3];
+};
+__device__ __forceinline__ Pose load_pose(const PairState* st) {
+  Pose p;
+#pragma unroll
+  for (int q = 0; q < 9; q++) p.Ri[q] = st->Rinv[q];
+#pragma unroll
+  for (int q = 0; q < 3; q++) p.Ti[q] = st->Tinv[q];
+  return p;
+}
 
-__device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __restrict__ D, int i,
+__device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __restrict__ D, const Pose& pose, int i,
                                           const RowData& r, int j, float& a_out, float4& yt_out) {
   float sk = 1, ck = 1, k = 1, geo_sim = 1;
   if (P.use_geotype) {  // compute_geometric_type_ip, CvoGPU.cu:203-215
@@ -189,7 +206,10 @@ __device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __
     geo_sim = dab * dab / (n2a * n2b);
     if ((double)geo_sim < 0.01) return false;
   }
-  const float4 yt = D->yt4[j];
+  // transform_point_R_T (CvoGPU_impl.cu:31-82) of the INITIAL target, recomputed where it is needed
+  const float4 y0 = D->y4[j];
+  const V3 ytv = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
+  const float4 yt = make_float4(ytv.x, ytv.y, ytv.z, 0.f);
   yt_out = yt;
   if (P.use_geo) {
     const float dx = yt.x - r.x, dy = yt.y - r.y, dz = yt.z - r.z;
@@ -251,14 +271,14 @@ struct RowAcc {
 };
 
 // One accepted/rejected pair (i, j): CvoGPU.cu:528-589 + the flow terms of 758-782.
-__device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* __restrict__ D, int i, int N,
-                                           const RowData& r, const V3& pxe, int j, RowAcc& A) {
+__device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* __restrict__ D, const Pose& pose, int i,
+                                           int r_sorted, int N, const RowData& r, const V3& pxe, int j, RowAcc& A) {
   float a;
   float4 yt;
-  if (!eval_pair(P, D, i, r, j, a, yt)) return;
+  if (!eval_pair(P, D, pose, i, r, j, a, yt)) return;
   if (a > P.sp_thres) {
-    D->ell_a[(size_t)A.nnz * N + i] = a;
-    D->ell_j[(size_t)A.nnz * N + i] = j;
+    D->ell_a[(size_t)A.nnz * N + r_sorted] = a;
+    D->ell_j[(size_t)A.nnz * N + r_sorted] = j;
     A.nnz++;
     const V3 pye{yt.x, yt.y, yt.z};
     const V3 cr = cross_dev(pxe, pye);
@@ -275,11 +295,12 @@ __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* _
 
 template <typename IdxT, int ASSOC_CAP>
 __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restrict__ descs,
-                                                          const DevParams* __restrict__ Pp) {
+                                                          const DevParams* __restrict__ Pp,
+                                                          const int* __restrict__ status) {
   constexpr int ASSOC_STRIDE = ASSOC_CAP + 1;  // odd stride: conflict-free per-thread lists
+  if (status[blockIdx.y] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.y;
-  PairState* st = D->st;
-  if (st->status != 0) return;
+  const PairState* st = D->st;
   const DevParams P = *Pp;
   const int N = D->N, M = D->M;
   const int r_sorted = blockIdx.x * ASSOC_THREADS + threadIdx.x;
@@ -292,56 +313,73 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
   unsigned overflowed = 0;
   if (r_sorted < N) {
     const int i = D->xorder[r_sorted];
-    const float4 x = D->x4[i];
-    const float2 rc = D->rowc[i];
+    const float4 x = D->xs4[r_sorted];
+    const float2 rc = D->rowc[r_sorted];
     const RowData r{x.x, x.y, x.z, rc.x, rc.y};
     const V3 pxe{x.x, x.y, x.z};
+    const Pose pose = load_pose(st);
     // ---- gather this row's candidates (sorted-space bitmap) and restore ascending original j
     unsigned short* frow = D->flags + (size_t)r_sorted * D->nsl_pad;
     const unsigned long long* mrow = D->masks + (size_t)r_sorted * D->nchunks;
     const int* yorder = D->yorder;
-    const int nsl = D->nslices;
+    const int ng = (D->nslices + 7) >> 3;  // 16-byte groups of 8 flag words
     int cnt = 0;
-    for (int s0 = 0; s0 < nsl; s0 += 8) {
-      uint4 w = *reinterpret_cast<const uint4*>(frow + s0);
-      if ((w.x | w.y | w.z | w.w) == 0) continue;
-      *reinterpret_cast<uint4*>(frow + s0) = make_uint4(0, 0, 0, 0);  // self-cleaning flags
-      const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+    const unsigned rsum = D->rowsum[r_sorted];
+    if (rsum) {
+      D->rowsum[r_sorted] = 0;  // self-cleaning, like the flags
+      for (int g0 = 0; g0 < ng; g0 += 4) {
+        uint4 w4[4];
 #pragma unroll
-      for (int h = 0; h < 8; h++) {
-        unsigned f = (ww[h >> 1] >> ((h & 1) * 16)) & 0xffffu;
-        while (f) {
-          const int t = __builtin_ctz(f);
-          f &= f - 1;
-          const int chunk = (s0 + h) * T + t;
-          unsigned long long m = mrow[chunk];
-          ncand += (unsigned long long)__builtin_popcountll(m);
-          while (m && !overflowed) {
-            const int b = __builtin_ctzll(m);
-            m &= m - 1;
-            const int j = yorder[chunk * 64 + b];
-            if (cnt == ASSOC_CAP) {
-              overflowed = 1;
-              break;
+        for (int q = 0; q < 4; q++) {  // up to four independent loads in flight
+          const int g = g0 + q;
+          w4[q] = make_uint4(0, 0, 0, 0);
+          if (g < ng && ((rsum >> (g & 31)) & 1u)) w4[q] = *reinterpret_cast<const uint4*>(frow + 8 * g);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint4 w = w4[q];
+          if ((w.x | w.y | w.z | w.w) == 0) continue;
+          const int s0 = 8 * (g0 + q);
+          *reinterpret_cast<uint4*>(frow + s0) = make_uint4(0, 0, 0, 0);
+          const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+          for (int h = 0; h < 8; h++) {
+            unsigned f = (ww[h >> 1] >> ((h & 1) * 16)) & 0xffffu;
+            while (f) {
+              const int t = __builtin_ctz(f);
+              f &= f - 1;
+              const int chunk = (s0 + h) * T + t;
+              unsigned long long m = mrow[chunk];
+              ncand += (unsigned long long)__builtin_popcountll(m);
+              while (m && !overflowed) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const int j = yorder[chunk * 64 + b];
+                if (cnt == ASSOC_CAP) {
+                  overflowed = 1;
+                  break;
+                }
+                int k = cnt++;  // insertion sort, ascending j
+                while (k > 0 && (int)list[k - 1] > j) {
+                  list[k] = list[k - 1];
+                  k--;
+                }
+                list[k] = (IdxT)j;
+              }
             }
-            int k = cnt++;  // insertion sort, ascending j
-            while (k > 0 && (int)list[k - 1] > j) {
-              list[k] = list[k - 1];
-              k--;
-            }
-            list[k] = (IdxT)j;
           }
         }
       }
     }
     if (!overflowed) {
-      for (int k = 0; k < cnt && A.nnz < (unsigned)K; k++) visit_pair(P, D, i, N, r, pxe, (int)list[k], A);
+      for (int k = 0; k < cnt && A.nnz < (unsigned)K; k++)
+        visit_pair(P, D, pose, i, r_sorted, N, r, pxe, (int)list[k], A);
     } else {
       // more candidates than the list holds (dense regime): the reference's literal ordered scan,
       // `if (num_inds == num_neighbors) break;` included (CvoGPU.cu:524-527)
-      for (int j = 0; j < M && A.nnz < (unsigned)K; j++) visit_pair(P, D, i, N, r, pxe, j, A);
+      for (int j = 0; j < M && A.nnz < (unsigned)K; j++) visit_pair(P, D, pose, i, r_sorted, N, r, pxe, j, A);
     }
-    D->nnz_row[i] = A.nnz;
+    D->nnz_row[r_sorted] = A.nnz;
   }
   // per-row (omega_i / c, v_i / d) cast to double, then reduced in double (CvoGPU.cu:784-787, 824-825)
   double red[7] = {(double)(A.o0 / P.c), (double)(A.o1 / P.c), (double)(A.o2 / P.c), (double)(A.v0 / P.d),
@@ -391,20 +429,32 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
 // ------------------------------------------------------------------------------------------
 // k_coeff: normalised twist (compute_flow host half, CvoGPU.cu:824-835) + B,C,D,E partials.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp) {
+__global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
+                                               const int* __restrict__ status) {
+  if (status[blockIdx.y] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.y;
   PairState* st = D->st;
-  if (st->status != 0) return;
   const DevParams P = *Pp;
   if (P.mode != 0) return;
   __shared__ double s_ov[6];
   __shared__ XiMats s_M;
   __shared__ double s_red[4][4];
-  const int nblk = D->nblk_assoc;
-  if (threadIdx.x < 6) {  // sequential double sum over the row blocks (fixed order)
-    double s = 0;
-    for (int b = 0; b < nblk; b++) s += D->flow_part[(size_t)b * 8 + threadIdx.x];
-    s_ov[threadIdx.x] = s;
+  // thrust::reduce of omega_gpu / v_gpu (CvoGPU.cu:824-825) from k_assoc's block partials: thread t owns
+  // component (t & 7) of blocks t>>3, t>>3 + 32, ... (all loads in flight), then a fixed-order finish.
+  __shared__ double s_part[32][8];
+  {
+    const int nblk = D->nblk_assoc;
+    const int c = threadIdx.x & 7;
+    double acc = 0;
+    for (int b = threadIdx.x >> 3; b < nblk; b += 32) acc += D->flow_part[(size_t)b * 8 + c];
+    s_part[threadIdx.x >> 3][c] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double t = 0;
+#pragma unroll 8
+    for (int g = 0; g < 32; g++) t += s_part[g][threadIdx.x];
+    s_ov[threadIdx.x] = t;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -426,12 +476,13 @@ __global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ desc
   }
   __syncthreads();
   const int N = D->N;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 256 + threadIdx.x;  // sorted row
   double Bi = 0, Ci = 0, Di = 0, Ei = 0;
   if (i < N) {
     const unsigned nnz = D->nnz_row[i];
     if (nnz) {
-      const float4 x = D->x4[i];
+      const float4 x = D->xs4[i];
+      const Pose pose = load_pose(st);
       float temp_ell = st->ell;
       if (P.use_range_ell) {
         const float d2_sqrt = sqrtf(dot3_dev(x.x, x.y, x.z, x.x, x.y, x.z));
@@ -442,8 +493,9 @@ __global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ desc
       for (unsigned s = 0; s < nnz; s++) {
         const int idx = D->ell_j[(size_t)s * N + i];
         const float A_ij = D->ell_a[(size_t)s * N + i];
-        const float4 y = D->yt4[idx];
-        const V3 yy{y.x, y.y, y.z};
+        const float4 y0 = D->y4[idx];
+        const V3 yy = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
+        const float4 y = make_float4(yy.x, yy.y, yy.z, 0.f);
         // compute_step_size_xi for target idx (CvoGPU.cu:974-986)
         const V3 c = cross_dev(w, yy);
         const V3 xiz{c.x + s_M.v[0], c.y + s_M.v[1], c.z + s_M.v[2]};
@@ -494,34 +546,52 @@ __global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ desc
 // iteration (no bookkeeping, state comes from the host).
 // ------------------------------------------------------------------------------------------
 template <bool INIT>
-__global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp) {
+__global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
+                                               const int* __restrict__ status) {
+  if (!INIT && status[blockIdx.x] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.x;
-  PairState* st = D->st;
+  PairState* const gst = D->st;
   __shared__ double s_c[4];
   __shared__ unsigned long long s_n[4];
+  // the scalar part of the state is staged through LDS: one coalesced burst in, one out, instead of
+  // dozens of dependent global accesses from a single lane
+  constexpr int HOT_DWORDS = (int)(offsetof(PairState, sq) / 4);
+  __shared__ unsigned s_hot[HOT_DWORDS];
   const DevParams P = *Pp;
   const int tid = threadIdx.x;
+  for (int q = tid; q < HOT_DWORDS; q += 64) s_hot[q] = reinterpret_cast<const unsigned*>(gst)[q];
+  PairState* const st = reinterpret_cast<PairState*>(s_hot);
+  float* const sq = gst->sq;
+  float* const eq = gst->eq;
   if (!INIT) {
-    if (st->status != 0) return;
+    // The four thrust::reduce of compute_step_size (CvoGPU.cu:1118-1121) and the nonzero / max counts
+    // (SparseKernelMat.cu:37-46, CvoGPU.cu:1518): lane l owns component (l & 3) of blocks l>>2, l>>2 + 16, ...
+    // so all loads are in flight at once; a fixed xor-shuffle tree finishes (deterministic order).
     const int nba = D->nblk_assoc, nbc = D->nblk_coeff;
-    if (tid < 4) {  // the four thrust::reduce of compute_step_size (CvoGPU.cu:1118-1121)
-      double s = 0;
-      if (P.mode == 0)
-        for (int b = 0; b < nbc; b++) s += D->coef_part[(size_t)b * 4 + tid];
-      else if (tid == 0)
-        for (int b = 0; b < nba; b++) s += D->flow_part[(size_t)b * 8 + 6];
-      s_c[tid] = s;
-    } else if (tid >= 8 && tid < 12) {
-      const int c = tid - 8;
-      unsigned long long s = 0;
-      for (int b = 0; b < nba; b++) {
-        const unsigned long long q = D->cnt_part[(size_t)b * 4 + c];
-        s = (c == 1) ? max(s, q) : s + q;
-      }
-      s_n[c] = s;
+    const int c = tid & 3;
+    double s = 0;
+    if (P.mode == 0) {
+      for (int b = tid >> 2; b < nbc; b += 16) s += D->coef_part[(size_t)b * 4 + c];
+    } else if (c == 0) {
+      for (int b = tid >> 2; b < nba; b += 16) s += D->flow_part[(size_t)b * 8 + 6];
     }
-    __syncthreads();
+    unsigned long long q = 0;
+    for (int b = tid >> 2; b < nba; b += 16) {
+      const unsigned long long v = D->cnt_part[(size_t)b * 4 + c];
+      q = (c == 1) ? max(q, v) : q + v;
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+      s += __shfl_xor(s, o);
+      const unsigned long long v = __shfl_xor(q, o);
+      q = (c == 1) ? max(q, v) : q + v;
+    }
+    if (tid < 4) {
+      s_c[tid] = s;
+      s_n[tid] = q;
+    }
   }
+  __syncthreads();
   if (tid == 0) {
     int done = 0;
     if (!INIT) {
@@ -579,7 +649,7 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
           for (int q = 0; q < 3; q++) st->T[q] = T[q] = Tn[q];
           dist = se3_log_norm(dR, dT);  // CvoGPU.cu:1473-1476
           const float ip_curr = (float)((double)nnz / sqrt((double)D->N * (double)D->M));  // 1486
-          const bool need_decay_ell = indicator_update(st, ip_curr, P.window, P.stable_thr);
+          const bool need_decay_ell = indicator_update(st, sq, eq, ip_curr, P.window, P.stable_thr);
           if (dist < (double)P.eps_2) {  // CvoGPU.cu:1505-1508
             done = 1;
             st->iterations = k;
@@ -639,6 +709,8 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
       *D->status_out = 1;
     }
   }
+  __syncthreads();
+  for (int q = tid; q < HOT_DWORDS; q += 64) reinterpret_cast<unsigned*>(gst)[q] = s_hot[q];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -657,10 +729,11 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
 constexpr int PREP_THREADS = 512;
 
 __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restrict__ descs,
-                                                        const DevParams* __restrict__ Pp) {
+                                                        const DevParams* __restrict__ Pp,
+                                                        const int* __restrict__ status) {
+  if (status[blockIdx.y] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.y;
   const PairState* st = D->st;
-  if (st->status != 0) return;
   const DevParams P = *Pp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float INF = __builtin_inff();
@@ -681,7 +754,6 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
       const int j = D->yorder[sidx];
       const float4 p = D->y4[j];
       const V3 q = transform_point(Ri, Ti, p.x, p.y, p.z);
-      D->yt4[j] = make_float4(q.x, q.y, q.z, 0.f);
       ux = q.x - cx;
       uy = q.y - cy;
       uz = q.z - cz;
@@ -736,13 +808,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
   float ux = 0, uy = 0, uz = 0, cw = -INF, rad = 0;
   float lox = INF, loy = INF, loz = INF, hix = -INF, hiy = -INF, hiz = -INF;
   if (rs < N) {
-    const int i = D->xorder[rs];
-    const float4 x = D->x4[i];
+    const float4 x = D->xs4[rs];
     const float a_to_sensor = sqrtf(__builtin_fmaf(x.z, x.z, __builtin_fmaf(x.y, x.y, x.x * x.x)));
     const float l = compute_range_ell(ell, a_to_sensor);
     float thr = 1.f;
     if (P.use_geo) thr = (float)(-2.0 * l * l * (double)P.log_geo);
-    D->rowc[i] = make_float2(l, thr);
+    D->rowc[rs] = make_float2(l, thr);
     ux = x.x - cx;
     uy = x.y - cy;
     uz = x.z - cz;
