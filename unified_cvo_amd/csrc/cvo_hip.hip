@@ -239,11 +239,17 @@ void choose_scan_config(int n_pairs, int NG, int Mpad, int* T_out, int* gpb_out)
     int v = atoi(eT);
     if (v == 1 || v == 2 || v == 4 || v == 8) T = v;
   }
-  // Measured on MI355X (64 x 10k x 10k): 128-group blocks beat larger ones by 1.6x; work per wave is
-  // very uneven after culling, so many short waves balance better than few long ones.
-  (void)n_pairs;
-  (void)Mpad;
-  int gpb = std::min(128, (int)align_up((size_t)NG, 64));
+  // Measured on MI355X (64 x 10k x 10k, T = 2): one row segment per wave (5120 waves) beats 128-group
+  // blocks by 1.4x; a single pair needs the row range split to fill the chip.  Rule: the fewest
+  // segments that still give ~4096 waves.
+  const long slices = Mpad / (64 * T);
+  const int ngr = (int)align_up((size_t)NG, 64);
+  int gpb = ngr;
+  while (gpb > 64) {
+    const long waves = slices * ((ngr + gpb - 1) / gpb) * n_pairs;
+    if (waves >= 4096) break;
+    gpb = (int)align_up((size_t)gpb / 2, 64);
+  }
   const char* eG = getenv("CVO_SCAN_GROUPS");
   if (eG) {
     int v = atoi(eG);

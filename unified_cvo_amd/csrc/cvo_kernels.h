@@ -65,10 +65,15 @@ constexpr int XCULL_PAD = 32;  // rows k_scan may read past N (whole groups + pr
 #define CVO_CONST __attribute__((address_space(4)))
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // plain vector: loadable from any address space
 
+constexpr int SCAN_TILE_CAP = 128;  // (row group, slice) tiles a wave queues in LDS per round
+
 template <int T>
 __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
                                               const int* __restrict__ status, int force) {
   constexpr int RG = ROWS_PER_GROUP;
+  // per-wave tile queue: the row operands of every overlapping group, fetched by the lane that found it
+  __shared__ f32x4 s_rows[4][SCAN_TILE_CAP][RG];
+  __shared__ int s_tile_g[4][SCAN_TILE_CAP];
   if (!force && status[blockIdx.z] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.z;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -96,39 +101,46 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
   const CVO_CONST f32x4* sb = (const CVO_CONST f32x4*)D->sbox + 2 * slice;
   const f32x4 smin = sb[0], smax = sb[1];
   const CVO_GLOBAL f32x4* gbox = (const CVO_GLOBAL f32x4*)D->gbox;
-  const CVO_CONST f32x4* xc = (const CVO_CONST f32x4*)D->xcull;
+  const CVO_GLOBAL f32x4* xc = (const CVO_GLOBAL f32x4*)D->xcull;
   CVO_GLOBAL unsigned long long* masks = (CVO_GLOBAL unsigned long long*)D->masks;
   CVO_GLOBAL unsigned short* flags = (CVO_GLOBAL unsigned short*)D->flags;
   CVO_GLOBAL unsigned* rowsum = (CVO_GLOBAL unsigned*)D->rowsum;
   const unsigned rs_bit = 1u << ((slice >> 3) & 31);
   const int nchunks = D->nchunks;
   const int nsl_pad = D->nsl_pad;
+  f32x4(*rows)[RG] = s_rows[wave];
+  int* tile_g = s_tile_g[wave];
 
-  for (int gb = g_begin; gb < g_end; gb += 64) {
-    // ---- coarse level: lane l tests row group gb + l (boxes are already grown by the cut-off radius;
-    // pad groups carry empty boxes) against the slice box
-    const int g = gb + lane;
-    const f32x4 bmin = gbox[2 * (size_t)g], bmax = gbox[2 * (size_t)g + 1];
-    const bool overlap = (bmin.x <= smax.x) & (bmax.x >= smin.x) & (bmin.y <= smax.y) & (bmax.y >= smin.y) &
-                         (bmin.z <= smax.z) & (bmax.z >= smin.z) & (g < g_end);
-    unsigned long long todo = __ballot(overlap);
-    if (!todo) continue;
-    // ---- fine level over the overlapping groups, rows of the next group prefetched (scalar loads)
-    int b = __builtin_ctzll(todo);
-    todo &= todo - 1;
-    f32x4 cur[RG], nxt[RG];
-    {
-      const CVO_CONST f32x4* xr = xc + (size_t)(gb + b) * RG;
+  int gb = g_begin;
+  while (gb < g_end) {
+    // ---- coarse level: lane l tests row group gb + l against the slice box (group boxes are already
+    // grown by the cut-off radius; pad groups carry empty boxes).  The lane that finds an overlap
+    // fetches that group's RG row operands straight into the wave's LDS tile queue.
+    int ntiles = 0;
+    while (gb < g_end && ntiles + 64 <= SCAN_TILE_CAP) {
+      const int g = gb + lane;
+      const f32x4 bmin = gbox[2 * (size_t)g], bmax = gbox[2 * (size_t)g + 1];
+      const bool overlap = (bmin.x <= smax.x) & (bmax.x >= smin.x) & (bmin.y <= smax.y) & (bmax.y >= smin.y) &
+                           (bmin.z <= smax.z) & (bmax.z >= smin.z) & (g < g_end);
+      const unsigned long long m = __ballot(overlap);
+      if (overlap) {
+        const int slot = ntiles + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        const CVO_GLOBAL f32x4* xr = xc + (size_t)g * RG;
 #pragma unroll
-      for (int u = 0; u < RG; u++) cur[u] = xr[u];
-    }
-    for (;;) {
-      const int nb = todo ? __builtin_ctzll(todo) : b;
-      {
-        const CVO_CONST f32x4* xr = xc + (size_t)(gb + nb) * RG;
-#pragma unroll
-        for (int u = 0; u < RG; u++) nxt[u] = xr[u];
+        for (int u = 0; u < RG; u++) rows[slot][u] = xr[u];
+        tile_g[slot] = g;
       }
+      ntiles += __builtin_popcountll(m);
+      gb += 64;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- fine level over the queued tiles: 3 FMA per pair, a v_min3 tree per row, one compare per row
+    for (int ti = 0; ti < ntiles; ti++) {
+      f32x4 cur[RG];
+#pragma unroll
+      for (int u = 0; u < RG; u++) cur[u] = rows[ti][u];  // wave-uniform address: LDS broadcast
       float acc[RG][T];
       unsigned long long mu[RG];
       unsigned long long any = 0;
@@ -146,34 +158,32 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
         mu[u] = __ballot(mn < cur[u].w);
         any |= mu[u];
       }
-      if (any) {  // some row of the group has a candidate among this wave's 64*T targets
-        const int r = (gb + b) * RG;
+      if (any) {  // usual case once tiles are culled: the group has candidates among this wave's 64*T targets
+        // lane u*T+t keeps the bitmap word of (row u, chunk t); lane u keeps row u's flag word: the whole
+        // tile is emitted with one mask store, one flag store and one returnless atomic instruction
+        const int r = __builtin_amdgcn_readfirstlane(tile_g[ti]) * RG;
+        unsigned long long mine = 0;
+        unsigned myfl = 0;
 #pragma unroll
         for (int u = 0; u < RG; u++) {
-          if (mu[u]) {
-            unsigned long long mine = 0;
-            unsigned fl = 0;
+          unsigned fl = 0;
 #pragma unroll
-            for (int t = 0; t < T; t++) {
-              const unsigned long long m = __ballot(acc[u][t] < cur[u].w);
-              if (lane == t) mine = m;
-              fl |= (m != 0 ? 1u : 0u) << t;
-            }
-            if (lane < T && mine) masks[(size_t)(r + u) * nchunks + slice * T + lane] = mine;
-            if (lane == 0) {
-              flags[(size_t)(r + u) * nsl_pad + slice] = (unsigned short)fl;
-              // returnless atomic: tells k_assoc which 16-byte flag groups of this row to look at
-              __hip_atomic_fetch_or(rowsum + (r + u), rs_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+          for (int t = 0; t < T; t++) {
+            const unsigned long long m = __ballot(acc[u][t] < cur[u].w);
+            if (lane == u * T + t) mine = m;
+            fl |= (m != 0 ? 1u : 0u) << t;
           }
+          if (lane == u) myfl = fl;
+        }
+        if (lane < RG * T && mine) masks[(size_t)(r + lane / T) * nchunks + slice * T + (lane % T)] = mine;
+        if (lane < RG && myfl) {
+          flags[(size_t)(r + lane) * nsl_pad + slice] = (unsigned short)myfl;
+          // tells k_assoc which 16-byte flag groups of this row to look at
+          __hip_atomic_fetch_or(rowsum + (r + lane), rs_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      if (!todo) break;
-      b = nb;
-      todo &= todo - 1;
-#pragma unroll
-      for (int u = 0; u < RG; u++) cur[u] = nxt[u];
     }
+    __builtin_amdgcn_wave_barrier();  // the queue is reused by the next round
   }
 }
 
