@@ -133,12 +133,14 @@ def main():
         # ms per optimiser iteration of one frame pair, with `B` pairs in flight on each GPU
         ms_per_iter_pair = elapsed / args.steps / max(mean_iters, 1.0) / B * 1e3
         # ---- roofline of the dominant kernel (k_scan), timed live with HIP events on the ctx stream
-        scan_ms = gpu.debug_time_scan(20)
-        pairs_per_launch = float(n) * float(n) * B
-        bytes_per_launch = (n * 12 + n * 12) * B          # SURVEY.md 8(d), one pass, geometric payload
+        tiles, rpt, tpt = gpu.debug_scan_stats()        # over the last measured step (all pairs, all iterations)
+        scan_ms = gpu.debug_time_scan(20)               # re-launches k_scan on the final state of the batch
+        pairs_per_launch = float(n) * float(n) * B      # ALGORITHMIC pair tests (N*M per pair)
+        bytes_per_launch = (n * 12 + n * 12) * B        # SURVEY.md 8(d), one pass, geometric payload
         achieved_gbs = bytes_per_launch / (scan_ms * 1e-3) / 1e9
         pair_rate = pairs_per_launch / (scan_ms * 1e-3)
         valu_peak_pairs = FP32_VALU_PEAK_TFLOPS * 1e12 / C_CULL_FLOPS
+        executed_frac = tiles * rpt * tpt / (float(n) * float(n) * B * max(mean_iters, 1.0))
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tpath):
@@ -152,10 +154,14 @@ def main():
             "kernel": "cvo_dev::k_scan", "bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(scan_ms, 5),
-            # the path is an all-pairs accumulation with O(N+M) compulsory bytes: the binding roof is FP32 VALU
-            "valu": {"achieved_pair_tests_per_s": pair_rate, "peak_pair_tests_per_s": valu_peak_pairs,
-                     "frac": round(pair_rate / valu_peak_pairs, 4), "flops_per_pair_test": C_CULL_FLOPS,
-                     "peak_tflops": FP32_VALU_PEAK_TFLOPS},
+            # The path is an all-pairs accumulation with O(N+M) compulsory bytes: HBM is not the binding roof.
+            # The scan culls whole (4 rows x 128 targets) tiles by bounding boxes, so the ALGORITHMIC pair-test
+            # rate can exceed the FP32 VALU roof; `executed_fraction` is the share of the N*M tests really run.
+            "valu": {"algorithmic_pair_tests_per_s": pair_rate, "peak_pair_tests_per_s": valu_peak_pairs,
+                     "algorithmic_frac_of_roof": round(pair_rate / valu_peak_pairs, 4),
+                     "executed_fraction_of_pair_tests": round(executed_frac, 5),
+                     "executed_frac_of_roof": round(pair_rate * executed_frac / valu_peak_pairs, 4),
+                     "flops_per_pair_test": C_CULL_FLOPS, "peak_tflops": FP32_VALU_PEAK_TFLOPS},
         }
         cpu_baseline = None
         if not args.no_cpu_baseline and world == 1:
@@ -196,7 +202,8 @@ def main():
         log(f"[bench] inputs: generated in {t_gen:.2f}s, uploaded in {t_h2d:.3f}s ({h2d_rate:.2f} GB/s incl. host packing); "
             f"PCIe-inclusive rate = {aligns / (elapsed + args.steps * t_h2d):.2f} align/s")
         log(f"[bench] loop {loop_s:.3f}s/step on rank 0; scan kernel {scan_ms*1e3:.1f} us per launch of {B} pairs "
-            f"({pair_rate/1e12:.2f} T pair-tests/s = {100*pair_rate/valu_peak_pairs:.1f}% of FP32 VALU roof)")
+            f"({pair_rate/1e12:.2f} T algorithmic pair-tests/s; {100*executed_frac:.2f}% of the N*M tests executed after "
+            f"tile culling)")
         assert int(stat.abs().sum().item()) == 0, "some align() returned -1"
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -203,6 +203,9 @@ int cvo_debug_last_ell(cvo_ctx* ctx, int K, float* mat, int* ind, unsigned int* 
  * (used by bench.py to time the dominant kernel with HIP events on the context's stream).
  * Returns the average milliseconds per launch in *ms. */
 int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms);
+/* Tile-culling statistics of the last align call (all pairs, all iterations): number of fine tiles
+ * the scan executed and the tile shape; executed pair tests = tiles * rows_per_tile * targets_per_tile. */
+int cvo_debug_scan_stats(cvo_ctx* ctx, unsigned long long* tiles, int* rows_per_tile, int* targets_per_tile);
 /* Number of candidate pairs the scan of the last iteration produced (superset of nnz). */
 int cvo_debug_last_candidates(cvo_ctx* ctx, unsigned long long* out);
 const char* cvo_version(void);

@@ -315,3 +315,30 @@ def test_noise_free_alignment_recovers_motion_full_size():
     assert g.ret == 0
     # the loop ends jittering by +-min_step along a unit twist: algorithmic, not parity
     assert cases.max_abs_diff(g.transform, np.linalg.inv(synth.gt_motion())) < 3e-3
+
+
+def test_wide_target_cloud_uses_32bit_candidate_lists(oracle):
+    """M >= 65536 switches k_assoc to its 32-bit index instantiation; ragged N << M."""
+    rs = np.random.default_rng(11)
+    P = cases.load_params("geometric_gpu")
+    m = 70000
+    tgt = np.stack([rs.uniform(-40, 40, m), rs.uniform(-2, 2, m), rs.uniform(2, 82, m)], axis=1).astype(np.float32)
+    src = (tgt[rs.choice(m, 300, replace=False)] + rs.normal(0, 0.02, (300, 3))).astype(np.float32)
+    _single_iteration(oracle, P, CvoPointCloud.from_xyz(src), CvoPointCloud.from_xyz(tgt), np.eye(4, dtype=np.float32))
+
+
+def test_candidate_list_overflow_takes_literal_path(oracle):
+    """More candidates per row than the LDS list holds, but fewer hits than K: the literal ordered scan must
+    produce the same ELL as the sorted-list path would (mid-density regime)."""
+    P, src, tgt, init = cases.config2(n=3000)
+    g, o, (mat, ind, nz) = _single_iteration(oracle, P, src, tgt, init, ell=1.0, K=512)
+    assert nz.max() > 64  # beyond ASSOC_CAP16
+
+
+def test_result_does_not_depend_on_spatial_order(monkeypatch):
+    """The k-d ordering only steers the tile culling: identity order gives bit-identical poses."""
+    P, src, tgt, init = cases.config2(n=2500)
+    a = CvoGPU(params=P).align(src, tgt, init, max_iterations=200)
+    monkeypatch.setenv("CVO_NO_SORT", "1")
+    b = CvoGPU(params=P).align(src, tgt, init, max_iterations=200)
+    assert np.array_equal(a.transform, b.transform)

@@ -372,6 +372,12 @@ class CvoGPU:
         self._check(self.L.cvo_debug_time_scan(self.ctx, reps, C.byref(ms)))
         return ms.value
 
+    def debug_scan_stats(self):
+        """(tiles executed by k_scan during the last align call, rows per tile, targets per tile)."""
+        t, r, c = C.c_ulonglong(), C.c_int(), C.c_int()
+        self._check(self.L.cvo_debug_scan_stats(self.ctx, C.byref(t), C.byref(r), C.byref(c)))
+        return t.value, r.value, c.value
+
     def debug_last_candidates(self):
         v = C.c_ulonglong()
         self._check(self.L.cvo_debug_last_candidates(self.ctx, C.byref(v)))

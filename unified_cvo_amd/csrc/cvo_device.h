@@ -95,6 +95,7 @@ struct PairDesc {
   float4* sbox;   // [nslices][2]: AABB of each scan slice (T chunks)
   unsigned long long* masks;  // [N sorted rows][nchunks] candidate bit masks (valid where flagged)
   unsigned short* flags;      // [N sorted rows][nsl_pad]: which of a slice's T chunks are non-empty
+  unsigned long long* tile_count;  // [1]: fine tiles (ROWS_PER_GROUP rows x 64*T targets) executed so far this call
   unsigned* rowsum;           // [N sorted rows]: bit (g % 32) set <=> flags[row][8g .. 8g+7] may be non-zero
   float* ell_a;               // ELL kernel matrix values, [K_max][N], SORTED row index
   int* ell_j;                 // ELL column indices (ORIGINAL j, ascending), [K_max][N]

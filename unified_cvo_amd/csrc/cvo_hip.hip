@@ -35,7 +35,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, rowc, gbox, cbox, sbox, masks, flags, rowsum, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, rowc, gbox, cbox, sbox, masks, flags, rowsum, tile_count, ell_a, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -122,6 +122,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.masks = take(sizeof(unsigned long long) * (size_t)N * nchunks);
   L.flags = take(sizeof(unsigned short) * (size_t)N * nsl_pad);
   L.rowsum = take(sizeof(unsigned) * (size_t)N);
+  L.tile_count = take(sizeof(unsigned long long));
   L.ell_a = take(sizeof(float) * (size_t)N * Kmax);
   L.ell_j = take(sizeof(int) * (size_t)N * Kmax);
   L.nnz_row = take(sizeof(unsigned) * (size_t)N);
@@ -382,6 +383,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.masks = (unsigned long long*)(base + S->L.masks);
     D.flags = (unsigned short*)(base + S->L.flags);
     D.rowsum = (unsigned*)(base + S->L.rowsum);
+    D.tile_count = (unsigned long long*)(base + S->L.tile_count);
     D.ell_a = (float*)(base + S->L.ell_a);
     D.ell_j = (int*)(base + S->L.ell_j);
     D.nnz_row = (unsigned*)(base + S->L.nnz_row);
@@ -408,6 +410,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     // flags must start clean (they are self-cleaning afterwards)
     HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, sizeof(unsigned short) * (size_t)S->N * S->d.nsl_pad, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.rowsum, 0, sizeof(unsigned) * (size_t)S->N, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(D.tile_count, 0, sizeof(unsigned long long), ctx->stream));
   }
   // the blocks of k_assoc beyond a smaller pair's N still write their (zero) partials, but the
   // partial arrays of pairs whose N is smaller than the batch maximum are fully covered by nblk.
@@ -947,6 +950,21 @@ int cvo_debug_last_ell(cvo_ctx* ctx, int K, float* mat, int* ind, unsigned int* 
 int cvo_debug_last_candidates(cvo_ctx* ctx, unsigned long long* out) {
   if (!ctx || !out || ctx->last_pairs < 1) return fail(ctx, CVO_E_INVALID, "cvo_debug_last_candidates: bad argument");
   *out = ctx->h_states[0].ncand;
+  return CVO_OK;
+}
+
+int cvo_debug_scan_stats(cvo_ctx* ctx, unsigned long long* tiles, int* rows_per_tile, int* targets_per_tile) {
+  if (!ctx || !tiles || ctx->last_pairs < 1) return fail(ctx, CVO_E_INVALID, "cvo_debug_scan_stats: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  unsigned long long total = 0;
+  for (int p = 0; p < ctx->last_pairs; p++) {
+    unsigned long long v = 0;
+    HIP_TRY(ctx, hipMemcpy(&v, ctx->h_descs[p].tile_count, sizeof(v), hipMemcpyDeviceToHost));
+    total += v;
+  }
+  *tiles = total;
+  if (rows_per_tile) *rows_per_tile = ROWS_PER_GROUP;
+  if (targets_per_tile) *targets_per_tile = 64 * ctx->last_params.T;
   return CVO_OK;
 }
 

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
   int* tile_g = s_tile_g[wave];
 
   int gb = g_begin;
+  unsigned tiles_done = 0;
   while (gb < g_end) {
     // ---- coarse level: lane l tests row group gb + l against the slice box (group boxes are already
     // grown by the cut-off radius; pad groups carry empty boxes).  The lane that finds an overlap
@@ -183,8 +184,11 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
         }
       }
     }
+    tiles_done += (unsigned)ntiles;
     __builtin_amdgcn_wave_barrier();  // the queue is reused by the next round
   }
+  if (lane == 0 && tiles_done)  // statistics only (cvo_debug_scan_stats): one returnless atomic per wave
+    __hip_atomic_fetch_add(D->tile_count, (unsigned long long)tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------
