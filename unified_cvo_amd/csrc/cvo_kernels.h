@@ -65,7 +65,47 @@ constexpr int XCULL_PAD = 32;  // rows k_scan may read past N (whole groups + pr
 #define CVO_CONST __attribute__((address_space(4)))
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // plain vector: loadable from any address space
 
-constexpr int SCAN_TILE_CAP = 128;  // (row group, slice) tiles a wave queues in LDS per round
+// v_writelane_b32 with compile-time lanes: moves wave-uniform values (SGPRs: the halves of ballot
+// masks) into consecutive lanes of two VGPRs.  (The clang builtin is not declared for hipcc's host
+// pass, hence inline asm.)  An asm statement is opaque to the hazard recogniser, and a v_cmp that
+// has just written the SGPR must not be followed directly by the v_writelane that reads it (measured:
+// stale masks without the wait), so every statement opens with its own s_nop.
+template <int T, int BASE>
+__device__ __forceinline__ void scatter_row_masks(const unsigned long long (&m)[T], unsigned& lo, unsigned& hi) {
+  static_assert(T == 1 || T == 2 || T == 4 || T == 8, "T");
+  if constexpr (T == 1) {
+    asm("s_nop 4\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+        : "+v"(lo), "+v"(hi) : "s"((unsigned)m[0]), "s"((unsigned)(m[0] >> 32)), "n"(BASE));
+  } else if constexpr (T == 2) {
+    asm("s_nop 4\n\tv_writelane_b32 %0, %2, %6\n\tv_writelane_b32 %1, %3, %6\n\t"
+        "v_writelane_b32 %0, %4, %7\n\tv_writelane_b32 %1, %5, %7"
+        : "+v"(lo), "+v"(hi)
+        : "s"((unsigned)m[0]), "s"((unsigned)(m[0] >> 32)), "s"((unsigned)m[1]), "s"((unsigned)(m[1] >> 32)),
+          "n"(BASE), "n"(BASE + 1));
+  } else {
+    unsigned long long a[T / 2], b[T / 2];
+#pragma unroll
+    for (int t = 0; t < T / 2; t++) {
+      a[t] = m[t];
+      b[t] = m[T / 2 + t];
+    }
+    scatter_row_masks<T / 2, BASE>(a, lo, hi);
+    scatter_row_masks<T / 2, BASE + T / 2>(b, lo, hi);
+  }
+}
+template <int T, int U, int RG>
+struct ScatterTile {
+  static __device__ __forceinline__ void run(const unsigned long long (&mm)[RG][T], unsigned& lo, unsigned& hi) {
+    scatter_row_masks<T, U * T>(mm[U], lo, hi);
+    ScatterTile<T, U + 1, RG>::run(mm, lo, hi);
+  }
+};
+template <int T, int RG>
+struct ScatterTile<T, RG, RG> {
+  static __device__ __forceinline__ void run(const unsigned long long (&)[RG][T], unsigned&, unsigned&) {}
+};
+
+constexpr int SCAN_TILE_CAP = 64;  // (row group, slice) tiles a wave queues in LDS per round
 
 template <int T>
 __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
@@ -110,6 +150,9 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
   const int nsl_pad = D->nsl_pad;
   f32x4(*rows)[RG] = s_rows[wave];
   int* tile_g = s_tile_g[wave];
+  // per-lane parts of the emission addresses (lane q = u*T+t <-> row u, chunk t)
+  const size_t mask_off = (size_t)(lane / T) * nchunks + slice * T + (lane % T);
+  const size_t flag_off = (size_t)(lane / T) * nsl_pad + slice;
 
   int gb = g_begin;
   unsigned tiles_done = 0;
@@ -160,27 +203,29 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
         any |= mu[u];
       }
       if (any) {  // usual case once tiles are culled: the group has candidates among this wave's 64*T targets
-        // lane u*T+t keeps the bitmap word of (row u, chunk t); lane u keeps row u's flag word: the whole
-        // tile is emitted with one mask store, one flag store and one returnless atomic instruction
+        // Lane q = u*T+t receives the bitmap word of (row u, chunk t) with v_writelane; the T lanes of a row
+        // OR their "non-empty" bits with DPP shuffles and the row's first lane stores the flag word: the
+        // whole tile is emitted with one mask store, one flag store and one returnless atomic instruction.
         const int r = __builtin_amdgcn_readfirstlane(tile_g[ti]) * RG;
-        unsigned long long mine = 0;
-        unsigned myfl = 0;
+        unsigned long long mm[RG][T];
 #pragma unroll
         for (int u = 0; u < RG; u++) {
-          unsigned fl = 0;
 #pragma unroll
-          for (int t = 0; t < T; t++) {
-            const unsigned long long m = __ballot(acc[u][t] < cur[u].w);
-            if (lane == u * T + t) mine = m;
-            fl |= (m != 0 ? 1u : 0u) << t;
-          }
-          if (lane == u) myfl = fl;
+          for (int t = 0; t < T; t++) mm[u][t] = __ballot(acc[u][t] < cur[u].w);
         }
-        if (lane < RG * T && mine) masks[(size_t)(r + lane / T) * nchunks + slice * T + (lane % T)] = mine;
-        if (lane < RG && myfl) {
-          flags[(size_t)(r + lane) * nsl_pad + slice] = (unsigned short)myfl;
-          // tells k_assoc which 16-byte flag groups of this row to look at
-          __hip_atomic_fetch_or(rowsum + (r + lane), rs_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned lo = 0, hi = 0;
+        ScatterTile<T, 0, RG>::run(mm, lo, hi);
+        const bool nz = (lo | hi) != 0;
+        unsigned fl = nz ? (1u << (lane % T)) : 0u;
+#pragma unroll
+        for (int o = 1; o < T; o <<= 1) fl |= (unsigned)__shfl_xor((int)fl, o);
+        if (lane < RG * T) {
+          if (nz) masks[(size_t)r * nchunks + mask_off] = ((unsigned long long)hi << 32) | lo;
+          if (fl && (lane % T) == 0) {
+            flags[(size_t)r * nsl_pad + flag_off] = (unsigned short)fl;
+            // tells k_assoc which 16-byte flag groups of this row to look at
+            __hip_atomic_fetch_or(rowsum + (r + lane / T), rs_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
     }
