@@ -40,10 +40,10 @@ struct PairLayout {  // byte offsets of one pair's workspace inside the arena
 };
 
 struct GraphKey {
-  int n_pairs, T, gx, gy, nba, nbc, npb, idx16, U;
+  int n_pairs = 0, p0 = 0, T = 0, gx = 0, gy = 0, nba = 0, nbc = 0, npb = 0, idx16 = 0, U = 0;
   bool operator==(const GraphKey& o) const {
-    return n_pairs == o.n_pairs && T == o.T && gx == o.gx && gy == o.gy && nba == o.nba && nbc == o.nbc &&
-           npb == o.npb && idx16 == o.idx16 && U == o.U;
+    return n_pairs == o.n_pairs && p0 == o.p0 && T == o.T && gx == o.gx && gy == o.gy && nba == o.nba &&
+           nbc == o.nbc && npb == o.npb && idx16 == o.idx16 && U == o.U;
   }
 };
 
@@ -66,11 +66,17 @@ struct cvo_ctx {
   std::vector<PairDesc> h_descs;
   std::vector<PairState> h_states;
   int* h_status[2] = {nullptr, nullptr};  // pinned
-  hipEvent_t ev_chk[2] = {nullptr, nullptr};
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-  // graph cache
-  hipGraphExec_t graph_exec = nullptr;
-  GraphKey graph_key{0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // A batch is split into up to MAX_GROUPS sub-batches, each enqueued on its own stream: the pairs are
+  // independent, so one group's latency-bound kernels (k_update: one wave per pair) and launch tails
+  // overlap the other groups' wide kernels.  Group 0 runs on `stream`.
+  static constexpr int MAX_GROUPS = 4;
+  hipStream_t gstream[MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_chk[2][MAX_GROUPS] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
+  // graph cache (one per group)
+  hipGraphExec_t graph_exec[MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+  GraphKey graph_key[MAX_GROUPS] = {};
   // last call (debug hooks)
   int last_pairs = 0;
   int last_N = 0, last_M = 0, last_Kmax = 0;
@@ -157,6 +163,14 @@ void free_workspace(cvo_ctx* c) {
   c->cap_pairs = 0;
 }
 
+void drop_graphs(cvo_ctx* c) {
+  for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++)
+    if (c->graph_exec[g]) {
+      (void)hipGraphExecDestroy(c->graph_exec[g]);
+      c->graph_exec[g] = nullptr;
+    }
+}
+
 int ensure_workspace(cvo_ctx* c, int n_pairs, size_t bytes_per_pair) {
   if (n_pairs > c->cap_pairs) {
     if (c->d_descs) (void)hipFree(c->d_descs);
@@ -172,10 +186,7 @@ int ensure_workspace(cvo_ctx* c, int n_pairs, size_t bytes_per_pair) {
     HIP_TRY(c, hipMalloc(&c->d_status, sizeof(int) * (size_t)n_pairs));
     for (int i = 0; i < 2; i++) HIP_TRY(c, hipHostMalloc(&c->h_status[i], sizeof(int) * (size_t)n_pairs));
     c->cap_pairs = n_pairs;
-    if (c->graph_exec) {
-      (void)hipGraphExecDestroy(c->graph_exec);
-      c->graph_exec = nullptr;
-    }
+    drop_graphs(c);
   }
   const size_t need = bytes_per_pair * (size_t)n_pairs;
   if (need > c->arena_bytes) {
@@ -185,10 +196,7 @@ int ensure_workspace(cvo_ctx* c, int n_pairs, size_t bytes_per_pair) {
     hipError_t e = hipMalloc(&c->arena, need);
     if (e != hipSuccess) return fail(c, CVO_E_NOMEM, "workspace hipMalloc failed: " + std::string(hipGetErrorString(e)));
     c->arena_bytes = need;
-    if (c->graph_exec) {
-      (void)hipGraphExecDestroy(c->graph_exec);
-      c->graph_exec = nullptr;
-    }
+    drop_graphs(c);
   }
   return CVO_OK;
 }
@@ -277,25 +285,34 @@ void launch_assoc(hipStream_t s, bool idx16, dim3 grid, const PairDesc* descs, c
 }
 
 struct LaunchGeom {
-  int n_pairs, T, gx, gy, nba, nbc, npb;
+  int n_pairs, p0, T, gx, gy, nba, nbc, npb;
   bool idx16;
+  hipStream_t stream;
 };
 
 void launch_prep(cvo_ctx* c, const LaunchGeom& g) {
-  hipLaunchKernelGGL(k_prep, dim3(g.npb, g.n_pairs), dim3(PREP_THREADS), 0, c->stream, c->d_descs, c->d_params,
-                     c->d_status);
+  hipLaunchKernelGGL(k_prep, dim3(g.npb, g.n_pairs), dim3(PREP_THREADS), 0, g.stream, c->d_descs + g.p0,
+                     c->d_params, c->d_status + g.p0);
+}
+
+void launch_init(cvo_ctx* c, const LaunchGeom& g) {
+  hipLaunchKernelGGL(k_update<true>, dim3(g.n_pairs), dim3(64), 0, g.stream, c->d_descs + g.p0, c->d_params,
+                     c->d_status + g.p0);
+  launch_prep(c, g);
 }
 
 void launch_iteration(cvo_ctx* c, const LaunchGeom& g) {
-  launch_scan(c->stream, g.T, dim3(g.gx, g.gy, g.n_pairs), c->d_descs, c->d_params, c->d_status, 0);
-  launch_assoc(c->stream, g.idx16, dim3(g.nba, g.n_pairs), c->d_descs, c->d_params, c->d_status);
-  hipLaunchKernelGGL(k_coeff, dim3(g.nbc, g.n_pairs), dim3(256), 0, c->stream, c->d_descs, c->d_params, c->d_status);
-  hipLaunchKernelGGL(k_update<false>, dim3(g.n_pairs), dim3(64), 0, c->stream, c->d_descs, c->d_params, c->d_status);
+  const PairDesc* descs = c->d_descs + g.p0;
+  const int* st = c->d_status + g.p0;
+  launch_scan(g.stream, g.T, dim3(g.gx, g.gy, g.n_pairs), descs, c->d_params, st, 0);
+  launch_assoc(g.stream, g.idx16, dim3(g.nba, g.n_pairs), descs, c->d_params, st);
+  hipLaunchKernelGGL(k_coeff, dim3(g.nbc, g.n_pairs), dim3(256), 0, g.stream, descs, c->d_params, st);
+  hipLaunchKernelGGL(k_update<false>, dim3(g.n_pairs), dim3(64), 0, g.stream, descs, c->d_params, st);
   launch_prep(c, g);
 }
 
 struct BatchSetup {
-  int N, M, T, gpb, gx, gy;
+  int N, M, T, gpb, gx, gy, G;
   Dims d;
   PairLayout L;
   LaunchGeom geom;
@@ -329,7 +346,11 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->L = make_layout(N, M, Kmax, trace_cap, &S->d);
   int rc = ensure_workspace(ctx, n_pairs, S->L.total);
   if (rc != CVO_OK) return rc;
-  choose_scan_config(n_pairs, S->d.NG, S->d.Mpad, &S->T, &S->gpb);
+  // sub-batches on separate streams (see cvo_ctx): the scan geometry is chosen for one group's launch
+  S->G = n_pairs >= 32 ? 4 : (n_pairs >= 8 ? 2 : 1);
+  if (const char* e = getenv("CVO_STREAMS")) S->G = std::max(1, std::min(atoi(e), (int)cvo_ctx::MAX_GROUPS));
+  S->G = std::min(S->G, n_pairs);
+  choose_scan_config((n_pairs + S->G - 1) / S->G, S->d.NG, S->d.Mpad, &S->T, &S->gpb);
 
   DevParams dp = make_dev_params(*params);
   dp.mode = mode;
@@ -423,6 +444,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->gx = (S->d.Mpad / (64 * S->T) + 3) / 4;
   S->gy = ((int)align_up((size_t)S->d.NG, 64) + S->gpb - 1) / S->gpb;
   S->geom.n_pairs = n_pairs;
+  S->geom.p0 = 0;
+  S->geom.stream = ctx->stream;
   S->geom.T = S->T;
   S->geom.gx = S->gx;
   S->geom.gy = S->gy;
@@ -449,8 +472,7 @@ int run_single_eval(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
   const cvo_cloud* tgt[1] = {target};
   int rc = setup_batch(ctx, params, 1, src, tgt, Tm, nullptr, 1, ell, S, &dp);
   if (rc != CVO_OK) return rc;
-  hipLaunchKernelGGL(k_update<true>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params, ctx->d_status);
-  launch_prep(ctx, S->geom);
+  launch_init(ctx, S->geom);
   launch_scan(ctx->stream, S->T, dim3(S->gx, S->gy, 1), ctx->d_descs, ctx->d_params, ctx->d_status, 0);
   launch_assoc(ctx->stream, S->geom.idx16, dim3(S->d.nblk_assoc, 1), ctx->d_descs, ctx->d_params, ctx->d_status);
   hipLaunchKernelGGL(k_update<false>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params, ctx->d_status);
@@ -532,12 +554,18 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return CVO_E_HIP;
   cvo_ctx* c = new cvo_ctx();
   c->device = device;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc(&c->d_params, sizeof(DevParams)) != hipSuccess ||
-      hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_chk[0], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_chk[1], hipEventDisableTiming) != hipSuccess) {
-    delete c;
+  bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipMalloc(&c->d_params, sizeof(DevParams)) == hipSuccess && hipEventCreate(&c->ev_start) == hipSuccess &&
+            hipEventCreate(&c->ev_stop) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+  c->gstream[0] = c->stream;
+  for (int g = 0; ok && g < cvo_ctx::MAX_GROUPS; g++) {
+    if (g) ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2; i++) ok = ok && hipEventCreateWithFlags(&c->ev_chk[i][g], hipEventDisableTiming) == hipSuccess;
+  }
+  if (!ok) {
+    cvo_ctx_destroy(c);
     return CVO_E_HIP;
   }
   *out = c;
@@ -547,12 +575,18 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
 void cvo_ctx_destroy(cvo_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
-  if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++)
+    if (c->gstream[g]) (void)hipStreamSynchronize(c->gstream[g]);
+  drop_graphs(c);
   free_workspace(c);
   if (c->d_params) (void)hipFree(c->d_params);
-  for (int i = 0; i < 2; i++)
-    if (c->ev_chk[i]) (void)hipEventDestroy(c->ev_chk[i]);
+  for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++) {
+    for (int i = 0; i < 2; i++)
+      if (c->ev_chk[i][g]) (void)hipEventDestroy(c->ev_chk[i][g]);
+    if (c->ev_join[g]) (void)hipEventDestroy(c->ev_join[g]);
+    if (g && c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
+  }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -719,54 +753,82 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   const int graph_mode = opts ? opts->use_graph : 0;
   const bool use_graph = graph_mode != 1;
 
+  // sub-batches on separate streams (see cvo_ctx): contiguous blocks of pairs
+  const int G = S.G;
+  LaunchGeom geom[cvo_ctx::MAX_GROUPS];
+  for (int g = 0; g < G; g++) {
+    const int p0 = (int)((long)n_pairs * g / G), p1 = (int)((long)n_pairs * (g + 1) / G);
+    geom[g] = S.geom;
+    geom[g].p0 = p0;
+    geom[g].n_pairs = p1 - p0;
+    geom[g].stream = ctx->gstream[g];
+  }
+
   HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-  hipLaunchKernelGGL(k_update<true>, dim3(n_pairs), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params,
-                     ctx->d_status);
-  launch_prep(ctx, S.geom);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));  // the setup copies were enqueued on group 0's stream
+  for (int g = 0; g < G; g++) {
+    if (g) HIP_TRY(ctx, hipStreamWaitEvent(geom[g].stream, ctx->ev_fork, 0));
+    launch_init(ctx, geom[g]);
+  }
   HIP_TRY(ctx, hipGetLastError());
 
   if (max_iter > 0) {
     if (use_graph) {
-      GraphKey key{n_pairs, S.T, S.gx, S.gy, S.d.nblk_assoc, S.d.nblk_coeff, S.geom.npb, S.geom.idx16 ? 1 : 0, U};
-      if (!ctx->graph_exec || !(ctx->graph_key == key)) {
-        if (ctx->graph_exec) {
-          (void)hipGraphExecDestroy(ctx->graph_exec);
-          ctx->graph_exec = nullptr;
+      for (int g = 0; g < G; g++) {
+        GraphKey key;
+        key.n_pairs = geom[g].n_pairs;
+        key.p0 = geom[g].p0;
+        key.T = S.T;
+        key.gx = S.gx;
+        key.gy = S.gy;
+        key.nba = S.d.nblk_assoc;
+        key.nbc = S.d.nblk_coeff;
+        key.npb = S.geom.npb;
+        key.idx16 = S.geom.idx16 ? 1 : 0;
+        key.U = U;
+        if (!ctx->graph_exec[g] || !(ctx->graph_key[g] == key)) {
+          if (ctx->graph_exec[g]) {
+            (void)hipGraphExecDestroy(ctx->graph_exec[g]);
+            ctx->graph_exec[g] = nullptr;
+          }
+          hipGraph_t gr = nullptr;
+          HIP_TRY(ctx, hipStreamBeginCapture(geom[g].stream, hipStreamCaptureModeThreadLocal));
+          for (int u = 0; u < U; u++) launch_iteration(ctx, geom[g]);
+          HIP_TRY(ctx, hipStreamEndCapture(geom[g].stream, &gr));
+          hipError_t e = hipGraphInstantiate(&ctx->graph_exec[g], gr, nullptr, nullptr, 0);
+          (void)hipGraphDestroy(gr);
+          if (e != hipSuccess) return fail(ctx, CVO_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+          ctx->graph_key[g] = key;
         }
-        hipGraph_t g = nullptr;
-        HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        for (int u = 0; u < U; u++) launch_iteration(ctx, S.geom);
-        HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &g));
-        hipError_t e = hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        if (e != hipSuccess) return fail(ctx, CVO_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-        ctx->graph_key = key;
       }
     }
     const int n_chunks = (max_iter + U - 1) / U;
-    int waited = 0;  // chunks whose status has been inspected
     bool all_done = false;
     for (int ch = 0; ch < n_chunks && !all_done; ch++) {
-      if (use_graph) {
-        HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
-      } else {
-        for (int u = 0; u < U; u++) launch_iteration(ctx, S.geom);
-        HIP_TRY(ctx, hipGetLastError());
-      }
       const int slot = ch & 1;
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status[slot], ctx->d_status, sizeof(int) * (size_t)n_pairs,
-                                  hipMemcpyDeviceToHost, ctx->stream));
-      HIP_TRY(ctx, hipEventRecord(ctx->ev_chk[slot], ctx->stream));
+      for (int g = 0; g < G; g++) {
+        if (use_graph) {
+          HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g], geom[g].stream));
+        } else {
+          for (int u = 0; u < U; u++) launch_iteration(ctx, geom[g]);
+          HIP_TRY(ctx, hipGetLastError());
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status[slot] + geom[g].p0, ctx->d_status + geom[g].p0,
+                                    sizeof(int) * (size_t)geom[g].n_pairs, hipMemcpyDeviceToHost, geom[g].stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_chk[slot][g], geom[g].stream));
+      }
       // keep one chunk of speculation in flight: inspect the chunk before this one
       if (ch >= 1) {
         const int ws = (ch - 1) & 1;
-        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_chk[ws]));
-        waited = ch;
+        for (int g = 0; g < G; g++) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_chk[ws][g]));
         all_done = true;
         for (int p = 0; p < n_pairs; p++) all_done = all_done && ctx->h_status[ws][p] != 0;
       }
     }
-    (void)waited;
+  }
+  for (int g = 1; g < G; g++) {  // join
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_join[g], geom[g].stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[g], 0));
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_states.data(), ctx->d_states, sizeof(PairState) * (size_t)n_pairs,
