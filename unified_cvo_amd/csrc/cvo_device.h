@@ -72,7 +72,7 @@ struct PairState {
 // space so that 4-row groups and 64-target chunks are spatially compact and whole tiles can be
 // rejected by a bounding-box test; k_assoc maps candidates back and restores ascending original j.
 struct PairDesc {
-  int N, M, Mpad, nchunks, nslices, nsl_pad, nblk_assoc, nblk_coeff;
+  int N, M, Mpad, nchunks, nslices, rbw, nblk_assoc, nblk_coeff;  // rbw: 32-bit words of slice bits per row
   int NG;     // row groups of ROWS_PER_GROUP sorted rows
   int NGpad;  // NG rounded up for the coarse test (pad groups have empty boxes)
   float cx, cy, cz;  // centre subtracted in the cull arithmetic only
@@ -93,10 +93,11 @@ struct PairDesc {
   float4* gbox;   // [NGpad][2]: AABB of each sorted row group, grown by the group's cut-off radius
   float4* cbox;   // [nchunks][2]: AABB of each 64-target sorted chunk
   float4* sbox;   // [nslices][2]: AABB of each scan slice (T chunks)
-  unsigned long long* masks;  // [N sorted rows][nchunks] candidate bit masks (valid where flagged)
-  unsigned short* flags;      // [N sorted rows][nsl_pad]: which of a slice's T chunks are non-empty
-  unsigned long long* tile_count;  // [1]: fine tiles (ROWS_PER_GROUP rows x 64*T targets) executed so far this call
-  unsigned* rowsum;           // [N sorted rows]: bit (g % 32) set <=> flags[row][8g .. 8g+7] may be non-zero
+  unsigned long long* masks;  // [nslices][N sorted rows][T] candidate bit masks; a row's T words of a slice are
+                              // valid iff that slice's bit is set in the row's rowbits (never memset)
+  unsigned* rowbits;          // [N sorted rows][rbw]: bit s set <=> the row has candidates in scan slice s;
+                              // set by k_scan (returnless atomic OR), cleared by k_assoc
+  unsigned long long* tile_count;  // [1]: fine tiles executed so far this call (statistics)
   float* ell_a;               // ELL kernel matrix values, [K_max][N], SORTED row index
   int* ell_j;                 // ELL column indices (ORIGINAL j, ascending), [K_max][N]
   unsigned* nnz_row;          // nonzeros[N], SORTED row index

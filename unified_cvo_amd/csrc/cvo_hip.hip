@@ -35,7 +35,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, rowc, gbox, cbox, sbox, masks, flags, rowsum, tile_count, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, rowc, gbox, cbox, sbox, masks, rowbits, tile_count, ell_a, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -101,13 +101,13 @@ int fail(cvo_ctx* ctx, int code, const std::string& msg) {
   } while (0)
 
 struct Dims {
-  int Mpad, nchunks, nsl_pad, nblk_assoc, nblk_coeff, NG, NGpad;
+  int Mpad, nchunks, rbw_max, nblk_assoc, nblk_coeff, NG, NGpad;
 };
 
 PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   const int Mpad = (int)align_up((size_t)M, 512);
   const int nchunks = Mpad / 64;
-  const int nsl_pad = (int)align_up((size_t)nchunks, 8);  // enough for T = 1
+  const int rbw_max = (int)align_up((size_t)(nchunks + 31) / 32, 4);  // slice bits per row, enough for T = 1
   const int nba = (N + ASSOC_THREADS - 1) / ASSOC_THREADS;
   const int nbc = (N + 255) / 256;
   const int NG = (N + ROWS_PER_GROUP - 1) / ROWS_PER_GROUP;
@@ -125,9 +125,8 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.gbox = take(sizeof(float4) * 2 * (size_t)NGpad);
   L.cbox = take(sizeof(float4) * 2 * (size_t)nchunks);
   L.sbox = take(sizeof(float4) * 2 * (size_t)nchunks);
-  L.masks = take(sizeof(unsigned long long) * (size_t)N * nchunks);
-  L.flags = take(sizeof(unsigned short) * (size_t)N * nsl_pad);
-  L.rowsum = take(sizeof(unsigned) * (size_t)N);
+  L.masks = take(sizeof(unsigned long long) * ((size_t)N + 8) * nchunks);
+  L.rowbits = take(sizeof(unsigned) * (size_t)(N + 4) * rbw_max);
   L.tile_count = take(sizeof(unsigned long long));
   L.ell_a = take(sizeof(float) * (size_t)N * Kmax);
   L.ell_j = take(sizeof(int) * (size_t)N * Kmax);
@@ -139,7 +138,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.total = off;
   d->Mpad = Mpad;
   d->nchunks = nchunks;
-  d->nsl_pad = nsl_pad;
+  d->rbw_max = rbw_max;
   d->nblk_assoc = nba;
   d->nblk_coeff = nbc;
   d->NG = NG;
@@ -376,7 +375,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.Mpad = S->d.Mpad;
     D.nchunks = S->d.nchunks;
     D.nslices = S->d.Mpad / (64 * S->T);
-    D.nsl_pad = S->d.nsl_pad;
+    D.rbw = (int)align_up((size_t)(S->d.Mpad / (64 * S->T) + 31) / 32, 4);
     D.nblk_assoc = S->d.nblk_assoc;
     D.nblk_coeff = S->d.nblk_coeff;
     D.NG = (X->n + ROWS_PER_GROUP - 1) / ROWS_PER_GROUP;
@@ -402,8 +401,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.cbox = (float4*)(base + S->L.cbox);
     D.sbox = (float4*)(base + S->L.sbox);
     D.masks = (unsigned long long*)(base + S->L.masks);
-    D.flags = (unsigned short*)(base + S->L.flags);
-    D.rowsum = (unsigned*)(base + S->L.rowsum);
+    D.rowbits = (unsigned*)(base + S->L.rowbits);
     D.tile_count = (unsigned long long*)(base + S->L.tile_count);
     D.ell_a = (float*)(base + S->L.ell_a);
     D.ell_j = (int*)(base + S->L.ell_j);
@@ -428,9 +426,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
       st.ell = opts->ell0;
       st.K = opts->K0;
     }
-    // flags must start clean (they are self-cleaning afterwards)
-    HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, sizeof(unsigned short) * (size_t)S->N * S->d.nsl_pad, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(D.rowsum, 0, sizeof(unsigned) * (size_t)S->N, ctx->stream));
+    // the slice bits must start clean (they are self-cleaning afterwards)
+    HIP_TRY(ctx, hipMemsetAsync(D.rowbits, 0, sizeof(unsigned) * (size_t)(S->N + 4) * S->d.rbw_max, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.tile_count, 0, sizeof(unsigned long long), ctx->stream));
   }
   // the blocks of k_assoc beyond a smaller pair's N still write their (zero) partials, but the
@@ -1045,8 +1042,7 @@ int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms) {
   // the extra scans leave flags behind; clean them so the workspace stays consistent
   for (int p = 0; p < n_pairs; p++) {
     const PairDesc& D = ctx->h_descs[p];
-    HIP_TRY(ctx, hipMemsetAsync(D.flags, 0, sizeof(unsigned short) * (size_t)ctx->last_N * D.nsl_pad, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(D.rowsum, 0, sizeof(unsigned) * (size_t)ctx->last_N, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(D.rowbits, 0, sizeof(unsigned) * (size_t)(ctx->last_N + 4) * D.rbw, ctx->stream));
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   float t = 0;

@@ -143,16 +143,16 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
   const CVO_GLOBAL f32x4* gbox = (const CVO_GLOBAL f32x4*)D->gbox;
   const CVO_GLOBAL f32x4* xc = (const CVO_GLOBAL f32x4*)D->xcull;
   CVO_GLOBAL unsigned long long* masks = (CVO_GLOBAL unsigned long long*)D->masks;
-  CVO_GLOBAL unsigned short* flags = (CVO_GLOBAL unsigned short*)D->flags;
-  CVO_GLOBAL unsigned* rowsum = (CVO_GLOBAL unsigned*)D->rowsum;
-  const unsigned rs_bit = 1u << ((slice >> 3) & 31);
-  const int nchunks = D->nchunks;
-  const int nsl_pad = D->nsl_pad;
+  CVO_GLOBAL unsigned* rowbits = (CVO_GLOBAL unsigned*)D->rowbits;
+  const int rbw = D->rbw;
+  const unsigned slice_bit = 1u << (slice & 31);
+  const int N = D->N;
   f32x4(*rows)[RG] = s_rows[wave];
   int* tile_g = s_tile_g[wave];
-  // per-lane parts of the emission addresses (lane q = u*T+t <-> row u, chunk t)
-  const size_t mask_off = (size_t)(lane / T) * nchunks + slice * T + (lane % T);
-  const size_t flag_off = (size_t)(lane / T) * nsl_pad + slice;
+  // emission addresses: masks are [slice][row][T], so the RG*T words of a tile are one contiguous run
+  // (lane q = u*T+t <-> row u, chunk t) and rows that are neighbours in space share cache lines
+  CVO_GLOBAL unsigned long long* mask_lane = masks + (size_t)slice * N * T + lane;
+  CVO_GLOBAL unsigned* rowbits_lane = rowbits + (size_t)(lane / T) * rbw + (slice >> 5);
 
   int gb = g_begin;
   unsigned tiles_done = 0;
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
       }
       if (any) {  // usual case once tiles are culled: the group has candidates among this wave's 64*T targets
         // Lane q = u*T+t receives the bitmap word of (row u, chunk t) with v_writelane; the T lanes of a row
-        // OR their "non-empty" bits with DPP shuffles and the row's first lane stores the flag word: the
-        // whole tile is emitted with one mask store, one flag store and one returnless atomic instruction.
+        // OR their "non-empty" bits with DPP shuffles: the whole tile is emitted with one (contiguous) mask
+        // store and one returnless atomic instruction.
         const int r = __builtin_amdgcn_readfirstlane(tile_g[ti]) * RG;
         unsigned long long mm[RG][T];
 #pragma unroll
@@ -216,16 +216,13 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
         unsigned lo = 0, hi = 0;
         ScatterTile<T, 0, RG>::run(mm, lo, hi);
         const bool nz = (lo | hi) != 0;
-        unsigned fl = nz ? (1u << (lane % T)) : 0u;
+        unsigned fl = nz ? 1u : 0u;
 #pragma unroll
         for (int o = 1; o < T; o <<= 1) fl |= (unsigned)__shfl_xor((int)fl, o);
-        if (lane < RG * T) {
-          if (nz) masks[(size_t)r * nchunks + mask_off] = ((unsigned long long)hi << 32) | lo;
-          if (fl && (lane % T) == 0) {
-            flags[(size_t)r * nsl_pad + flag_off] = (unsigned short)fl;
-            // tells k_assoc which 16-byte flag groups of this row to look at
-            __hip_atomic_fetch_or(rowsum + (r + lane / T), rs_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+        if (lane < RG * T && fl) {  // all T words of a row that has any candidate in this slice
+          mask_lane[(size_t)r * T] = ((unsigned long long)hi << 32) | lo;
+          if ((lane % T) == 0)  // tells k_assoc that this (row, slice) has valid mask words
+            __hip_atomic_fetch_or(rowbits_lane + (size_t)r * rbw, slice_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
@@ -255,7 +252,7 @@ __device__ __forceinline__ Pose load_pose(const PairState* st) {
 }
 
 __device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __restrict__ D, const Pose& pose, int i,
-                                          const RowData& r, int j, float& a_out, float4& yt_out) {
+                                          const RowData& r, int j, const float4 y0, float& a_out, float4& yt_out) {
   float sk = 1, ck = 1, k = 1, geo_sim = 1;
   if (P.use_geotype) {  // compute_geometric_type_ip, CvoGPU.cu:203-215
     const float2 ga = D->xgeo[i], gb = D->ygeo[j];
@@ -265,8 +262,7 @@ __device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __
     geo_sim = dab * dab / (n2a * n2b);
     if ((double)geo_sim < 0.01) return false;
   }
-  // transform_point_R_T (CvoGPU_impl.cu:31-82) of the INITIAL target, recomputed where it is needed
-  const float4 y0 = D->y4[j];
+  // transform_point_R_T (CvoGPU_impl.cu:31-82) of the INITIAL target y0 = y4[j], recomputed where it is needed
   const V3 ytv = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
   const float4 yt = make_float4(ytv.x, ytv.y, ytv.z, 0.f);
   yt_out = yt;
@@ -331,10 +327,11 @@ struct RowAcc {
 
 // One accepted/rejected pair (i, j): CvoGPU.cu:528-589 + the flow terms of 758-782.
 __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* __restrict__ D, const Pose& pose, int i,
-                                           int r_sorted, int N, const RowData& r, const V3& pxe, int j, RowAcc& A) {
+                                           int r_sorted, int N, const RowData& r, const V3& pxe, int j, const float4 y0,
+                                           RowAcc& A) {
   float a;
   float4 yt;
-  if (!eval_pair(P, D, pose, i, r, j, a, yt)) return;
+  if (!eval_pair(P, D, pose, i, r, j, y0, a, yt)) return;
   if (a > P.sp_thres) {
     D->ell_a[(size_t)A.nnz * N + r_sorted] = a;
     D->ell_j[(size_t)A.nnz * N + r_sorted] = j;
@@ -378,65 +375,58 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
     const V3 pxe{x.x, x.y, x.z};
     const Pose pose = load_pose(st);
     // ---- gather this row's candidates (sorted-space bitmap) and restore ascending original j
-    unsigned short* frow = D->flags + (size_t)r_sorted * D->nsl_pad;
-    const unsigned long long* mrow = D->masks + (size_t)r_sorted * D->nchunks;
     const int* yorder = D->yorder;
-    const int ng = (D->nslices + 7) >> 3;  // 16-byte groups of 8 flag words
+    const int rbw = D->rbw;
+    unsigned* rb = D->rowbits + (size_t)r_sorted * rbw;
     int cnt = 0;
-    const unsigned rsum = D->rowsum[r_sorted];
-    if (rsum) {
-      D->rowsum[r_sorted] = 0;  // self-cleaning, like the flags
-      for (int g0 = 0; g0 < ng; g0 += 4) {
-        uint4 w4[4];
+    for (int w0 = 0; w0 < rbw; w0 += 4) {  // rbw is a multiple of 4 (one 16-byte load covers 128 slices)
+      const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
+      if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
+      *reinterpret_cast<uint4*>(rb + w0) = make_uint4(0, 0, 0, 0);  // self-cleaning
+      const unsigned bw[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
 #pragma unroll
-        for (int q = 0; q < 4; q++) {  // up to four independent loads in flight
-          const int g = g0 + q;
-          w4[q] = make_uint4(0, 0, 0, 0);
-          if (g < ng && ((rsum >> (g & 31)) & 1u)) w4[q] = *reinterpret_cast<const uint4*>(frow + 8 * g);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const uint4 w = w4[q];
-          if ((w.x | w.y | w.z | w.w) == 0) continue;
-          const int s0 = 8 * (g0 + q);
-          *reinterpret_cast<uint4*>(frow + s0) = make_uint4(0, 0, 0, 0);
-          const unsigned ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-          for (int h = 0; h < 8; h++) {
-            unsigned f = (ww[h >> 1] >> ((h & 1) * 16)) & 0xffffu;
-            while (f) {
-              const int t = __builtin_ctz(f);
-              f &= f - 1;
-              const int chunk = (s0 + h) * T + t;
-              unsigned long long m = mrow[chunk];
-              ncand += (unsigned long long)__builtin_popcountll(m);
-              while (m && !overflowed) {
-                const int b = __builtin_ctzll(m);
-                m &= m - 1;
-                const int j = yorder[chunk * 64 + b];
-                if (cnt == ASSOC_CAP) {
-                  overflowed = 1;
-                  break;
-                }
-                int k = cnt++;  // insertion sort, ascending j
-                while (k > 0 && (int)list[k - 1] > j) {
-                  list[k] = list[k - 1];
-                  k--;
-                }
-                list[k] = (IdxT)j;
+      for (int q = 0; q < 4; q++) {
+        unsigned f = bw[q];
+        while (f) {
+          const int sl = (w0 + q) * 32 + __builtin_ctz(f);
+          f &= f - 1;
+          const unsigned long long* mw = D->masks + ((size_t)sl * N + r_sorted) * T;
+          for (int t = 0; t < T; t++) {
+            unsigned long long m = mw[t];
+            ncand += (unsigned long long)__builtin_popcountll(m);
+            const int chunk = sl * T + t;
+            while (m && !overflowed) {
+              const int b = __builtin_ctzll(m);
+              m &= m - 1;
+              const int j = yorder[chunk * 64 + b];
+              if (cnt == ASSOC_CAP) {
+                overflowed = 1;
+                break;
               }
+              int k = cnt++;  // insertion sort, ascending j
+              while (k > 0 && (int)list[k - 1] > j) {
+                list[k] = list[k - 1];
+                k--;
+              }
+              list[k] = (IdxT)j;
             }
           }
         }
       }
     }
     if (!overflowed) {
-      for (int k = 0; k < cnt && A.nnz < (unsigned)K; k++)
-        visit_pair(P, D, pose, i, r_sorted, N, r, pxe, (int)list[k], A);
+      // exact evaluation in ascending original j; the next candidate's coordinates are fetched while the
+      // current one is evaluated
+      float4 ynext = cnt > 0 ? D->y4[(int)list[0]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < cnt && A.nnz < (unsigned)K; k++) {
+        const float4 ycur = ynext;
+        if (k + 1 < cnt) ynext = D->y4[(int)list[k + 1]];
+        visit_pair(P, D, pose, i, r_sorted, N, r, pxe, (int)list[k], ycur, A);
+      }
     } else {
       // more candidates than the list holds (dense regime): the reference's literal ordered scan,
       // `if (num_inds == num_neighbors) break;` included (CvoGPU.cu:524-527)
-      for (int j = 0; j < M && A.nnz < (unsigned)K; j++) visit_pair(P, D, pose, i, r_sorted, N, r, pxe, j, A);
+      for (int j = 0; j < M && A.nnz < (unsigned)K; j++) visit_pair(P, D, pose, i, r_sorted, N, r, pxe, j, D->y4[j], A);
     }
     D->nnz_row[r_sorted] = A.nnz;
   }
