@@ -82,7 +82,8 @@ struct PairDesc {
   const float4* xlabel;
   const float2* xgeo;
   const int* xorder;
-  const float4* y4;
+  const float4* y4;   // target xyz (initial cloud), ORIGINAL index
+  const float4* ys4;  // target xyz (initial cloud), SORTED order
   const float4* yfeat;
   const float4* ylabel;
   const float2* ygeo;

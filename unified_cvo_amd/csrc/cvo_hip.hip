@@ -40,10 +40,10 @@ struct PairLayout {  // byte offsets of one pair's workspace inside the arena
 };
 
 struct GraphKey {
-  int n_pairs = 0, p0 = 0, T = 0, gx = 0, gy = 0, nba = 0, nbc = 0, npb = 0, idx16 = 0, U = 0;
+  int n_pairs = 0, p0 = 0, T = 0, gx = 0, gy = 0, nba = 0, nbc = 0, npb = 0, idx16 = 0, general = 0, U = 0;
   bool operator==(const GraphKey& o) const {
     return n_pairs == o.n_pairs && p0 == o.p0 && T == o.T && gx == o.gx && gy == o.gy && nba == o.nba &&
-           nbc == o.nbc && npb == o.npb && idx16 == o.idx16 && U == o.U;
+           nbc == o.nbc && npb == o.npb && idx16 == o.idx16 && general == o.general && U == o.U;
   }
 };
 
@@ -276,16 +276,25 @@ void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const D
   }
 }
 
-void launch_assoc(hipStream_t s, bool idx16, dim3 grid, const PairDesc* descs, const DevParams* dp, const int* st) {
-  if (idx16)
-    hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16>), grid, dim3(ASSOC_THREADS), 0, s, descs, dp, st);
-  else
-    hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32>), grid, dim3(ASSOC_THREADS), 0, s, descs, dp, st);
+void launch_assoc(hipStream_t s, bool idx16, bool general, dim3 grid, const PairDesc* descs, const DevParams* dp,
+                  const int* st) {
+  const dim3 blk(ASSOC_THREADS);
+  if (idx16) {
+    if (general)
+      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, true>), grid, blk, 0, s, descs, dp, st);
+    else
+      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, false>), grid, blk, 0, s, descs, dp, st);
+  } else {
+    if (general)
+      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, true>), grid, blk, 0, s, descs, dp, st);
+    else
+      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, false>), grid, blk, 0, s, descs, dp, st);
+  }
 }
 
 struct LaunchGeom {
   int n_pairs, p0, T, gx, gy, nba, nbc, npb;
-  bool idx16;
+  bool idx16, general;
   hipStream_t stream;
 };
 
@@ -304,7 +313,7 @@ void launch_iteration(cvo_ctx* c, const LaunchGeom& g) {
   const PairDesc* descs = c->d_descs + g.p0;
   const int* st = c->d_status + g.p0;
   launch_scan(g.stream, g.T, dim3(g.gx, g.gy, g.n_pairs), descs, c->d_params, st, 0);
-  launch_assoc(g.stream, g.idx16, dim3(g.nba, g.n_pairs), descs, c->d_params, st);
+  launch_assoc(g.stream, g.idx16, g.general, dim3(g.nba, g.n_pairs), descs, c->d_params, st);
   hipLaunchKernelGGL(k_coeff, dim3(g.nbc, g.n_pairs), dim3(256), 0, g.stream, descs, c->d_params, st);
   hipLaunchKernelGGL(k_update<false>, dim3(g.n_pairs), dim3(64), 0, g.stream, descs, c->d_params, st);
   launch_prep(c, g);
@@ -390,6 +399,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.xgeo = X->geo;
     D.xorder = X->order;
     D.y4 = Y->x4;
+    D.ys4 = Y->xs4;
     D.yfeat = Y->feat;
     D.ylabel = Y->label;
     D.ygeo = Y->geo;
@@ -450,6 +460,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.nbc = S->d.nblk_coeff;
   S->geom.npb = S->d.Mpad / PREP_THREADS + (S->d.NGpad * ROWS_PER_GROUP + PREP_THREADS - 1) / PREP_THREADS;
   S->geom.idx16 = M < 65536;
+  S->geom.general = dp.use_col || dp.use_sem || dp.use_geotype;
   ctx->last_xorder = sources[0]->h_order;
   ctx->last_pairs = n_pairs;
   ctx->last_N = N;
@@ -471,7 +482,8 @@ int run_single_eval(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
   if (rc != CVO_OK) return rc;
   launch_init(ctx, S->geom);
   launch_scan(ctx->stream, S->T, dim3(S->gx, S->gy, 1), ctx->d_descs, ctx->d_params, ctx->d_status, 0);
-  launch_assoc(ctx->stream, S->geom.idx16, dim3(S->d.nblk_assoc, 1), ctx->d_descs, ctx->d_params, ctx->d_status);
+  launch_assoc(ctx->stream, S->geom.idx16, S->geom.general, dim3(S->d.nblk_assoc, 1), ctx->d_descs, ctx->d_params,
+               ctx->d_status);
   hipLaunchKernelGGL(k_update<false>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params, ctx->d_status);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_states.data(), ctx->d_states, sizeof(PairState), hipMemcpyDeviceToHost,
@@ -782,6 +794,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
         key.nbc = S.d.nblk_coeff;
         key.npb = S.geom.npb;
         key.idx16 = S.geom.idx16 ? 1 : 0;
+        key.general = S.geom.general ? 1 : 0;
         key.U = U;
         if (!ctx->graph_exec[g] || !(ctx->graph_key[g] == key)) {
           if (ctx->graph_exec[g]) {
