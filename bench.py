@@ -20,6 +20,11 @@ import time
 
 import numpy as np
 
+# The batch is enqueued on 4 HIP streams; RCCL adds streams of its own.  HIP maps streams onto 4 hardware
+# queues by default, and sharing a queue serialises two of our sub-batches (measured: 0.37 s instead of
+# 0.25 s per step under torchrun).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -78,8 +83,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # torchrun with one rank also exercises RCCL
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = args.points
@@ -108,7 +115,7 @@ def main():
         return res, poses, stat
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -206,7 +213,7 @@ def main():
             f"tile culling)")
         assert int(stat.abs().sum().item()) == 0, "some align() returned -1"
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return out

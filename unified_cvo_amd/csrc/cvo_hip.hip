@@ -70,12 +70,12 @@ struct cvo_ctx {
   // A batch is split into up to MAX_GROUPS sub-batches, each enqueued on its own stream: the pairs are
   // independent, so one group's latency-bound kernels (k_update: one wave per pair) and launch tails
   // overlap the other groups' wide kernels.  Group 0 runs on `stream`.
-  static constexpr int MAX_GROUPS = 4;
-  hipStream_t gstream[MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr int MAX_GROUPS = 8;
+  hipStream_t gstream[MAX_GROUPS] = {};
   hipEvent_t ev_chk[2][MAX_GROUPS] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
   // graph cache (one per group)
-  hipGraphExec_t graph_exec[MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+  hipGraphExec_t graph_exec[MAX_GROUPS] = {};
   GraphKey graph_key[MAX_GROUPS] = {};
   // last call (debug hooks)
   int last_pairs = 0;

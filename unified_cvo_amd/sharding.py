@@ -24,7 +24,7 @@ def gather_poses(local_poses, local_status, total, world, rank):
     n = local_poses.shape[0]
     pad_p[:n] = local_poses
     pad_s[:n] = local_status
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized():
         return pad_p[:total], pad_s[:total]
     all_p = torch.empty(world * per, 16, dtype=local_poses.dtype, device=dev)
     all_s = torch.empty(world * per, dtype=local_status.dtype, device=dev)
