@@ -141,9 +141,10 @@ def main():
         ms_per_iter_pair = elapsed / args.steps / max(mean_iters, 1.0) / B * 1e3
         # ---- roofline of the dominant kernel (k_scan), timed live with HIP events on the ctx stream
         tiles, rpt, tpt = gpu.debug_scan_stats()        # over the last measured step (all pairs, all iterations)
-        scan_ms = gpu.debug_time_scan(20)               # re-launches k_scan on the final state of the batch
-        pairs_per_launch = float(n) * float(n) * B      # ALGORITHMIC pair tests (N*M per pair)
-        bytes_per_launch = (n * 12 + n * 12) * B        # SURVEY.md 8(d), one pass, geometric payload
+        n_groups, ppl = gpu.debug_last_geometry()       # the batch runs as n_groups sub-batches of ppl pairs
+        scan_ms = gpu.debug_time_scan(20)               # avg per k_scan launch (ppl pairs), final state of the batch
+        pairs_per_launch = float(n) * float(n) * ppl    # ALGORITHMIC pair tests (N*M per pair)
+        bytes_per_launch = (n * 12 + n * 12) * ppl      # SURVEY.md 8(d), one pass, geometric payload
         achieved_gbs = bytes_per_launch / (scan_ms * 1e-3) / 1e9
         pair_rate = pairs_per_launch / (scan_ms * 1e-3)
         valu_peak_pairs = FP32_VALU_PEAK_TFLOPS * 1e12 / C_CULL_FLOPS
@@ -153,7 +154,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("points") == n and tj.get("pairs") == B:
+                if tj.get("points") == n and tj.get("pairs") == ppl:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -161,6 +162,7 @@ def main():
             "kernel": "cvo_dev::k_scan", "bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(scan_ms, 5),
+            "pairs_per_launch": ppl, "launches_per_iteration": n_groups,
             # The path is an all-pairs accumulation with O(N+M) compulsory bytes: HBM is not the binding roof.
             # The scan culls whole (4 rows x 128 targets) tiles by bounding boxes, so the ALGORITHMIC pair-test
             # rate can exceed the FP32 VALU roof; `executed_fraction` is the share of the N*M tests really run.
@@ -208,7 +210,7 @@ def main():
         h2d_rate = (2 * n * 16 * 1.0) * B / max(t_h2d, 1e-9) / 1e9
         log(f"[bench] inputs: generated in {t_gen:.2f}s, uploaded in {t_h2d:.3f}s ({h2d_rate:.2f} GB/s incl. host packing); "
             f"PCIe-inclusive rate = {aligns / (elapsed + args.steps * t_h2d):.2f} align/s")
-        log(f"[bench] loop {loop_s:.3f}s/step on rank 0; scan kernel {scan_ms*1e3:.1f} us per launch of {B} pairs "
+        log(f"[bench] loop {loop_s:.3f}s/step on rank 0; scan kernel {scan_ms*1e3:.1f} us per launch of {ppl} pairs "
             f"({pair_rate/1e12:.2f} T algorithmic pair-tests/s; {100*executed_frac:.2f}% of the N*M tests executed after "
             f"tile culling)")
         assert int(stat.abs().sum().item()) == 0, "some align() returned -1"

@@ -199,9 +199,12 @@ int cvo_association(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
 /* Dumps the ELL kernel matrix of the LAST iteration executed by cvo_align_ex (row stride K):
  * mat/ind sized n_source*K, nonzeros sized n_source; K = the num_neighbors of that iteration. */
 int cvo_debug_last_ell(cvo_ctx* ctx, int K, float* mat, int* ind, unsigned int* nonzeros);
-/* Runs only the N x M candidate scan `reps` times on the current state of the last pair
- * (used by bench.py to time the dominant kernel with HIP events on the context's stream).
- * Returns the average milliseconds per launch in *ms. */
+/* A batch is enqueued as n_groups sub-batches (one stream each) of pairs_per_group pairs: these are the
+ * launches a profiler sees. */
+int cvo_debug_last_geometry(cvo_ctx* ctx, int* n_groups, int* pairs_per_group);
+/* Re-issues the k_scan launches of one optimiser iteration (one per sub-batch) `reps` times on the final
+ * state of the last call, timed with HIP events on the context's stream (bench.py's roofline leg).
+ * *ms = average milliseconds per k_scan launch (of pairs_per_group pairs). */
 int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms);
 /* Tile-culling statistics of the last align call (all pairs, all iterations): number of fine tiles
  * the scan executed and the tile shape; executed pair tests = tiles * rows_per_tile * targets_per_tile. */

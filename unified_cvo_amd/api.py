@@ -372,6 +372,12 @@ class CvoGPU:
         self._check(self.L.cvo_debug_time_scan(self.ctx, reps, C.byref(ms)))
         return ms.value
 
+    def debug_last_geometry(self):
+        """(sub-batches of the last call, pairs per sub-batch): the k_scan launches a profiler sees."""
+        g, p = C.c_int(), C.c_int()
+        self._check(self.L.cvo_debug_last_geometry(self.ctx, C.byref(g), C.byref(p)))
+        return g.value, p.value
+
     def debug_scan_stats(self):
         """(tiles executed by k_scan during the last align call, rows per tile, targets per tile)."""
         t, r, c = C.c_ulonglong(), C.c_int(), C.c_int()

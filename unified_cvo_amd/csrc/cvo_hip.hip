@@ -83,6 +83,7 @@ struct cvo_ctx {
   DevParams last_params{};
   int last_gx = 0, last_gy = 0;
   std::vector<int> last_xorder;  // pair 0's source order: sorted row -> original row
+  int last_groups = 1;           // sub-batches (streams) of the last call
   PairLayout last_layout{};
 };
 
@@ -462,6 +463,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.idx16 = M < 65536;
   S->geom.general = dp.use_col || dp.use_sem || dp.use_geotype;
   ctx->last_xorder = sources[0]->h_order;
+  ctx->last_groups = S->G;
   ctx->last_pairs = n_pairs;
   ctx->last_N = N;
   ctx->last_M = M;
@@ -1040,19 +1042,33 @@ int cvo_debug_scan_stats(cvo_ctx* ctx, unsigned long long* tiles, int* rows_per_
   return CVO_OK;
 }
 
+int cvo_debug_last_geometry(cvo_ctx* ctx, int* n_groups, int* pairs_per_group) {
+  if (!ctx || ctx->last_pairs < 1) return fail(ctx, CVO_E_INVALID, "cvo_debug_last_geometry: bad argument");
+  if (n_groups) *n_groups = ctx->last_groups;
+  if (pairs_per_group) *pairs_per_group = (ctx->last_pairs + ctx->last_groups - 1) / ctx->last_groups;
+  return CVO_OK;
+}
+
 int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms) {
   if (!ctx || !ms || reps <= 0 || ctx->last_pairs < 1)
     return fail(ctx, CVO_E_INVALID, "cvo_debug_time_scan: bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const int n_pairs = ctx->last_pairs;
+  // the same launches the optimiser loop issues: one k_scan per sub-batch, here back to back on one stream
+  const int n_pairs = ctx->last_pairs, G = ctx->last_groups;
   const DevParams& dp = ctx->last_params;
-  dim3 grid(ctx->last_gx, ctx->last_gy, n_pairs);
-  launch_scan(ctx->stream, dp.T, grid, ctx->d_descs, ctx->d_params, ctx->d_status, 1);  // warm-up
+  auto sweep = [&]() {
+    for (int g = 0; g < G; g++) {
+      const int p0 = (int)((long)n_pairs * g / G), p1 = (int)((long)n_pairs * (g + 1) / G);
+      launch_scan(ctx->stream, dp.T, dim3(ctx->last_gx, ctx->last_gy, p1 - p0), ctx->d_descs + p0, ctx->d_params,
+                  ctx->d_status + p0, 1);
+    }
+  };
+  sweep();  // warm-up
   HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-  for (int r = 0; r < reps; r++) launch_scan(ctx->stream, dp.T, grid, ctx->d_descs, ctx->d_params, ctx->d_status, 1);
+  for (int r = 0; r < reps; r++) sweep();
   HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
-  // the extra scans leave flags behind; clean them so the workspace stays consistent
+  // the extra scans leave slice bits behind; clean them so the workspace stays consistent
   for (int p = 0; p < n_pairs; p++) {
     const PairDesc& D = ctx->h_descs[p];
     HIP_TRY(ctx, hipMemsetAsync(D.rowbits, 0, sizeof(unsigned) * (size_t)(ctx->last_N + 4) * D.rbw, ctx->stream));
@@ -1060,7 +1076,7 @@ int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   float t = 0;
   HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->ev_start, ctx->ev_stop));
-  *ms = t / reps;
+  *ms = t / (reps * G);
   return CVO_OK;
 }
 
