@@ -72,7 +72,8 @@ struct PairState {
 // space so that 4-row groups and 64-target chunks are spatially compact and whole tiles can be
 // rejected by a bounding-box test; k_assoc maps candidates back and restores ascending original j.
 struct PairDesc {
-  int N, M, Mpad, nchunks, nslices, rbw, nblk_assoc, nblk_coeff;  // rbw: 32-bit words of slice bits per row
+  int N, M, Mpad, nchunks, nslices, rbw, nblk_assoc, nblk_coeff;
+  // flow_part / cnt_part hold nblk_assoc row-block partials followed by DENSE_BLOCKS partials of k_assoc_dense  // rbw: 32-bit words of slice bits per row
   int NG;     // row groups of ROWS_PER_GROUP sorted rows
   int NGpad;  // NG rounded up for the coarse test (pad groups have empty boxes)
   float cx, cy, cz;  // centre subtracted in the cull arithmetic only
@@ -99,6 +100,8 @@ struct PairDesc {
   unsigned* rowbits;          // [N sorted rows][rbw]: bit s set <=> the row has candidates in scan slice s;
                               // set by k_scan (returnless atomic OR), cleared by k_assoc
   unsigned long long* tile_count;  // [1]: fine tiles executed so far this call (statistics)
+  int* ovf_rows;   // [N]: sorted rows whose candidate list overflowed in k_assoc (handled by k_assoc_dense)
+  int* ovf_count;  // [1]: how many; reset by k_update
   float* ell_a;               // ELL kernel matrix values, [K_max][N], SORTED row index
   int* ell_j;                 // ELL column indices (ORIGINAL j, ascending), [K_max][N]
   unsigned* nnz_row;          // nonzeros[N], SORTED row index
@@ -111,6 +114,7 @@ struct PairDesc {
 };
 
 constexpr int ROWS_PER_GROUP = 4;
+constexpr int DENSE_BLOCKS = 64;  // k_assoc_dense blocks per pair (4 waves each, one overflow row per wave at a time)
 
 // ---- arithmetic conventions (DESIGN.md "Numerics") ------------------------------------------
 __device__ __forceinline__ float dot3_dev(float a0, float a1, float a2, float b0, float b1, float b2) {

@@ -20,7 +20,8 @@ using namespace cvo_dev;
 #define CVO_VERSION_STRING "unified_cvo_amd 0.1 (gfx950)"
 
 struct cvo_cloud {
-  cvo_ctx* ctx = nullptr;
+  cvo_ctx* ctx = nullptr;  // identity check only: never dereferenced after upload (the context may be gone)
+  int device = 0;
   int n = 0;
   float4* x4 = nullptr;
   float4* xs4 = nullptr;    // x4 permuted into the spatial order
@@ -35,7 +36,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, rowc, gbox, cbox, sbox, masks, rowbits, tile_count, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, rowc, gbox, cbox, sbox, masks, rowbits, tile_count, ovf_rows, ovf_count, ell_a, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -129,11 +130,13 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.masks = take(sizeof(unsigned long long) * ((size_t)N + 8) * nchunks);
   L.rowbits = take(sizeof(unsigned) * (size_t)(N + 4) * rbw_max);
   L.tile_count = take(sizeof(unsigned long long));
+  L.ovf_rows = take(sizeof(int) * (size_t)N);
+  L.ovf_count = take(sizeof(int));
   L.ell_a = take(sizeof(float) * (size_t)N * Kmax);
   L.ell_j = take(sizeof(int) * (size_t)N * Kmax);
   L.nnz_row = take(sizeof(unsigned) * (size_t)N);
-  L.flow_part = take(sizeof(double) * 8 * (size_t)nba);
-  L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)nba);
+  L.flow_part = take(sizeof(double) * 8 * (size_t)(nba + DENSE_BLOCKS));
+  L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)(nba + DENSE_BLOCKS));
   L.coef_part = take(sizeof(double) * 4 * (size_t)nbc);
   L.trace = take(sizeof(cvo_trace_t) * (size_t)std::max(trace_capacity, 0));
   L.total = off;
@@ -293,6 +296,13 @@ void launch_assoc(hipStream_t s, bool idx16, bool general, dim3 grid, const Pair
   }
 }
 
+void launch_dense(hipStream_t s, bool general, int n_pairs, const PairDesc* descs, const DevParams* dp, const int* st) {
+  if (general)
+    hipLaunchKernelGGL(k_assoc_dense<true>, dim3(DENSE_BLOCKS, n_pairs), dim3(256), 0, s, descs, dp, st);
+  else
+    hipLaunchKernelGGL(k_assoc_dense<false>, dim3(DENSE_BLOCKS, n_pairs), dim3(256), 0, s, descs, dp, st);
+}
+
 struct LaunchGeom {
   int n_pairs, p0, T, gx, gy, nba, nbc, npb;
   bool idx16, general;
@@ -315,6 +325,7 @@ void launch_iteration(cvo_ctx* c, const LaunchGeom& g) {
   const int* st = c->d_status + g.p0;
   launch_scan(g.stream, g.T, dim3(g.gx, g.gy, g.n_pairs), descs, c->d_params, st, 0);
   launch_assoc(g.stream, g.idx16, g.general, dim3(g.nba, g.n_pairs), descs, c->d_params, st);
+  launch_dense(g.stream, g.general, g.n_pairs, descs, c->d_params, st);
   hipLaunchKernelGGL(k_coeff, dim3(g.nbc, g.n_pairs), dim3(256), 0, g.stream, descs, c->d_params, st);
   hipLaunchKernelGGL(k_update<false>, dim3(g.n_pairs), dim3(64), 0, g.stream, descs, c->d_params, st);
   launch_prep(c, g);
@@ -348,6 +359,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     M = std::max(M, targets[p]->n);
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be attributed to this one
   const int trace_cap = (opts && opts->trace) ? opts->trace_capacity : 0;
   const int Kmax = params->nearest_neighbors_max;
   S->N = N;
@@ -414,6 +426,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.masks = (unsigned long long*)(base + S->L.masks);
     D.rowbits = (unsigned*)(base + S->L.rowbits);
     D.tile_count = (unsigned long long*)(base + S->L.tile_count);
+    D.ovf_rows = (int*)(base + S->L.ovf_rows);
+    D.ovf_count = (int*)(base + S->L.ovf_count);
     D.ell_a = (float*)(base + S->L.ell_a);
     D.ell_j = (int*)(base + S->L.ell_j);
     D.nnz_row = (unsigned*)(base + S->L.nnz_row);
@@ -440,6 +454,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     // the slice bits must start clean (they are self-cleaning afterwards)
     HIP_TRY(ctx, hipMemsetAsync(D.rowbits, 0, sizeof(unsigned) * (size_t)(S->N + 4) * S->d.rbw_max, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.tile_count, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(D.ovf_count, 0, sizeof(int), ctx->stream));
   }
   // the blocks of k_assoc beyond a smaller pair's N still write their (zero) partials, but the
   // partial arrays of pairs whose N is smaller than the batch maximum are fully covered by nblk.
@@ -486,6 +501,7 @@ int run_single_eval(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
   launch_scan(ctx->stream, S->T, dim3(S->gx, S->gy, 1), ctx->d_descs, ctx->d_params, ctx->d_status, 0);
   launch_assoc(ctx->stream, S->geom.idx16, S->geom.general, dim3(S->d.nblk_assoc, 1), ctx->d_descs, ctx->d_params,
                ctx->d_status);
+  launch_dense(ctx->stream, S->geom.general, 1, ctx->d_descs, ctx->d_params, ctx->d_status);
   hipLaunchKernelGGL(k_update<false>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params, ctx->d_status);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_states.data(), ctx->d_states, sizeof(PairState), hipMemcpyDeviceToHost,
@@ -656,6 +672,7 @@ static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, cons
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   cvo_cloud* c = new cvo_cloud();
   c->ctx = ctx;
+  c->device = ctx->device;
   c->n = n;
   double sx = 0, sy = 0, sz = 0;
   for (int i = 0; i < n; i++) {
@@ -738,7 +755,7 @@ int cvo_cloud_size(const cvo_cloud* c) { return c ? c->n : 0; }
 
 void cvo_cloud_free(cvo_cloud* c) {
   if (!c) return;
-  if (c->ctx) (void)hipSetDevice(c->ctx->device);
+  (void)hipSetDevice(c->device);
   if (c->x4) (void)hipFree(c->x4);
   if (c->xs4) (void)hipFree(c->xs4);
   if (c->feat) (void)hipFree(c->feat);

@@ -383,10 +383,30 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
     const int rbw = D->rbw;
     unsigned* rb = D->rowbits + (size_t)r_sorted * rbw;
     int cnt = 0;
+    // pass 1: how many candidates does the row have?  (Rows beyond the list capacity go straight to
+    // k_assoc_dense without building a list; the mask words are re-read from L1/L2 in pass 2.)
+    for (int w0 = 0; w0 < rbw; w0 += 4) {
+      const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
+      if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
+      const unsigned bw[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        unsigned f = bw[q];
+        while (f) {
+          const int sl = (w0 + q) * 32 + __builtin_ctz(f);
+          f &= f - 1;
+          const unsigned long long* mw = D->masks + ((size_t)sl * N + r_sorted) * T;
+          for (int t = 0; t < T; t++) ncand += (unsigned long long)__builtin_popcountll(mw[t]);
+        }
+      }
+    }
+    overflowed = ncand > (unsigned long long)ASSOC_CAP ? 1u : 0u;
+    // pass 2: clear the slice bits; unless overflowed, gather the candidates and restore ascending original j
     for (int w0 = 0; w0 < rbw; w0 += 4) {  // rbw is a multiple of 4 (one 16-byte load covers 128 slices)
       const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
       if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
       *reinterpret_cast<uint4*>(rb + w0) = make_uint4(0, 0, 0, 0);  // self-cleaning
+      if (overflowed) continue;
       const unsigned bw[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -397,16 +417,11 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
           const unsigned long long* mw = D->masks + ((size_t)sl * N + r_sorted) * T;
           for (int t = 0; t < T; t++) {
             unsigned long long m = mw[t];
-            ncand += (unsigned long long)__builtin_popcountll(m);
             const int chunk = sl * T + t;
-            while (m && !overflowed) {
+            while (m) {
               const int b = __builtin_ctzll(m);
               m &= m - 1;
               const int j = yorder[chunk * 64 + b];
-              if (cnt == ASSOC_CAP) {
-                overflowed = 1;
-                break;
-              }
               int k = cnt++;  // insertion sort, ascending j
               while (k > 0 && (int)list[k - 1] > j) {
                 list[k] = list[k - 1];
@@ -428,12 +443,12 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
         visit_pair<GENERAL>(P, D, pose, i, r_sorted, N, r, pxe, (int)list[k], ycur, A);
       }
     } else {
-      // more candidates than the list holds (dense regime): the reference's literal ordered scan,
-      // `if (num_inds == num_neighbors) break;` included (CvoGPU.cu:524-527)
-      for (int j = 0; j < M && A.nnz < (unsigned)K; j++)
-        visit_pair<GENERAL>(P, D, pose, i, r_sorted, N, r, pxe, j, D->y4[j], A);
+      // more candidates than the list holds (dense regime, e.g. rows sitting on K_max): handed to
+      // k_assoc_dense, which evaluates 64 targets at a time per row
+      const int slot = atomicAdd(D->ovf_count, 1);
+      D->ovf_rows[slot] = r_sorted;
     }
-    D->nnz_row[r_sorted] = A.nnz;
+    if (!overflowed) D->nnz_row[r_sorted] = A.nnz;
   }
   // per-row (omega_i / c, v_i / d) cast to double, then reduced in double (CvoGPU.cu:784-787, 824-825)
   double red[7] = {(double)(A.o0 / P.c), (double)(A.o1 / P.c), (double)(A.o2 / P.c), (double)(A.v0 / P.d),
@@ -481,6 +496,112 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// k_assoc_dense: the rows k_assoc could not list (more than ASSOC_CAP candidates).  One wave per row at
+// a time runs the reference's literal ordered scan over ALL targets (CvoGPU.cu:522-590), 64 targets per
+// step: lanes evaluate the exact pair arithmetic in parallel, a ballot + prefix count gives every hit its
+// ELL slot in ascending j (so the first-K truncation and its early exit are exact), and the float flow
+// accumulation of compute_flow_gpu_no_eigen is replayed serially in lane (= j) order with v_readlane.
+// ------------------------------------------------------------------------------------------
+template <bool GENERAL>
+__global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
+                                                     const int* __restrict__ status) {
+  if (status[blockIdx.y] != 0) return;
+  const PairDesc* __restrict__ D = descs + blockIdx.y;
+  const PairState* st = D->st;
+  const DevParams P = *Pp;
+  const int N = D->N, M = D->M;
+  const int K = st->K;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n_ovf = *D->ovf_count;
+  double red[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long nnz_sum = 0;
+  unsigned nnz_max = 0;
+  if (n_ovf > 0) {
+    const Pose pose = load_pose(st);
+    for (int q = blockIdx.x * 4 + wave; q < n_ovf; q += DENSE_BLOCKS * 4) {
+      const int r_sorted = D->ovf_rows[q];
+      const int i = D->xorder[r_sorted];
+      const float4 x = D->xs4[r_sorted];
+      const float2 rc = D->rowc[r_sorted];
+      const RowData r{x.x, x.y, x.z, rc.x, rc.y};
+      const V3 pxe{x.x, x.y, x.z};
+      float o0 = 0, o1 = 0, o2 = 0, v0 = 0, v1 = 0, v2 = 0;
+      double asum = 0;
+      unsigned nnz = 0;
+      for (int j0 = 0; j0 < M && nnz < (unsigned)K; j0 += 64) {
+        const int j = j0 + lane;
+        float a = 0.f;
+        float4 yt = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool ok = false;
+        if (j < M) {
+          const float4 y0 = D->y4[j];
+          ok = eval_pair<GENERAL>(P, D, pose, i, r, j, y0, a, yt) && (a > P.sp_thres);
+        }
+        const unsigned long long m = __ballot(ok);
+        if (!m) continue;
+        const unsigned rank = nnz + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        const bool keep = ok && rank < (unsigned)K;  // `if (num_inds == num_neighbors) break;`
+        if (keep) {
+          D->ell_a[(size_t)rank * N + r_sorted] = a;
+          D->ell_j[(size_t)rank * N + r_sorted] = j;
+        }
+        // flow terms of this lane's pair (CvoGPU.cu:767-769)
+        const V3 pye{yt.x, yt.y, yt.z};
+        const V3 cr = cross_dev(pxe, pye);
+        const float dx = pye.x - pxe.x, dy = pye.y - pxe.y, dz = pye.z - pxe.z;
+        unsigned long long mk = __ballot(keep);
+        nnz += (unsigned)__builtin_popcountll(mk);
+        while (mk) {  // ascending j: the reference's float accumulation order (CvoGPU.cu:779-780)
+          const int l = __builtin_ctzll(mk);
+          mk &= mk - 1;
+          const float al = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), l));
+          o0 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cr.x), l)), al, o0);
+          o1 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cr.y), l)), al, o1);
+          o2 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cr.z), l)), al, o2);
+          v0 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dx), l)), al, v0);
+          v1 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dy), l)), al, v1);
+          v2 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dz), l)), al, v2);
+          asum += (double)al;
+        }
+      }
+      if (lane == 0) {
+        D->nnz_row[r_sorted] = nnz;
+        red[0] += (double)(o0 / P.c);
+        red[1] += (double)(o1 / P.c);
+        red[2] += (double)(o2 / P.c);
+        red[3] += (double)(v0 / P.d);
+        red[4] += (double)(v1 / P.d);
+        red[5] += (double)(v2 / P.d);
+        red[6] += asum;
+        nnz_sum += nnz;
+        nnz_max = max(nnz_max, nnz);
+      }
+    }
+  }
+  // block partials are always written (zeros when there was nothing to do): k_coeff / k_update sum them
+  __shared__ double s_red[4][8];
+  __shared__ unsigned long long s_cnt[4][2];
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 7; c++) s_red[wave][c] = red[c];
+    s_cnt[wave][0] = nnz_sum;
+    s_cnt[wave][1] = nnz_max;
+  }
+  __syncthreads();
+  const size_t slot = (size_t)D->nblk_assoc + blockIdx.x;
+  if (threadIdx.x < 7) {
+    const int c = threadIdx.x;
+    D->flow_part[slot * 8 + c] = ((s_red[0][c] + s_red[1][c]) + s_red[2][c]) + s_red[3][c];
+  } else if (threadIdx.x == 8) {
+    unsigned long long* cp = D->cnt_part + slot * 4;
+    cp[0] = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+    cp[1] = max(max(s_cnt[0][1], s_cnt[1][1]), max(s_cnt[2][1], s_cnt[3][1]));
+    cp[2] = 0;
+    cp[3] = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_coeff: normalised twist (compute_flow host half, CvoGPU.cu:824-835) + B,C,D,E partials.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
@@ -497,7 +618,7 @@ __global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ desc
   // component (t & 7) of blocks t>>3, t>>3 + 32, ... (all loads in flight), then a fixed-order finish.
   __shared__ double s_part[32][8];
   {
-    const int nblk = D->nblk_assoc;
+    const int nblk = D->nblk_assoc + DENSE_BLOCKS;
     const int c = threadIdx.x & 7;
     double acc = 0;
     for (int b = threadIdx.x >> 3; b < nblk; b += 32) acc += D->flow_part[(size_t)b * 8 + c];
@@ -631,7 +752,7 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
     // The four thrust::reduce of compute_step_size (CvoGPU.cu:1118-1121) and the nonzero / max counts
     // (SparseKernelMat.cu:37-46, CvoGPU.cu:1518): lane l owns component (l & 3) of blocks l>>2, l>>2 + 16, ...
     // so all loads are in flight at once; a fixed xor-shuffle tree finishes (deterministic order).
-    const int nba = D->nblk_assoc, nbc = D->nblk_coeff;
+    const int nba = D->nblk_assoc + DENSE_BLOCKS, nbc = D->nblk_coeff;
     const int c = tid & 3;
     double s = 0;
     if (P.mode == 0) {
@@ -657,6 +778,7 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
   }
   __syncthreads();
   if (tid == 0) {
+    *D->ovf_count = 0;  // next iteration's overflow list starts empty
     int done = 0;
     if (!INIT) {
       const unsigned nnz = (unsigned)s_n[0], max_nnz = (unsigned)s_n[1];
