@@ -209,7 +209,10 @@ int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms);
 /* Tile-culling statistics of the last align call (all pairs, all iterations): number of fine tiles
  * the scan executed and the tile shape; executed pair tests = tiles * rows_per_tile * targets_per_tile. */
 int cvo_debug_scan_stats(cvo_ctx* ctx, unsigned long long* tiles, int* rows_per_tile, int* targets_per_tile);
-/* Number of candidate pairs the scan of the last iteration produced (superset of nnz). */
+/* Candidate-list reuse of the last align call: how many times the candidate bitmap was (re)built by
+ * k_scan, summed over the pairs, and the optimiser iterations those pairs ran. */
+int cvo_debug_list_builds(cvo_ctx* ctx, unsigned long long* builds, unsigned long long* iterations);
+/* Number of candidate pairs in the bitmap the last iteration used (superset of nnz). */
 int cvo_debug_last_candidates(cvo_ctx* ctx, unsigned long long* out);
 const char* cvo_version(void);
 

@@ -384,6 +384,11 @@ class CvoGPU:
         self._check(self.L.cvo_debug_scan_stats(self.ctx, C.byref(t), C.byref(r), C.byref(c)))
         return t.value, r.value, c.value
 
+    def debug_list_builds(self):
+        b, it = C.c_ulonglong(), C.c_ulonglong()
+        self._check(self.L.cvo_debug_list_builds(self.ctx, C.byref(b), C.byref(it)))
+        return b.value, it.value
+
     def debug_last_candidates(self):
         v = C.c_ulonglong()
         self._check(self.L.cvo_debug_last_candidates(self.ctx, C.byref(v)))

@@ -35,6 +35,11 @@ struct DevParams {
   int mode;  // 0 = align loop, 1 = single evaluation (inner product / association)
   int T;     // target chunks (of 64) per scan wave: 1, 2, 4 or 8
   int groups_per_block;  // row groups per k_scan block (a multiple of 64)
+  // Candidate-list reuse (DESIGN.md "Reusing the candidate list"): the scan runs with the cut-off radius
+  // grown by skin = skin_frac * ell * sqrt(-2 log_geo); its bitmap stays valid while the targets have moved
+  // less than the skin and ell has not grown.  0 = scan every iteration.
+  float skin_frac;
+  float rebuild_shrink;  // rebuild when ell < rebuild_shrink * ell_build (the list would be far too long)
 };
 
 // Running state of one frame pair; lives in HBM, only touched by one thread of k_step.
@@ -57,6 +62,11 @@ struct PairState {
   unsigned long long noverflow;  // rows that took k_assoc's literal path
   int n_trace;
   float out_T[16];  // column-major [R^T | -R^T T]
+  // candidate-list reuse: pose / ell the current bitmap was built with, its skin, and whether the kernels
+  // of the coming iteration have to rebuild it
+  float Rb[9], Tb[3];
+  float ell_build, skin;
+  int rebuild, n_builds;
   // A_sparsity_indicator_ell_update FIFOs (CvoGPU.cu:1167-1285): bookkeeping here, storage below
   int s_head, s_size, e_head, e_size;
   float s_sum, e_sum;
@@ -77,6 +87,7 @@ struct PairDesc {
   int NG;     // row groups of ROWS_PER_GROUP sorted rows
   int NGpad;  // NG rounded up for the coarse test (pad groups have empty boxes)
   float cx, cy, cz;  // centre subtracted in the cull arithmetic only
+  float ymax;        // largest |y0| of the target cloud (bounds how far a pose change moves any target)
   const float4* x4;   // source xyz, ORIGINAL index
   const float4* xs4;  // source xyz, SORTED order (coalesced row reads)
   const float4* xfeat;
@@ -91,17 +102,18 @@ struct PairDesc {
   const int* yorder;
   float4* ycull;  // SORTED: {y~x, y~y, y~z, |y~|^2}, y~ = yt - centre; pads are {0,0,0,+inf}
   float4* xcull;  // SORTED: {-2x~x, -2x~y, -2x~z, thres_i + margin_i - |x~|^2}
-  float2* rowc;   // SORTED row: {l_i, d2_thres_i}
+  int* cand_cnt;   // [N] candidates of each sorted row in the current bitmap
+  void* cand_j;    // [ASSOC_CAP][N] cached candidate lists (original target index, ascending), u16 or i32
   float4* gbox;   // [NGpad][2]: AABB of each sorted row group, grown by the group's cut-off radius
-  float4* cbox;   // [nchunks][2]: AABB of each 64-target sorted chunk
+  float4* cellbox;  // [NGpad/16][2]: AABB of each cell of 16 row groups (level 1 of the scan)
   float4* sbox;   // [nslices][2]: AABB of each scan slice (T chunks)
   unsigned long long* masks;  // [nslices][N sorted rows][T] candidate bit masks; a row's T words of a slice are
                               // valid iff that slice's bit is set in the row's rowbits (never memset)
   unsigned* rowbits;          // [N sorted rows][rbw]: bit s set <=> the row has candidates in scan slice s;
                               // set by k_scan (returnless atomic OR), cleared by k_assoc
   unsigned long long* tile_count;  // [1]: fine tiles executed so far this call (statistics)
-  int* ovf_rows;   // [N]: sorted rows whose candidate list overflowed in k_assoc (handled by k_assoc_dense)
-  int* ovf_count;  // [1]: how many; reset by k_update
+  int* ovf_rows;   // [N]: sorted rows with more candidates than a list holds (handled by k_assoc_dense)
+  int* ovf_count;  // [1]: how many; reset by k_prep when the bitmap is rebuilt
   float* ell_a;               // ELL kernel matrix values, [K_max][N], SORTED row index
   int* ell_j;                 // ELL column indices (ORIGINAL j, ascending), [K_max][N]
   unsigned* nnz_row;          // nonzeros[N], SORTED row index

@@ -31,12 +31,13 @@ struct cvo_cloud {
   int* order = nullptr;        // spatial (k-d) order: sorted position -> original index
   std::vector<int> h_order;  // host copy (the ELL is stored by sorted row; exports map it back)
   float cx = 0, cy = 0, cz = 0;  // centroid (used only as the cull centre)
+  float rmax = 0;                // largest |p| (bounds the motion of any point under a pose change)
 };
 
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, rowc, gbox, cbox, sbox, masks, rowbits, tile_count, ovf_rows, ovf_count, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, tile_count, ovf_rows, ovf_count, cand_cnt, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -123,15 +124,16 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   };
   L.ycull = take(sizeof(float4) * (size_t)Mpad);
   L.xcull = take(sizeof(float4) * (size_t)(N + XCULL_PAD));
-  L.rowc = take(sizeof(float2) * (size_t)N);
   L.gbox = take(sizeof(float4) * 2 * (size_t)NGpad);
-  L.cbox = take(sizeof(float4) * 2 * (size_t)nchunks);
+  L.cellbox = take(sizeof(float4) * 2 * (size_t)(NGpad / 16));
   L.sbox = take(sizeof(float4) * 2 * (size_t)nchunks);
   L.masks = take(sizeof(unsigned long long) * ((size_t)N + 8) * nchunks);
   L.rowbits = take(sizeof(unsigned) * (size_t)(N + 4) * rbw_max);
   L.tile_count = take(sizeof(unsigned long long));
   L.ovf_rows = take(sizeof(int) * (size_t)N);
   L.ovf_count = take(sizeof(int));
+  L.cand_cnt = take(sizeof(int) * (size_t)N);
+  L.cand_j = take((size_t)128 * (size_t)N);  // ASSOC_CAP16 x u16 == ASSOC_CAP32 x i32 == 128 bytes per row
   L.ell_a = take(sizeof(float) * (size_t)N * Kmax);
   L.ell_j = take(sizeof(int) * (size_t)N * Kmax);
   L.nnz_row = take(sizeof(unsigned) * (size_t)N);
@@ -238,6 +240,9 @@ DevParams make_dev_params(const cvo_params_t& p) {
   d.use_sem = p.is_using_semantics != 0;
   d.use_range_ell = p.is_using_range_ell != 0;
   d.use_geotype = p.is_using_geometric_type != 0;
+  d.skin_frac = 0.1f;
+  d.rebuild_shrink = 0.7f;
+  if (const char* e = getenv("CVO_SKIN")) d.skin_frac = std::max(0.f, (float)atof(e));
   return d;
 }
 
@@ -283,6 +288,10 @@ void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const D
 void launch_assoc(hipStream_t s, bool idx16, bool general, dim3 grid, const PairDesc* descs, const DevParams* dp,
                   const int* st) {
   const dim3 blk(ASSOC_THREADS);
+  if (idx16)  // no-op unless k_update asked for a rebuild of the candidate bitmap
+    hipLaunchKernelGGL((k_list<unsigned short, ASSOC_CAP16>), grid, blk, 0, s, descs, dp, st);
+  else
+    hipLaunchKernelGGL((k_list<int, ASSOC_CAP32>), grid, blk, 0, s, descs, dp, st);
   if (idx16) {
     if (general)
       hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, true>), grid, blk, 0, s, descs, dp, st);
@@ -402,6 +411,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.nblk_coeff = S->d.nblk_coeff;
     D.NG = (X->n + ROWS_PER_GROUP - 1) / ROWS_PER_GROUP;
     D.NGpad = S->d.NGpad;
+    D.ymax = Y->rmax;
     D.cx = X->cx;
     D.cy = X->cy;
     D.cz = X->cz;
@@ -419,15 +429,16 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.yorder = Y->order;
     D.ycull = (float4*)(base + S->L.ycull);
     D.xcull = (float4*)(base + S->L.xcull);
-    D.rowc = (float2*)(base + S->L.rowc);
     D.gbox = (float4*)(base + S->L.gbox);
-    D.cbox = (float4*)(base + S->L.cbox);
+    D.cellbox = (float4*)(base + S->L.cellbox);
     D.sbox = (float4*)(base + S->L.sbox);
     D.masks = (unsigned long long*)(base + S->L.masks);
     D.rowbits = (unsigned*)(base + S->L.rowbits);
     D.tile_count = (unsigned long long*)(base + S->L.tile_count);
     D.ovf_rows = (int*)(base + S->L.ovf_rows);
     D.ovf_count = (int*)(base + S->L.ovf_count);
+    D.cand_cnt = (int*)(base + S->L.cand_cnt);
+    D.cand_j = (void*)(base + S->L.cand_j);
     D.ell_a = (float*)(base + S->L.ell_a);
     D.ell_j = (int*)(base + S->L.ell_j);
     D.nnz_row = (unsigned*)(base + S->L.nnz_row);
@@ -674,12 +685,16 @@ static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, cons
   c->ctx = ctx;
   c->device = ctx->device;
   c->n = n;
-  double sx = 0, sy = 0, sz = 0;
+  double sx = 0, sy = 0, sz = 0, r2max = 0;
   for (int i = 0; i < n; i++) {
-    sx += x4[4 * (size_t)i];
-    sy += x4[4 * (size_t)i + 1];
-    sz += x4[4 * (size_t)i + 2];
+    const double px = x4[4 * (size_t)i], py = x4[4 * (size_t)i + 1], pz = x4[4 * (size_t)i + 2];
+    sx += px;
+    sy += py;
+    sz += pz;
+    const double r2 = px * px + py * py + pz * pz;
+    if (!(r2 <= r2max)) r2max = r2;  // NaN sticks: an unbounded cloud never reuses a candidate list
   }
+  c->rmax = (float)(std::sqrt(r2max) * 1.000001);
   if (n > 0) {
     c->cx = (float)(sx / n);
     c->cy = (float)(sy / n);
@@ -1044,6 +1059,18 @@ int cvo_debug_last_candidates(cvo_ctx* ctx, unsigned long long* out) {
   return CVO_OK;
 }
 
+int cvo_debug_list_builds(cvo_ctx* ctx, unsigned long long* builds, unsigned long long* iterations) {
+  if (!ctx || !builds || ctx->last_pairs < 1) return fail(ctx, CVO_E_INVALID, "cvo_debug_list_builds: bad argument");
+  unsigned long long b = 0, it = 0;
+  for (int p = 0; p < ctx->last_pairs; p++) {
+    b += (unsigned long long)ctx->h_states[p].n_builds;
+    it += (unsigned long long)ctx->h_states[p].iterations;
+  }
+  *builds = b;
+  if (iterations) *iterations = it;
+  return CVO_OK;
+}
+
 int cvo_debug_scan_stats(cvo_ctx* ctx, unsigned long long* tiles, int* rows_per_tile, int* targets_per_tile) {
   if (!ctx || !tiles || ctx->last_pairs < 1) return fail(ctx, CVO_E_INVALID, "cvo_debug_scan_stats: bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1073,11 +1100,13 @@ int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms) {
   // the same launches the optimiser loop issues: one k_scan per sub-batch, here back to back on one stream
   const int n_pairs = ctx->last_pairs, G = ctx->last_groups;
   const DevParams& dp = ctx->last_params;
+  int variant = 1;  // CVO_SCAN_DEBUG: 1 = no emission, 2 = no fine tiles (cost breakdown only)
+  if (const char* e = getenv("CVO_SCAN_DEBUG")) variant |= atoi(e) << 1;
   auto sweep = [&]() {
     for (int g = 0; g < G; g++) {
       const int p0 = (int)((long)n_pairs * g / G), p1 = (int)((long)n_pairs * (g + 1) / G);
       launch_scan(ctx->stream, dp.T, dim3(ctx->last_gx, ctx->last_gy, p1 - p0), ctx->d_descs + p0, ctx->d_params,
-                  ctx->d_status + p0, 1);
+                  ctx->d_status + p0, variant);
     }
   };
   sweep();  // warm-up

@@ -105,7 +105,7 @@ struct ScatterTile<T, RG, RG> {
   static __device__ __forceinline__ void run(const unsigned long long (&)[RG][T], unsigned&, unsigned&) {}
 };
 
-constexpr int SCAN_TILE_CAP = 64;  // (row group, slice) tiles a wave queues in LDS per round
+constexpr int SCAN_TILE_CAP = 128;  // (row group, slice) tiles a wave queues in LDS per round
 
 template <int T>
 __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
@@ -116,16 +116,19 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
   __shared__ int s_tile_g[4][SCAN_TILE_CAP];
   if (!force && status[blockIdx.z] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.z;
+  if (!force && !D->st->rebuild) return;  // the bitmap of an earlier iteration is still a superset
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int slice = blockIdx.x * 4 + wave;
   const int nslices = D->nslices;
   if (slice >= nslices) return;
-  const int gpb = Pp->groups_per_block;  // a multiple of 64
-  const int NG = D->NG;
-  const int g_begin = blockIdx.y * gpb;
-  if (g_begin >= NG) return;
-  const int g_end = min(g_begin + gpb, NG);
+  // The gridDim.y blocks of a slice share its rows cell by cell (cell = 16 groups = 64 sorted rows): block k
+  // owns cells k, k + S, k + 2S, ...  Interleaving matters: the cells a slice overlaps are neighbours in
+  // the k-d order, so contiguous row segments would leave all the fine work of a slice to one wave.
+  const int NCr = (D->NG + 15) >> 4;  // cells with real rows
+  const int S = gridDim.y, kseg = blockIdx.y;
+  if (kseg >= NCr) return;
+  const int c_end = (NCr - kseg + S - 1) / S;  // this block's cells: i * S + kseg, i < c_end
 
   const CVO_GLOBAL f32x4* yc = (const CVO_GLOBAL f32x4*)D->ycull;
   float y1[T], y2[T], y3[T], yy[T];
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
   // bounding box of this wave's 64*T targets (wave-uniform -> scalar loads)
   const CVO_CONST f32x4* sb = (const CVO_CONST f32x4*)D->sbox + 2 * slice;
   const f32x4 smin = sb[0], smax = sb[1];
+  const CVO_GLOBAL f32x4* cellbox = (const CVO_GLOBAL f32x4*)D->cellbox;
   const CVO_GLOBAL f32x4* gbox = (const CVO_GLOBAL f32x4*)D->gbox;
   const CVO_GLOBAL f32x4* xc = (const CVO_GLOBAL f32x4*)D->xcull;
   CVO_GLOBAL unsigned long long* masks = (CVO_GLOBAL unsigned long long*)D->masks;
@@ -154,18 +158,45 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
   CVO_GLOBAL unsigned long long* mask_lane = masks + (size_t)slice * N * T + lane;
   CVO_GLOBAL unsigned* rowbits_lane = rowbits + (size_t)(lane / T) * rbw + (slice >> 5);
 
-  int gb = g_begin;
+  // Two-level cull.  Level 1: lane l tests the box of row cell c (64 rows that the k-d ordering made a
+  // compact block) against the slice box -> m1.  Level 2: four overlapping cells at a time, lane l tests
+  // group (l & 15) of cell (l >> 4); the lane that finds an overlap fetches that group's RG row operands
+  // straight into the wave's LDS tile queue.  Boxes are already grown by the cut-off radius; pad groups
+  // and pad cells carry empty boxes.
+  unsigned long long m1 = 0;
+  int cb = 0;  // cell of bit 0 of m1
+  int next_cb = 0;
   unsigned tiles_done = 0;
-  while (gb < g_end) {
-    // ---- coarse level: lane l tests row group gb + l against the slice box (group boxes are already
-    // grown by the cut-off radius; pad groups carry empty boxes).  The lane that finds an overlap
-    // fetches that group's RG row operands straight into the wave's LDS tile queue.
+  for (;;) {
     int ntiles = 0;
-    while (gb < g_end && ntiles + 64 <= SCAN_TILE_CAP) {
-      const int g = gb + lane;
+    while (ntiles + 64 <= SCAN_TILE_CAP) {
+      if (m1 == 0) {
+        if (next_cb >= c_end) break;
+        cb = next_cb;
+        next_cb += 64;
+        const int c = cb + lane;
+        const int cc = min(c, c_end - 1);
+        const int cell = cc * S + kseg;
+        const f32x4 bmin = cellbox[2 * (size_t)cell], bmax = cellbox[2 * (size_t)cell + 1];
+        const bool ov = (bmin.x <= smax.x) & (bmax.x >= smin.x) & (bmin.y <= smax.y) & (bmax.y >= smin.y) &
+                        (bmin.z <= smax.z) & (bmax.z >= smin.z) & (c < c_end);
+        m1 = __ballot(ov);
+        continue;
+      }
+      const int s0 = __builtin_ctzll(m1);
+      m1 &= m1 - 1;
+      const int s1 = m1 ? __builtin_ctzll(m1) : -1;
+      m1 &= m1 - 1;
+      const int s2 = m1 ? __builtin_ctzll(m1) : -1;
+      m1 &= m1 - 1;
+      const int s3 = m1 ? __builtin_ctzll(m1) : -1;
+      m1 &= m1 - 1;
+      const int q = lane >> 4;
+      const int sel = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));
+      const int g = (((cb + max(sel, 0)) * S + kseg) << 4) + (lane & 15);
       const f32x4 bmin = gbox[2 * (size_t)g], bmax = gbox[2 * (size_t)g + 1];
       const bool overlap = (bmin.x <= smax.x) & (bmax.x >= smin.x) & (bmin.y <= smax.y) & (bmax.y >= smin.y) &
-                           (bmin.z <= smax.z) & (bmax.z >= smin.z) & (g < g_end);
+                           (bmin.z <= smax.z) & (bmax.z >= smin.z) & (sel >= 0);
       const unsigned long long m = __ballot(overlap);
       if (overlap) {
         const int slot = ntiles + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -175,16 +206,29 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
         tile_g[slot] = g;
       }
       ntiles += __builtin_popcountll(m);
-      gb += 64;
     }
+    if (ntiles == 0) break;  // the segment is exhausted
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // ---- fine level over the queued tiles: 3 FMA per pair, a v_min3 tree per row, one compare per row
-    for (int ti = 0; ti < ntiles; ti++) {
+    const int nproc = (force & 4) ? 0 : ntiles;  // timing variants of cvo_debug_time_scan
+    // software pipeline: the LDS reads of tile ti + 1 are in flight while tile ti is evaluated
+    f32x4 nxt[RG];
+#pragma unroll
+    for (int u = 0; u < RG; u++) nxt[u] = rows[0][u];  // wave-uniform address: LDS broadcast
+    int tg_nxt = tile_g[0];
+    for (int ti = 0; ti < nproc; ti++) {
       f32x4 cur[RG];
 #pragma unroll
-      for (int u = 0; u < RG; u++) cur[u] = rows[ti][u];  // wave-uniform address: LDS broadcast
+      for (int u = 0; u < RG; u++) cur[u] = nxt[u];
+      const int tg = tg_nxt;
+      {
+        const int tn = min(ti + 1, nproc - 1);
+#pragma unroll
+        for (int u = 0; u < RG; u++) nxt[u] = rows[tn][u];
+        tg_nxt = tile_g[tn];
+      }
       float acc[RG][T];
       unsigned long long mu[RG];
       unsigned long long any = 0;
@@ -202,11 +246,11 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
         mu[u] = __ballot(mn < cur[u].w);
         any |= mu[u];
       }
-      if (any) {  // usual case once tiles are culled: the group has candidates among this wave's 64*T targets
+      if (any && !(force & 2)) {  // usual case once tiles are culled: the group has candidates among this wave's 64*T targets
         // Lane q = u*T+t receives the bitmap word of (row u, chunk t) with v_writelane; the T lanes of a row
-        // OR their "non-empty" bits with DPP shuffles: the whole tile is emitted with one (contiguous) mask
+        // the whole tile is emitted with one (contiguous) mask
         // store and one returnless atomic instruction.
-        const int r = __builtin_amdgcn_readfirstlane(tile_g[ti]) * RG;
+        const int r = __builtin_amdgcn_readfirstlane(tg) * RG;
         unsigned long long mm[RG][T];
 #pragma unroll
         for (int u = 0; u < RG; u++) {
@@ -215,11 +259,12 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
         }
         unsigned lo = 0, hi = 0;
         ScatterTile<T, 0, RG>::run(mm, lo, hi);
-        const bool nz = (lo | hi) != 0;
-        unsigned fl = nz ? 1u : 0u;
+        // lanes u*T .. u*T+T-1 of every row u that has a candidate in this slice (wave-uniform mask: no
+        // cross-lane traffic); all T words of such a row are stored
+        unsigned rowsel = 0;
 #pragma unroll
-        for (int o = 1; o < T; o <<= 1) fl |= (unsigned)__shfl_xor((int)fl, o);
-        if (lane < RG * T && fl) {  // all T words of a row that has any candidate in this slice
+        for (int u = 0; u < RG; u++) rowsel |= mu[u] ? (((1u << T) - 1u) << (u * T)) : 0u;
+        if (lane < RG * T && ((rowsel >> lane) & 1u)) {
           mask_lane[(size_t)r * T] = ((unsigned long long)hi << 32) | lo;
           if ((lane % T) == 0)  // tells k_assoc that this (row, slice) has valid mask words
             __hip_atomic_fetch_or(rowbits_lane + (size_t)r * rbw, slice_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -239,6 +284,14 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
 struct RowData {
   float x, y, z, l, d2_thres;
 };
+// per-row constants of fill_in_A_mat_gpu (CvoGPU.cu:504-510)
+__device__ __forceinline__ RowData make_row(const DevParams& P, const float4 x, float ell) {
+  const float a_to_sensor = sqrtf(__builtin_fmaf(x.z, x.z, __builtin_fmaf(x.y, x.y, x.x * x.x)));
+  const float l = compute_range_ell(ell, a_to_sensor);
+  float thr = 1.f;
+  if (P.use_geo) thr = (float)(-2.0 * l * l * (double)P.log_geo);
+  return RowData{x.x, x.y, x.z, l, thr};
+}
 struct Pose {  // the transform applied to the target cloud this iteration (update_tf, CvoGPU.cu:94-112)
   float Ri[9], Ti[3];
 };
@@ -353,102 +406,145 @@ __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* _
   }
 }
 
-template <typename IdxT, int ASSOC_CAP, bool GENERAL>
-__global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restrict__ descs,
-                                                          const DevParams* __restrict__ Pp,
-                                                          const int* __restrict__ status) {
+// ------------------------------------------------------------------------------------------
+// k_list: runs only when the bitmap was rebuilt.  One thread per (sorted) source row decodes the row's
+// candidates from the bitmap, maps them to original target indices and sorts them ascending; the list is
+// cached in HBM ([slot][row], coalesced) and serves every iteration until the next rebuild.  Rows with
+// more candidates than the list holds go to the overflow list of k_assoc_dense (also cached).
+// ------------------------------------------------------------------------------------------
+template <typename IdxT, int ASSOC_CAP>
+__global__ __launch_bounds__(ASSOC_THREADS) void k_list(const PairDesc* __restrict__ descs,
+                                                         const DevParams* __restrict__ Pp,
+                                                         const int* __restrict__ status) {
   constexpr int ASSOC_STRIDE = ASSOC_CAP + 1;  // odd stride: conflict-free per-thread lists
   if (status[blockIdx.y] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.y;
-  const PairState* st = D->st;
-  const DevParams P = *Pp;
-  const int N = D->N, M = D->M;
+  if (!D->st->rebuild) return;
+  const int N = D->N;
   const int r_sorted = blockIdx.x * ASSOC_THREADS + threadIdx.x;
-  const int K = st->K;
-  const int T = P.T;
+  const int T = Pp->T;
   __shared__ IdxT s_list[ASSOC_THREADS * ASSOC_STRIDE];
   IdxT* list = s_list + threadIdx.x * ASSOC_STRIDE;
-  RowAcc A;
-  unsigned long long ncand = 0;
-  unsigned overflowed = 0;
-  if (r_sorted < N) {
-    const int i = D->xorder[r_sorted];
-    const float4 x = D->xs4[r_sorted];
-    const float2 rc = D->rowc[r_sorted];
-    const RowData r{x.x, x.y, x.z, rc.x, rc.y};
-    const V3 pxe{x.x, x.y, x.z};
-    const Pose pose = load_pose(st);
-    // ---- gather this row's candidates (sorted-space bitmap) and restore ascending original j
-    const int* yorder = D->yorder;
-    const int rbw = D->rbw;
-    unsigned* rb = D->rowbits + (size_t)r_sorted * rbw;
-    int cnt = 0;
-    // pass 1: how many candidates does the row have?  (Rows beyond the list capacity go straight to
-    // k_assoc_dense without building a list; the mask words are re-read from L1/L2 in pass 2.)
-    for (int w0 = 0; w0 < rbw; w0 += 4) {
-      const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
-      if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
-      const unsigned bw[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
+  if (r_sorted >= N) return;
+  const int* yorder = D->yorder;
+  const int rbw = D->rbw;
+  const unsigned* rb = D->rowbits + (size_t)r_sorted * rbw;
+  // pass 1: how many candidates does the row have?
+  int ncand = 0;
+  for (int w0 = 0; w0 < rbw; w0 += 4) {  // rbw is a multiple of 4 (one 16-byte load covers 128 slices)
+    const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
+    if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
+    const unsigned bw[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        unsigned f = bw[q];
-        while (f) {
-          const int sl = (w0 + q) * 32 + __builtin_ctz(f);
-          f &= f - 1;
-          const unsigned long long* mw = D->masks + ((size_t)sl * N + r_sorted) * T;
-          for (int t = 0; t < T; t++) ncand += (unsigned long long)__builtin_popcountll(mw[t]);
-        }
+    for (int q = 0; q < 4; q++) {
+      unsigned f = bw[q];
+      while (f) {
+        const int sl = (w0 + q) * 32 + __builtin_ctz(f);
+        f &= f - 1;
+        const unsigned long long* mw = D->masks + ((size_t)sl * N + r_sorted) * T;
+        for (int t = 0; t < T; t++) ncand += __builtin_popcountll(mw[t]);
       }
     }
-    overflowed = ncand > (unsigned long long)ASSOC_CAP ? 1u : 0u;
-    // pass 2: clear the slice bits; unless overflowed, gather the candidates and restore ascending original j
-    for (int w0 = 0; w0 < rbw; w0 += 4) {  // rbw is a multiple of 4 (one 16-byte load covers 128 slices)
-      const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
-      if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
-      *reinterpret_cast<uint4*>(rb + w0) = make_uint4(0, 0, 0, 0);  // self-cleaning
-      if (overflowed) continue;
-      const unsigned bw[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
+  }
+  D->cand_cnt[r_sorted] = ncand;
+  if (ncand > ASSOC_CAP) {
+    // more candidates than a list holds (dense regime, e.g. rows sitting on K_max): k_assoc_dense
+    // evaluates these rows against all targets, 64 at a time
+    const int slot = atomicAdd(D->ovf_count, 1);
+    D->ovf_rows[slot] = r_sorted;
+    return;
+  }
+  // pass 2: sorted-space positions of the candidates (the mask words come from L1/L2 this time)
+  int cnt = 0;
+  for (int w0 = 0; w0 < rbw; w0 += 4) {
+    const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
+    if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
+    const unsigned bw[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        unsigned f = bw[q];
-        while (f) {
-          const int sl = (w0 + q) * 32 + __builtin_ctz(f);
-          f &= f - 1;
-          const unsigned long long* mw = D->masks + ((size_t)sl * N + r_sorted) * T;
-          for (int t = 0; t < T; t++) {
-            unsigned long long m = mw[t];
-            const int chunk = sl * T + t;
-            while (m) {
-              const int b = __builtin_ctzll(m);
-              m &= m - 1;
-              const int j = yorder[chunk * 64 + b];
-              int k = cnt++;  // insertion sort, ascending j
-              while (k > 0 && (int)list[k - 1] > j) {
-                list[k] = list[k - 1];
-                k--;
-              }
-              list[k] = (IdxT)j;
-            }
+    for (int q = 0; q < 4; q++) {
+      unsigned f = bw[q];
+      while (f) {
+        const int sl = (w0 + q) * 32 + __builtin_ctz(f);
+        f &= f - 1;
+        const unsigned long long* mw = D->masks + ((size_t)sl * N + r_sorted) * T;
+        for (int t = 0; t < T; t++) {
+          unsigned long long m = mw[t];
+          const int chunk = sl * T + t;
+          while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            list[cnt++] = (IdxT)(chunk * 64 + b);
           }
         }
       }
     }
-    if (!overflowed) {
-      // exact evaluation in ascending original j; the next candidate's coordinates are fetched while the
-      // current one is evaluated
-      float4 ynext = cnt > 0 ? D->y4[(int)list[0]] : make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int k = 0; k < cnt && A.nnz < (unsigned)K; k++) {
-        const float4 ycur = ynext;
-        if (k + 1 < cnt) ynext = D->y4[(int)list[k + 1]];
-        visit_pair<GENERAL>(P, D, pose, i, r_sorted, N, r, pxe, (int)list[k], ycur, A);
-      }
-    } else {
-      // more candidates than the list holds (dense regime, e.g. rows sitting on K_max): handed to
-      // k_assoc_dense, which evaluates 64 targets at a time per row
-      const int slot = atomicAdd(D->ovf_count, 1);
-      D->ovf_rows[slot] = r_sorted;
+  }
+  // original indices: independent gathers, four in flight
+  for (int k0 = 0; k0 < cnt; k0 += 4) {
+    int jj[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) jj[u] = yorder[(int)list[min(k0 + u, cnt - 1)]];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (k0 + u < cnt) list[k0 + u] = (IdxT)jj[u];
+  }
+  // ascending original j (the order of the reference's first-K truncation and float accumulation)
+  for (int k = 1; k < cnt; k++) {
+    const int j = (int)list[k];
+    int q = k;
+    while (q > 0 && (int)list[q - 1] > j) {
+      list[q] = list[q - 1];
+      q--;
     }
-    if (!overflowed) D->nnz_row[r_sorted] = A.nnz;
+    list[q] = (IdxT)j;
+  }
+  IdxT* out = reinterpret_cast<IdxT*>(D->cand_j);
+  for (int k = 0; k < cnt; k++) out[(size_t)k * N + r_sorted] = list[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_assoc: ordered association + flow, one thread per (sorted) source row, over the cached candidate list.
+// ------------------------------------------------------------------------------------------
+template <typename IdxT, int ASSOC_CAP, bool GENERAL>
+__global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restrict__ descs,
+                                                          const DevParams* __restrict__ Pp,
+                                                          const int* __restrict__ status) {
+  if (status[blockIdx.y] != 0) return;
+  const PairDesc* __restrict__ D = descs + blockIdx.y;
+  const PairState* st = D->st;
+  const DevParams P = *Pp;
+  const int N = D->N;
+  const int r_sorted = blockIdx.x * ASSOC_THREADS + threadIdx.x;
+  const int K = st->K;
+  RowAcc A;
+  unsigned long long ncand = 0;
+  unsigned overflowed = 0;
+  if (r_sorted < N) {
+    const int cnt = D->cand_cnt[r_sorted];
+    ncand = (unsigned long long)cnt;
+    overflowed = cnt > ASSOC_CAP ? 1u : 0u;
+    if (!overflowed) {
+      const int i = D->xorder[r_sorted];
+      const float4 x = D->xs4[r_sorted];
+      const RowData r = make_row(P, x, st->ell);
+      const V3 pxe{x.x, x.y, x.z};
+      const Pose pose = load_pose(st);
+      const IdxT* cj = reinterpret_cast<const IdxT*>(D->cand_j) + r_sorted;
+      // exact evaluation in ascending original j; index and coordinates of the next candidates are in
+      // flight while the current one is evaluated
+      int j1 = cnt > 0 ? (int)cj[0] : 0;
+      int j2 = cnt > 1 ? (int)cj[N] : 0;
+      float4 y1 = D->y4[j1];
+      for (int k = 0; k < cnt && A.nnz < (unsigned)K; k++) {
+        const int j = j1;
+        const float4 ycur = y1;
+        j1 = j2;
+        if (k + 1 < cnt) y1 = D->y4[j1];
+        if (k + 2 < cnt) j2 = (int)cj[(size_t)(k + 2) * N];
+        visit_pair<GENERAL>(P, D, pose, i, r_sorted, N, r, pxe, j, ycur, A);
+      }
+      D->nnz_row[r_sorted] = A.nnz;
+    }
   }
   // per-row (omega_i / c, v_i / d) cast to double, then reduced in double (CvoGPU.cu:784-787, 824-825)
   double red[7] = {(double)(A.o0 / P.c), (double)(A.o1 / P.c), (double)(A.o2 / P.c), (double)(A.v0 / P.d),
@@ -522,8 +618,7 @@ __global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict_
       const int r_sorted = D->ovf_rows[q];
       const int i = D->xorder[r_sorted];
       const float4 x = D->xs4[r_sorted];
-      const float2 rc = D->rowc[r_sorted];
-      const RowData r{x.x, x.y, x.z, rc.x, rc.y};
+      const RowData r = make_row(P, x, st->ell);
       const V3 pxe{x.x, x.y, x.z};
       float o0 = 0, o1 = 0, o2 = 0, v0 = 0, v1 = 0, v2 = 0;
       double asum = 0;
@@ -778,7 +873,6 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
   }
   __syncthreads();
   if (tid == 0) {
-    *D->ovf_count = 0;  // next iteration's overflow list starts empty
     int done = 0;
     if (!INIT) {
       const unsigned nnz = (unsigned)s_n[0], max_nnz = (unsigned)s_n[1];
@@ -882,6 +976,44 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
     // update_tf (CvoGPU.cu:94-112): the transform applied next, and the returned matrix when done
     float Ri[9], Ti[3];
     update_tf(st->R, st->T, Ri, Ti);
+    {
+      // Candidate-list reuse.  A target moves by at most |Ri - Rb|_F * max|y0| + |Ti - Tb| between the pose
+      // the bitmap was built with and the one applied next; as long as that stays below the skin the scan
+      // added to every cut-off radius (and ell, hence every radius, has not grown) the bitmap still
+      // contains every pair the exact test of k_assoc can accept.
+      const float ell_next = st->ell;
+      const float radius = ell_next * sqrtf(fmaxf(-2.f * P.log_geo, 0.f));  // cut-off radius for l = ell
+      float dr = 0, dt = 0, dr1 = 0, dt1 = 0, tn = 0;
+      for (int q = 0; q < 9; q++) {
+        const float a = Ri[q] - st->Rb[q], b = Ri[q] - st->Rinv[q];
+        dr += a * a;
+        dr1 += b * b;
+      }
+      for (int q = 0; q < 3; q++) {
+        const float a = Ti[q] - st->Tb[q], b = Ti[q] - st->Tinv[q];
+        dt += a * a;
+        dt1 += b * b;
+        tn += Ti[q] * Ti[q];
+      }
+      const float ymax = D->ymax;
+      const float slack = 1e-5f * (ymax + sqrtf(tn) + 1.f);  // rounding of the two transform evaluations
+      const float moved = (sqrtf(dr) * ymax + sqrtf(dt)) * 1.001f + slack;
+      bool rebuild = INIT || P.mode != 0 || !(moved <= st->skin) || ell_next > st->ell_build ||
+                     ell_next < P.rebuild_shrink * st->ell_build;
+      if (rebuild) {
+        for (int q = 0; q < 9; q++) st->Rb[q] = Ri[q];
+        for (int q = 0; q < 3; q++) st->Tb[q] = Ti[q];
+        st->ell_build = ell_next;
+        // a list only pays if it survives a few iterations: no skin while the pose still moves fast
+        const float step_move = sqrtf(dr1) * ymax + sqrtf(dt1);
+        float skin = P.skin_frac * radius;
+        if (!INIT && !(4.f * step_move < skin)) skin = 0.f;
+        if (P.mode != 0 || !P.use_geo || !(skin == skin)) skin = 0.f;
+        st->skin = skin;
+        st->n_builds = INIT ? 1 : st->n_builds + 1;
+      }
+      st->rebuild = rebuild ? 1 : 0;
+    }
     for (int q = 0; q < 9; q++) st->Rinv[q] = Ri[q];
     for (int q = 0; q < 3; q++) st->Tinv[q] = Ti[q];
     for (int i = 0; i < 3; i++) {
@@ -920,6 +1052,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
   if (status[blockIdx.y] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.y;
   const PairState* st = D->st;
+  if (!st->rebuild) return;  // k_update: the bitmap of an earlier iteration still covers this one
   const DevParams P = *Pp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float INF = __builtin_inff();
@@ -989,16 +1122,18 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
   const int N = D->N;
   const int rs = (blockIdx.x - ntb) * PREP_THREADS + tid;
   if (rs >= D->NGpad * ROWS_PER_GROUP) return;  // whole waves drop out together (NGpad*4 is a multiple of 256)
-  const float ell = st->ell;
+  const float ell = st->ell;  // == st->ell_build: a rebuild always uses the current lengthscale
+  if (rs == 0) *D->ovf_count = 0;  // k_list refills the overflow list of k_assoc_dense
+  const float skin = st->skin;
   float ux = 0, uy = 0, uz = 0, cw = -INF, rad = 0;
   float lox = INF, loy = INF, loz = INF, hix = -INF, hiy = -INF, hiz = -INF;
   if (rs < N) {
     const float4 x = D->xs4[rs];
-    const float a_to_sensor = sqrtf(__builtin_fmaf(x.z, x.z, __builtin_fmaf(x.y, x.y, x.x * x.x)));
-    const float l = compute_range_ell(ell, a_to_sensor);
-    float thr = 1.f;
-    if (P.use_geo) thr = (float)(-2.0 * l * l * (double)P.log_geo);
-    D->rowc[rs] = make_float2(l, thr);
+    const RowData r = make_row(P, x, ell);
+    // cut-off of the scan: (sqrt(thr) + skin)^2, rounded up, so that the bitmap stays a superset of the
+    // exact test while the targets move by less than `skin` (and ell does not grow)
+    const float rs_ = __builtin_fmaf(sqrtf(fmaxf(r.d2_thres, 0.f)), 1.000001f, skin);
+    const float thr = rs_ * rs_ * 1.000001f;
     ux = x.x - cx;
     uy = x.y - cy;
     uz = x.z - cz;
@@ -1013,6 +1148,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
     lox = hix = ux;
     loy = hiy = uy;
     loz = hiz = uz;
+    // the bitmap is rebuilt from scratch: drop this row's slice bits (k_scan runs after this kernel)
+    unsigned* rb = D->rowbits + (size_t)rs * D->rbw;
+    for (int w0 = 0; w0 < D->rbw; w0 += 4) *reinterpret_cast<uint4*>(rb + w0) = make_uint4(0, 0, 0, 0);
   }
   if (rs < N + XCULL_PAD) D->xcull[rs] = make_float4(-2.f * ux, -2.f * uy, -2.f * uz, cw);
 #pragma unroll
@@ -1025,10 +1163,31 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
     hiz = fmaxf(hiz, __shfl_xor(hiz, o));
     rad = fmaxf(rad, __shfl_xor(rad, o));
   }
+  lox -= rad;
+  loy -= rad;
+  loz -= rad;
+  hix += rad;
+  hiy += rad;
+  hiz += rad;
   if ((rs & (ROWS_PER_GROUP - 1)) == 0) {
     const int g = rs / ROWS_PER_GROUP;
-    D->gbox[2 * (size_t)g] = make_float4(lox - rad, loy - rad, loz - rad, 0.f);
-    D->gbox[2 * (size_t)g + 1] = make_float4(hix + rad, hiy + rad, hiz + rad, 0.f);
+    D->gbox[2 * (size_t)g] = make_float4(lox, loy, loz, 0.f);
+    D->gbox[2 * (size_t)g + 1] = make_float4(hix, hiy, hiz, 0.f);
+  }
+  // level-1 boxes of k_scan: one per wave = cell of 64 sorted rows (16 groups)
+#pragma unroll
+  for (int o = ROWS_PER_GROUP; o < 64; o <<= 1) {
+    lox = fminf(lox, __shfl_xor(lox, o));
+    loy = fminf(loy, __shfl_xor(loy, o));
+    loz = fminf(loz, __shfl_xor(loz, o));
+    hix = fmaxf(hix, __shfl_xor(hix, o));
+    hiy = fmaxf(hiy, __shfl_xor(hiy, o));
+    hiz = fmaxf(hiz, __shfl_xor(hiz, o));
+  }
+  if (lane == 0) {
+    const int c = rs >> 6;
+    D->cellbox[2 * (size_t)c] = make_float4(lox, loy, loz, 0.f);
+    D->cellbox[2 * (size_t)c + 1] = make_float4(hix, hiy, hiz, 0.f);
   }
 }
 
