@@ -40,6 +40,7 @@ struct DevParams {
   // less than the skin and ell has not grown.  0 = scan every iteration.
   float skin_frac;
   float rebuild_shrink;  // rebuild when ell < rebuild_shrink * ell_build (the list would be far too long)
+  int lean_U;            // iterations between two rebuild opportunities in the lean graph
 };
 
 // Running state of one frame pair; lives in HBM, only touched by one thread of k_step.
@@ -67,6 +68,7 @@ struct PairState {
   float Rb[9], Tb[3];
   float ell_build, skin;
   int rebuild, n_builds;
+  int want_full, n_stalls;  // host hint: this pair needs the graph with per-iteration rebuild / dense kernels
   // A_sparsity_indicator_ell_update FIFOs (CvoGPU.cu:1167-1285): bookkeeping here, storage below
   int s_head, s_size, e_head, e_size;
   float s_sum, e_sum;
@@ -123,6 +125,8 @@ struct PairDesc {
   PairState* st;
   cvo_trace_t* trace;
   int* status_out;  // mirror of st->status for cheap host polling
+  int* want_out;    // mirror of st->want_full
+  int* gate;        // [1] blocks of k_list that finished the current rebuild (the last one validates the list)
 };
 
 constexpr int ROWS_PER_GROUP = 4;

@@ -37,7 +37,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, tile_count, ovf_rows, ovf_count, cand_cnt, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, tile_count, ovf_rows, ovf_count, gate, cand_cnt, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -77,8 +77,9 @@ struct cvo_ctx {
   hipEvent_t ev_chk[2][MAX_GROUPS] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
   // graph cache (one per group)
-  hipGraphExec_t graph_exec[MAX_GROUPS] = {};
-  GraphKey graph_key[MAX_GROUPS] = {};
+  hipGraphExec_t graph_exec[MAX_GROUPS][2] = {};  // [group][0 = full chunk, 1 = lean chunk]
+  GraphKey graph_key[MAX_GROUPS][2] = {};
+  int last_chunks = 0, last_lean_launches = 0, last_full_launches = 0;
   // last call (debug hooks)
   int last_pairs = 0;
   int last_N = 0, last_M = 0, last_Kmax = 0;
@@ -132,6 +133,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.tile_count = take(sizeof(unsigned long long));
   L.ovf_rows = take(sizeof(int) * (size_t)N);
   L.ovf_count = take(sizeof(int));
+  L.gate = take(sizeof(int));
   L.cand_cnt = take(sizeof(int) * (size_t)N);
   L.cand_j = take((size_t)128 * (size_t)N);  // ASSOC_CAP16 x u16 == ASSOC_CAP32 x i32 == 128 bytes per row
   L.ell_a = take(sizeof(float) * (size_t)N * Kmax);
@@ -170,10 +172,11 @@ void free_workspace(cvo_ctx* c) {
 
 void drop_graphs(cvo_ctx* c) {
   for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++)
-    if (c->graph_exec[g]) {
-      (void)hipGraphExecDestroy(c->graph_exec[g]);
-      c->graph_exec[g] = nullptr;
-    }
+    for (int v = 0; v < 2; v++)
+      if (c->graph_exec[g][v]) {
+        (void)hipGraphExecDestroy(c->graph_exec[g][v]);
+        c->graph_exec[g][v] = nullptr;
+      }
 }
 
 int ensure_workspace(cvo_ctx* c, int n_pairs, size_t bytes_per_pair) {
@@ -188,8 +191,9 @@ int ensure_workspace(cvo_ctx* c, int n_pairs, size_t bytes_per_pair) {
     c->d_status = nullptr;
     HIP_TRY(c, hipMalloc(&c->d_descs, sizeof(PairDesc) * (size_t)n_pairs));
     HIP_TRY(c, hipMalloc(&c->d_states, sizeof(PairState) * (size_t)n_pairs));
-    HIP_TRY(c, hipMalloc(&c->d_status, sizeof(int) * (size_t)n_pairs));
-    for (int i = 0; i < 2; i++) HIP_TRY(c, hipHostMalloc(&c->h_status[i], sizeof(int) * (size_t)n_pairs));
+    // [0, n): st->status mirrors, [n, 2n): st->want_full mirrors
+    HIP_TRY(c, hipMalloc(&c->d_status, sizeof(int) * 2 * (size_t)n_pairs));
+    for (int i = 0; i < 2; i++) HIP_TRY(c, hipHostMalloc(&c->h_status[i], sizeof(int) * 2 * (size_t)n_pairs));
     c->cap_pairs = n_pairs;
     drop_graphs(c);
   }
@@ -285,23 +289,27 @@ void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const D
   }
 }
 
-void launch_assoc(hipStream_t s, bool idx16, bool general, dim3 grid, const PairDesc* descs, const DevParams* dp,
-                  const int* st) {
+void launch_list(hipStream_t s, bool idx16, dim3 grid, const PairDesc* descs, const DevParams* dp, const int* st) {
   const dim3 blk(ASSOC_THREADS);
-  if (idx16)  // no-op unless k_update asked for a rebuild of the candidate bitmap
+  if (idx16)
     hipLaunchKernelGGL((k_list<unsigned short, ASSOC_CAP16>), grid, blk, 0, s, descs, dp, st);
   else
     hipLaunchKernelGGL((k_list<int, ASSOC_CAP32>), grid, blk, 0, s, descs, dp, st);
+}
+
+void launch_assoc(hipStream_t s, bool idx16, bool general, dim3 grid, const PairDesc* descs, const DevParams* dp,
+                  const int* st, int lean) {
+  const dim3 blk(ASSOC_THREADS);
   if (idx16) {
     if (general)
-      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, true>), grid, blk, 0, s, descs, dp, st);
+      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, true>), grid, blk, 0, s, descs, dp, st, lean);
     else
-      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, false>), grid, blk, 0, s, descs, dp, st);
+      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, false>), grid, blk, 0, s, descs, dp, st, lean);
   } else {
     if (general)
-      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, true>), grid, blk, 0, s, descs, dp, st);
+      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, true>), grid, blk, 0, s, descs, dp, st, lean);
     else
-      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, false>), grid, blk, 0, s, descs, dp, st);
+      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, false>), grid, blk, 0, s, descs, dp, st, lean);
   }
 }
 
@@ -318,26 +326,45 @@ struct LaunchGeom {
   hipStream_t stream;
 };
 
-void launch_prep(cvo_ctx* c, const LaunchGeom& g) {
-  hipLaunchKernelGGL(k_prep, dim3(g.npb, g.n_pairs), dim3(PREP_THREADS), 0, g.stream, c->d_descs + g.p0,
-                     c->d_params, c->d_status + g.p0);
-}
-
 void launch_init(cvo_ctx* c, const LaunchGeom& g) {
   hipLaunchKernelGGL(k_update<true>, dim3(g.n_pairs), dim3(64), 0, g.stream, c->d_descs + g.p0, c->d_params,
-                     c->d_status + g.p0);
-  launch_prep(c, g);
+                     c->d_status + g.p0, 0);
 }
 
-void launch_iteration(cvo_ctx* c, const LaunchGeom& g) {
+// The rebuild kernels: no-ops (early exit) unless k_update flagged the pair's candidate list as expired.
+void launch_rebuild(cvo_ctx* c, const LaunchGeom& g) {
   const PairDesc* descs = c->d_descs + g.p0;
   const int* st = c->d_status + g.p0;
+  hipLaunchKernelGGL(k_prep, dim3(g.npb, g.n_pairs), dim3(PREP_THREADS), 0, g.stream, descs, c->d_params, st);
   launch_scan(g.stream, g.T, dim3(g.gx, g.gy, g.n_pairs), descs, c->d_params, st, 0);
-  launch_assoc(g.stream, g.idx16, g.general, dim3(g.nba, g.n_pairs), descs, c->d_params, st);
-  launch_dense(g.stream, g.general, g.n_pairs, descs, c->d_params, st);
-  hipLaunchKernelGGL(k_coeff, dim3(g.nbc, g.n_pairs), dim3(256), 0, g.stream, descs, c->d_params, st);
-  hipLaunchKernelGGL(k_update<false>, dim3(g.n_pairs), dim3(64), 0, g.stream, descs, c->d_params, st);
-  launch_prep(c, g);
+  launch_list(g.stream, g.idx16, dim3(g.nba, g.n_pairs), descs, c->d_params, st);
+}
+
+// One optimiser iteration over the current lists.  lean: no k_assoc_dense; `update_flags` see k_update.
+void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int update_flags) {
+  const PairDesc* descs = c->d_descs + g.p0;
+  const int* st = c->d_status + g.p0;
+  launch_assoc(g.stream, g.idx16, g.general, dim3(g.nba, g.n_pairs), descs, c->d_params, st, lean ? 1 : 0);
+  if (!lean) launch_dense(g.stream, g.general, g.n_pairs, descs, c->d_params, st);
+  hipLaunchKernelGGL(k_coeff, dim3(g.nbc, g.n_pairs), dim3(256), 0, g.stream, descs, c->d_params, st, lean ? 1 : 0);
+  hipLaunchKernelGGL(k_update<false>, dim3(g.n_pairs), dim3(64), 0, g.stream, descs, c->d_params, st, update_flags);
+}
+
+// A chunk of U iterations.  Full: every iteration can rebuild its candidate list and serve overflow rows.
+// Lean: rebuild opportunities only every lean_U iterations; pairs that need more wait for a full chunk.
+void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U) {
+  if (!lean) {
+    for (int u = 0; u < U; u++) {
+      launch_rebuild(c, g);
+      launch_core(c, g, false, 2);
+    }
+    return;
+  }
+  for (int u = 0; u < U; u++) {
+    if (u % lean_U == 0) launch_rebuild(c, g);
+    const bool last = (u % lean_U == lean_U - 1) || u == U - 1;
+    launch_core(c, g, true, 1 | (last ? 2 : 0) | (lean_U << 8));
+  }
 }
 
 struct BatchSetup {
@@ -386,6 +413,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   dp.mode = mode;
   dp.T = S->T;
   dp.groups_per_block = S->gpb;
+  dp.lean_U = 8;
+  if (const char* e = getenv("CVO_LEAN_U")) dp.lean_U = std::max(1, atoi(e));
   if (opts && opts->max_iterations > 0) dp.max_iter = std::min(dp.max_iter, opts->max_iterations);
   dp.trace_capacity = trace_cap;
   dp.trace_dense = opts ? opts->trace_dense : 0;
@@ -448,6 +477,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.st = ctx->d_states + p;
     D.trace = trace_cap > 0 ? (cvo_trace_t*)(base + S->L.trace) : nullptr;
     D.status_out = ctx->d_status + p;
+    D.want_out = ctx->d_status + ctx->cap_pairs + p;
+    D.gate = (int*)(base + S->L.gate);
 
     PairState& st = ctx->h_states[p];
     std::memset(&st, 0, sizeof(st));
@@ -466,6 +497,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     HIP_TRY(ctx, hipMemsetAsync(D.rowbits, 0, sizeof(unsigned) * (size_t)(S->N + 4) * S->d.rbw_max, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.tile_count, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.ovf_count, 0, sizeof(int), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(D.gate, 0, sizeof(int), ctx->stream));
   }
   // the blocks of k_assoc beyond a smaller pair's N still write their (zero) partials, but the
   // partial arrays of pairs whose N is smaller than the batch maximum are fully covered by nblk.
@@ -473,7 +505,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
                               hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_states, ctx->h_states.data(), sizeof(PairState) * (size_t)n_pairs,
                               hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int) * (size_t)n_pairs, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int) * 2 * (size_t)ctx->cap_pairs, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_params, &dp, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
   S->gx = (S->d.Mpad / (64 * S->T) + 3) / 4;
   S->gy = ((int)align_up((size_t)S->d.NG, 64) + S->gpb - 1) / S->gpb;
@@ -509,11 +541,8 @@ int run_single_eval(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
   int rc = setup_batch(ctx, params, 1, src, tgt, Tm, nullptr, 1, ell, S, &dp);
   if (rc != CVO_OK) return rc;
   launch_init(ctx, S->geom);
-  launch_scan(ctx->stream, S->T, dim3(S->gx, S->gy, 1), ctx->d_descs, ctx->d_params, ctx->d_status, 0);
-  launch_assoc(ctx->stream, S->geom.idx16, S->geom.general, dim3(S->d.nblk_assoc, 1), ctx->d_descs, ctx->d_params,
-               ctx->d_status);
-  launch_dense(ctx->stream, S->geom.general, 1, ctx->d_descs, ctx->d_params, ctx->d_status);
-  hipLaunchKernelGGL(k_update<false>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params, ctx->d_status);
+  launch_rebuild(ctx, S->geom);
+  launch_core(ctx, S->geom, false, 2);  // mode 1: k_coeff is a no-op, k_update collects the sums
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_states.data(), ctx->d_states, sizeof(PairState), hipMemcpyDeviceToHost,
                               ctx->stream));
@@ -816,49 +845,63 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   HIP_TRY(ctx, hipGetLastError());
 
   if (max_iter > 0) {
-    if (use_graph) {
-      for (int g = 0; g < G; g++) {
-        GraphKey key;
-        key.n_pairs = geom[g].n_pairs;
-        key.p0 = geom[g].p0;
-        key.T = S.T;
-        key.gx = S.gx;
-        key.gy = S.gy;
-        key.nba = S.d.nblk_assoc;
-        key.nbc = S.d.nblk_coeff;
-        key.npb = S.geom.npb;
-        key.idx16 = S.geom.idx16 ? 1 : 0;
-        key.general = S.geom.general ? 1 : 0;
-        key.U = U;
-        if (!ctx->graph_exec[g] || !(ctx->graph_key[g] == key)) {
-          if (ctx->graph_exec[g]) {
-            (void)hipGraphExecDestroy(ctx->graph_exec[g]);
-            ctx->graph_exec[g] = nullptr;
-          }
-          hipGraph_t gr = nullptr;
-          HIP_TRY(ctx, hipStreamBeginCapture(geom[g].stream, hipStreamCaptureModeThreadLocal));
-          for (int u = 0; u < U; u++) launch_iteration(ctx, geom[g]);
-          HIP_TRY(ctx, hipStreamEndCapture(geom[g].stream, &gr));
-          hipError_t e = hipGraphInstantiate(&ctx->graph_exec[g], gr, nullptr, nullptr, 0);
-          (void)hipGraphDestroy(gr);
-          if (e != hipSuccess) return fail(ctx, CVO_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-          ctx->graph_key[g] = key;
-        }
+    const int lean_U = std::max(1, std::min(dp.lean_U, U));
+    auto get_graph = [&](int g, int v) -> int {
+      GraphKey key;
+      key.n_pairs = geom[g].n_pairs;
+      key.p0 = geom[g].p0;
+      key.T = S.T;
+      key.gx = S.gx;
+      key.gy = S.gy;
+      key.nba = S.d.nblk_assoc;
+      key.nbc = S.d.nblk_coeff;
+      key.npb = S.geom.npb;
+      key.idx16 = S.geom.idx16 ? 1 : 0;
+      key.general = S.geom.general ? 1 : 0;
+      key.U = U * 256 + lean_U;
+      if (ctx->graph_exec[g][v] && ctx->graph_key[g][v] == key) return CVO_OK;
+      if (ctx->graph_exec[g][v]) {
+        (void)hipGraphExecDestroy(ctx->graph_exec[g][v]);
+        ctx->graph_exec[g][v] = nullptr;
       }
-    }
+      hipGraph_t gr = nullptr;
+      HIP_TRY(ctx, hipStreamBeginCapture(geom[g].stream, hipStreamCaptureModeThreadLocal));
+      launch_chunk(ctx, geom[g], U, v == 1, lean_U);
+      HIP_TRY(ctx, hipStreamEndCapture(geom[g].stream, &gr));
+      hipError_t e = hipGraphInstantiate(&ctx->graph_exec[g][v], gr, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(gr);
+      if (e != hipSuccess) return fail(ctx, CVO_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+      ctx->graph_key[g][v] = key;
+      return CVO_OK;
+    };
+    // Chunks are enqueued until every pair has finished.  A pair advances one iteration per slot unless it is
+    // waiting in a lean chunk for a rebuild / dense kernel, so the bound below is only a safety net.
     const int n_chunks = (max_iter + U - 1) / U;
+    const int chunk_cap = 4 * n_chunks + 16;
+    const bool allow_lean = getenv("CVO_NO_LEAN") == nullptr;
+    bool lean_next[cvo_ctx::MAX_GROUPS];
+    for (int g = 0; g < G; g++) lean_next[g] = false;  // the first iterations move fast: full graph
     bool all_done = false;
-    for (int ch = 0; ch < n_chunks && !all_done; ch++) {
+    int ch = 0;
+    int n_lean_launch = 0, n_full_launch = 0;
+    for (; ch < chunk_cap && !all_done; ch++) {
       const int slot = ch & 1;
       for (int g = 0; g < G; g++) {
+        const int v = lean_next[g] ? 1 : 0;
+        (v ? n_lean_launch : n_full_launch)++;
         if (use_graph) {
-          HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g], geom[g].stream));
+          rc = get_graph(g, v);
+          if (rc != CVO_OK) return rc;
+          HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g][v], geom[g].stream));
         } else {
-          for (int u = 0; u < U; u++) launch_iteration(ctx, geom[g]);
+          launch_chunk(ctx, geom[g], U, v == 1, lean_U);
           HIP_TRY(ctx, hipGetLastError());
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status[slot] + geom[g].p0, ctx->d_status + geom[g].p0,
                                     sizeof(int) * (size_t)geom[g].n_pairs, hipMemcpyDeviceToHost, geom[g].stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status[slot] + ctx->cap_pairs + geom[g].p0,
+                                    ctx->d_status + ctx->cap_pairs + geom[g].p0, sizeof(int) * (size_t)geom[g].n_pairs,
+                                    hipMemcpyDeviceToHost, geom[g].stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_chk[slot][g], geom[g].stream));
       }
       // keep one chunk of speculation in flight: inspect the chunk before this one
@@ -867,7 +910,23 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
         for (int g = 0; g < G; g++) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_chk[ws][g]));
         all_done = true;
         for (int p = 0; p < n_pairs; p++) all_done = all_done && ctx->h_status[ws][p] != 0;
+        for (int g = 0; g < G; g++) {
+          bool want_full = false;
+          for (int p = geom[g].p0; p < geom[g].p0 + geom[g].n_pairs; p++)
+            want_full = want_full || (ctx->h_status[ws][p] == 0 && ctx->h_status[ws][ctx->cap_pairs + p] != 0);
+          lean_next[g] = allow_lean && !want_full;
+        }
       }
+    }
+    ctx->last_chunks = ch;
+    ctx->last_lean_launches = n_lean_launch;
+    ctx->last_full_launches = n_full_launch;
+    if (!all_done) {  // the in-flight chunk may have finished the stragglers; otherwise report it
+      for (int g = 0; g < G; g++) HIP_TRY(ctx, hipStreamSynchronize(geom[g].stream));
+      const int ws = (ch - 1) & 1;
+      bool fin = true;
+      for (int p = 0; p < n_pairs; p++) fin = fin && ctx->h_status[ws][p] != 0;
+      if (!fin && ch >= chunk_cap) return fail(ctx, CVO_E_HIP, "cvo_align_batch: optimiser loop did not terminate");
     }
   }
   for (int g = 1; g < G; g++) {  // join
@@ -880,6 +939,16 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   float ms = 0;
   HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+  if (getenv("CVO_VERBOSE")) {
+    long builds = 0, stalls = 0, its = 0;
+    for (int p = 0; p < n_pairs; p++) {
+      builds += ctx->h_states[p].n_builds;
+      stalls += ctx->h_states[p].n_stalls;
+      its += ctx->h_states[p].status ? ctx->h_states[p].iterations : ctx->h_states[p].k;
+    }
+    fprintf(stderr, "[cvo] %d pairs, %d groups: %d chunks (%d full + %d lean group launches), iterations %ld, list builds %ld, waits %ld, %.3f ms\n",
+            n_pairs, G, ctx->last_chunks, ctx->last_full_launches, ctx->last_lean_launches, its, builds, stalls, ms);
+  }
   for (int p = 0; p < n_pairs; p++) {
     const PairState& st = ctx->h_states[p];
     std::memcpy(out_T + 16 * (size_t)p, st.out_T, sizeof(float) * 16);

@@ -425,81 +425,93 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_list(const PairDesc* __restri
   const int T = Pp->T;
   __shared__ IdxT s_list[ASSOC_THREADS * ASSOC_STRIDE];
   IdxT* list = s_list + threadIdx.x * ASSOC_STRIDE;
-  if (r_sorted >= N) return;
-  const int* yorder = D->yorder;
-  const int rbw = D->rbw;
-  const unsigned* rb = D->rowbits + (size_t)r_sorted * rbw;
-  // pass 1: how many candidates does the row have?
-  int ncand = 0;
-  for (int w0 = 0; w0 < rbw; w0 += 4) {  // rbw is a multiple of 4 (one 16-byte load covers 128 slices)
-    const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
-    if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
-    const unsigned bw[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
+  if (r_sorted < N) {
+    const int* yorder = D->yorder;
+    const int rbw = D->rbw;
+    const unsigned* rb = D->rowbits + (size_t)r_sorted * rbw;
+    // pass 1: how many candidates does the row have?
+    int ncand = 0;
+    for (int w0 = 0; w0 < rbw; w0 += 4) {  // rbw is a multiple of 4 (one 16-byte load covers 128 slices)
+      const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
+      if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
+      const unsigned bw[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      unsigned f = bw[q];
-      while (f) {
-        const int sl = (w0 + q) * 32 + __builtin_ctz(f);
-        f &= f - 1;
-        const unsigned long long* mw = D->masks + ((size_t)sl * N + r_sorted) * T;
-        for (int t = 0; t < T; t++) ncand += __builtin_popcountll(mw[t]);
-      }
-    }
-  }
-  D->cand_cnt[r_sorted] = ncand;
-  if (ncand > ASSOC_CAP) {
-    // more candidates than a list holds (dense regime, e.g. rows sitting on K_max): k_assoc_dense
-    // evaluates these rows against all targets, 64 at a time
-    const int slot = atomicAdd(D->ovf_count, 1);
-    D->ovf_rows[slot] = r_sorted;
-    return;
-  }
-  // pass 2: sorted-space positions of the candidates (the mask words come from L1/L2 this time)
-  int cnt = 0;
-  for (int w0 = 0; w0 < rbw; w0 += 4) {
-    const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
-    if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
-    const unsigned bw[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      unsigned f = bw[q];
-      while (f) {
-        const int sl = (w0 + q) * 32 + __builtin_ctz(f);
-        f &= f - 1;
-        const unsigned long long* mw = D->masks + ((size_t)sl * N + r_sorted) * T;
-        for (int t = 0; t < T; t++) {
-          unsigned long long m = mw[t];
-          const int chunk = sl * T + t;
-          while (m) {
-            const int b = __builtin_ctzll(m);
-            m &= m - 1;
-            list[cnt++] = (IdxT)(chunk * 64 + b);
-          }
+      for (int q = 0; q < 4; q++) {
+        unsigned f = bw[q];
+        while (f) {
+          const int sl = (w0 + q) * 32 + __builtin_ctz(f);
+          f &= f - 1;
+          const unsigned long long* mw = D->masks + ((size_t)sl * N + r_sorted) * T;
+          for (int t = 0; t < T; t++) ncand += __builtin_popcountll(mw[t]);
         }
       }
     }
-  }
-  // original indices: independent gathers, four in flight
-  for (int k0 = 0; k0 < cnt; k0 += 4) {
-    int jj[4];
+    D->cand_cnt[r_sorted] = ncand;
+    if (ncand > ASSOC_CAP) {
+      // more candidates than a list holds (dense regime, e.g. rows sitting on K_max): k_assoc_dense
+      // evaluates these rows against all targets, 64 at a time
+      const int slot = atomicAdd(D->ovf_count, 1);
+      D->ovf_rows[slot] = r_sorted;
+    } else {
+      // pass 2: sorted-space positions of the candidates (the mask words come from L1/L2 this time)
+      int cnt = 0;
+      for (int w0 = 0; w0 < rbw; w0 += 4) {
+        const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
+        if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
+        const unsigned bw[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
 #pragma unroll
-    for (int u = 0; u < 4; u++) jj[u] = yorder[(int)list[min(k0 + u, cnt - 1)]];
+        for (int q = 0; q < 4; q++) {
+          unsigned f = bw[q];
+          while (f) {
+            const int sl = (w0 + q) * 32 + __builtin_ctz(f);
+            f &= f - 1;
+            const unsigned long long* mw = D->masks + ((size_t)sl * N + r_sorted) * T;
+            for (int t = 0; t < T; t++) {
+              unsigned long long m = mw[t];
+              const int chunk = sl * T + t;
+              while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                list[cnt++] = (IdxT)(chunk * 64 + b);
+              }
+            }
+          }
+        }
+      }
+      // original indices: independent gathers, four in flight
+      for (int k0 = 0; k0 < cnt; k0 += 4) {
+        int jj[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (k0 + u < cnt) list[k0 + u] = (IdxT)jj[u];
-  }
-  // ascending original j (the order of the reference's first-K truncation and float accumulation)
-  for (int k = 1; k < cnt; k++) {
-    const int j = (int)list[k];
-    int q = k;
-    while (q > 0 && (int)list[q - 1] > j) {
-      list[q] = list[q - 1];
-      q--;
+        for (int u = 0; u < 4; u++) jj[u] = yorder[(int)list[min(k0 + u, cnt - 1)]];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (k0 + u < cnt) list[k0 + u] = (IdxT)jj[u];
+      }
+      // ascending original j (the order of the reference's first-K truncation and float accumulation)
+      for (int k = 1; k < cnt; k++) {
+        const int j = (int)list[k];
+        int q = k;
+        while (q > 0 && (int)list[q - 1] > j) {
+          list[q] = list[q - 1];
+          q--;
+        }
+        list[q] = (IdxT)j;
+      }
+      IdxT* out = reinterpret_cast<IdxT*>(D->cand_j);
+      for (int k = 0; k < cnt; k++) out[(size_t)k * N + r_sorted] = list[k];
     }
-    list[q] = (IdxT)j;
   }
-  IdxT* out = reinterpret_cast<IdxT*>(D->cand_j);
-  for (int k = 0; k < cnt; k++) out[(size_t)k * N + r_sorted] = list[k];
+  // The block that finishes last validates the list: every block has read `rebuild` by then, and the
+  // kernels of the iteration (stream order) see rebuild == 0 <=> bitmap, lists and overflow list are current.
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int done = atomicAdd(D->gate, 1);
+    if (done == (int)gridDim.x - 1) {
+      *D->gate = 0;
+      D->st->rebuild = 0;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -508,10 +520,13 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_list(const PairDesc* __restri
 template <typename IdxT, int ASSOC_CAP, bool GENERAL>
 __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restrict__ descs,
                                                           const DevParams* __restrict__ Pp,
-                                                          const int* __restrict__ status) {
+                                                          const int* __restrict__ status, int lean) {
   if (status[blockIdx.y] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.y;
   const PairState* st = D->st;
+  // lean graph (no rebuild / dense kernels inside the iteration): a pair whose list has expired, or that has
+  // rows for k_assoc_dense, waits for the graph that can serve it (k_coeff and k_update skip it too)
+  if (lean && (st->rebuild || *D->ovf_count > 0)) return;
   const DevParams P = *Pp;
   const int N = D->N;
   const int r_sorted = blockIdx.x * ASSOC_THREADS + threadIdx.x;
@@ -700,10 +715,11 @@ __global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict_
 // k_coeff: normalised twist (compute_flow host half, CvoGPU.cu:824-835) + B,C,D,E partials.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
-                                               const int* __restrict__ status) {
+                                               const int* __restrict__ status, int lean) {
   if (status[blockIdx.y] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.y;
   PairState* st = D->st;
+  if (lean && (st->rebuild || *D->ovf_count > 0)) return;  // waiting, see k_assoc
   const DevParams P = *Pp;
   if (P.mode != 0) return;
   __shared__ double s_ov[6];
@@ -827,10 +843,27 @@ __global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ desc
 // ------------------------------------------------------------------------------------------
 template <bool INIT>
 __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
-                                               const int* __restrict__ status) {
+                                               const int* __restrict__ status, int flags) {
+  // flags: bit 0 = lean graph, bit 1 = the rebuild kernels run right after this iteration, bits 8.. = how many
+  // iterations the list has to survive without another rebuild opportunity (0 in the full graph)
   if (!INIT && status[blockIdx.x] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.x;
   PairState* const gst = D->st;
+  const bool lean = (flags & 1) != 0, trio_follows = INIT || (flags & 2) != 0;
+  const int horizon = flags >> 8;
+  if (!INIT && lean) {
+    const int ovf = *D->ovf_count;
+    if (gst->rebuild || ovf > 0) {  // waiting, see k_assoc; tell the host which graph this pair needs
+      if (threadIdx.x == 0) {
+        gst->n_stalls++;
+        if (ovf > 0) {
+          gst->want_full = 1;
+          *D->want_out = 1;
+        }
+      }
+      return;
+    }
+  }
   __shared__ double s_c[4];
   __shared__ unsigned long long s_n[4];
   // the scalar part of the state is staged through LDS: one coalesced burst in, one out, instead of
@@ -998,21 +1031,44 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
       const float ymax = D->ymax;
       const float slack = 1e-5f * (ymax + sqrtf(tn) + 1.f);  // rounding of the two transform evaluations
       const float moved = (sqrtf(dr) * ymax + sqrtf(dt)) * 1.001f + slack;
+      const float step_move = sqrtf(dr1) * ymax + sqrtf(dt1);  // bound on what this iteration alone moved
+      // the list is unusable for the coming iteration ...
       bool rebuild = INIT || P.mode != 0 || !(moved <= st->skin) || ell_next > st->ell_build ||
                      ell_next < P.rebuild_shrink * st->ell_build;
+      // ... or would expire before the next rebuild opportunity of the lean graph
+      if (trio_follows && horizon > 0 && !(moved + 1.25f * (float)horizon * step_move <= st->skin)) rebuild = true;
       if (rebuild) {
         for (int q = 0; q < 9; q++) st->Rb[q] = Ri[q];
         for (int q = 0; q < 3; q++) st->Tb[q] = Ti[q];
         st->ell_build = ell_next;
-        // a list only pays if it survives a few iterations: no skin while the pose still moves fast
-        const float step_move = sqrtf(dr1) * ymax + sqrtf(dt1);
-        float skin = P.skin_frac * radius;
-        if (!INIT && !(4.f * step_move < skin)) skin = 0.f;
-        if (P.mode != 0 || !P.use_geo || !(skin == skin)) skin = 0.f;
-        st->skin = skin;
+        // Skin: a longer-lived list costs (1 + s)^3 more candidates per iteration, a shorter-lived one more
+        // rebuilds; s ~ 1.5 sqrt(step / radius) balances the two for this kernel set.  The lean graph only has a
+        // rebuild opportunity every lean_U iterations, so it needs s >= ~1.3 lean_U step / radius; when that is
+        // too much (fast motion) or rows overflow their lists, ask the host for the full graph.
+        int want_full = 1;
+        float s = 0.f;
+        if (!INIT && P.mode == 0 && P.use_geo && radius > 0.f && P.skin_frac > 0.f) {
+          const float rel = step_move / radius;
+          s = P.skin_frac * fminf(fmaxf(1.5f * sqrtf(rel), 0.05f), 0.5f);
+          const float s_lean = fmaxf(s, 1.3f * (float)P.lean_U * rel);
+          if (s_lean <= 0.5f && *D->ovf_count == 0) {
+            s = s_lean;
+            want_full = 0;
+          } else if (!(s >= 2.f * rel)) {
+            s = 0.f;  // would not survive two iterations: plain scan every iteration
+          }
+        }
+        if (!(s == s)) s = 0.f;
+        st->skin = s * radius;
+        st->want_full = want_full;
+        *D->want_out = want_full;
         st->n_builds = INIT ? 1 : st->n_builds + 1;
+        st->rebuild = 1;  // cleared by k_list once bitmap and lists are current
+      } else if (st->want_full && *D->ovf_count == 0 &&
+                 moved + 1.3f * (float)P.lean_U * step_move <= st->skin) {
+        st->want_full = 0;  // the motion has slowed down enough for the lean graph
+        *D->want_out = 0;
       }
-      st->rebuild = rebuild ? 1 : 0;
     }
     for (int q = 0; q < 9; q++) st->Rinv[q] = Ri[q];
     for (int q = 0; q < 3; q++) st->Tinv[q] = Ti[q];
