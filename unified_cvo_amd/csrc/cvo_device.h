@@ -68,7 +68,9 @@ struct PairState {
   float Rb[9], Tb[3];
   float ell_build, skin;
   int rebuild, n_builds;
-  int want_full, n_stalls;  // host hint: this pair needs the graph with per-iteration rebuild / dense kernels
+  int want_full, n_stalls;
+  int epoch, pad_epoch;  // iterations completed through k_update (generation of k_iter's barriers)
+   // host hint: this pair needs the graph with per-iteration rebuild / dense kernels
   // A_sparsity_indicator_ell_update FIFOs (CvoGPU.cu:1167-1285): bookkeeping here, storage below
   int s_head, s_size, e_head, e_size;
   float s_sum, e_sum;
@@ -127,6 +129,8 @@ struct PairDesc {
   int* status_out;  // mirror of st->status for cheap host polling
   int* want_out;    // mirror of st->want_full
   int* gate;        // [1] blocks of k_list that finished the current rebuild (the last one validates the list)
+  int* bar;         // [1] k_iter: blocks that finished the association phase (monotonic)
+  int* done;        // [1] k_iter: blocks that finished the coefficient phase (monotonic)
 };
 
 constexpr int ROWS_PER_GROUP = 4;

@@ -37,7 +37,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, tile_count, ovf_rows, ovf_count, gate, cand_cnt, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, tile_count, ovf_rows, ovf_count, gate, bar, done, cand_cnt, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -113,7 +113,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   const int nchunks = Mpad / 64;
   const int rbw_max = (int)align_up((size_t)(nchunks + 31) / 32, 4);  // slice bits per row, enough for T = 1
   const int nba = (N + ASSOC_THREADS - 1) / ASSOC_THREADS;
-  const int nbc = (N + 255) / 256;
+  const int nbc = nba;  // the coefficient phase uses the association's row blocks
   const int NG = (N + ROWS_PER_GROUP - 1) / ROWS_PER_GROUP;
   const int NGpad = (int)align_up((size_t)NG, 64) + 64;
   PairLayout L{};
@@ -134,6 +134,8 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.ovf_rows = take(sizeof(int) * (size_t)N);
   L.ovf_count = take(sizeof(int));
   L.gate = take(sizeof(int));
+  L.bar = take(sizeof(int));
+  L.done = take(sizeof(int));
   L.cand_cnt = take(sizeof(int) * (size_t)N);
   L.cand_j = take((size_t)128 * (size_t)N);  // ASSOC_CAP16 x u16 == ASSOC_CAP32 x i32 == 128 bytes per row
   L.ell_a = take(sizeof(float) * (size_t)N * Kmax);
@@ -340,14 +342,16 @@ void launch_rebuild(cvo_ctx* c, const LaunchGeom& g) {
   launch_list(g.stream, g.idx16, dim3(g.nba, g.n_pairs), descs, c->d_params, st);
 }
 
-// One optimiser iteration over the current lists.  lean: no k_assoc_dense; `update_flags` see k_update.
-void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int update_flags) {
+// One optimiser iteration over the current lists: association, [overflow rows], coefficients + update (the last
+// block of k_coeff).  Lean: no k_assoc_dense, pairs with overflow rows or an expired list wait.  `flags` see
+// update_body.
+void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags) {
   const PairDesc* descs = c->d_descs + g.p0;
   const int* st = c->d_status + g.p0;
   launch_assoc(g.stream, g.idx16, g.general, dim3(g.nba, g.n_pairs), descs, c->d_params, st, lean ? 1 : 0);
   if (!lean) launch_dense(g.stream, g.general, g.n_pairs, descs, c->d_params, st);
-  hipLaunchKernelGGL(k_coeff, dim3(g.nbc, g.n_pairs), dim3(256), 0, g.stream, descs, c->d_params, st, lean ? 1 : 0);
-  hipLaunchKernelGGL(k_update<false>, dim3(g.n_pairs), dim3(64), 0, g.stream, descs, c->d_params, st, update_flags);
+  hipLaunchKernelGGL(k_coeff, dim3(g.nbc, g.n_pairs), dim3(ASSOC_THREADS), 0, g.stream, descs, c->d_params, st,
+                     flags | (lean ? 1 : 0));
 }
 
 // A chunk of U iterations.  Full: every iteration can rebuild its candidate list and serve overflow rows.
@@ -363,7 +367,7 @@ void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U)
   for (int u = 0; u < U; u++) {
     if (u % lean_U == 0) launch_rebuild(c, g);
     const bool last = (u % lean_U == lean_U - 1) || u == U - 1;
-    launch_core(c, g, true, 1 | (last ? 2 : 0) | (lean_U << 8));
+    launch_core(c, g, true, (last ? 2 : 0) | (lean_U << 8));
   }
 }
 
@@ -479,6 +483,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.status_out = ctx->d_status + p;
     D.want_out = ctx->d_status + ctx->cap_pairs + p;
     D.gate = (int*)(base + S->L.gate);
+    D.bar = (int*)(base + S->L.bar);
+    D.done = (int*)(base + S->L.done);
 
     PairState& st = ctx->h_states[p];
     std::memset(&st, 0, sizeof(st));
@@ -498,6 +504,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     HIP_TRY(ctx, hipMemsetAsync(D.tile_count, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.ovf_count, 0, sizeof(int), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.gate, 0, sizeof(int), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(D.bar, 0, sizeof(int), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(D.done, 0, sizeof(int), ctx->stream));
   }
   // the blocks of k_assoc beyond a smaller pair's N still write their (zero) partials, but the
   // partial arrays of pairs whose N is smaller than the batch maximum are fully covered by nblk.
@@ -542,7 +550,8 @@ int run_single_eval(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
   if (rc != CVO_OK) return rc;
   launch_init(ctx, S->geom);
   launch_rebuild(ctx, S->geom);
-  launch_core(ctx, S->geom, false, 2);  // mode 1: k_coeff is a no-op, k_update collects the sums
+  launch_core(ctx, S->geom, false, 2);  // mode 1: k_coeff is a no-op ...
+  hipLaunchKernelGGL(k_update<false>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_descs, ctx->d_params, ctx->d_status, 2);  // ... k_update collects the sums
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_states.data(), ctx->d_states, sizeof(PairState), hipMemcpyDeviceToHost,
                               ctx->stream));
@@ -939,6 +948,9 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   float ms = 0;
   HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+  for (int p = 0; p < n_pairs; p++)
+    if (ctx->h_status[0][p] == 3 || ctx->h_status[1][p] == 3)
+      return fail(ctx, CVO_E_HIP, "cvo_align_batch: device-side barrier timed out");
   if (getenv("CVO_VERBOSE")) {
     long builds = 0, stalls = 0, its = 0;
     for (int p = 0; p < n_pairs; p++) {

@@ -49,6 +49,23 @@ __device__ __forceinline__ float wave_max_f32(float v) {
   return v;
 }
 
+// Values exchanged between the blocks of one launch (k_iter): on this multi-die part the L2 of an XCD is not
+// coherent with the others inside a kernel, and agent-scope fences write back / invalidate whole caches.  Relaxed
+// agent-scope atomics carry the coherence bits on the instruction itself, which is all a handful of partial
+// sums needs.  COH = false: plain accesses (the producer is an earlier kernel).
+template <bool COH, typename T>
+__device__ __forceinline__ void st_x(T* p, T v) {
+  if (COH)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    *p = v;
+}
+template <bool COH, typename T>
+__device__ __forceinline__ T ld_x(const T* p) {
+  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+
 // ------------------------------------------------------------------------------------------
 // k_scan<T>: each wave owns T consecutive 64-target chunks (one "slice") and a range of rows.
 // Test per pair (conservative, DESIGN.md "Cull arithmetic"):
@@ -382,10 +399,10 @@ struct RowAcc {
 };
 
 // One accepted/rejected pair (i, j): CvoGPU.cu:528-589 + the flow terms of 758-782.
-template <bool GENERAL>
+template <bool GENERAL, bool CACHE>
 __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* __restrict__ D, const Pose& pose, int i,
                                            int r_sorted, int N, const RowData& r, const V3& pxe, int j, const float4 y0,
-                                           RowAcc& A) {
+                                           RowAcc& A, float4* cache) {
   float a;
   float4 yt;
   if (!eval_pair<GENERAL>(P, D, pose, i, r, j, y0, a, yt)) return;
@@ -515,19 +532,17 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_list(const PairDesc* __restri
 }
 
 // ------------------------------------------------------------------------------------------
-// k_assoc: ordered association + flow, one thread per (sorted) source row, over the cached candidate list.
+// Association phase: ordered association + flow, one thread per (sorted) source row, over the cached
+// candidate list.  Shared by k_assoc and the fused k_iter.
 // ------------------------------------------------------------------------------------------
-template <typename IdxT, int ASSOC_CAP, bool GENERAL>
-__global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restrict__ descs,
-                                                          const DevParams* __restrict__ Pp,
-                                                          const int* __restrict__ status, int lean) {
-  if (status[blockIdx.y] != 0) return;
-  const PairDesc* __restrict__ D = descs + blockIdx.y;
-  const PairState* st = D->st;
-  // lean graph (no rebuild / dense kernels inside the iteration): a pair whose list has expired, or that has
-  // rows for k_assoc_dense, waits for the graph that can serve it (k_coeff and k_update skip it too)
-  if (lean && (st->rebuild || *D->ovf_count > 0)) return;
-  const DevParams P = *Pp;
+struct AssocShared {
+  double red[ASSOC_THREADS / 64][8];
+  unsigned long long cnt[ASSOC_THREADS / 64][4];
+};
+
+template <typename IdxT, int ASSOC_CAP, bool GENERAL, bool CACHE>
+__device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* __restrict__ D, const PairState* st,
+                                            AssocShared& S, float4* cache, unsigned& nnz_out) {
   const int N = D->N;
   const int r_sorted = blockIdx.x * ASSOC_THREADS + threadIdx.x;
   const int K = st->K;
@@ -556,17 +571,16 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
         j1 = j2;
         if (k + 1 < cnt) y1 = D->y4[j1];
         if (k + 2 < cnt) j2 = (int)cj[(size_t)(k + 2) * N];
-        visit_pair<GENERAL>(P, D, pose, i, r_sorted, N, r, pxe, j, ycur, A);
+        visit_pair<GENERAL, CACHE>(P, D, pose, i, r_sorted, N, r, pxe, j, ycur, A, cache);
       }
       D->nnz_row[r_sorted] = A.nnz;
     }
   }
+  nnz_out = overflowed ? 0u : A.nnz;
   // per-row (omega_i / c, v_i / d) cast to double, then reduced in double (CvoGPU.cu:784-787, 824-825)
   double red[7] = {(double)(A.o0 / P.c), (double)(A.o1 / P.c), (double)(A.o2 / P.c), (double)(A.v0 / P.d),
                    (double)(A.v1 / P.d), (double)(A.v2 / P.d), A.asum};
   constexpr int NW = ASSOC_THREADS / 64;
-  __shared__ double s_red[NW][8];
-  __shared__ unsigned long long s_cnt[NW][4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int c = 0; c < 7; c++) red[c] = wave_sum(red[c]);
@@ -576,34 +590,50 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
   const unsigned long long nov = wave_sum_u64(overflowed);
   if (lane == 0) {
 #pragma unroll
-    for (int c = 0; c < 7; c++) s_red[wave][c] = red[c];
-    s_cnt[wave][0] = nn;
-    s_cnt[wave][1] = mx;
-    s_cnt[wave][2] = nc;
-    s_cnt[wave][3] = nov;
+    for (int c = 0; c < 7; c++) S.red[wave][c] = red[c];
+    S.cnt[wave][0] = nn;
+    S.cnt[wave][1] = mx;
+    S.cnt[wave][2] = nc;
+    S.cnt[wave][3] = nov;
   }
   __syncthreads();
   if (threadIdx.x < 7) {
     const int c = threadIdx.x;
-    double t = s_red[0][c];
+    double t = S.red[0][c];
 #pragma unroll
-    for (int w = 1; w < NW; w++) t += s_red[w][c];
-    D->flow_part[(size_t)blockIdx.x * 8 + c] = t;
+    for (int w = 1; w < NW; w++) t += S.red[w][c];
+    st_x<CACHE>(D->flow_part + (size_t)blockIdx.x * 8 + c, t);
   } else if (threadIdx.x == 8) {
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
     for (int w = 0; w < NW; w++) {
-      a0 += s_cnt[w][0];
-      a1 = max(a1, s_cnt[w][1]);
-      a2 += s_cnt[w][2];
-      a3 += s_cnt[w][3];
+      a0 += S.cnt[w][0];
+      a1 = max(a1, S.cnt[w][1]);
+      a2 += S.cnt[w][2];
+      a3 += S.cnt[w][3];
     }
     unsigned long long* cp = D->cnt_part + (size_t)blockIdx.x * 4;
-    cp[0] = a0;
-    cp[1] = a1;
-    cp[2] = a2;
-    cp[3] = a3;
+    st_x<CACHE>(cp + 0, a0);
+    st_x<CACHE>(cp + 1, a1);
+    st_x<CACHE>(cp + 2, a2);
+    st_x<CACHE>(cp + 3, a3);
   }
+}
+
+template <typename IdxT, int ASSOC_CAP, bool GENERAL>
+__global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restrict__ descs,
+                                                          const DevParams* __restrict__ Pp,
+                                                          const int* __restrict__ status, int lean) {
+  if (status[blockIdx.y] != 0) return;
+  const PairDesc* __restrict__ D = descs + blockIdx.y;
+  // lean graph (no rebuild / dense kernels inside the iteration): a pair whose list has expired, or that has
+  // rows for k_assoc_dense, does not advance; it waits for the next rebuild opportunity / for the host to
+  // switch its group to the full graph (k_coeff skips it too and tells the host)
+  if (lean && (D->st->rebuild || *D->ovf_count > 0)) return;
+  const DevParams P = *Pp;
+  __shared__ AssocShared S;
+  unsigned nnz;
+  assoc_phase<IdxT, ASSOC_CAP, GENERAL, false>(P, D, D->st, S, nullptr, nnz);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -712,76 +742,106 @@ __global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// k_coeff: normalised twist (compute_flow host half, CvoGPU.cu:824-835) + B,C,D,E partials.
+// Coefficient phase: normalised twist (compute_flow host half, CvoGPU.cu:824-835) + B,C,D,E partials, one
+// thread per (sorted) row, blocks of ASSOC_THREADS rows.  Shared by k_coeff and the fused k_iter.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
-                                               const int* __restrict__ status, int lean) {
-  if (status[blockIdx.y] != 0) return;
-  const PairDesc* __restrict__ D = descs + blockIdx.y;
-  PairState* st = D->st;
-  if (lean && (st->rebuild || *D->ovf_count > 0)) return;  // waiting, see k_assoc
-  const DevParams P = *Pp;
-  if (P.mode != 0) return;
-  __shared__ double s_ov[6];
-  __shared__ XiMats s_M;
-  __shared__ double s_red[4][4];
-  // thrust::reduce of omega_gpu / v_gpu (CvoGPU.cu:824-825) from k_assoc's block partials: thread t owns
-  // component (t & 7) of blocks t>>3, t>>3 + 32, ... (all loads in flight), then a fixed-order finish.
-  __shared__ double s_part[32][8];
+struct CoeffShared {
+  double ov[6];
+  XiMats M;
+  double red[ASSOC_THREADS / 64][4];
+  double part[ASSOC_THREADS / 8][8];
+};
+
+// thrust::reduce of omega_gpu / v_gpu (CvoGPU.cu:824-825) from the association block partials: thread t owns
+// component (t & 7) of blocks t>>3, t>>3 + 16, ... (all loads in flight), then a fixed-order finish.
+template <bool COH>
+__device__ __forceinline__ void coeff_twist(const PairDesc* __restrict__ D, CoeffShared& S, int nparts) {
+  constexpr int NGRP = ASSOC_THREADS / 8;
   {
-    const int nblk = D->nblk_assoc + DENSE_BLOCKS;
     const int c = threadIdx.x & 7;
     double acc = 0;
-    for (int b = threadIdx.x >> 3; b < nblk; b += 32) acc += D->flow_part[(size_t)b * 8 + c];
-    s_part[threadIdx.x >> 3][c] = acc;
+    for (int b = threadIdx.x >> 3; b < nparts; b += NGRP) acc += ld_x<COH>(D->flow_part + (size_t)b * 8 + c);
+    S.part[threadIdx.x >> 3][c] = acc;
   }
   __syncthreads();
   if (threadIdx.x < 6) {
     double t = 0;
 #pragma unroll 8
-    for (int g = 0; g < 32; g++) t += s_part[g][threadIdx.x];
-    s_ov[threadIdx.x] = t;
+    for (int g = 0; g < NGRP; g++) t += S.part[g][threadIdx.x];
+    S.ov[threadIdx.x] = t;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     float ov[6];
-    for (int c = 0; c < 6; c++) ov[c] = (float)s_ov[c];
+    for (int c = 0; c < 6; c++) ov[c] = (float)S.ov[c];
     float z = 0;  // Eigen normalize(): z = squaredNorm(); if (z > 0) *this /= sqrt(z)
     for (int c = 0; c < 6; c++) z = z + ov[c] * ov[c];
     if (z > 0) {
-      const float s = sqrtf(z);
-      for (int c = 0; c < 6; c++) ov[c] = ov[c] / s;
+      const float sq = sqrtf(z);
+      for (int c = 0; c < 6; c++) ov[c] = ov[c] / sq;
     }
-    xi_mats(ov, ov + 3, s_M);
-    if (blockIdx.x == 0) {
-      for (int c = 0; c < 3; c++) {
-        st->omega[c] = ov[c];
-        st->v[c] = ov[3 + c];
-      }
-    }
+    xi_mats(ov, ov + 3, S.M);
   }
   __syncthreads();
+}
+
+// one nonzero (i, j): compute_step_size_xi for target j (CvoGPU.cu:974-986) + compute_step_size_poly_coeff
+// (CvoGPU.cu:1053-1078); yy is the transformed target
+__device__ __forceinline__ void coeff_entry(const XiMats& M, const float4 x, float temp_coef, const V3 yy, float A_ij,
+                                            double& Bi, double& Ci, double& Di, double& Ei) {
+  const V3 w{M.omega[0], M.omega[1], M.omega[2]};
+  const V3 c = cross_dev(w, yy);
+  const V3 xiz{c.x + M.v[0], c.y + M.v[1], c.z + M.v[2]};
+  V3 t = matvec_dev(M.m2, yy);
+  const V3 xi2z{t.x + M.ohv.x, t.y + M.ohv.y, t.z + M.ohv.z};
+  t = matvec_dev(M.m3, yy);
+  const V3 xi3z{t.x + M.m2v.x, t.y + M.m2v.y, t.z + M.m2v.z};
+  t = matvec_dev(M.m4, yy);
+  const V3 xi4z{t.x + M.m3v.x, t.y + M.m3v.y, t.z + M.m3v.z};
+  const float normxiz2 = dot3_dev(xiz.x, xiz.y, xiz.z, xiz.x, xiz.y, xiz.z);
+  const float xiz_dot_xi2z = -dot3_dev(xiz.x, xiz.y, xiz.z, xi2z.x, xi2z.y, xi2z.z);
+  const float epsil_const = __builtin_fmaf(2.0f, dot3_dev(xiz.x, xiz.y, xiz.z, xi3z.x, xi3z.y, xi3z.z),
+                                           dot3_dev(xi2z.x, xi2z.y, xi2z.z, xi2z.x, xi2z.y, xi2z.z));
+  const float dfx = x.x - yy.x, dfy = x.y - yy.y, dfz = x.z - yy.z;
+  const float beta_ij = (float)(-2.0 * temp_coef * (double)dot3_dev(xiz.x, xiz.y, xiz.z, dfx, dfy, dfz));
+  const float gamma_ij =
+      (-temp_coef) * (normxiz2 + dot3_dev(2.0f * xi2z.x, 2.0f * xi2z.y, 2.0f * xi2z.z, dfx, dfy, dfz));
+  const float delta_ij =
+      (float)(2.0 * temp_coef * (double)(xiz_dot_xi2z + dot3_dev(-xi3z.x, -xi3z.y, -xi3z.z, dfx, dfy, dfz)));
+  const float epsil_ij =
+      (-temp_coef) * (epsil_const + dot3_dev(2.0f * xi4z.x, 2.0f * xi4z.y, 2.0f * xi4z.z, dfx, dfy, dfz));
+  Bi += (double)(A_ij * beta_ij);
+  Ci += (double)A_ij * ((double)gamma_ij + (double)(beta_ij * beta_ij) / 2.0);
+  Di += (double)A_ij * ((double)__builtin_fmaf(beta_ij, gamma_ij, delta_ij) +
+                        (double)(beta_ij * beta_ij * beta_ij) / 6.0);
+  Ei += (double)A_ij * ((double)__builtin_fmaf(beta_ij, delta_ij, epsil_ij) +
+                        1 / 2.0 * beta_ij * beta_ij * gamma_ij + 1 / 2.0 * gamma_ij * gamma_ij +
+                        1 / 24.0 * beta_ij * beta_ij * beta_ij * beta_ij);
+}
+
+// Rows of this block.  COH: the block partial is read by another block of the same launch.
+template <bool COH>
+__device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* __restrict__ D, const PairState* st,
+                                           CoeffShared& S) {
   const int N = D->N;
-  const int i = blockIdx.x * 256 + threadIdx.x;  // sorted row
+  const int i = blockIdx.x * ASSOC_THREADS + threadIdx.x;  // sorted row
   double Bi = 0, Ci = 0, Di = 0, Ei = 0;
   if (i < N) {
     const unsigned nnz = D->nnz_row[i];
     if (nnz) {
       const float4 x = D->xs4[i];
-      const Pose pose = load_pose(st);
       float temp_ell = st->ell;
       if (P.use_range_ell) {
         const float d2_sqrt = sqrtf(dot3_dev(x.x, x.y, x.z, x.x, x.y, x.z));
         temp_ell = compute_range_ell(temp_ell, d2_sqrt);
       }
       const float temp_coef = (float)(1 / (2.0 * temp_ell * temp_ell));
-      const V3 w{s_M.omega[0], s_M.omega[1], s_M.omega[2]};
+      const Pose pose = load_pose(st);
       // software pipeline: entry s+1's index / value / target are in flight while entry s is evaluated
       int idx_n = D->ell_j[i];
       float a_n = D->ell_a[i];
       float4 y_n = D->y4[idx_n];
       for (unsigned s = 0; s < nnz; s++) {
-        const int idx = idx_n;
         const float A_ij = a_n;
         const float4 y0 = y_n;
         if (s + 1 < nnz) {
@@ -789,51 +849,25 @@ __global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ desc
           a_n = D->ell_a[(size_t)(s + 1) * N + i];
           y_n = D->y4[idx_n];
         }
-        (void)idx;
         const V3 yy = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
-        const float4 y = make_float4(yy.x, yy.y, yy.z, 0.f);
-        // compute_step_size_xi for target idx (CvoGPU.cu:974-986)
-        const V3 c = cross_dev(w, yy);
-        const V3 xiz{c.x + s_M.v[0], c.y + s_M.v[1], c.z + s_M.v[2]};
-        V3 t = matvec_dev(s_M.m2, yy);
-        const V3 xi2z{t.x + s_M.ohv.x, t.y + s_M.ohv.y, t.z + s_M.ohv.z};
-        t = matvec_dev(s_M.m3, yy);
-        const V3 xi3z{t.x + s_M.m2v.x, t.y + s_M.m2v.y, t.z + s_M.m2v.z};
-        t = matvec_dev(s_M.m4, yy);
-        const V3 xi4z{t.x + s_M.m3v.x, t.y + s_M.m3v.y, t.z + s_M.m3v.z};
-        const float normxiz2 = dot3_dev(xiz.x, xiz.y, xiz.z, xiz.x, xiz.y, xiz.z);
-        const float xiz_dot_xi2z = -dot3_dev(xiz.x, xiz.y, xiz.z, xi2z.x, xi2z.y, xi2z.z);
-        const float epsil_const = __builtin_fmaf(2.0f, dot3_dev(xiz.x, xiz.y, xiz.z, xi3z.x, xi3z.y, xi3z.z),
-                                                 dot3_dev(xi2z.x, xi2z.y, xi2z.z, xi2z.x, xi2z.y, xi2z.z));
-        // compute_step_size_poly_coeff (CvoGPU.cu:1053-1078)
-        const float dfx = x.x - y.x, dfy = x.y - y.y, dfz = x.z - y.z;
-        const float beta_ij = (float)(-2.0 * temp_coef * (double)dot3_dev(xiz.x, xiz.y, xiz.z, dfx, dfy, dfz));
-        const float gamma_ij =
-            (-temp_coef) * (normxiz2 + dot3_dev(2.0f * xi2z.x, 2.0f * xi2z.y, 2.0f * xi2z.z, dfx, dfy, dfz));
-        const float delta_ij =
-            (float)(2.0 * temp_coef * (double)(xiz_dot_xi2z + dot3_dev(-xi3z.x, -xi3z.y, -xi3z.z, dfx, dfy, dfz)));
-        const float epsil_ij =
-            (-temp_coef) * (epsil_const + dot3_dev(2.0f * xi4z.x, 2.0f * xi4z.y, 2.0f * xi4z.z, dfx, dfy, dfz));
-        Bi += (double)(A_ij * beta_ij);
-        Ci += (double)A_ij * ((double)gamma_ij + (double)(beta_ij * beta_ij) / 2.0);
-        Di += (double)A_ij * ((double)__builtin_fmaf(beta_ij, gamma_ij, delta_ij) +
-                              (double)(beta_ij * beta_ij * beta_ij) / 6.0);
-        Ei += (double)A_ij * ((double)__builtin_fmaf(beta_ij, delta_ij, epsil_ij) +
-                              1 / 2.0 * beta_ij * beta_ij * gamma_ij + 1 / 2.0 * gamma_ij * gamma_ij +
-                              1 / 24.0 * beta_ij * beta_ij * beta_ij * beta_ij);
+        coeff_entry(S.M, x, temp_coef, yy, A_ij, Bi, Ci, Di, Ei);
       }
     }
   }
   double red[4] = {Bi, Ci, Di, Ei};
+  constexpr int NW = ASSOC_THREADS / 64;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int c = 0; c < 4; c++) red[c] = wave_sum(red[c]);
   if (lane == 0)
-    for (int c = 0; c < 4; c++) s_red[wave][c] = red[c];
+    for (int c = 0; c < 4; c++) S.red[wave][c] = red[c];
   __syncthreads();
   if (threadIdx.x < 4) {
     const int c = threadIdx.x;
-    D->coef_part[(size_t)blockIdx.x * 4 + c] = ((s_red[0][c] + s_red[1][c]) + s_red[2][c]) + s_red[3][c];
+    double t = S.red[0][c];
+#pragma unroll
+    for (int w = 1; w < NW; w++) t += S.red[w][c];
+    st_x<COH>(D->coef_part + (size_t)blockIdx.x * 4 + c, t);
   }
 }
 
@@ -841,56 +875,51 @@ __global__ __launch_bounds__(256) void k_coeff(const PairDesc* __restrict__ desc
 // k_update: per-pair scalar bookkeeping, one wave per pair.  INIT = true is the launch before the first
 // iteration (no bookkeeping, state comes from the host).
 // ------------------------------------------------------------------------------------------
-template <bool INIT>
-__global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
-                                               const int* __restrict__ status, int flags) {
-  // flags: bit 0 = lean graph, bit 1 = the rebuild kernels run right after this iteration, bits 8.. = how many
-  // iterations the list has to survive without another rebuild opportunity (0 in the full graph)
-  if (!INIT && status[blockIdx.x] != 0) return;
-  const PairDesc* __restrict__ D = descs + blockIdx.x;
+struct UpdateShared {
+  double c[4];
+  unsigned long long n[4];
+  unsigned hot[offsetof(PairState, sq) / 4];  // the scalar part of the state (the 4 KB of indicator FIFOs stay in HBM)
+};
+
+// Executed by the first wave of the calling block (the other threads only take part in the barriers).
+// flags: bit 1 = the rebuild kernels run right after this iteration, bit 2 = called from k_iter, bits 8.. = how many
+// iterations the list has to survive without another rebuild opportunity (0 in the full graph).  n_flow_parts: association partials to
+// sum (the lean graph has no k_assoc_dense, so its slots are not read).
+template <bool INIT, bool COH>
+__device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, const DevParams& P, int flags,
+                                            int n_flow_parts, UpdateShared& U, const float* twist) {
   PairState* const gst = D->st;
-  const bool lean = (flags & 1) != 0, trio_follows = INIT || (flags & 2) != 0;
+  const bool trio_follows = INIT || (flags & 2) != 0;
   const int horizon = flags >> 8;
-  if (!INIT && lean) {
-    const int ovf = *D->ovf_count;
-    if (gst->rebuild || ovf > 0) {  // waiting, see k_assoc; tell the host which graph this pair needs
-      if (threadIdx.x == 0) {
-        gst->n_stalls++;
-        if (ovf > 0) {
-          gst->want_full = 1;
-          *D->want_out = 1;
-        }
-      }
-      return;
-    }
-  }
-  __shared__ double s_c[4];
-  __shared__ unsigned long long s_n[4];
+  double* const s_c = U.c;
+  unsigned long long* const s_n = U.n;
+  unsigned* const s_hot = U.hot;
+  constexpr int HOT_DWORDS = (int)(offsetof(PairState, sq) / 4);
+  const int tid = threadIdx.x;
+  const bool act = tid < 64;
+
   // the scalar part of the state is staged through LDS: one coalesced burst in, one out, instead of
   // dozens of dependent global accesses from a single lane
-  constexpr int HOT_DWORDS = (int)(offsetof(PairState, sq) / 4);  // the 4 KB of indicator FIFOs stay in HBM
-  __shared__ unsigned s_hot[HOT_DWORDS];
-  const DevParams P = *Pp;
-  const int tid = threadIdx.x;
-  for (int q = tid; q < HOT_DWORDS; q += 64) s_hot[q] = reinterpret_cast<const unsigned*>(gst)[q];
+  if (act)
+    for (int q = tid; q < HOT_DWORDS; q += 64) s_hot[q] = reinterpret_cast<const unsigned*>(gst)[q];
   PairState* const st = reinterpret_cast<PairState*>(s_hot);
   float* const sq = gst->sq;
   float* const eq = gst->eq;
-  if (!INIT) {
+  if (!INIT && act) {
     // The four thrust::reduce of compute_step_size (CvoGPU.cu:1118-1121) and the nonzero / max counts
     // (SparseKernelMat.cu:37-46, CvoGPU.cu:1518): lane l owns component (l & 3) of blocks l>>2, l>>2 + 16, ...
     // so all loads are in flight at once; a fixed xor-shuffle tree finishes (deterministic order).
-    const int nba = D->nblk_assoc + DENSE_BLOCKS, nbc = D->nblk_coeff;
+    const int nba = n_flow_parts, nbc = D->nblk_coeff;
     const int c = tid & 3;
     double s = 0;
     if (P.mode == 0) {
-      for (int b = tid >> 2; b < nbc; b += 16) s += D->coef_part[(size_t)b * 4 + c];
+      for (int b = tid >> 2; b < nbc; b += 16) s += ld_x<COH>(D->coef_part + (size_t)b * 4 + c);
     } else if (c == 0) {
-      for (int b = tid >> 2; b < nba; b += 16) s += D->flow_part[(size_t)b * 8 + 6];
+      for (int b = tid >> 2; b < nba; b += 16) s += ld_x<COH>(D->flow_part + (size_t)b * 8 + 6);
     }
     unsigned long long q = 0;
     for (int b = tid >> 2; b < nba; b += 16) {
-      const unsigned long long v = D->cnt_part[(size_t)b * 4 + c];
+      const unsigned long long v = ld_x<COH>(D->cnt_part + (size_t)b * 4 + c);
       q = (c == 1) ? max(q, v) : q + v;
     }
 #pragma unroll
@@ -907,7 +936,14 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
   __syncthreads();
   if (tid == 0) {
     int done = 0;
+    if (twist) {  // k_iter: every block derived the same normalised twist
+      for (int c = 0; c < 3; c++) {
+        st->omega[c] = twist[c];
+        st->v[c] = twist[3 + c];
+      }
+    }
     if (!INIT) {
+      if (flags & 4) st->epoch++;  // barrier generation of k_iter
       const unsigned nnz = (unsigned)s_n[0], max_nnz = (unsigned)s_n[1];
       st->nnz = nnz;
       st->max_nnz = max_nnz;
@@ -1084,7 +1120,68 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
     }
   }
   __syncthreads();
-  for (int q = tid; q < HOT_DWORDS; q += 64) reinterpret_cast<unsigned*>(gst)[q] = s_hot[q];
+  if (act)
+    for (int q = tid; q < HOT_DWORDS; q += 64) reinterpret_cast<unsigned*>(gst)[q] = s_hot[q];
+}
+
+template <bool INIT>
+__global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
+                                               const int* __restrict__ status, int flags) {
+  if (!INIT && status[blockIdx.x] != 0) return;
+  const PairDesc* __restrict__ D = descs + blockIdx.x;
+  const DevParams P = *Pp;
+  __shared__ UpdateShared U;
+  update_body<INIT, false>(D, P, flags, D->nblk_assoc + DENSE_BLOCKS, U, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_coeff: coefficient phase + (align loop) the update.  The block of a pair that finishes last runs update_body:
+// one launch less on the critical path of every iteration, and no block ever waits for another one.  Partials
+// cross blocks inside the launch, hence the coherent stores / loads (st_x / ld_x).
+// flags: bit 0 = lean graph, the rest see update_body.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restrict__ descs,
+                                                         const DevParams* __restrict__ Pp,
+                                                         const int* __restrict__ status, int flags) {
+  if (status[blockIdx.y] != 0) return;
+  const PairDesc* __restrict__ D = descs + blockIdx.y;
+  PairState* const st = D->st;
+  if (flags & 1) {
+    const int ovf = *D->ovf_count;
+    if (st->rebuild || ovf > 0) {  // waiting, see k_assoc; tell the host which graph this pair needs
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->n_stalls++;
+        if (ovf > 0) {
+          st->want_full = 1;
+          *D->want_out = 1;
+        }
+      }
+      return;
+    }
+  }
+  const DevParams P = *Pp;
+  if (P.mode != 0) return;
+  const int epoch = st->epoch;  // launches of this kernel the pair has completed (bumped by the updating block)
+  __shared__ union {
+    CoeffShared c;
+    UpdateShared u;
+  } S;
+  __shared__ int s_last;
+  coeff_twist<false>(D, S.c, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS);
+  float twist[6];
+  for (int c = 0; c < 3; c++) {
+    twist[c] = S.c.M.omega[c];
+    twist[3 + c] = S.c.M.v[c];
+  }
+  coeff_rows<true>(P, D, st, S.c);
+  __syncthreads();  // (its release waits for this block's coherent partial stores)
+  if (threadIdx.x == 0) {
+    const int done = __hip_atomic_fetch_add(D->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = done == (epoch + 1) * (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  update_body<false, true>(D, P, flags | 4, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, S.u, twist);
 }
 
 // ------------------------------------------------------------------------------------------
