@@ -106,8 +106,12 @@ struct PairDesc {
   const int* yorder;
   float4* ycull;  // SORTED: {y~x, y~y, y~z, |y~|^2}, y~ = yt - centre; pads are {0,0,0,+inf}
   float4* xcull;  // SORTED: {-2x~x, -2x~y, -2x~z, thres_i + margin_i - |x~|^2}
-  int* cand_cnt;   // [N] candidates of each sorted row in the current bitmap
-  void* cand_j;    // [ASSOC_CAP][N] cached candidate lists (original target index, ascending), u16 or i32
+  // k_list orders the rows of every 256-row window by candidate count; POSITION = index in that order
+  int* cand_cnt;   // [N] candidates of the row at each position
+  int* rowperm;    // [N] position -> sorted row
+  float4* xp4;     // [N] source xyz of the row at each position
+  int* ip;         // [N] ORIGINAL index of the row at each position
+  void* cand_j;    // [ASSOC_CAP][N] cached candidate lists by position (original target index, ascending), u16 or i32
   float4* gbox;   // [NGpad][2]: AABB of each sorted row group, grown by the group's cut-off radius
   float4* cellbox;  // [NGpad/16][2]: AABB of each cell of 16 row groups (level 1 of the scan)
   float4* sbox;   // [nslices][2]: AABB of each scan slice (T chunks)
@@ -118,7 +122,7 @@ struct PairDesc {
   unsigned long long* tile_count;  // [1]: fine tiles executed so far this call (statistics)
   int* ovf_rows;   // [N]: sorted rows with more candidates than a list holds (handled by k_assoc_dense)
   int* ovf_count;  // [1]: how many; reset by k_prep when the bitmap is rebuilt
-  float* ell_a;               // ELL kernel matrix values, [K_max][N], SORTED row index
+  float* ell_a;               // ELL kernel matrix values, [K_max][N], indexed by POSITION
   int* ell_j;                 // ELL column indices (ORIGINAL j, ascending), [K_max][N]
   unsigned* nnz_row;          // nonzeros[N], SORTED row index
   double* flow_part;          // [nblk_assoc][8]: omega(3), v(3), sum a, pad

@@ -37,7 +37,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, tile_count, ovf_rows, ovf_count, gate, bar, done, cand_cnt, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, tile_count, ovf_rows, ovf_count, gate, bar, done, cand_cnt, rowperm, xp4, ip, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -137,6 +137,9 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.bar = take(sizeof(int));
   L.done = take(sizeof(int));
   L.cand_cnt = take(sizeof(int) * (size_t)N);
+  L.rowperm = take(sizeof(int) * (size_t)N);
+  L.xp4 = take(sizeof(float4) * (size_t)N);
+  L.ip = take(sizeof(int) * (size_t)N);
   L.cand_j = take((size_t)128 * (size_t)N);  // ASSOC_CAP16 x u16 == ASSOC_CAP32 x i32 == 128 bytes per row
   L.ell_a = take(sizeof(float) * (size_t)N * Kmax);
   L.ell_j = take(sizeof(int) * (size_t)N * Kmax);
@@ -291,27 +294,32 @@ void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const D
   }
 }
 
-void launch_list(hipStream_t s, bool idx16, dim3 grid, const PairDesc* descs, const DevParams* dp, const int* st) {
-  const dim3 blk(ASSOC_THREADS);
+// 1-D grid of the XCD-aware row-block kernels (see pair_block)
+inline dim3 row_grid(int nblk, int n_pairs) { return dim3((unsigned)(nblk * ((n_pairs + 7) / 8 * 8))); }
+
+void launch_list(hipStream_t s, bool idx16, int N, int n_pairs, const PairDesc* descs, const DevParams* dp,
+                 const int* st) {
+  const int nblk = (N + LIST_THREADS - 1) / LIST_THREADS;
+  const dim3 blk(LIST_THREADS), grid = row_grid(nblk, n_pairs);
   if (idx16)
-    hipLaunchKernelGGL((k_list<unsigned short, ASSOC_CAP16>), grid, blk, 0, s, descs, dp, st);
+    hipLaunchKernelGGL((k_list<unsigned short, ASSOC_CAP16>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
   else
-    hipLaunchKernelGGL((k_list<int, ASSOC_CAP32>), grid, blk, 0, s, descs, dp, st);
+    hipLaunchKernelGGL((k_list<int, ASSOC_CAP32>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
 }
 
-void launch_assoc(hipStream_t s, bool idx16, bool general, dim3 grid, const PairDesc* descs, const DevParams* dp,
-                  const int* st, int lean) {
-  const dim3 blk(ASSOC_THREADS);
+void launch_assoc(hipStream_t s, bool idx16, bool general, int nblk, int n_pairs, const PairDesc* descs,
+                  const DevParams* dp, const int* st, int lean) {
+  const dim3 blk(ASSOC_THREADS), grid = row_grid(nblk, n_pairs);
   if (idx16) {
     if (general)
-      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, true>), grid, blk, 0, s, descs, dp, st, lean);
+      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, true>), grid, blk, 0, s, descs, dp, st, lean, nblk, n_pairs);
     else
-      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, false>), grid, blk, 0, s, descs, dp, st, lean);
+      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, false>), grid, blk, 0, s, descs, dp, st, lean, nblk, n_pairs);
   } else {
     if (general)
-      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, true>), grid, blk, 0, s, descs, dp, st, lean);
+      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, true>), grid, blk, 0, s, descs, dp, st, lean, nblk, n_pairs);
     else
-      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, false>), grid, blk, 0, s, descs, dp, st, lean);
+      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, false>), grid, blk, 0, s, descs, dp, st, lean, nblk, n_pairs);
   }
 }
 
@@ -323,7 +331,7 @@ void launch_dense(hipStream_t s, bool general, int n_pairs, const PairDesc* desc
 }
 
 struct LaunchGeom {
-  int n_pairs, p0, T, gx, gy, nba, nbc, npb;
+  int n_pairs, p0, T, gx, gy, nba, nbc, npb, N;
   bool idx16, general;
   hipStream_t stream;
 };
@@ -339,7 +347,7 @@ void launch_rebuild(cvo_ctx* c, const LaunchGeom& g) {
   const int* st = c->d_status + g.p0;
   hipLaunchKernelGGL(k_prep, dim3(g.npb, g.n_pairs), dim3(PREP_THREADS), 0, g.stream, descs, c->d_params, st);
   launch_scan(g.stream, g.T, dim3(g.gx, g.gy, g.n_pairs), descs, c->d_params, st, 0);
-  launch_list(g.stream, g.idx16, dim3(g.nba, g.n_pairs), descs, c->d_params, st);
+  launch_list(g.stream, g.idx16, g.N, g.n_pairs, descs, c->d_params, st);
 }
 
 // One optimiser iteration over the current lists: association, [overflow rows], coefficients + update (the last
@@ -348,10 +356,10 @@ void launch_rebuild(cvo_ctx* c, const LaunchGeom& g) {
 void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags) {
   const PairDesc* descs = c->d_descs + g.p0;
   const int* st = c->d_status + g.p0;
-  launch_assoc(g.stream, g.idx16, g.general, dim3(g.nba, g.n_pairs), descs, c->d_params, st, lean ? 1 : 0);
+  launch_assoc(g.stream, g.idx16, g.general, g.nba, g.n_pairs, descs, c->d_params, st, lean ? 1 : 0);
   if (!lean) launch_dense(g.stream, g.general, g.n_pairs, descs, c->d_params, st);
-  hipLaunchKernelGGL(k_coeff, dim3(g.nbc, g.n_pairs), dim3(ASSOC_THREADS), 0, g.stream, descs, c->d_params, st,
-                     flags | (lean ? 1 : 0));
+  hipLaunchKernelGGL(k_coeff, row_grid(g.nba, g.n_pairs), dim3(ASSOC_THREADS), 0, g.stream, descs, c->d_params, st,
+                     flags | (lean ? 1 : 0), g.nba, g.n_pairs);
 }
 
 // A chunk of U iterations.  Full: every iteration can rebuild its candidate list and serve overflow rows.
@@ -471,6 +479,9 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.ovf_rows = (int*)(base + S->L.ovf_rows);
     D.ovf_count = (int*)(base + S->L.ovf_count);
     D.cand_cnt = (int*)(base + S->L.cand_cnt);
+    D.rowperm = (int*)(base + S->L.rowperm);
+    D.xp4 = (float4*)(base + S->L.xp4);
+    D.ip = (int*)(base + S->L.ip);
     D.cand_j = (void*)(base + S->L.cand_j);
     D.ell_a = (float*)(base + S->L.ell_a);
     D.ell_j = (int*)(base + S->L.ell_j);
@@ -524,6 +535,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.gx = S->gx;
   S->geom.gy = S->gy;
   S->geom.nba = S->d.nblk_assoc;
+  S->geom.N = N;
   S->geom.nbc = S->d.nblk_coeff;
   S->geom.npb = S->d.Mpad / PREP_THREADS + (S->d.NGpad * ROWS_PER_GROUP + PREP_THREADS - 1) / PREP_THREADS;
   S->geom.idx16 = M < 65536;
@@ -1058,19 +1070,34 @@ int cvo_function_angle(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud
   return CVO_OK;
 }
 
+// The per-row outputs of the last evaluation, re-indexed from k_list's positions to SORTED rows.
 static int fetch_ell(cvo_ctx* ctx, int pair, std::vector<unsigned>& nz, std::vector<float>& a, std::vector<int>& j,
                      unsigned* max_out) {
   const PairDesc& D = ctx->h_descs[pair];
   const int N = D.N;
-  nz.resize(N);
-  HIP_TRY(ctx, hipMemcpy(nz.data(), D.nnz_row, sizeof(unsigned) * (size_t)N, hipMemcpyDeviceToHost));
+  std::vector<unsigned> nzp(N);
+  std::vector<int> perm(N);
+  HIP_TRY(ctx, hipMemcpy(nzp.data(), D.nnz_row, sizeof(unsigned) * (size_t)N, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(perm.data(), D.rowperm, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
   unsigned mx = 0;
-  for (int i = 0; i < N; i++) mx = std::max(mx, nz[i]);
-  a.resize((size_t)mx * N);
-  j.resize((size_t)mx * N);
+  for (int i = 0; i < N; i++) mx = std::max(mx, nzp[i]);
+  std::vector<float> ap((size_t)mx * N);
+  std::vector<int> jp((size_t)mx * N);
   if (mx) {
-    HIP_TRY(ctx, hipMemcpy(a.data(), D.ell_a, sizeof(float) * (size_t)mx * N, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(j.data(), D.ell_j, sizeof(int) * (size_t)mx * N, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(ap.data(), D.ell_a, sizeof(float) * (size_t)mx * N, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(jp.data(), D.ell_j, sizeof(int) * (size_t)mx * N, hipMemcpyDeviceToHost));
+  }
+  nz.assign(N, 0);
+  a.assign((size_t)mx * N, 0.f);
+  j.assign((size_t)mx * N, -1);
+  for (int pos = 0; pos < N; pos++) {
+    const int r = perm[pos];
+    if (r < 0 || r >= N) return fail(ctx, CVO_E_HIP, "fetch_ell: corrupt row permutation");
+    nz[r] = nzp[pos];
+    for (unsigned s = 0; s < nzp[pos]; s++) {
+      a[(size_t)s * N + r] = ap[(size_t)s * N + pos];
+      j[(size_t)s * N + r] = jp[(size_t)s * N + pos];
+    }
   }
   *max_out = mx;
   return CVO_OK;

@@ -49,6 +49,23 @@ __device__ __forceinline__ float wave_max_f32(float v) {
   return v;
 }
 
+// XCD-aware placement of the row-block kernels (k_list, k_assoc, k_coeff): the dispatcher is observed to place
+// workgroup b on XCD b % 8, so a 1-D grid is decoded as pair = (b / 8 / nblk) * 8 + b % 8, row block = (b / 8) % nblk:
+// all blocks of a pair run on one XCD and its lists, targets and ELL rows stay in that XCD's 4 MB L2 across
+// kernels and iterations (with the default mapping every XCD touches every pair: ~8x the L2 footprint).  Purely a
+// speed choice: nothing depends on where a block actually runs.  Grid = nblk * round_up(n_pairs, 8).
+struct PairBlock {
+  int pair, bx;
+};
+__device__ __forceinline__ bool pair_block(int nblk, int n_pairs, PairBlock& pb) {
+  const int b = (int)blockIdx.x;
+  const int slot = b >> 3;
+  const int grp = slot / nblk;
+  pb.pair = grp * 8 + (b & 7);
+  pb.bx = slot - grp * nblk;
+  return pb.pair < n_pairs;
+}
+
 // Values exchanged between the blocks of one launch (k_iter): on this multi-die part the L2 of an XCD is not
 // coherent with the others inside a kernel, and agent-scope fences write back / invalidate whole caches.  Relaxed
 // agent-scope atomics carry the coherence bits on the instruction itself, which is all a handful of partial
@@ -401,14 +418,14 @@ struct RowAcc {
 // One accepted/rejected pair (i, j): CvoGPU.cu:528-589 + the flow terms of 758-782.
 template <bool GENERAL, bool CACHE>
 __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* __restrict__ D, const Pose& pose, int i,
-                                           int r_sorted, int N, const RowData& r, const V3& pxe, int j, const float4 y0,
+                                           int pos, int N, const RowData& r, const V3& pxe, int j, const float4 y0,
                                            RowAcc& A, float4* cache) {
   float a;
   float4 yt;
   if (!eval_pair<GENERAL>(P, D, pose, i, r, j, y0, a, yt)) return;
   if (a > P.sp_thres) {
-    D->ell_a[(size_t)A.nnz * N + r_sorted] = a;
-    D->ell_j[(size_t)A.nnz * N + r_sorted] = j;
+    D->ell_a[(size_t)A.nnz * N + pos] = a;
+    D->ell_j[(size_t)A.nnz * N + pos] = j;
     A.nnz++;
     const V3 pye{yt.x, yt.y, yt.z};
     const V3 cr = cross_dev(pxe, pye);
@@ -424,30 +441,42 @@ __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* _
 }
 
 // ------------------------------------------------------------------------------------------
-// k_list: runs only when the bitmap was rebuilt.  One thread per (sorted) source row decodes the row's
-// candidates from the bitmap, maps them to original target indices and sorts them ascending; the list is
-// cached in HBM ([slot][row], coalesced) and serves every iteration until the next rebuild.  Rows with
-// more candidates than the list holds go to the overflow list of k_assoc_dense (also cached).
+// k_list: runs only when the bitmap was rebuilt.  A block owns a window of LIST_THREADS consecutive (sorted)
+// source rows.  It counts every row's candidates, then re-orders the rows of the window by that count: position
+// p of the window holds the row with the p-th smallest count (stable).  Everything the per-iteration kernels touch
+// is stored by POSITION (lists, counts, row coordinates, ELL), so their loads stay coalesced while the 64 lanes
+// of a wave get rows with similar trip counts - the association and coefficient loops are thread-per-row and a
+// wave runs as long as its longest row.  One thread per position then decodes its row's candidates from the
+// bitmap, maps them to original target indices and sorts them ascending ([slot][position], coalesced); the list
+// serves every iteration until the next rebuild.  Rows with more candidates than a list holds go to the
+// overflow list of k_assoc_dense (also cached).
 // ------------------------------------------------------------------------------------------
+constexpr int LIST_THREADS = 256;
+
 template <typename IdxT, int ASSOC_CAP>
-__global__ __launch_bounds__(ASSOC_THREADS) void k_list(const PairDesc* __restrict__ descs,
-                                                         const DevParams* __restrict__ Pp,
-                                                         const int* __restrict__ status) {
+__global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restrict__ descs,
+                                                        const DevParams* __restrict__ Pp,
+                                                        const int* __restrict__ status, int nblk, int n_pairs) {
   constexpr int ASSOC_STRIDE = ASSOC_CAP + 1;  // odd stride: conflict-free per-thread lists
-  if (status[blockIdx.y] != 0) return;
-  const PairDesc* __restrict__ D = descs + blockIdx.y;
+  PairBlock pb;
+  if (!pair_block(nblk, n_pairs, pb)) return;
+  if (status[pb.pair] != 0) return;
+  const PairDesc* __restrict__ D = descs + pb.pair;
   if (!D->st->rebuild) return;
   const int N = D->N;
-  const int r_sorted = blockIdx.x * ASSOC_THREADS + threadIdx.x;
   const int T = Pp->T;
-  __shared__ IdxT s_list[ASSOC_THREADS * ASSOC_STRIDE];
-  IdxT* list = s_list + threadIdx.x * ASSOC_STRIDE;
-  if (r_sorted < N) {
-    const int* yorder = D->yorder;
-    const int rbw = D->rbw;
-    const unsigned* rb = D->rowbits + (size_t)r_sorted * rbw;
-    // pass 1: how many candidates does the row have?
-    int ncand = 0;
+  const int rbw = D->rbw;
+  __shared__ IdxT s_list[LIST_THREADS * ASSOC_STRIDE];
+  __shared__ int s_key[LIST_THREADS];
+  __shared__ int s_row[LIST_THREADS];
+  const int tid = threadIdx.x;
+  const int w0row = pb.bx * LIST_THREADS;
+  // ---- candidates of row w0row + tid
+  int ncand = ASSOC_CAP + 2;  // rows past N sort behind every real row
+  if (w0row + tid < N) {
+    const int r = w0row + tid;
+    const unsigned* rb = D->rowbits + (size_t)r * rbw;
+    ncand = 0;
     for (int w0 = 0; w0 < rbw; w0 += 4) {  // rbw is a multiple of 4 (one 16-byte load covers 128 slices)
       const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
       if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
@@ -458,20 +487,44 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_list(const PairDesc* __restri
         while (f) {
           const int sl = (w0 + q) * 32 + __builtin_ctz(f);
           f &= f - 1;
-          const unsigned long long* mw = D->masks + ((size_t)sl * N + r_sorted) * T;
+          const unsigned long long* mw = D->masks + ((size_t)sl * N + r) * T;
           for (int t = 0; t < T; t++) ncand += __builtin_popcountll(mw[t]);
         }
       }
     }
-    D->cand_cnt[r_sorted] = ncand;
-    if (ncand > ASSOC_CAP) {
+  }
+  // ---- stable rank by min(count, CAP + 1): every thread counts the keys that sort before its own
+  s_key[tid] = (w0row + tid < N) ? min(ncand, ASSOC_CAP + 1) : ASSOC_CAP + 2;  // overflow rows last, pad rows behind them
+  __syncthreads();
+  {
+    const int mine = s_key[tid];
+    int rank = 0;
+    for (int t = 0; t < LIST_THREADS; t++) {
+      const int o = s_key[t];
+      rank += (o < mine || (o == mine && t < tid)) ? 1 : 0;
+    }
+    s_row[rank] = tid | (ncand << 8);  // position `rank` of the window holds row tid (ncand <= ~M < 2^23)
+  }
+  __syncthreads();
+  // ---- position w0row + tid: build the list of the row that was ranked there
+  const int pos = w0row + tid;
+  const int rr = w0row + (s_row[tid] & 0xff);
+  const int cnt_all = s_row[tid] >> 8;
+  IdxT* list = s_list + tid * ASSOC_STRIDE;
+  if (rr < N) {  // real rows occupy the positions below N
+    const int* yorder = D->yorder;
+    D->cand_cnt[pos] = cnt_all;
+    D->rowperm[pos] = rr;
+    D->xp4[pos] = D->xs4[rr];
+    D->ip[pos] = D->xorder[rr];
+    if (cnt_all > ASSOC_CAP) {
       // more candidates than a list holds (dense regime, e.g. rows sitting on K_max): k_assoc_dense
       // evaluates these rows against all targets, 64 at a time
       const int slot = atomicAdd(D->ovf_count, 1);
-      D->ovf_rows[slot] = r_sorted;
+      D->ovf_rows[slot] = pos;
     } else {
-      // pass 2: sorted-space positions of the candidates (the mask words come from L1/L2 this time)
-      int cnt = 0;
+      const unsigned* rb = D->rowbits + (size_t)rr * rbw;
+      int cnt = 0;  // sorted-space positions of the candidates (the mask words come from L1/L2 this time)
       for (int w0 = 0; w0 < rbw; w0 += 4) {
         const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
         if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
@@ -482,7 +535,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_list(const PairDesc* __restri
           while (f) {
             const int sl = (w0 + q) * 32 + __builtin_ctz(f);
             f &= f - 1;
-            const unsigned long long* mw = D->masks + ((size_t)sl * N + r_sorted) * T;
+            const unsigned long long* mw = D->masks + ((size_t)sl * N + rr) * T;
             for (int t = 0; t < T; t++) {
               unsigned long long m = mw[t];
               const int chunk = sl * T + t;
@@ -515,16 +568,16 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_list(const PairDesc* __restri
         list[q] = (IdxT)j;
       }
       IdxT* out = reinterpret_cast<IdxT*>(D->cand_j);
-      for (int k = 0; k < cnt; k++) out[(size_t)k * N + r_sorted] = list[k];
+      for (int k = 0; k < cnt; k++) out[(size_t)k * N + pos] = list[k];
     }
   }
   // The block that finishes last validates the list: every block has read `rebuild` by then, and the
   // kernels of the iteration (stream order) see rebuild == 0 <=> bitmap, lists and overflow list are current.
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     __threadfence();
     const int done = atomicAdd(D->gate, 1);
-    if (done == (int)gridDim.x - 1) {
+    if (done == nblk - 1) {
       *D->gate = 0;
       D->st->rebuild = 0;
     }
@@ -542,24 +595,24 @@ struct AssocShared {
 
 template <typename IdxT, int ASSOC_CAP, bool GENERAL, bool CACHE>
 __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* __restrict__ D, const PairState* st,
-                                            AssocShared& S, float4* cache, unsigned& nnz_out) {
+                                            AssocShared& S, float4* cache, unsigned& nnz_out, const int bx) {
   const int N = D->N;
-  const int r_sorted = blockIdx.x * ASSOC_THREADS + threadIdx.x;
+  const int pos = bx * ASSOC_THREADS + threadIdx.x;  // position in k_list's count-ordered row windows
   const int K = st->K;
   RowAcc A;
   unsigned long long ncand = 0;
   unsigned overflowed = 0;
-  if (r_sorted < N) {
-    const int cnt = D->cand_cnt[r_sorted];
+  if (pos < N) {
+    const int cnt = D->cand_cnt[pos];
     ncand = (unsigned long long)cnt;
     overflowed = cnt > ASSOC_CAP ? 1u : 0u;
     if (!overflowed) {
-      const int i = D->xorder[r_sorted];
-      const float4 x = D->xs4[r_sorted];
+      const int i = D->ip[pos];
+      const float4 x = D->xp4[pos];
       const RowData r = make_row(P, x, st->ell);
       const V3 pxe{x.x, x.y, x.z};
       const Pose pose = load_pose(st);
-      const IdxT* cj = reinterpret_cast<const IdxT*>(D->cand_j) + r_sorted;
+      const IdxT* cj = reinterpret_cast<const IdxT*>(D->cand_j) + pos;
       // exact evaluation in ascending original j; index and coordinates of the next candidates are in
       // flight while the current one is evaluated
       int j1 = cnt > 0 ? (int)cj[0] : 0;
@@ -571,9 +624,9 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
         j1 = j2;
         if (k + 1 < cnt) y1 = D->y4[j1];
         if (k + 2 < cnt) j2 = (int)cj[(size_t)(k + 2) * N];
-        visit_pair<GENERAL, CACHE>(P, D, pose, i, r_sorted, N, r, pxe, j, ycur, A, cache);
+        visit_pair<GENERAL, CACHE>(P, D, pose, i, pos, N, r, pxe, j, ycur, A, cache);
       }
-      D->nnz_row[r_sorted] = A.nnz;
+      D->nnz_row[pos] = A.nnz;
     }
   }
   nnz_out = overflowed ? 0u : A.nnz;
@@ -602,7 +655,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
     double t = S.red[0][c];
 #pragma unroll
     for (int w = 1; w < NW; w++) t += S.red[w][c];
-    st_x<CACHE>(D->flow_part + (size_t)blockIdx.x * 8 + c, t);
+    st_x<CACHE>(D->flow_part + (size_t)bx * 8 + c, t);
   } else if (threadIdx.x == 8) {
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
@@ -612,7 +665,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
       a2 += S.cnt[w][2];
       a3 += S.cnt[w][3];
     }
-    unsigned long long* cp = D->cnt_part + (size_t)blockIdx.x * 4;
+    unsigned long long* cp = D->cnt_part + (size_t)bx * 4;
     st_x<CACHE>(cp + 0, a0);
     st_x<CACHE>(cp + 1, a1);
     st_x<CACHE>(cp + 2, a2);
@@ -623,9 +676,12 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
 template <typename IdxT, int ASSOC_CAP, bool GENERAL>
 __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restrict__ descs,
                                                           const DevParams* __restrict__ Pp,
-                                                          const int* __restrict__ status, int lean) {
-  if (status[blockIdx.y] != 0) return;
-  const PairDesc* __restrict__ D = descs + blockIdx.y;
+                                                          const int* __restrict__ status, int lean, int nblk,
+                                                          int n_pairs) {
+  PairBlock pb;
+  if (!pair_block(nblk, n_pairs, pb)) return;
+  if (status[pb.pair] != 0) return;
+  const PairDesc* __restrict__ D = descs + pb.pair;
   // lean graph (no rebuild / dense kernels inside the iteration): a pair whose list has expired, or that has
   // rows for k_assoc_dense, does not advance; it waits for the next rebuild opportunity / for the host to
   // switch its group to the full graph (k_coeff skips it too and tells the host)
@@ -633,7 +689,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
   const DevParams P = *Pp;
   __shared__ AssocShared S;
   unsigned nnz;
-  assoc_phase<IdxT, ASSOC_CAP, GENERAL, false>(P, D, D->st, S, nullptr, nnz);
+  assoc_phase<IdxT, ASSOC_CAP, GENERAL, false>(P, D, D->st, S, nullptr, nnz, pb.bx);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -660,9 +716,9 @@ __global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict_
   if (n_ovf > 0) {
     const Pose pose = load_pose(st);
     for (int q = blockIdx.x * 4 + wave; q < n_ovf; q += DENSE_BLOCKS * 4) {
-      const int r_sorted = D->ovf_rows[q];
-      const int i = D->xorder[r_sorted];
-      const float4 x = D->xs4[r_sorted];
+      const int r_sorted = D->ovf_rows[q];  // a position of k_list's ordering (all per-row outputs are stored by position)
+      const int i = D->ip[r_sorted];
+      const float4 x = D->xp4[r_sorted];
       const RowData r = make_row(P, x, st->ell);
       const V3 pxe{x.x, x.y, x.z};
       float o0 = 0, o1 = 0, o2 = 0, v0 = 0, v1 = 0, v2 = 0;
@@ -822,14 +878,14 @@ __device__ __forceinline__ void coeff_entry(const XiMats& M, const float4 x, flo
 // Rows of this block.  COH: the block partial is read by another block of the same launch.
 template <bool COH>
 __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* __restrict__ D, const PairState* st,
-                                           CoeffShared& S) {
+                                           CoeffShared& S, const int bx) {
   const int N = D->N;
-  const int i = blockIdx.x * ASSOC_THREADS + threadIdx.x;  // sorted row
+  const int i = bx * ASSOC_THREADS + threadIdx.x;  // position (see k_list)
   double Bi = 0, Ci = 0, Di = 0, Ei = 0;
   if (i < N) {
     const unsigned nnz = D->nnz_row[i];
     if (nnz) {
-      const float4 x = D->xs4[i];
+      const float4 x = D->xp4[i];
       float temp_ell = st->ell;
       if (P.use_range_ell) {
         const float d2_sqrt = sqrtf(dot3_dev(x.x, x.y, x.z, x.x, x.y, x.z));
@@ -867,7 +923,7 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
     double t = S.red[0][c];
 #pragma unroll
     for (int w = 1; w < NW; w++) t += S.red[w][c];
-    st_x<COH>(D->coef_part + (size_t)blockIdx.x * 4 + c, t);
+    st_x<COH>(D->coef_part + (size_t)bx * 4 + c, t);
   }
 }
 
@@ -1142,14 +1198,17 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restrict__ descs,
                                                          const DevParams* __restrict__ Pp,
-                                                         const int* __restrict__ status, int flags) {
-  if (status[blockIdx.y] != 0) return;
-  const PairDesc* __restrict__ D = descs + blockIdx.y;
+                                                         const int* __restrict__ status, int flags, int nblk,
+                                                         int n_pairs) {
+  PairBlock pb;
+  if (!pair_block(nblk, n_pairs, pb)) return;
+  if (status[pb.pair] != 0) return;
+  const PairDesc* __restrict__ D = descs + pb.pair;
   PairState* const st = D->st;
   if (flags & 1) {
     const int ovf = *D->ovf_count;
     if (st->rebuild || ovf > 0) {  // waiting, see k_assoc; tell the host which graph this pair needs
-      if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (pb.bx == 0 && threadIdx.x == 0) {
         st->n_stalls++;
         if (ovf > 0) {
           st->want_full = 1;
@@ -1173,11 +1232,11 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     twist[c] = S.c.M.omega[c];
     twist[3 + c] = S.c.M.v[c];
   }
-  coeff_rows<true>(P, D, st, S.c);
+  coeff_rows<true>(P, D, st, S.c, pb.bx);
   __syncthreads();  // (its release waits for this block's coherent partial stores)
   if (threadIdx.x == 0) {
     const int done = __hip_atomic_fetch_add(D->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = done == (epoch + 1) * (int)gridDim.x - 1;
+    s_last = done == (epoch + 1) * nblk - 1;
   }
   __syncthreads();
   if (!s_last) return;
