@@ -139,37 +139,53 @@ def main():
         mean_iters = float(np.mean(iters))
         # ms per optimiser iteration of one frame pair, with `B` pairs in flight on each GPU
         ms_per_iter_pair = elapsed / args.steps / max(mean_iters, 1.0) / B * 1e3
-        # ---- roofline of the dominant kernel (k_scan), timed live with HIP events on the ctx stream
-        tiles, rpt, tpt = gpu.debug_scan_stats()        # over the last measured step (all pairs, all iterations)
+        # ---- roofline of the dominant kernel, timed live with HIP events on the ctx stream.
+        # One optimiser iteration of a sub-batch is two launches: k_assoc (pass 1 of SURVEY.md 8(d): K1+K2+K3 over the
+        # cached candidate lists) and k_coeff (pass 2: K4+K5, plus the scalar update in its last block); k_scan only
+        # runs when a pair's candidate list has expired.  k_coeff holds the largest share of GPU time.
+        tiles, rpt, tpt = gpu.debug_scan_stats()        # over the last measured step (all pairs, all list builds)
+        builds, iters_total, cand_evals = gpu.debug_list_builds()
         n_groups, ppl = gpu.debug_last_geometry()       # the batch runs as n_groups sub-batches of ppl pairs
-        scan_ms = gpu.debug_time_scan(20)               # avg per k_scan launch (ppl pairs), final state of the batch
-        pairs_per_launch = float(n) * float(n) * ppl    # ALGORITHMIC pair tests (N*M per pair)
-        bytes_per_launch = (n * 12 + n * 12) * ppl      # SURVEY.md 8(d), one pass, geometric payload
-        achieved_gbs = bytes_per_launch / (scan_ms * 1e-3) / 1e9
-        pair_rate = pairs_per_launch / (scan_ms * 1e-3)
+        assoc_ms, coeff_ms = gpu.debug_time_kernels(20)  # avg per launch (ppl pairs), final state of the batch
+        scan_ms = gpu.debug_time_scan(20)
+        bytes_pass = (n * 12 + n * 12) * ppl            # one pass over one iteration's inputs, geometric payload
+        pair_tests_iter = 2.0 * float(n) * float(n)     # two passes over N x M per iteration and pair
+        pair_rate = pair_tests_iter * iters_total * args.steps / elapsed if args.steps else 0.0
         valu_peak_pairs = FP32_VALU_PEAK_TFLOPS * 1e12 / C_CULL_FLOPS
-        executed_frac = tiles * rpt * tpt / (float(n) * float(n) * B * max(mean_iters, 1.0))
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
+        executed_tests = float(tiles) * rpt * tpt + 2.0 * float(cand_evals)   # scan tiles + both passes over the lists
+        executed_frac = executed_tests / (pair_tests_iter * max(float(iters_total), 1.0))
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "kernel_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("points") == n and tj.get("pairs") == ppl:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic = tj.get("hbm_bytes_per_launch", {})
             except Exception:
-                traffic = None
+                traffic = {}
+
+        def kernel_entry(name, ms, share):
+            gbs = bytes_pass / (ms * 1e-3) / 1e9
+            return {"kernel": name, "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6),
+                    "avg_launch_ms": round(ms, 5), "launches_per_iteration_and_subbatch": share,
+                    "traffic": traffic.get(name.split("::")[-1])}
+
+        dom = kernel_entry("cvo_dev::k_coeff", coeff_ms, 1.0)
         roofline = {
-            "kernel": "cvo_dev::k_scan", "bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
-            "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(scan_ms, 5),
-            "pairs_per_launch": ppl, "launches_per_iteration": n_groups,
-            # The path is an all-pairs accumulation with O(N+M) compulsory bytes: HBM is not the binding roof.
-            # The scan culls whole (4 rows x 128 targets) tiles by bounding boxes, so the ALGORITHMIC pair-test
-            # rate can exceed the FP32 VALU roof; `executed_fraction` is the share of the N*M tests really run.
+            "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom["frac"], "traffic": dom["traffic"],
+            "algorithmic_bytes_per_launch": bytes_pass, "avg_launch_ms": dom["avg_launch_ms"],
+            "pairs_per_launch": ppl, "sub_batches": n_groups,
+            "other_kernels": [kernel_entry("cvo_dev::k_assoc", assoc_ms, 1.0),
+                              kernel_entry("cvo_dev::k_scan", scan_ms, round(builds / max(iters_total, 1), 5))],
+            # The path is an all-pairs accumulation with O(N+M) compulsory bytes: HBM is not the binding roof
+            # (SURVEY.md 8(d)).  The VALU view: algorithmic pair tests per second of the whole job against the FP32
+            # vector roof for the 8-flop cull test.  Bounding-box culling and candidate-list reuse skip almost all of
+            # the N*M tests, so the algorithmic rate exceeds the roof; `executed_fraction` is the share really run.
             "valu": {"algorithmic_pair_tests_per_s": pair_rate, "peak_pair_tests_per_s": valu_peak_pairs,
                      "algorithmic_frac_of_roof": round(pair_rate / valu_peak_pairs, 4),
-                     "executed_fraction_of_pair_tests": round(executed_frac, 5),
-                     "executed_frac_of_roof": round(pair_rate * executed_frac / valu_peak_pairs, 4),
+                     "executed_fraction_of_pair_tests": round(executed_frac, 6),
+                     "list_builds_per_iteration": round(builds / max(iters_total, 1), 5),
                      "flops_per_pair_test": C_CULL_FLOPS, "peak_tflops": FP32_VALU_PEAK_TFLOPS},
         }
         cpu_baseline = None
@@ -210,9 +226,9 @@ def main():
         h2d_rate = (2 * n * 16 * 1.0) * B / max(t_h2d, 1e-9) / 1e9
         log(f"[bench] inputs: generated in {t_gen:.2f}s, uploaded in {t_h2d:.3f}s ({h2d_rate:.2f} GB/s incl. host packing); "
             f"PCIe-inclusive rate = {aligns / (elapsed + args.steps * t_h2d):.2f} align/s")
-        log(f"[bench] loop {loop_s:.3f}s/step on rank 0; scan kernel {scan_ms*1e3:.1f} us per launch of {ppl} pairs "
-            f"({pair_rate/1e12:.2f} T algorithmic pair-tests/s; {100*executed_frac:.2f}% of the N*M tests executed after "
-            f"tile culling)")
+        log(f"[bench] loop {loop_s:.3f}s/step on rank 0; per launch of {ppl} pairs: k_assoc {assoc_ms*1e3:.1f} us, "
+            f"k_coeff {coeff_ms*1e3:.1f} us, k_scan {scan_ms*1e3:.1f} us (runs in {100.0*builds/max(iters_total,1):.1f}% of the "
+            f"iterations); {pair_rate/1e12:.1f} T algorithmic pair-tests/s, {100*executed_frac:.3f}% of them executed")
         assert int(stat.abs().sum().item()) == 0, "some align() returned -1"
         print(json.dumps(out), flush=True)
     if use_dist:

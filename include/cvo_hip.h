@@ -209,9 +209,14 @@ int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms);
 /* Tile-culling statistics of the last align call (all pairs, all iterations): number of fine tiles
  * the scan executed and the tile shape; executed pair tests = tiles * rows_per_tile * targets_per_tile. */
 int cvo_debug_scan_stats(cvo_ctx* ctx, unsigned long long* tiles, int* rows_per_tile, int* targets_per_tile);
-/* Candidate-list reuse of the last align call: how many times the candidate bitmap was (re)built by
- * k_scan, summed over the pairs, and the optimiser iterations those pairs ran. */
-int cvo_debug_list_builds(cvo_ctx* ctx, unsigned long long* builds, unsigned long long* iterations);
+/* Re-issues the two per-iteration kernels (k_assoc; k_coeff including its update tail) one launch per sub-batch,
+ * `reps` times, on the state the last call left behind and without writing anything back; timed with HIP events on
+ * the context's stream.  *ms_* = average milliseconds per launch (of pairs_per_group pairs). */
+int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_coeff);
+/* Candidate-list reuse of the last align call, summed over the pairs: how many times the candidate bitmap was
+ * (re)built by k_scan, the optimiser iterations run, and the candidate pairs k_assoc evaluated exactly. */
+int cvo_debug_list_builds(cvo_ctx* ctx, unsigned long long* builds, unsigned long long* iterations,
+                          unsigned long long* candidate_evaluations);
 /* Number of candidate pairs in the bitmap the last iteration used (superset of nnz). */
 int cvo_debug_last_candidates(cvo_ctx* ctx, unsigned long long* out);
 const char* cvo_version(void);

@@ -24,4 +24,4 @@ for it in [int(x) for x in os.environ.get("PROBE_ITERS", "50,500,0").split(",")]
     per_launch = (t1 - t0) / ((reps + 1) * ng)
     print(f"iters={res[0].iterations} groups={ng} ppl={ppl} scan={ms*1e3:.1f}us tiles/launch={per_launch:.0f} "
           f"frac={per_launch*rpt*tpt/(n*n*ppl):.4f} avg_frac_run={t0*rpt*tpt/(float(n)*n*B*max(res[0].iterations,1)):.4f} "
-          f"cand={gpu.debug_last_candidates()} builds/iters={gpu.debug_list_builds()} secs={res[0].seconds:.4f}", flush=True)
+          f"cand={gpu.debug_last_candidates()} builds,iters,cand_evals={gpu.debug_list_builds()} secs={res[0].seconds:.4f}", flush=True)

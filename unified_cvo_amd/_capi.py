@@ -127,7 +127,7 @@ EXPORTED = [
     "cvo_params_default", "cvo_ctx_create", "cvo_ctx_destroy", "cvo_last_error", "cvo_ctx_stream",
     "cvo_ctx_synchronize", "cvo_cloud_upload", "cvo_cloud_upload_aos192", "cvo_cloud_size", "cvo_cloud_free",
     "cvo_align", "cvo_align_ex", "cvo_align_batch", "cvo_batch_poses_to_device", "cvo_inner_product",
-    "cvo_function_angle", "cvo_association", "cvo_debug_last_ell", "cvo_debug_time_scan",
+    "cvo_function_angle", "cvo_association", "cvo_debug_last_ell", "cvo_debug_time_scan", "cvo_debug_time_kernels",
     "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
 ]
 
@@ -173,8 +173,9 @@ def lib():
                                   C.POINTER(C.c_int), fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cvo_debug_last_ell.argtypes = [vp, ip, fp, C.POINTER(C.c_int), C.POINTER(C.c_uint)]
     L.cvo_debug_time_scan.argtypes = [vp, ip, fp]
+    L.cvo_debug_time_kernels.argtypes = [vp, ip, fp, fp]
     L.cvo_debug_last_candidates.argtypes = [vp, C.POINTER(C.c_ulonglong)]
-    L.cvo_debug_list_builds.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    L.cvo_debug_list_builds.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.cvo_debug_last_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cvo_debug_scan_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     for name in EXPORTED:

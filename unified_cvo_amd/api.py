@@ -372,6 +372,11 @@ class CvoGPU:
         self._check(self.L.cvo_debug_time_scan(self.ctx, reps, C.byref(ms)))
         return ms.value
 
+    def debug_time_kernels(self, reps=20):
+        a, c = C.c_float(), C.c_float()
+        self._check(self.L.cvo_debug_time_kernels(self.ctx, reps, C.byref(a), C.byref(c)))
+        return a.value, c.value
+
     def debug_last_geometry(self):
         """(sub-batches of the last call, pairs per sub-batch): the k_scan launches a profiler sees."""
         g, p = C.c_int(), C.c_int()
@@ -385,9 +390,9 @@ class CvoGPU:
         return t.value, r.value, c.value
 
     def debug_list_builds(self):
-        b, it = C.c_ulonglong(), C.c_ulonglong()
-        self._check(self.L.cvo_debug_list_builds(self.ctx, C.byref(b), C.byref(it)))
-        return b.value, it.value
+        b, it, ce = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+        self._check(self.L.cvo_debug_list_builds(self.ctx, C.byref(b), C.byref(it), C.byref(ce)))
+        return b.value, it.value, ce.value
 
     def debug_last_candidates(self):
         v = C.c_ulonglong()

@@ -61,6 +61,7 @@ struct PairState {
   double asum;  // sum of kernel values (mode 1)
   unsigned long long ncand;
   unsigned long long noverflow;  // rows that took k_assoc's literal path
+  unsigned long long ncand_total;  // candidate pairs evaluated exactly, summed over the iterations (statistics)
   int n_trace;
   float out_T[16];  // column-major [R^T | -R^T T]
   // candidate-list reuse: pose / ell the current bitmap was built with, its skin, and whether the kernels

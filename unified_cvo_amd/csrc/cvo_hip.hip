@@ -1167,15 +1167,57 @@ int cvo_debug_last_candidates(cvo_ctx* ctx, unsigned long long* out) {
   return CVO_OK;
 }
 
-int cvo_debug_list_builds(cvo_ctx* ctx, unsigned long long* builds, unsigned long long* iterations) {
+int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_coeff) {
+  if (!ctx || reps <= 0 || ctx->last_pairs < 1 || !ms_assoc || !ms_coeff)
+    return fail(ctx, CVO_E_INVALID, "cvo_debug_time_kernels: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // the per-iteration launches of the optimiser loop (one per sub-batch), replayed on the state the last call
+  // left behind: same lists, same rows, same arithmetic; k_coeff's last block runs the update without writing
+  // anything back
+  const int n_pairs = ctx->last_pairs, G = ctx->last_groups;
+  const bool idx16 = ctx->last_M < 65536;
+  const DevParams& dp = ctx->last_params;
+  const bool general = dp.use_col || dp.use_sem || dp.use_geotype;
+  const int nba = (ctx->last_N + ASSOC_THREADS - 1) / ASSOC_THREADS;
+  float out[2] = {0.f, 0.f};
+  for (int which = 0; which < 2; which++) {
+    auto sweep = [&]() {
+      for (int g = 0; g < G; g++) {
+        const int p0 = (int)((long)n_pairs * g / G), p1 = (int)((long)n_pairs * (g + 1) / G);
+        if (which == 0)
+          launch_assoc(ctx->stream, idx16, general, nba, p1 - p0, ctx->d_descs + p0, ctx->d_params,
+                       ctx->d_status + p0, 2);
+        else
+          hipLaunchKernelGGL(k_coeff, row_grid(nba, p1 - p0), dim3(ASSOC_THREADS), 0, ctx->stream,
+                             ctx->d_descs + p0, ctx->d_params, ctx->d_status + p0, 8 | 2, nba, p1 - p0);
+      }
+    };
+    sweep();  // warm-up
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    for (int r = 0; r < reps; r++) sweep();
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipEventElapsedTime(&out[which], ctx->ev_start, ctx->ev_stop));
+    out[which] /= (float)(reps * G);
+  }
+  *ms_assoc = out[0];
+  *ms_coeff = out[1];
+  return CVO_OK;
+}
+
+int cvo_debug_list_builds(cvo_ctx* ctx, unsigned long long* builds, unsigned long long* iterations,
+                          unsigned long long* candidate_evaluations) {
   if (!ctx || !builds || ctx->last_pairs < 1) return fail(ctx, CVO_E_INVALID, "cvo_debug_list_builds: bad argument");
-  unsigned long long b = 0, it = 0;
+  unsigned long long b = 0, it = 0, ce = 0;
   for (int p = 0; p < ctx->last_pairs; p++) {
     b += (unsigned long long)ctx->h_states[p].n_builds;
     it += (unsigned long long)ctx->h_states[p].iterations;
+    ce += ctx->h_states[p].ncand_total;
   }
   *builds = b;
   if (iterations) *iterations = it;
+  if (candidate_evaluations) *candidate_evaluations = ce;
   return CVO_OK;
 }
 

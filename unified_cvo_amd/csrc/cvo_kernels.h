@@ -680,12 +680,13 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
                                                           int n_pairs) {
   PairBlock pb;
   if (!pair_block(nblk, n_pairs, pb)) return;
-  if (status[pb.pair] != 0) return;
+  const bool replay = (lean & 2) != 0;  // cvo_debug_time_kernels: re-run on the state the last call left behind
+  if (!replay && status[pb.pair] != 0) return;
   const PairDesc* __restrict__ D = descs + pb.pair;
   // lean graph (no rebuild / dense kernels inside the iteration): a pair whose list has expired, or that has
   // rows for k_assoc_dense, does not advance; it waits for the next rebuild opportunity / for the host to
   // switch its group to the full graph (k_coeff skips it too and tells the host)
-  if (lean && (D->st->rebuild || *D->ovf_count > 0)) return;
+  if ((lean & 1) && (D->st->rebuild || *D->ovf_count > 0)) return;
   const DevParams P = *Pp;
   __shared__ AssocShared S;
   unsigned nnz;
@@ -938,7 +939,8 @@ struct UpdateShared {
 };
 
 // Executed by the first wave of the calling block (the other threads only take part in the barriers).
-// flags: bit 1 = the rebuild kernels run right after this iteration, bit 2 = called from k_iter, bits 8.. = how many
+// flags: bit 1 = the rebuild kernels run right after this iteration, bit 2 = called from k_coeff, bit 3 = replay for
+// timing (nothing is written back), bits 8.. = how many
 // iterations the list has to survive without another rebuild opportunity (0 in the full graph).  n_flow_parts: association partials to
 // sum (the lean graph has no k_assoc_dense, so its slots are not read).
 template <bool INIT, bool COH>
@@ -946,6 +948,7 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
                                             int n_flow_parts, UpdateShared& U, const float* twist) {
   PairState* const gst = D->st;
   const bool trio_follows = INIT || (flags & 2) != 0;
+  const bool dry = (flags & 8) != 0;  // timing replay: compute everything, write nothing back
   const int horizon = flags >> 8;
   double* const s_c = U.c;
   unsigned long long* const s_n = U.n;
@@ -969,13 +972,23 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
     const int c = tid & 3;
     double s = 0;
     if (P.mode == 0) {
-      for (int b = tid >> 2; b < nbc; b += 16) s += ld_x<COH>(D->coef_part + (size_t)b * 4 + c);
+      // eight (coherent) loads in flight per lane, summed in block order
+      for (int b0 = tid >> 2; b0 < nbc; b0 += 128) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int b = b0 + 16 * u;
+          v[u] = b < nbc ? ld_x<COH>(D->coef_part + (size_t)b * 4 + c) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+      }
     } else if (c == 0) {
-      for (int b = tid >> 2; b < nba; b += 16) s += ld_x<COH>(D->flow_part + (size_t)b * 8 + 6);
+      for (int b = tid >> 2; b < nba; b += 16) s += D->flow_part[(size_t)b * 8 + 6];
     }
-    unsigned long long q = 0;
+    unsigned long long q = 0;  // (written by the association kernel(s), i.e. before this launch: plain loads)
     for (int b = tid >> 2; b < nba; b += 16) {
-      const unsigned long long v = ld_x<COH>(D->cnt_part + (size_t)b * 4 + c);
+      const unsigned long long v = D->cnt_part[(size_t)b * 4 + c];
       q = (c == 1) ? max(q, v) : q + v;
     }
 #pragma unroll
@@ -999,11 +1012,12 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
       }
     }
     if (!INIT) {
-      if (flags & 4) st->epoch++;  // barrier generation of k_iter
+      if (flags & 4) st->epoch++;  // generation of k_coeff's last-block counter
       const unsigned nnz = (unsigned)s_n[0], max_nnz = (unsigned)s_n[1];
       st->nnz = nnz;
       st->max_nnz = max_nnz;
       st->ncand = s_n[2];
+      st->ncand_total += s_n[2];
       st->noverflow = s_n[3];
       if (P.mode != 0) {  // single evaluation: A_sum (SparseKernelMat.cu:62-68)
         st->asum = s_c[0];
@@ -1054,7 +1068,7 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
           for (int q = 0; q < 3; q++) st->T[q] = T[q] = Tn[q];
           dist = se3_log_norm(dR, dT);  // CvoGPU.cu:1473-1476
           const float ip_curr = (float)((double)nnz / sqrt((double)D->N * (double)D->M));  // 1486
-          const bool need_decay_ell = indicator_update(st, sq, eq, ip_curr, P.window, P.stable_thr);
+          const bool need_decay_ell = dry ? false : indicator_update(st, sq, eq, ip_curr, P.window, P.stable_thr);
           if (dist < (double)P.eps_2) {  // CvoGPU.cu:1505-1508
             done = 1;
             st->iterations = k;
@@ -1074,7 +1088,7 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
         }
         st->dist = dist;
         // optional per-iteration trace (the reference's is_logging history files, CvoGPU.cu:1495-1503)
-        if (D->trace && st->n_trace < P.trace_capacity &&
+        if (!dry && D->trace && st->n_trace < P.trace_capacity &&
             (k < P.trace_dense || (P.trace_every > 0 && k % P.trace_every == 0))) {
           cvo_trace_t* tr = D->trace + st->n_trace;
           tr->k = k;
@@ -1153,13 +1167,13 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
         if (!(s == s)) s = 0.f;
         st->skin = s * radius;
         st->want_full = want_full;
-        *D->want_out = want_full;
+        if (!dry) *D->want_out = want_full;
         st->n_builds = INIT ? 1 : st->n_builds + 1;
         st->rebuild = 1;  // cleared by k_list once bitmap and lists are current
       } else if (st->want_full && *D->ovf_count == 0 &&
                  moved + 1.3f * (float)P.lean_U * step_move <= st->skin) {
         st->want_full = 0;  // the motion has slowed down enough for the lean graph
-        *D->want_out = 0;
+        if (!dry) *D->want_out = 0;
       }
     }
     for (int q = 0; q < 9; q++) st->Rinv[q] = Ri[q];
@@ -1170,13 +1184,13 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
     }
     st->out_T[3] = st->out_T[7] = st->out_T[11] = 0;
     st->out_T[15] = 1;
-    if (done) {
+    if (done && !dry) {
       st->status = 1;
       *D->status_out = 1;
     }
   }
   __syncthreads();
-  if (act)
+  if (act && !dry)
     for (int q = tid; q < HOT_DWORDS; q += 64) reinterpret_cast<unsigned*>(gst)[q] = s_hot[q];
 }
 
@@ -1202,7 +1216,8 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
                                                          int n_pairs) {
   PairBlock pb;
   if (!pair_block(nblk, n_pairs, pb)) return;
-  if (status[pb.pair] != 0) return;
+  const bool replay = (flags & 8) != 0;  // cvo_debug_time_kernels: same work, nothing written back
+  if (!replay && status[pb.pair] != 0) return;
   const PairDesc* __restrict__ D = descs + pb.pair;
   PairState* const st = D->st;
   if (flags & 1) {
@@ -1236,7 +1251,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
   __syncthreads();  // (its release waits for this block's coherent partial stores)
   if (threadIdx.x == 0) {
     const int done = __hip_atomic_fetch_add(D->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = done == (epoch + 1) * nblk - 1;
+    s_last = replay ? (done % nblk == nblk - 1) : (done == (epoch + 1) * nblk - 1);
   }
   __syncthreads();
   if (!s_last) return;
