@@ -23,6 +23,7 @@ struct cvo_cloud {
   cvo_ctx* ctx = nullptr;  // identity check only: never dereferenced after upload (the context may be gone)
   int device = 0;
   int n = 0;
+  char* slab = nullptr;     // the one device allocation behind the pointers below
   float4* x4 = nullptr;
   float4* xs4 = nullptr;    // x4 permuted into the spatial order
   float4* feat = nullptr;   // 2 float4 per point
@@ -693,7 +694,11 @@ int cvo_ctx_synchronize(cvo_ctx* ctx) {
 // splits fall on multiples of 512 / 64 / 4 points, so that every aligned run of 512, 64 (a k_scan
 // chunk) or 4 (a k_scan row group) consecutive sorted points is a compact box.  Only the speed of
 // k_scan's tile culling depends on it, never a result (CVO_NO_SORT=1 keeps the identity order).
-static void kd_split(std::vector<int>& idx, int lo, int hi, const std::vector<float>& x4) {
+struct KdPoint {
+  float c[3];
+  int i;
+};
+static void kd_split(KdPoint* pts, int lo, int hi) {
   const int n = hi - lo;
   if (n <= 4) return;
   const int unit = n > 512 ? 512 : (n > 64 ? 64 : 4);
@@ -703,29 +708,36 @@ static void kd_split(std::vector<int>& idx, int lo, int hi, const std::vector<fl
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int k = lo; k < hi; k++)
     for (int c = 0; c < 3; c++) {
-      const float v = x4[4 * (size_t)idx[k] + c];
+      const float v = pts[k].c[c];
       mn[c] = std::min(mn[c], v);
       mx[c] = std::max(mx[c], v);
     }
   int axis = 0;
   for (int c = 1; c < 3; c++)
     if (mx[c] - mn[c] > mx[axis] - mn[axis]) axis = c;
-  std::nth_element(idx.begin() + lo, idx.begin() + lo + left, idx.begin() + hi, [&](int a, int b) {
-    const float va = x4[4 * (size_t)a + axis], vb = x4[4 * (size_t)b + axis];
-    return va < vb || (va == vb && a < b);
+  // the records themselves are permuted (no index indirection in the comparator: ~4x faster at 10k points)
+  std::nth_element(pts + lo, pts + lo + left, pts + hi, [axis](const KdPoint& a, const KdPoint& b) {
+    return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.i < b.i);
   });
-  kd_split(idx, lo, lo + left, x4);
-  kd_split(idx, lo + left, hi, x4);
+  kd_split(pts, lo, lo + left);
+  kd_split(pts, lo + left, hi);
 }
 
 static void spatial_order(const std::vector<float>& x4, int n, std::vector<int>& order) {
   order.resize(n);
   for (int i = 0; i < n; i++) order[i] = i;
   if (n < 8 || getenv("CVO_NO_SORT")) return;
-  for (int i = 0; i < n; i++)
-    for (int c = 0; c < 3; c++)
-      if (!std::isfinite(x4[4 * (size_t)i + c])) return;  // keep the identity order for odd inputs
-  kd_split(order, 0, n, x4);
+  std::vector<KdPoint> pts((size_t)n);
+  for (int i = 0; i < n; i++) {
+    for (int c = 0; c < 3; c++) {
+      const float v = x4[4 * (size_t)i + c];
+      if (!std::isfinite(v)) return;  // keep the identity order for odd inputs
+      pts[i].c[c] = v;
+    }
+    pts[i].i = i;
+  }
+  kd_split(pts.data(), 0, n);
+  for (int r = 0; r < n; r++) order[r] = pts[r].i;
 }
 
 static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, const std::vector<float>& feat,
@@ -751,32 +763,41 @@ static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, cons
     c->cz = (float)(sz / n);
   }
   if (!std::isfinite(c->cx) || !std::isfinite(c->cy) || !std::isfinite(c->cz)) c->cx = c->cy = c->cz = 0.f;
+  // one device allocation and one host-to-device copy per cloud (a hipMalloc / a synchronous copy cost ~100 us
+  // each: six of both took longer than the spatial ordering itself)
   const size_t nn = (size_t)std::max(n, 1);
-  hipError_t e = hipMalloc(&c->x4, sizeof(float4) * nn);
-  if (e == hipSuccess) e = hipMalloc(&c->xs4, sizeof(float4) * nn);
-  if (e == hipSuccess) e = hipMalloc(&c->feat, sizeof(float4) * 2 * nn);
-  if (e == hipSuccess) e = hipMalloc(&c->label, sizeof(float4) * 5 * nn);
-  if (e == hipSuccess) e = hipMalloc(&c->geo, sizeof(float2) * nn);
-  if (e == hipSuccess) e = hipMalloc(&c->order, sizeof(int) * nn);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  const size_t o_x4 = take(sizeof(float4) * nn), o_xs4 = take(sizeof(float4) * nn), o_feat = take(sizeof(float4) * 2 * nn),
+               o_label = take(sizeof(float4) * 5 * nn), o_geo = take(sizeof(float2) * nn), o_order = take(sizeof(int) * nn);
+  hipError_t e = hipMalloc(&c->slab, off);
   if (e != hipSuccess) {
     cvo_cloud_free(c);
     return fail(ctx, CVO_E_NOMEM, std::string("cloud hipMalloc: ") + hipGetErrorString(e));
   }
+  c->x4 = (float4*)(c->slab + o_x4);
+  c->xs4 = (float4*)(c->slab + o_xs4);
+  c->feat = (float4*)(c->slab + o_feat);
+  c->label = (float4*)(c->slab + o_label);
+  c->geo = (float2*)(c->slab + o_geo);
+  c->order = (int*)(c->slab + o_order);
   if (n > 0) {
-    HIP_TRY(ctx, hipMemcpyAsync(c->x4, x4.data(), sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(c->feat, feat.data(), sizeof(float) * FD_PAD * (size_t)n, hipMemcpyHostToDevice,
-                                ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(c->label, label.data(), sizeof(float) * NC_PAD * (size_t)n, hipMemcpyHostToDevice,
-                                ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(c->geo, geo.data(), sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<char> stage(off, 0);
+    std::memcpy(&stage[o_x4], x4.data(), sizeof(float) * 4 * (size_t)n);
+    std::memcpy(&stage[o_feat], feat.data(), sizeof(float) * FD_PAD * (size_t)n);
+    std::memcpy(&stage[o_label], label.data(), sizeof(float) * NC_PAD * (size_t)n);
+    std::memcpy(&stage[o_geo], geo.data(), sizeof(float) * 2 * (size_t)n);
     std::vector<int> order;
     spatial_order(x4, n, order);
-    std::vector<float> xs(4 * (size_t)n);
+    float* xs = reinterpret_cast<float*>(&stage[o_xs4]);
     for (int r = 0; r < n; r++) std::memcpy(&xs[4 * (size_t)r], &x4[4 * (size_t)order[r]], 16);
-    HIP_TRY(ctx, hipMemcpyAsync(c->order, order.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(c->xs4, xs.data(), sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    c->h_order = order;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the staging vectors die with the caller
+    std::memcpy(&stage[o_order], order.data(), sizeof(int) * (size_t)n);
+    c->h_order = std::move(order);
+    HIP_TRY(ctx, hipMemcpy(c->slab, stage.data(), off, hipMemcpyHostToDevice));
   }
   *out = c;
   return CVO_OK;
@@ -821,12 +842,7 @@ int cvo_cloud_size(const cvo_cloud* c) { return c ? c->n : 0; }
 void cvo_cloud_free(cvo_cloud* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->x4) (void)hipFree(c->x4);
-  if (c->xs4) (void)hipFree(c->xs4);
-  if (c->feat) (void)hipFree(c->feat);
-  if (c->label) (void)hipFree(c->label);
-  if (c->geo) (void)hipFree(c->geo);
-  if (c->order) (void)hipFree(c->order);
+  if (c->slab) (void)hipFree(c->slab);
   delete c;
 }
 
