@@ -342,3 +342,50 @@ def test_result_does_not_depend_on_spatial_order(monkeypatch):
     monkeypatch.setenv("CVO_NO_SORT", "1")
     b = CvoGPU(params=P).align(src, tgt, init, max_iterations=200)
     assert np.array_equal(a.transform, b.transform)
+
+
+def test_result_does_not_depend_on_list_reuse(monkeypatch):
+    """Candidate lists are reused across iterations (scan with a skin, lean graph): a superset of the exact test,
+    so scanning every iteration (CVO_SKIN=0) or never using the lean graph gives bit-identical poses."""
+    P, src, tgt, init = cases.config2(n=3000)
+    gpu = CvoGPU(params=P)
+    a = gpu.align(src, tgt, init, max_iterations=600)
+    builds, iters, cand = gpu.debug_list_builds()
+    assert iters == 600 and 0 < builds < 300      # the lists really were reused
+    monkeypatch.setenv("CVO_NO_LEAN", "1")
+    b = CvoGPU(params=P).align(src, tgt, init, max_iterations=600)
+    monkeypatch.setenv("CVO_SKIN", "0")
+    g0 = CvoGPU(params=P)
+    c = g0.align(src, tgt, init, max_iterations=600)
+    assert g0.debug_list_builds()[0] >= 600       # one scan per iteration (+ the request after the last one)
+    assert a.iterations == b.iterations == c.iterations == 600
+    assert np.array_equal(a.transform, b.transform)
+    assert np.array_equal(a.transform, c.transform)
+
+
+def test_lean_graph_waits_do_not_change_results(monkeypatch):
+    """A rebuild opportunity only every 16 iterations makes pairs wait for their next list; the trajectory is the
+    same as with an opportunity in every iteration."""
+    P, src, tgt, init = cases.config2(n=2000)
+    a = CvoGPU(params=P).align(src, tgt, init, max_iterations=500)
+    monkeypatch.setenv("CVO_LEAN_U", "16")
+    b = CvoGPU(params=P).align(src, tgt, init, max_iterations=500)
+    monkeypatch.setenv("CVO_LEAN_U", "3")
+    c = CvoGPU(params=P).align(src, tgt, init, max_iterations=500)
+    assert a.iterations == b.iterations == c.iterations == 500
+    assert np.array_equal(a.transform, b.transform)
+    assert np.array_equal(a.transform, c.transform)
+
+
+def test_timing_replay_leaves_the_context_usable():
+    """cvo_debug_time_kernels / cvo_debug_time_scan replay launches without writing anything back."""
+    P, src, tgt, init = cases.config2(n=2000)
+    gpu = CvoGPU(params=P)
+    a = gpu.align(src, tgt, init, max_iterations=200)
+    t_assoc, t_coeff = gpu.debug_time_kernels(3)
+    t_scan = gpu.debug_time_scan(3)
+    assert t_assoc > 0 and t_coeff > 0 and t_scan > 0
+    b = gpu.align(src, tgt, init, max_iterations=200)
+    assert np.array_equal(a.transform, b.transform)
+    ip0 = gpu.inner_product_gpu(src, tgt, init, P.ell_init)
+    assert ip0 == gpu.inner_product_gpu(src, tgt, init, P.ell_init)
