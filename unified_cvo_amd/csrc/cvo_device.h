@@ -70,7 +70,7 @@ struct PairState {
   float ell_build, skin;
   int rebuild, n_builds;
   int want_full, n_stalls;
-  int epoch, pad_epoch;  // iterations completed through k_update (generation of k_iter's barriers)
+  int epoch, pad_epoch;  // k_coeff launches this pair completed (generation of its last-block counter)
    // host hint: this pair needs the graph with per-iteration rebuild / dense kernels
   // A_sparsity_indicator_ell_update FIFOs (CvoGPU.cu:1167-1285): bookkeeping here, storage below
   int s_head, s_size, e_head, e_size;
@@ -134,8 +134,7 @@ struct PairDesc {
   int* status_out;  // mirror of st->status for cheap host polling
   int* want_out;    // mirror of st->want_full
   int* gate;        // [1] blocks of k_list that finished the current rebuild (the last one validates the list)
-  int* bar;         // [1] k_iter: blocks that finished the association phase (monotonic)
-  int* done;        // [1] k_iter: blocks that finished the coefficient phase (monotonic)
+  int* done;        // [1] k_coeff: blocks that stored their partials (monotonic; the last one runs the update)
 };
 
 constexpr int ROWS_PER_GROUP = 4;

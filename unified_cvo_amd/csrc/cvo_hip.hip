@@ -38,7 +38,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, tile_count, ovf_rows, ovf_count, gate, bar, done, cand_cnt, rowperm, xp4, ip, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, tile_count, ovf_rows, ovf_count, gate, done, cand_cnt, rowperm, xp4, ip, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -135,7 +135,6 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.ovf_rows = take(sizeof(int) * (size_t)N);
   L.ovf_count = take(sizeof(int));
   L.gate = take(sizeof(int));
-  L.bar = take(sizeof(int));
   L.done = take(sizeof(int));
   L.cand_cnt = take(sizeof(int) * (size_t)N);
   L.rowperm = take(sizeof(int) * (size_t)N);
@@ -495,7 +494,6 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.status_out = ctx->d_status + p;
     D.want_out = ctx->d_status + ctx->cap_pairs + p;
     D.gate = (int*)(base + S->L.gate);
-    D.bar = (int*)(base + S->L.bar);
     D.done = (int*)(base + S->L.done);
 
     PairState& st = ctx->h_states[p];
@@ -516,7 +514,6 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     HIP_TRY(ctx, hipMemsetAsync(D.tile_count, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.ovf_count, 0, sizeof(int), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.gate, 0, sizeof(int), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(D.bar, 0, sizeof(int), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.done, 0, sizeof(int), ctx->stream));
   }
   // the blocks of k_assoc beyond a smaller pair's N still write their (zero) partials, but the

@@ -1,26 +1,27 @@
 // cvo_kernels.h -- the hand-written gfx950 kernels of the pairwise align() hot path.
 //
-// One optimiser iteration of every in-flight frame pair is five launches (blockIdx.z/y = pair):
+// Every iteration of every in-flight frame pair (the pair is part of the grid):
 //
-//   k_scan   N x M candidate scan in spatially sorted index space.  Replaces the O(N*M) part of
-//            fill_in_A_mat_gpu (CvoGPU.cu:477-593).  Lanes hold targets (coalesced float4 loads of
-//            the SoA `ycull`), source rows are wave-uniform (scalar loads of `xcull`).  Coarse
-//            level: 64 four-row groups at a time are tested box-against-box with the wave's target
-//            slice; only overlapping tiles get the fine test of 3 v_fma_f32 per 64 pairs, a
-//            v_min3 tree and one v_cmp whose lane mask IS the candidate bitmap word.
-//   k_assoc  one thread per source row gathers its candidates, restores ascending ORIGINAL j
-//            (insertion sort in LDS) and runs the reference's exact per-pair arithmetic (double
-//            exp, colour / semantic kernels, a > sp_thres, first-K truncation), writes the ELL
-//            matrix and accumulates the per-row flow (compute_flow_gpu_no_eigen,
-//            CvoGPU.cu:729-790).  Rows with more candidates than the LDS list holds run the
-//            reference's literal ordered scan over all targets.
-//   k_coeff  reduces the flow partials to the normalised twist, then one thread per row
-//            accumulates B,C,D,E (compute_step_size_xi + _poly_coeff, CvoGPU.cu:953-1082).
-//   k_update one wave per pair: reduces B..E and runs the reference's host-side scalar code on one
-//            lane (cubic, Exp, pose update, SE(3) log, indicator, ell decay, K update;
-//            CvoGPU.cu:1122-1158, 1452-1531).
-//   k_prep   wide: prepares the next iteration (update_tf + transform_pointcloud_thrust + per-row
-//            cut-offs + cull operands + bounding boxes).
+//   k_assoc  one thread per source row walks the row's CACHED candidate list in ascending ORIGINAL j and runs the
+//            reference's exact per-pair arithmetic (double exp, colour / semantic kernels, a > sp_thres, first-K
+//            truncation; fill_in_A_mat_gpu, CvoGPU.cu:477-593), writes the ELL matrix and accumulates the
+//            per-row flow (compute_flow_gpu_no_eigen, CvoGPU.cu:729-790).
+//   k_coeff  reduces the flow partials to the normalised twist, then one thread per row accumulates B,C,D,E
+//            (compute_step_size_xi + _poly_coeff, CvoGPU.cu:953-1082); the block of the pair that finishes last
+//            runs the reference's host-side scalar code (cubic, Exp, pose update, SE(3) log, indicator, ell decay,
+//            K update; CvoGPU.cu:1122-1158, 1452-1531) and decides whether the candidate lists are still valid.
+//
+// Only when a pair's lists have expired (the targets moved further than the skin the scan added to every cut-off):
+//
+//   k_prep   update_tf + transform_pointcloud_thrust + per-row cut-offs as cull operands and bounding boxes.
+//   k_scan   N x M candidate scan in spatially sorted index space: the O(N*M) part of fill_in_A_mat_gpu.  Lanes
+//            hold targets, row operands are broadcast from an LDS tile queue; a two-level bounding-box cull leaves
+//            a few percent of the (4 rows x 128 targets) tiles; 3 FMAs per pair, and the lane mask of the
+//            compare IS the candidate bitmap word.
+//   k_list   per-row sorted candidate lists from the bitmap, rows re-ordered by candidate count inside 256-row
+//            windows (load balance of the thread-per-row kernels).
+//   k_assoc_dense  rows with more candidates than a list holds: the reference's literal ordered scan, a wave per
+//            row (full graph only).
 //
 // No host round trip happens inside the loop; finished pairs early-exit on their status word.
 #pragma once
@@ -66,7 +67,7 @@ __device__ __forceinline__ bool pair_block(int nblk, int n_pairs, PairBlock& pb)
   return pb.pair < n_pairs;
 }
 
-// Values exchanged between the blocks of one launch (k_iter): on this multi-die part the L2 of an XCD is not
+// Values exchanged between the blocks of one launch (k_coeff's partials -> its last block): on this multi-die part the L2 of an XCD is not
 // coherent with the others inside a kernel, and agent-scope fences write back / invalidate whole caches.  Relaxed
 // agent-scope atomics carry the coherence bits on the instruction itself, which is all a handful of partial
 // sums needs.  COH = false: plain accesses (the producer is an earlier kernel).
@@ -416,10 +417,10 @@ struct RowAcc {
 };
 
 // One accepted/rejected pair (i, j): CvoGPU.cu:528-589 + the flow terms of 758-782.
-template <bool GENERAL, bool CACHE>
+template <bool GENERAL>
 __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* __restrict__ D, const Pose& pose, int i,
                                            int pos, int N, const RowData& r, const V3& pxe, int j, const float4 y0,
-                                           RowAcc& A, float4* cache) {
+                                           RowAcc& A) {
   float a;
   float4 yt;
   if (!eval_pair<GENERAL>(P, D, pose, i, r, j, y0, a, yt)) return;
@@ -586,16 +587,16 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
 
 // ------------------------------------------------------------------------------------------
 // Association phase: ordered association + flow, one thread per (sorted) source row, over the cached
-// candidate list.  Shared by k_assoc and the fused k_iter.
+// candidate list.
 // ------------------------------------------------------------------------------------------
 struct AssocShared {
   double red[ASSOC_THREADS / 64][8];
   unsigned long long cnt[ASSOC_THREADS / 64][4];
 };
 
-template <typename IdxT, int ASSOC_CAP, bool GENERAL, bool CACHE>
+template <typename IdxT, int ASSOC_CAP, bool GENERAL>
 __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* __restrict__ D, const PairState* st,
-                                            AssocShared& S, float4* cache, unsigned& nnz_out, const int bx) {
+                                            AssocShared& S, const int bx) {
   const int N = D->N;
   const int pos = bx * ASSOC_THREADS + threadIdx.x;  // position in k_list's count-ordered row windows
   const int K = st->K;
@@ -624,12 +625,11 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
         j1 = j2;
         if (k + 1 < cnt) y1 = D->y4[j1];
         if (k + 2 < cnt) j2 = (int)cj[(size_t)(k + 2) * N];
-        visit_pair<GENERAL, CACHE>(P, D, pose, i, pos, N, r, pxe, j, ycur, A, cache);
+        visit_pair<GENERAL>(P, D, pose, i, pos, N, r, pxe, j, ycur, A);
       }
       D->nnz_row[pos] = A.nnz;
     }
   }
-  nnz_out = overflowed ? 0u : A.nnz;
   // per-row (omega_i / c, v_i / d) cast to double, then reduced in double (CvoGPU.cu:784-787, 824-825)
   double red[7] = {(double)(A.o0 / P.c), (double)(A.o1 / P.c), (double)(A.o2 / P.c), (double)(A.v0 / P.d),
                    (double)(A.v1 / P.d), (double)(A.v2 / P.d), A.asum};
@@ -655,7 +655,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
     double t = S.red[0][c];
 #pragma unroll
     for (int w = 1; w < NW; w++) t += S.red[w][c];
-    st_x<CACHE>(D->flow_part + (size_t)bx * 8 + c, t);
+    D->flow_part[(size_t)bx * 8 + c] = t;
   } else if (threadIdx.x == 8) {
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
@@ -666,10 +666,10 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
       a3 += S.cnt[w][3];
     }
     unsigned long long* cp = D->cnt_part + (size_t)bx * 4;
-    st_x<CACHE>(cp + 0, a0);
-    st_x<CACHE>(cp + 1, a1);
-    st_x<CACHE>(cp + 2, a2);
-    st_x<CACHE>(cp + 3, a3);
+    cp[0] = a0;
+    cp[1] = a1;
+    cp[2] = a2;
+    cp[3] = a3;
   }
 }
 
@@ -689,8 +689,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
   if ((lean & 1) && (D->st->rebuild || *D->ovf_count > 0)) return;
   const DevParams P = *Pp;
   __shared__ AssocShared S;
-  unsigned nnz;
-  assoc_phase<IdxT, ASSOC_CAP, GENERAL, false>(P, D, D->st, S, nullptr, nnz, pb.bx);
+  assoc_phase<IdxT, ASSOC_CAP, GENERAL>(P, D, D->st, S, pb.bx);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -800,7 +799,7 @@ __global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict_
 
 // ------------------------------------------------------------------------------------------
 // Coefficient phase: normalised twist (compute_flow host half, CvoGPU.cu:824-835) + B,C,D,E partials, one
-// thread per (sorted) row, blocks of ASSOC_THREADS rows.  Shared by k_coeff and the fused k_iter.
+// thread per row position, blocks of ASSOC_THREADS rows.
 // ------------------------------------------------------------------------------------------
 struct CoeffShared {
   double ov[6];
@@ -1005,7 +1004,7 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
   __syncthreads();
   if (tid == 0) {
     int done = 0;
-    if (twist) {  // k_iter: every block derived the same normalised twist
+    if (twist) {  // k_coeff: every block derived the same normalised twist
       for (int c = 0; c < 3; c++) {
         st->omega[c] = twist[c];
         st->v[c] = twist[3 + c];
