@@ -345,12 +345,152 @@ CUBIC_QUAL void CUBIC_NAME(const double coef[4], double re[3], double im[3]) {
   }
 }
 
+// ---- the same roots with the independent real-root searches spread over lanes 0..2 of the calling wave ----
+// Doubling phase of cubic_solve_outward, statement for statement; returns true with the bracket [lo, hi] that
+// cubic_solve_bracket has to refine, or false with the final value.
+__device__ inline bool cubic_outward_bracket(double a, double b, double c, double x0, double dir, double bound, double& lo,
+                                             double& hi, double& val) {
+  auto f = [&](double x) { return ((x + a) * x + b) * x + c; };
+  double h = fabs(x0) * 0.5;
+  if (h < 1e-3) h = 1e-3;
+  double prev = x0;
+  for (int it = 0; it < 1100; it++) {
+    double x = x0 + dir * h;
+    if (fabs(x) > bound) x = dir * bound;
+    const double fx = f(x);
+    if ((dir > 0.0) ? (fx >= 0.0) : (fx <= 0.0)) {
+      if (dir > 0.0) {
+        lo = prev;
+        hi = x;
+      } else {
+        lo = x;
+        hi = prev;
+      }
+      return true;
+    }
+    if (fabs(x) >= bound) {
+      val = x;
+      return false;
+    }
+    prev = x;
+    h *= 2.0;
+  }
+  val = prev;
+  return false;
+}
+
+// cubic_roots for a whole wave (all 64 lanes call with the same coefficients and get the same result).  Every
+// real root comes out of exactly the scalar code above - only who executes it changes: the up to three searches
+// run side by side on lanes 0..2 (first their doubling phases, then their Newton refinements), which takes the
+// time of the slowest one instead of the sum.
+__device__ inline void cubic_roots_wave(const double coef[4], double re[3], double im[3]) {
+  const int lane = (int)(threadIdx.x & 63);
+  const double nan = __builtin_nan("");
+  const double a = coef[1] / coef[0], b = coef[2] / coef[0], c = coef[3] / coef[0];
+  if (!isfinite(a) || !isfinite(b) || !isfinite(c)) {
+    for (int i = 0; i < 3; i++) re[i] = im[i] = nan;
+    return;
+  }
+  auto f = [&](double x) { return ((x + a) * x + b) * x + c; };
+  double bound = fabs(a);
+  if (fabs(b) > bound) bound = fabs(b);
+  if (fabs(c) > bound) bound = fabs(c);
+  bound = 1.0 + bound;
+  // task list in the order cubic_roots fills r[]: kind 1 = the value x0 itself, 2 = outward search from x0 in
+  // direction x1, 3 = bracket [x0, x1]
+  int kind0 = 0, kind1 = 0, kind2 = 0, nr = 0;
+  double p0 = 0, q0 = 0, p1 = 0, q1 = 0, p2 = 0, q2 = 0;
+  auto push = [&](int kind, double p, double q) {
+    if (nr == 0) {
+      kind0 = kind;
+      p0 = p;
+      q0 = q;
+    } else if (nr == 1) {
+      kind1 = kind;
+      p1 = p;
+      q1 = q;
+    } else {
+      kind2 = kind;
+      p2 = p;
+      q2 = q;
+    }
+    nr++;
+  };
+  const double dq = a * a - 3.0 * b;
+  if (!(dq > 0.0)) {
+    const double xi = -a / 3.0;
+    const double fi = f(xi);
+    if (fi == 0.0)
+      push(1, xi, 0.0);
+    else
+      push(2, xi, fi < 0.0 ? 1.0 : -1.0);
+  } else {
+    const double s = sqrt(dq);
+    const double t = (a >= 0.0) ? (-a - s) : (-a + s);
+    const double xa = t / 3.0, xb = (t != 0.0) ? b / t : 0.0;
+    const double x1 = xa < xb ? xa : xb, x2 = xa < xb ? xb : xa;
+    const double f1 = f(x1), f2 = f(x2);
+    if (f1 >= 0.0) push(f1 == 0.0 ? 1 : 2, x1, -1.0);
+    if (f1 > 0.0 && f2 < 0.0) push(3, x1, x2);
+    if (f2 <= 0.0) push(f2 == 0.0 ? 1 : 2, x2, 1.0);
+  }
+  const int kind = lane == 0 ? kind0 : (lane == 1 ? kind1 : (lane == 2 ? kind2 : 0));
+  const double p = lane == 0 ? p0 : (lane == 1 ? p1 : p2), q = lane == 0 ? q0 : (lane == 1 ? q1 : q2);
+  double val = 0.0, lo = 0.0, hi = 0.0;
+  bool refine = false;
+  if (kind == 1) {
+    val = p;
+  } else if (kind == 2) {
+    refine = cubic_outward_bracket(a, b, c, p, q, bound, lo, hi, val);
+  } else if (kind == 3) {
+    lo = p;
+    hi = q;
+    refine = true;
+  }
+  if (refine) val = cubic_solve_bracket(a, b, c, lo, hi);
+  double r[3];
+  r[0] = __shfl(val, 0);
+  r[1] = __shfl(val, 1);
+  r[2] = __shfl(val, 2);
+  if (nr == 3) {
+    for (int i = 0; i < 3; i++) {
+      re[i] = r[i];
+      im[i] = 0.0;
+    }
+  } else if (nr == 2) {
+    re[0] = r[0];
+    re[1] = r[1];
+    re[2] = -a - r[0] - r[1];
+    im[0] = im[1] = im[2] = 0.0;
+  } else {
+    const double r0 = r[0];
+    double rr, mod2;
+    if (fabs(r0) >= 0.5 * fabs(a) && r0 != 0.0) {
+      mod2 = -c / r0;
+      rr = (b - mod2) / (2.0 * r0);
+    } else {
+      rr = 0.5 * (-a - r0);
+      mod2 = b - 2.0 * r0 * rr;
+    }
+    const double ii = mod2 - rr * rr;
+    re[0] = r0;
+    im[0] = 0.0;
+    re[1] = re[2] = rr;
+    im[1] = ii > 0.0 ? sqrt(ii) : 0.0;
+    im[2] = -im[1];
+  }
+}
+
 // compute_step_size host half (CvoGPU.cu:1122-1158), overwrite quirk included.
+template <bool WAVE>
 __device__ inline float select_step(double B, double C, double D, double E, float min_step, float max_step) {
   const double DMAX = 1.7976931348623157e308;
   double p_coef[4] = {4.0 * E, 3.0 * D, 2.0 * C, B};
   double re[3], im[3];
-  cubic_roots(p_coef, re, im);
+  if (WAVE)
+    cubic_roots_wave(p_coef, re, im);  // all lanes of the wave are here
+  else
+    cubic_roots(p_coef, re, im);
   double temp_step = DMAX;
   for (int i = 0; i < 3; i++)
     if (re[i] > 0 && re[i] < temp_step && fabs(im[i]) < 1e-5) temp_step = re[i];

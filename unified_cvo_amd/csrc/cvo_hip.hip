@@ -252,6 +252,7 @@ DevParams make_dev_params(const cvo_params_t& p) {
   d.skin_frac = 0.1f;
   d.rebuild_shrink = 0.7f;
   if (const char* e = getenv("CVO_SKIN")) d.skin_frac = std::max(0.f, (float)atof(e));
+  if (const char* e = getenv("CVO_SHRINK")) d.rebuild_shrink = std::min(0.99f, std::max(0.f, (float)atof(e)));
   return d;
 }
 

@@ -931,10 +931,11 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
 // k_update: per-pair scalar bookkeeping, one wave per pair.  INIT = true is the launch before the first
 // iteration (no bookkeeping, state comes from the host).
 // ------------------------------------------------------------------------------------------
+constexpr int HOT_DWORDS = (int)(offsetof(PairState, sq) / 4);  // the scalar part of the state (the 4 KB of indicator FIFOs stay in HBM)
 struct UpdateShared {
   double c[4];
   unsigned long long n[4];
-  unsigned hot[offsetof(PairState, sq) / 4];  // the scalar part of the state (the 4 KB of indicator FIFOs stay in HBM)
+  unsigned hot[HOT_DWORDS];
 };
 
 // Executed by the first wave of the calling block (the other threads only take part in the barriers).
@@ -944,21 +945,21 @@ struct UpdateShared {
 // sum (the lean graph has no k_assoc_dense, so its slots are not read).
 template <bool INIT, bool COH>
 __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, const DevParams& P, int flags,
-                                            int n_flow_parts, UpdateShared& U, const float* twist) {
+                                            int n_flow_parts, UpdateShared& U, const float* twist,
+                                            unsigned* preloaded_hot) {
   PairState* const gst = D->st;
   const bool trio_follows = INIT || (flags & 2) != 0;
   const bool dry = (flags & 8) != 0;  // timing replay: compute everything, write nothing back
   const int horizon = flags >> 8;
   double* const s_c = U.c;
   unsigned long long* const s_n = U.n;
-  unsigned* const s_hot = U.hot;
-  constexpr int HOT_DWORDS = (int)(offsetof(PairState, sq) / 4);
+  unsigned* const s_hot = preloaded_hot ? preloaded_hot : U.hot;
   const int tid = threadIdx.x;
   const bool act = tid < 64;
 
   // the scalar part of the state is staged through LDS: one coalesced burst in, one out, instead of
   // dozens of dependent global accesses from a single lane
-  if (act)
+  if (act && !preloaded_hot)
     for (int q = tid; q < HOT_DWORDS; q += 64) s_hot[q] = reinterpret_cast<const unsigned*>(gst)[q];
   PairState* const st = reinterpret_cast<PairState*>(s_hot);
   float* const sq = gst->sq;
@@ -1002,6 +1003,9 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
     }
   }
   __syncthreads();
+  // the step of this iteration: the cubic's real roots are searched on three lanes side by side
+  float step_w = 0.f;
+  if (!INIT && act && P.mode == 0) step_w = select_step<true>(s_c[0], s_c[1], s_c[2], s_c[3], P.min_step, P.max_step);
   if (tid == 0) {
     int done = 0;
     if (twist) {  // k_coeff: every block derived the same normalised twist
@@ -1027,7 +1031,7 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
         st->C = C;
         st->D = Dd;
         st->E = E;
-        const float step = select_step(B, C, Dd, E, P.min_step, P.max_step);
+        const float step = step_w;
         st->step = step;
         const int k = st->k;
         const int K_used = st->K;
@@ -1200,7 +1204,7 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
   const PairDesc* __restrict__ D = descs + blockIdx.x;
   const DevParams P = *Pp;
   __shared__ UpdateShared U;
-  update_body<INIT, false>(D, P, flags, D->nblk_assoc + DENSE_BLOCKS, U, nullptr);
+  update_body<INIT, false>(D, P, flags, D->nblk_assoc + DENSE_BLOCKS, U, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1254,7 +1258,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
   }
   __syncthreads();
   if (!s_last) return;
-  update_body<false, true>(D, P, flags | 4, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, S.u, twist);
+  update_body<false, true>(D, P, flags | 4, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, S.u, twist, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
