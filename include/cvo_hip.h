@@ -195,6 +195,19 @@ int cvo_association(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
                     const cvo_cloud* target, const float T[16], float ell, int* row_ptr, int* col,
                     float* val, size_t capacity, size_t* nnz_out);
 
+/* ---- multi-frame edge kernel: BinaryStateGPU::update_inner_product (IRLS_State_GPU.cu:43-79) -------------
+ * A frame is a resident cloud under a pose (3x4 ROW-major floats, CvoFrameGPU.cu:7-61).
+ * cvo_cloud_transformed = CvoFrameGPU::transform_pointcloud (transform_point_pose_vec, CvoGPU_impl.cu:85-185):
+ * a new resident cloud with every point moved by the pose (features / labels / geometric types copied).
+ * cvo_edge_kernel_matrix = fill_in_A_mat_gpu(frame1, frame2, num_neighbors, ell) + compute_nonzeros +
+ * copy_internal_SparseKernelMat_gpu_to_cpu: mat / ind row-major [n1 x num_neighbors] in the reference's cleared
+ * layout (0 / -1 beyond a row's entries), nonzeros [n1], *nonzero_sum = their sum (what the caller hands to
+ * Ceres).  Any of the output pointers may be NULL. */
+int cvo_cloud_transformed(cvo_ctx* ctx, const cvo_cloud* in, const float pose_3x4_rowmajor[12], cvo_cloud** out);
+int cvo_edge_kernel_matrix(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* frame1_transformed,
+                           const cvo_cloud* frame2_transformed, float ell, int num_neighbors, float* mat, int* ind,
+                           unsigned int* nonzeros, unsigned int* nonzero_sum);
+
 /* ---- test / profiling hooks ---------------------------------------------------------- */
 /* Dumps the ELL kernel matrix of the LAST iteration executed by cvo_align_ex (row stride K):
  * mat/ind sized n_source*K, nonzeros sized n_source; K = the num_neighbors of that iteration. */

@@ -882,6 +882,19 @@ void oracle_update_tf(const float R[9], const float T[3], float R_inv[9], float 
 void oracle_transform(const float R_inv[9], const float T_inv[3], int m, const float* y0, float* yt) {
   for (int j = 0; j < m; j++) transform_point(R_inv, T_inv, y0 + 3 * j, yt + 3 * j);
 }
+// transform_point_pose_vec (CvoGPU_impl.cu:85-161), used by CvoFrameGPU::transform_pointcloud (CvoFrameGPU.cu:44-61)
+// for the multi-frame edge kernel.  `Eigen::Vector3f trans = T * input` with T 3x4 row-major and input (x, y, z, 1):
+// Eigen's unrolled 4-term inner product is (c0 + c1) + (c2 + c3); under nvcc -fmad=true the first product of each
+// sum is assumed to be the fused one and T3 * 1.0f folds to T3.  (Assumption, like every device-side contraction
+// here: no reference build exists to pin it.)
+void oracle_transform_pose_vec(const float pose12[12], int n, const float* xyz_in, float* xyz_out) {
+  const float* T = pose12;
+  for (int i = 0; i < n; i++) {
+    const float x = xyz_in[3 * i], y = xyz_in[3 * i + 1], z = xyz_in[3 * i + 2];
+    for (int r = 0; r < 3; r++)
+      xyz_out[3 * i + r] = std::fmaf(T[4 * r], x, T[4 * r + 1] * y) + std::fmaf(T[4 * r + 2], z, T[4 * r + 3]);
+  }
+}
 void oracle_se_kernel(const OracleParams* p, const OracleCloud* x, const OracleCloud* y, int K, float ell,
                       float* mat, int* ind, unsigned int* nonzeros, int literal) {
   // reset_state_at_new_iter: mat = 0, ind = -1 over rows*K (CvoState.cu:143-157)

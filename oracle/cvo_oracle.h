@@ -73,6 +73,8 @@ void oracle_indicator_run(const float* indicators, int n, int window, float thr,
 /* ---- kernel-level ---- */
 void oracle_update_tf(const float R[9], const float T[3], float R_inv[9], float T_inv[3]);
 void oracle_transform(const float R_inv[9], const float T_inv[3], int m, const float* y0, float* yt);
+/* transform_point_pose_vec (CvoGPU_impl.cu:85-161) over a cloud: 3x4 ROW-major pose times (x, y, z, 1). */
+void oracle_transform_pose_vec(const float pose12[12], int n, const float* xyz_in, float* xyz_out);
 /* fill_in_A_mat_gpu: ELL output with row stride K. mat/ind sized n*K, nonzeros sized n. */
 void oracle_se_kernel(const OracleParams* p, const OracleCloud* x, const OracleCloud* y_transformed,
                       int K, float ell, float* mat, int* ind, unsigned int* nonzeros, int literal);

@@ -74,6 +74,8 @@ def lib():
     L.oracle_update_tf.argtypes = [fp, fp, fp, fp]
     L.oracle_update_tf.restype = None
     L.oracle_transform.argtypes = [fp, fp, C.c_int, fp, fp]
+    L.oracle_transform_pose_vec.restype = None
+    L.oracle_transform_pose_vec.argtypes = [fp, C.c_int, fp, fp]
     L.oracle_transform.restype = None
     L.oracle_se_kernel.argtypes = [pp, cp, cp, C.c_int, C.c_float, fp, ip, C.POINTER(C.c_uint), C.c_int]
     L.oracle_se_kernel.restype = None
@@ -176,6 +178,14 @@ def transform_cloud(R, T, y0):
     yt = np.zeros_like(y0)
     lib().oracle_transform(_f(Ri), _f(Ti), y0.shape[0], _f(y0), _f(yt))
     return Ri.reshape(3, 3), Ti, yt
+
+
+def transform_pose_vec(pose12, xyz):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    out = np.zeros_like(xyz)
+    pose = np.ascontiguousarray(np.asarray(pose12, np.float64).reshape(12).astype(np.float32))
+    lib().oracle_transform_pose_vec(_f(pose), xyz.shape[0], _f(xyz), _f(out))
+    return out
 
 
 def se_kernel(p, x, y_transformed, K, ell, literal=False):

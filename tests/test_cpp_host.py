@@ -75,3 +75,51 @@ def test_demo_driver_matches_python_api(tmp_path):
     assert "ret 0" in out and g.ret == 0
     assert np.max(np.abs(T_cpp - g.transform)) < 5e-8  # printed with 8 decimals
     assert os.path.exists(tmp_path / "after_align.pcd")
+
+
+@pytest.mark.gpu
+def test_multiframe_edge_driver_matches_python_mirror(tmp_path):
+    """cvo::CvoFrameGPU + cvo::BinaryStateGPU (SURVEY.md 8(f) rank 2) through the C++ veneer == the Python mirror."""
+    from unified_cvo_amd import CvoGPU, CvoPointCloud, CvoFrameGPU, BinaryStateGPU
+    edge_bin = os.path.join(HOST, "cvo_multiframe_edge")
+    sx, sr, tx, tr = cases.demo_clouds()
+    _write_pcd(tmp_path / "f1.pcd", sx, sr)
+    _write_pcd(tmp_path / "f2.pcd", tx, tr)
+    yaml = os.path.join(cases.CONFIGS, "outdoor.yaml")
+    pose2 = np.array([[0.9998, -0.0175, 0.01, 0.2], [0.0175, 0.9998, 0.0, -0.1], [-0.01, 0.0002, 0.99995, 0.05]])
+    K, ell = 64, 0.5
+    out = subprocess.check_output([edge_bin, str(tmp_path / "f1.pcd"), str(tmp_path / "f2.pcd"), yaml, str(K), str(ell)] +
+                                  [repr(float(v)) for v in pose2.reshape(-1)], text=True)
+    rows = {l.split()[0]: l.split() for l in out.strip().splitlines()}
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        P = read_cvo_params_yaml(yaml)
+    gpu = CvoGPU(params=P)
+    c1, c2 = CvoPointCloud.from_xyzrgb(sx, sr), CvoPointCloud.from_xyzrgb(tx, tr)
+    f1 = CvoFrameGPU(gpu, c1, np.hstack([np.eye(3), np.zeros((3, 1))]))
+    f2 = CvoFrameGPU(gpu, c2, pose2)
+    st = BinaryStateGPU(f1, f2, K, ell)
+
+    def summary():
+        m, i = st.mat, st.ind
+        w = np.arange(1, i.shape[1] + 1)
+        valid = i >= 0
+        return int(st.nonzero_sum), i.shape[1], float(m[valid].astype(np.float64).sum()), int((i * w * valid).sum())
+
+    st.update_inner_product()
+    for tag in ("first", "second"):
+        if tag == "second":
+            st.update_inner_product()
+        r = rows[tag]
+        nz, k, vs, cs = summary()
+        assert (int(r[2]), int(r[4]), int(r[8])) == (nz, k, cs), tag
+        assert float(r[6]) == pytest.approx(vs, rel=1e-6)
+    st.ell = st.ell * P.multiframe_ell_decay_rate if st.ell > P.multiframe_ell_min else st.ell
+    f2.pose_vec[3] += 0.25
+    f2.transform_pointcloud()
+    st.update_inner_product()
+    nz, k, vs, cs = summary()
+    r = rows["moved"]
+    assert (int(r[2]), int(r[4]), int(r[8])) == (nz, k, cs)
+    assert float(r[10]) == pytest.approx(st.ell, rel=1e-6)

@@ -389,3 +389,51 @@ def test_timing_replay_leaves_the_context_usable():
     assert np.array_equal(a.transform, b.transform)
     ip0 = gpu.inner_product_gpu(src, tgt, init, P.ell_init)
     assert ip0 == gpu.inner_product_gpu(src, tgt, init, P.ell_init)
+
+
+def _pose34(angle_deg, axis, t):
+    a = np.asarray(axis, np.float64) / np.linalg.norm(axis)
+    th = np.deg2rad(angle_deg)
+    Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    return np.hstack([R, np.asarray(t, np.float64).reshape(3, 1)])
+
+
+@pytest.mark.parametrize("builder,kw,K", [(cases.config2, dict(n=1500), 64), (cases.config3, dict(n=1200), 32),
+                                          (cases.config4, dict(n=1000), 128)])
+def test_multiframe_edge_kernel_matrix(oracle, builder, kw, K):
+    """SURVEY.md 8(f) rank 2: BinaryStateGPU::update_inner_product = both frames under their own 3x4 pose, then
+    fill_in_A_mat_gpu with the edge's K and ell, returned in the reference's host layout.  Bit-exact vs the oracle."""
+    P, c1, c2, _ = builder(**kw)
+    pose1 = _pose34(2.0, (0.1, 1.0, 0.2), (0.05, -0.02, 0.1))
+    pose2 = _pose34(-1.0, (1.0, 0.2, 0.0), (-0.3, 0.05, -0.35))
+    gpu = CvoGPU(params=P)
+    f1, f2 = gpu.transformed(gpu.upload(c1), pose1), gpu.transformed(gpu.upload(c2), pose2)
+    ell = 0.6
+    mat, ind, nz, total = gpu.edge_kernel_matrix(f1, f2, ell, K)
+    x1, fe1, la1, ge1 = c1.device_arrays()
+    x2, fe2, la2, ge2 = c2.device_arrays()
+    o1 = oracle.Cloud(oracle.transform_pose_vec(pose1, x1), fe1, la1, ge1)
+    o2 = oracle.Cloud(oracle.transform_pose_vec(pose2, x2), fe2, la2, ge2)
+    omat, oind, onz = oracle.se_kernel(oracle.params_from(P), o1, o2, K, ell)
+    assert total == int(onz.sum()) and total > 0
+    assert np.array_equal(nz, onz)
+    assert np.array_equal(ind, oind)                  # ordered first-K truncation, -1 padding
+    assert np.allclose(mat, omat, rtol=2e-6, atol=0)  # exp() is the only difference (ocml vs glibc, <= 1 ulp)
+
+
+def test_binary_state_gpu_adapts_neighbours():
+    """The reference's neighbour-count adaptation (IRLS_State_GPU.cu:45-47) around the same kernel."""
+    from unified_cvo_amd import CvoFrameGPU, BinaryStateGPU
+    P, c1, c2, _ = cases.config2(n=1200)
+    gpu = CvoGPU(params=P)
+    f1 = CvoFrameGPU(gpu, c1, _pose34(0.0, (0, 0, 1), (0, 0, 0)))
+    f2 = CvoFrameGPU(gpu, c2, np.linalg.inv(np.vstack([synth.gt_motion()[:3], [0, 0, 0, 1]]))[:3])
+    st = BinaryStateGPU(f1, f2, num_neighbor=128, init_ell=0.3)
+    n0 = st.update_inner_product()
+    assert n0 > 0 and st.mat.shape == (1200, 128)
+    assert st.update_inner_product() == n0            # same frames, K shrinks to 1.1 * max row count but keeps every entry
+    assert st.num_neighbors == min(128, int(int(st.nonzeros.max()) * 1.1))
+    f2.pose_vec[3] += 0.4                            # move frame 2 and refresh it: the matrix changes
+    f2.transform_pointcloud()
+    assert st.update_inner_product() != n0

@@ -145,3 +145,19 @@ def test_alignment_recovers_ground_truth(oracle):
     r = oracle.align(op, oracle.Cloud.from_pointcloud(src), oracle.Cloud.from_pointcloud(tgt), init)
     assert r["iterations"] == P.MAX_ITER  # clamped at min_step, never reaches eps_2
     assert np.max(np.abs(r["transform"] - np.linalg.inv(synth.gt_motion()))) < 3e-3
+
+
+def test_transform_pose_vec_matches_float64(oracle):
+    """transform_point_pose_vec (multi-frame frames): float32 result within a few ulp of the float64 product."""
+    rs = np.random.default_rng(5)
+    xyz = rs.uniform(-30, 30, (2000, 3)).astype(np.float32)
+    ang = 0.3
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    pose = np.hstack([R, np.array([[0.5], [-1.25], [2.0]])])
+    got = oracle.transform_pose_vec(pose, xyz)
+    pose32 = pose.astype(np.float32).astype(np.float64)
+    want = xyz.astype(np.float64) @ pose32[:, :3].T + pose32[:, 3]
+    assert np.max(np.abs(got - want)) < 2e-5          # |coords| <= ~45: a handful of float32 ulps
+    # identity pose reproduces the input exactly (the edge kernel relies on it)
+    I = np.hstack([np.eye(3), np.zeros((3, 1))])
+    assert np.array_equal(oracle.transform_pose_vec(I, xyz), xyz)

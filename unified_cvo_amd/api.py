@@ -358,6 +358,32 @@ class CvoGPU:
                                            col.ctypes.data_as(C.POINTER(C.c_int)), _fptr(val), cap, C.byref(nnz)))
         return row_ptr, col[:nnz.value], val[:nnz.value]
 
+    # -- multi-frame edge kernel (BinaryStateGPU::update_inner_product, IRLS_State_GPU.cu:43-79) ----
+    def transformed(self, cloud, pose_3x4):
+        """CvoFrameGPU::transform_pointcloud: a new resident cloud moved by a 3x4 row-major pose."""
+        src = self._dev(cloud)
+        pose = np.ascontiguousarray(np.asarray(pose_3x4, np.float64).reshape(12).astype(np.float32))
+        h = C.c_void_p()
+        self._check(self.L.cvo_cloud_transformed(self.ctx, src.handle, _fptr(pose), C.byref(h)))
+        out = DeviceCloud.__new__(DeviceCloud)
+        out.gpu, out.n, out._keep, out.handle = self, src.n, None, h
+        return out
+
+    def edge_kernel_matrix(self, frame1, frame2, ell, num_neighbors):
+        """fill_in_A_mat_gpu on two transformed frames -> (mat, ind, nonzeros, nonzero_sum) in the reference's host
+        layout ([n1 x K] row-major, 0 / -1 padded)."""
+        f1, f2 = self._dev(frame1), self._dev(frame2)
+        K = int(num_neighbors)
+        mat = np.zeros((f1.n, K), np.float32)
+        ind = np.zeros((f1.n, K), np.int32)
+        nz = np.zeros(f1.n, np.uint32)
+        total = C.c_uint()
+        p = self.params.to_ctypes()
+        self._check(self.L.cvo_edge_kernel_matrix(self.ctx, C.byref(p), f1.handle, f2.handle, float(ell), K, _fptr(mat),
+                                                  ind.ctypes.data_as(C.POINTER(C.c_int)),
+                                                  nz.ctypes.data_as(C.POINTER(C.c_uint)), C.byref(total)))
+        return mat, ind, nz, total.value
+
     # -- test / profiling hooks --------------------------------------------------------------------
     def debug_last_ell(self, n_rows, K):
         mat = np.zeros((n_rows, K), np.float32)
@@ -398,3 +424,49 @@ class CvoGPU:
         v = C.c_ulonglong()
         self._check(self.L.cvo_debug_last_candidates(self.ctx, C.byref(v)))
         return v.value
+
+
+class CvoFrameGPU:
+    """cvo::CvoFrameGPU (CvoFrameGPU.hpp:14-36): a point cloud under a 3x4 row-major pose; transform_pointcloud()
+    refreshes the transformed copy resident on the device."""
+
+    def __init__(self, gpu, pts, poses):
+        self.gpu = gpu
+        self.points = pts
+        self.pose_vec = np.asarray(poses, np.float64).reshape(12).copy()
+        self._init = gpu.upload(pts)
+        self._transformed = None
+        self.transform_pointcloud()
+
+    def transform_pointcloud(self):
+        if self._transformed is not None:
+            self._transformed.free()
+        self._transformed = self.gpu.transformed(self._init, self.pose_vec)
+
+    def points_transformed_gpu(self):
+        return self._transformed
+
+
+class BinaryStateGPU:
+    """cvo::BinaryStateGPU (IRLS_State_GPU.hpp:21-89) without the Ceres half: update_inner_product() recomputes the
+    edge's kernel matrix from the two frames' current transformed clouds, with the reference's neighbour-count
+    adaptation (IRLS_State_GPU.cu:45-47)."""
+
+    def __init__(self, frame1, frame2, num_neighbor, init_ell):
+        self.frame1, self.frame2 = frame1, frame2
+        self.init_num_neighbors = int(num_neighbor)
+        self.num_neighbors = int(num_neighbor)
+        self.ell = float(init_ell)
+        self.iter = 0
+        self.mat = self.ind = self.nonzeros = None
+        self.nonzero_sum = 0
+
+    def update_inner_product(self):
+        last = int(self.nonzeros.max()) if self.nonzeros is not None and self.nonzeros.size else 0
+        if last > 0:
+            self.num_neighbors = min(self.init_num_neighbors, int(last * 1.1))
+        gpu = self.frame1.gpu
+        self.mat, self.ind, self.nonzeros, self.nonzero_sum = gpu.edge_kernel_matrix(
+            self.frame1.points_transformed_gpu(), self.frame2.points_transformed_gpu(), self.ell, self.num_neighbors)
+        self.iter += 1
+        return self.nonzero_sum

@@ -39,7 +39,7 @@ struct DevParams {
   // grown by skin = skin_frac * ell * sqrt(-2 log_geo); its bitmap stays valid while the targets have moved
   // less than the skin and ell has not grown.  0 = scan every iteration.
   float skin_frac;
-  float rebuild_shrink;  // rebuild when ell < rebuild_shrink * ell_build (the list would be far too long)
+  float rebuild_shrink;  // rebuild when ell < rebuild_shrink * ell_build (the lists would be (1/shrink)^3 too long)
   int lean_U;            // iterations between two rebuild opportunities in the lean graph
 };
 
@@ -175,6 +175,16 @@ __device__ __forceinline__ V3 matvec_dev(const M3& a, V3 v) {
 __device__ __forceinline__ V3 transform_point(const float* Ri, const float* Ti, float x, float y, float z) {
   return {dot3_dev(Ri[0], Ri[1], Ri[2], x, y, z) + Ti[0], dot3_dev(Ri[3], Ri[4], Ri[5], x, y, z) + Ti[1],
           dot3_dev(Ri[6], Ri[7], Ri[8], x, y, z) + Ti[2]};
+}
+
+// transform_point_pose_vec (CvoGPU_impl.cu:85-161): a 3x4 ROW-major pose times (x, y, z, 1).  Eigen evaluates the
+// fixed-size 4-term inner product as (c0 + c1) + (c2 + c3); with nvcc's fmad contraction that is assumed to lower to
+// fma(T0, x, T1*y) + fma(T2, z, T3) (the first product of each sum is fused; T3 * 1.0f folds).  The oracle mirrors
+// exactly this form; like everything else here it is unpinned against a real reference build.
+__device__ __forceinline__ V3 transform_point_pose_vec(const float* T, float x, float y, float z) {
+  return {__builtin_fmaf(T[0], x, T[1] * y) + __builtin_fmaf(T[2], z, T[3]),
+          __builtin_fmaf(T[4], x, T[5] * y) + __builtin_fmaf(T[6], z, T[7]),
+          __builtin_fmaf(T[8], x, T[9] * y) + __builtin_fmaf(T[10], z, T[11])};
 }
 
 // compute_range_ell (CvoGPU.cu:86-90)

@@ -24,6 +24,7 @@ struct cvo_cloud {
   int device = 0;
   int n = 0;
   char* slab = nullptr;     // the one device allocation behind the pointers below
+  size_t slab_bytes = 0;
   float4* x4 = nullptr;
   float4* xs4 = nullptr;    // x4 permuted into the spatial order
   float4* feat = nullptr;   // 2 float4 per point
@@ -250,7 +251,7 @@ DevParams make_dev_params(const cvo_params_t& p) {
   d.use_range_ell = p.is_using_range_ell != 0;
   d.use_geotype = p.is_using_geometric_type != 0;
   d.skin_frac = 0.1f;
-  d.rebuild_shrink = 0.7f;
+  d.rebuild_shrink = 0.9f;
   if (const char* e = getenv("CVO_SKIN")) d.skin_frac = std::max(0.f, (float)atof(e));
   if (const char* e = getenv("CVO_SHRINK")) d.rebuild_shrink = std::min(0.99f, std::max(0.f, (float)atof(e)));
   return d;
@@ -773,6 +774,7 @@ static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, cons
   const size_t o_x4 = take(sizeof(float4) * nn), o_xs4 = take(sizeof(float4) * nn), o_feat = take(sizeof(float4) * 2 * nn),
                o_label = take(sizeof(float4) * 5 * nn), o_geo = take(sizeof(float2) * nn), o_order = take(sizeof(int) * nn);
   hipError_t e = hipMalloc(&c->slab, off);
+  c->slab_bytes = off;
   if (e != hipSuccess) {
     cvo_cloud_free(c);
     return fail(ctx, CVO_E_NOMEM, std::string("cloud hipMalloc: ") + hipGetErrorString(e));
@@ -833,6 +835,53 @@ int cvo_cloud_upload_aos192(cvo_ctx* ctx, int n, const void* pts, cvo_cloud** ou
     std::memcpy(&g2[2 * (size_t)i], r + 120, 8);
   }
   return upload_packed(ctx, n, x4, f8, l20, g2, out);
+}
+
+// ---- multi-frame edge kernel ---------------------------------------------------------
+int cvo_cloud_transformed(cvo_ctx* ctx, const cvo_cloud* in, const float pose12[12], cvo_cloud** out) {
+  if (!ctx || !in || !pose12 || !out) return fail(ctx, CVO_E_INVALID, "cvo_cloud_transformed: bad argument");
+  if (in->ctx != ctx) return fail(ctx, CVO_E_INVALID, "cloud belongs to another context");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  cvo_cloud* c = new cvo_cloud();
+  c->ctx = ctx;
+  c->device = ctx->device;
+  c->n = in->n;
+  c->h_order = in->h_order;
+  c->slab_bytes = in->slab_bytes;
+  hipError_t e = hipMalloc(&c->slab, std::max<size_t>(in->slab_bytes, 256));
+  if (e != hipSuccess) {
+    delete c;
+    return fail(ctx, CVO_E_NOMEM, std::string("cloud hipMalloc: ") + hipGetErrorString(e));
+  }
+  // same slab layout: features, labels, geometric types and the spatial order are copied, coordinates rewritten
+  auto rebase = [&](const void* p) { return c->slab + ((const char*)p - in->slab); };
+  c->x4 = (float4*)rebase(in->x4);
+  c->xs4 = (float4*)rebase(in->xs4);
+  c->feat = (float4*)rebase(in->feat);
+  c->label = (float4*)rebase(in->label);
+  c->geo = (float2*)rebase(in->geo);
+  c->order = (int*)rebase(in->order);
+  Pose12 P;
+  for (int q = 0; q < 12; q++) P.T[q] = pose12[q];
+  if (in->n > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(c->slab, in->slab, in->slab_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_transform_pose, dim3((in->n + 255) / 256), dim3(256), 0, ctx->stream, in->n, P, in->x4, in->xs4,
+                       c->x4, c->xs4);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // cull centre and motion bound of the moved cloud (neither influences a result)
+  const float* T = pose12;
+  c->cx = T[0] * in->cx + T[1] * in->cy + T[2] * in->cz + T[3];
+  c->cy = T[4] * in->cx + T[5] * in->cy + T[6] * in->cz + T[7];
+  c->cz = T[8] * in->cx + T[9] * in->cy + T[10] * in->cz + T[11];
+  if (!std::isfinite(c->cx) || !std::isfinite(c->cy) || !std::isfinite(c->cz)) c->cx = c->cy = c->cz = 0.f;
+  double fro = 0;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) fro += (double)T[4 * i + j] * T[4 * i + j];
+  c->rmax = (float)((std::sqrt(fro) * in->rmax + std::sqrt((double)T[3] * T[3] + (double)T[7] * T[7] + (double)T[11] * T[11])) * 1.000001);
+  *out = c;
+  return CVO_OK;
 }
 
 int cvo_cloud_size(const cvo_cloud* c) { return c ? c->n : 0; }
@@ -1151,6 +1200,44 @@ int cvo_association(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
   row_ptr[N] = (int)cnt;
   if (nnz_out) *nnz_out = cnt;
   if (cnt > capacity) return fail(ctx, CVO_E_NOMEM, "association capacity too small");
+  return CVO_OK;
+}
+
+int cvo_edge_kernel_matrix(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* frame1, const cvo_cloud* frame2,
+                           float ell, int num_neighbors, float* mat, int* ind, unsigned int* nonzeros,
+                           unsigned int* nonzero_sum) {
+  if (!ctx || !params || num_neighbors <= 0)
+    return fail(ctx, CVO_E_INVALID, "cvo_edge_kernel_matrix: bad argument");
+  if (!frame1 || !frame2) return fail(ctx, CVO_E_INVALID, "null cloud");
+  if (nonzero_sum) *nonzero_sum = 0;
+  if (frame1->n == 0 || frame2->n == 0) return CVO_OK;
+  // fill_in_A_mat_gpu on the two (already transformed) frames with the caller's K and ell: a single evaluation
+  // at the identity pose (R = I, T = 0 reproduces every coordinate exactly)
+  cvo_params_t p = *params;
+  p.nearest_neighbors_max = num_neighbors;
+  const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  BatchSetup S;
+  int rc = run_single_eval(ctx, &p, frame1, frame2, I, ell, &S);
+  if (rc != CVO_OK) return rc;
+  std::vector<unsigned> nz;
+  std::vector<float> a;
+  std::vector<int> jj;
+  unsigned mx = 0;
+  rc = fetch_ell(ctx, 0, nz, a, jj, &mx);
+  if (rc != CVO_OK) return rc;
+  const int N = frame1->n, K = num_neighbors;
+  unsigned long long sum = 0;
+  for (int r = 0; r < N; r++) {
+    const int i = ctx->last_xorder[r];  // sorted row r holds original row i
+    if (nonzeros) nonzeros[i] = nz[r];
+    sum += nz[r];
+    for (int s2 = 0; s2 < K; s2++) {  // the reference's cleared layout: mat = 0, ind = -1 beyond the row's entries
+      const bool ok = (unsigned)s2 < nz[r];
+      if (mat) mat[(size_t)i * K + s2] = ok ? a[(size_t)s2 * N + r] : 0.f;
+      if (ind) ind[(size_t)i * K + s2] = ok ? jj[(size_t)s2 * N + r] : -1;
+    }
+  }
+  if (nonzero_sum) *nonzero_sum = (unsigned int)sum;
   return CVO_OK;
 }
 

@@ -1421,4 +1421,24 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_transform_pose: CvoFrameGPU::transform_pointcloud (CvoFrameGPU.cu:44-61) - the points of a frame under its
+// 3x4 row-major pose, for the multi-frame edge kernel.  Both copies of the coordinates (original and spatial
+// order) are rewritten; a rigid motion keeps the spatial order compact, so it is reused.
+// ------------------------------------------------------------------------------------------
+struct Pose12 {
+  float T[12];
+};
+__global__ __launch_bounds__(256) void k_transform_pose(int n, Pose12 pose, const float4* __restrict__ in_x4,
+                                                        const float4* __restrict__ in_xs4, float4* __restrict__ out_x4,
+                                                        float4* __restrict__ out_xs4) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 a = in_x4[i], b = in_xs4[i];
+  const V3 ta = transform_point_pose_vec(pose.T, a.x, a.y, a.z);
+  const V3 tb = transform_point_pose_vec(pose.T, b.x, b.y, b.z);
+  out_x4[i] = make_float4(ta.x, ta.y, ta.z, 0.f);
+  out_xs4[i] = make_float4(tb.x, tb.y, tb.z, 0.f);
+}
+
 }  // namespace cvo_dev
