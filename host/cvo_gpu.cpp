@@ -182,4 +182,32 @@ void CvoGPU::compute_association_gpu(const CvoPointCloud& a, const CvoPointCloud
   fill_association(ctx, params, s.h, t.h, T, ell, association);
 }
 
+void CvoGPU::compute_association_gpu(const CvoPointCloud& a, const CvoPointCloud& b, const Mat4f& T, const Mat3f& kernel,
+                                     Association& association) const {
+  if (a.num_points() == 0 || b.num_points() == 0) return;
+  DeviceCloud s, t;
+  upload(ctx, a, s);
+  upload(ctx, b, t);
+  const int n = a.num_points();
+  Association& as = association;
+  as.source_inliers.clear();
+  as.target_inliers.clear();
+  as.pairs.rows = n;
+  as.pairs.cols = b.num_points();
+  as.pairs.row_ptr.assign(n + 1, 0);
+  size_t nnz = 0;
+  int rc = cvo_association_non_isotropic(ctx, &params, s.h, t.h, T.data(), kernel.data(), as.pairs.row_ptr.data(), nullptr,
+                                         nullptr, 0, &nnz);
+  if (rc != CVO_E_NOMEM) check(ctx, rc, "cvo_association_non_isotropic");
+  as.pairs.col.assign(nnz, 0);
+  as.pairs.val.assign(nnz, 0.f);
+  if (nnz)
+    check(ctx, cvo_association_non_isotropic(ctx, &params, s.h, t.h, T.data(), kernel.data(), as.pairs.row_ptr.data(),
+                                             as.pairs.col.data(), as.pairs.val.data(), nnz, &nnz),
+          "cvo_association_non_isotropic");
+  for (int i = 0; i < n; i++)
+    if (as.pairs.row_ptr[i + 1] > as.pairs.row_ptr[i]) as.source_inliers.push_back(i);
+  as.target_inliers = as.pairs.col;
+}
+
 }  // namespace cvo

@@ -48,6 +48,10 @@ class CvoGPU {
   void compute_association_gpu(const CvoPointCloud& source_points, const CvoPointCloud& target_points,
                                const Mat4f& T_target_frame_to_source_frame, float lengthscale,
                                Association& association) const;
+  // Non-isotropic (Mahalanobis) kernel d^T K^-1 d: no geometric cut-off, geometric types off (CvoGPU.cu:1967-1988).
+  void compute_association_gpu(const CvoPointCloud& source_points, const CvoPointCloud& target_points,
+                               const Mat4f& T_target_frame_to_source_frame, const Mat3f& non_isotropic_kernel,
+                               Association& association) const;
 
  private:
   CvoParams params;

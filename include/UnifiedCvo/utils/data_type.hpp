@@ -32,6 +32,20 @@ struct Mat4f {
   Mat4f inverse_rigid() const;  // [R | t]^-1 = [R^T | -R^T t]
 };
 
+// 3x3 float matrix, COLUMN-major like Eigen::Matrix3f: element (r, c) is m[3*c + r].
+struct Mat3f {
+  float m[9];
+  static Mat3f Identity() {
+    Mat3f I{};
+    I.m[0] = I.m[4] = I.m[8] = 1.f;
+    return I;
+  }
+  float& operator()(int r, int c) { return m[3 * c + r]; }
+  float operator()(int r, int c) const { return m[3 * c + r]; }
+  float* data() { return m; }
+  const float* data() const { return m; }
+};
+
 // Dynamic float matrix, COLUMN-major like Eigen::MatrixXf (features_: N x F, labels_: N x C).
 class MatXf {
  public:

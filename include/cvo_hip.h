@@ -195,6 +195,14 @@ int cvo_association(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
                     const cvo_cloud* target, const float T[16], float ell, int* row_ptr, int* col,
                     float* val, size_t capacity, size_t* nnz_out);
 
+/* ---- compute_association_gpu(..., const Eigen::Matrix3f& non_isotropic_kernel) (CvoGPU.cu:1913-1995) ---------
+ * Association under a Mahalanobis distance d^T kernel^-1 d (fill_in_A_mat_gpu_dense_mat_kernel, CvoGPU.cu:217-327):
+ * no geometric cut-off, geometric types off, K = nearest_neighbors_max.  kernel: 9 floats in Eigen::Matrix3f
+ * (column-major) layout.  Output as cvo_association. */
+int cvo_association_non_isotropic(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source,
+                                  const cvo_cloud* target, const float T[16], const float kernel_colmajor[9],
+                                  int* row_ptr, int* col, float* val, size_t capacity, size_t* nnz_out);
+
 /* ---- multi-frame edge kernel: BinaryStateGPU::update_inner_product (IRLS_State_GPU.cu:43-79) -------------
  * A frame is a resident cloud under a pose (3x4 ROW-major floats, CvoFrameGPU.cu:7-61).
  * cvo_cloud_transformed = CvoFrameGPU::transform_pointcloud (transform_point_pose_vec, CvoGPU_impl.cu:85-185):

@@ -1049,6 +1049,104 @@ int oracle_association(const OracleParams* p, const OracleCloud* x, const Oracle
   return cnt;
 }
 
+// ---- non-isotropic kernel (CvoGPU.cu:152-171, 217-327, 1913-1995) ---------------------------------------------
+// Eigen 3.3.9 Matrix3f::inverse() (Inverse.h, compute_inverse<..., 3>): cofactors, det = c00*m00 + (c10*m10 +
+// c20*m20), result = cofactor^T * (1/det); host code, plain float arithmetic.  m and out are ROW-major here.
+static void inverse3_eigen(const float m[9], float out[9]) {
+  auto M = [&](int i, int j) { return m[3 * i + j]; };
+  auto cof = [&](int i, int j) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return M(i1, j1) * M(i2, j2) - M(i1, j2) * M(i2, j1);
+  };
+  const float c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
+  const float p0 = c0 * M(0, 0), p1 = c1 * M(1, 0), p2 = c2 * M(2, 0);
+  const float det = p0 + (p1 + p2);
+  const float invdet = 1.0f / det;
+  out[0] = c0 * invdet;  // result.row(0) = cofactors_col0 * invdet
+  out[1] = c1 * invdet;
+  out[2] = c2 * invdet;
+  out[3] = cof(0, 1) * invdet;
+  out[4] = cof(1, 1) * invdet;
+  out[5] = cof(2, 1) * invdet;
+  out[6] = cof(0, 2) * invdet;
+  out[7] = cof(1, 2) * invdet;
+  out[8] = cof(2, 2) * invdet;
+}
+
+int oracle_association_non_isotropic(const OracleParams* p, const OracleCloud* x, const OracleCloud* y0,
+                                     const float Tm[16], const float kernel_cm[9], int* row_ptr, int* col, float* val,
+                                     float* kinv_out) {
+  OracleParams P = *p;
+  P.is_using_geometric_type = 0;  // CvoGPU.cu:1950-1951
+  const CloudView X = view(x), Y0 = view(y0);
+  float R[9], T[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Tm[4 * j + i];
+    T[i] = Tm[12 + i];
+  }
+  float Ri[9], Ti[3];
+  update_tf_impl(R, T, Ri, Ti);
+  std::vector<float> yt(3 * (size_t)Y0.n);
+  for (int j = 0; j < Y0.n; j++) transform_point(Ri, Ti, Y0.p(j), &yt[3 * (size_t)j]);
+  CloudView Y = Y0;
+  Y.xyz = yt.data();
+  float km[9], kinv[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) km[3 * i + j] = kernel_cm[3 * j + i];
+  inverse3_eigen(km, kinv);
+  if (kinv_out)
+    for (int q = 0; q < 9; q++) kinv_out[q] = kinv[q];
+  // prologue of fill_in_A_mat_gpu_dense_mat_kernel (CvoGPU.cu:233-252): squares kept in float, no geometric cut-off
+  const float sigma_square = P.sigma * P.sigma, c_ell_square = P.c_ell * P.c_ell, s_ell_square = P.s_ell * P.s_ell;
+  const float c_sigma_square = P.c_sigma * P.c_sigma, s_sigma_square = P.s_sigma * P.s_sigma;
+  float d2_c_thres = 1, d2_s_thres = 1;
+  if (P.is_using_intensity) d2_c_thres = (float)(-2.0 * c_ell_square * (double)std::log(P.sp_thres / c_sigma_square));
+  if (P.is_using_semantics) d2_s_thres = (float)(-2.0 * s_ell_square * (double)std::log(P.sp_thres / s_sigma_square));
+  const int K = P.nearest_neighbors_max;
+  int cnt = 0;
+  // fill_in_A_mat_gpu_dense_mat_kernel, CvoGPU.cu:217-327 (literal; rows sequential so the CSR is built in place)
+  for (int i = 0; i < X.n; i++) {
+    row_ptr[i] = cnt;
+    unsigned num_inds = 0;
+    for (int j = 0; j < Y.n; j++) {
+      if (num_inds == (unsigned)K) break;
+      float a = 1, sk = 1, ck = 1, k = 1, geo_sim = 1;
+      if (P.is_using_geometry) {
+        // mahananobis_distance (CvoGPU.cu:152-171): dist = a - b; (dist^T * kernel_inv) * dist, device code
+        const float d0 = X.p(i)[0] - Y.p(j)[0], d1 = X.p(i)[1] - Y.p(j)[1], d2v = X.p(i)[2] - Y.p(j)[2];
+        const float r0 = dot3_dev(d0, d1, d2v, kinv[0], kinv[3], kinv[6]);
+        const float r1 = dot3_dev(d0, d1, d2v, kinv[1], kinv[4], kinv[7]);
+        const float r2 = dot3_dev(d0, d1, d2v, kinv[2], kinv[5], kinv[8]);
+        const float d2 = dot3_dev(r0, r1, r2, d0, d1, d2v);
+        k = (float)((double)sigma_square * std::exp((double)(-d2) / 2.0));
+      }
+      if (P.is_using_intensity) {
+        float d2_color = squared_dist_n(X.f(i), Y.f(j), FD);
+        if (d2_color < d2_c_thres)
+          ck = (float)((double)c_sigma_square * std::exp((double)(-d2_color) / (2.0 * c_ell_square)));
+        else
+          continue;
+      }
+      if (P.is_using_semantics) {
+        float d2_semantic = squared_dist_n(X.l(i), Y.l(j), NC);
+        if (d2_semantic < d2_s_thres)
+          sk = (float)((double)s_sigma_square * std::exp((double)(-d2_semantic) / (2.0 * s_ell_square)));
+        else
+          continue;
+      }
+      a = ck * k * sk * geo_sim;
+      if (a > P.sp_thres) {
+        col[cnt] = j;
+        val[cnt] = a;
+        cnt++;
+        num_inds++;
+      }
+    }
+  }
+  row_ptr[X.n] = cnt;
+  return cnt;
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -104,6 +104,13 @@ int oracle_association(const OracleParams* p, const OracleCloud* x, const Oracle
                        const float T_colmajor[16], float ell, int* row_ptr /* n+1 */, int* col,
                        float* val);
 
+/* Non-isotropic kernel: compute_association_gpu(..., const Eigen::Matrix3f& kernel) (CvoGPU.cu:217-327, 1913-1995):
+ * Mahalanobis distance d^T kernel^-1 d, no geometric cut-off, geometric types off.  kernel_colmajor: 9 floats in
+ * Eigen::Matrix3f layout.  kernel_inv_rowmajor_out (optional, 9 floats) receives the restated Eigen inverse. */
+int oracle_association_non_isotropic(const OracleParams* p, const OracleCloud* x, const OracleCloud* y,
+                                     const float T_colmajor[16], const float kernel_colmajor[9], int* row_ptr,
+                                     int* col, float* val, float* kernel_inv_rowmajor_out);
+
 int oracle_num_threads(void);
 void oracle_set_num_threads(int n);
 

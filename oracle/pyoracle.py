@@ -74,6 +74,8 @@ def lib():
     L.oracle_update_tf.argtypes = [fp, fp, fp, fp]
     L.oracle_update_tf.restype = None
     L.oracle_transform.argtypes = [fp, fp, C.c_int, fp, fp]
+    L.oracle_association_non_isotropic.restype = C.c_int
+    L.oracle_association_non_isotropic.argtypes = [pp, cp, cp, fp, fp, ip, ip, fp, fp]
     L.oracle_transform_pose_vec.restype = None
     L.oracle_transform_pose_vec.argtypes = [fp, C.c_int, fp, fp]
     L.oracle_transform.restype = None
@@ -249,6 +251,22 @@ def association(p, x, y, T, ell):
     cnt = lib().oracle_association(C.byref(p), C.byref(x.c), C.byref(y.c), _f(_cm(T)), ell,
                                    row_ptr.ctypes.data_as(ip), col.ctypes.data_as(ip), _f(val))
     return row_ptr, col[:cnt], val[:cnt]
+
+
+def association_non_isotropic(p, x, y, T, kernel):
+    """CSR (row_ptr, col, val) + the restated inverse of `kernel` (3x3)."""
+    n = x.n
+    K = p.nearest_neighbors_max
+    cap = n * min(K, y.n)
+    row_ptr = np.zeros(n + 1, np.int32)
+    col = np.zeros(max(cap, 1), np.int32)
+    val = np.zeros(max(cap, 1), np.float32)
+    kcm = np.ascontiguousarray(np.asarray(kernel, np.float32).reshape(3, 3).T).reshape(9)
+    kinv = np.zeros(9, np.float32)
+    cnt = lib().oracle_association_non_isotropic(C.byref(p), C.byref(x.c), C.byref(y.c), _f(_cm(T)), _f(kcm),
+                                                 row_ptr.ctypes.data_as(C.POINTER(C.c_int)),
+                                                 col.ctypes.data_as(C.POINTER(C.c_int)), _f(val), _f(kinv))
+    return row_ptr, col[:cnt], val[:cnt], kinv.reshape(3, 3)
 
 
 def num_threads():

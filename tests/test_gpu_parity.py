@@ -437,3 +437,39 @@ def test_binary_state_gpu_adapts_neighbours():
     f2.pose_vec[3] += 0.4                            # move frame 2 and refresh it: the matrix changes
     f2.transform_pointcloud()
     assert st.update_inner_product() != n0
+
+
+def _rot(angle_deg, axis):
+    return _pose34(angle_deg, axis, (0, 0, 0))[:, :3]
+
+
+@pytest.mark.parametrize("builder,kw", [(cases.config2, dict(n=1500)), (cases.config3, dict(n=1200)),
+                                        (cases.config4, dict(n=1000))])
+def test_non_isotropic_association(oracle, builder, kw):
+    """compute_association_gpu(..., Matrix3f kernel) - Mahalanobis distance, no geometric cut-off,
+    geometric types off.  The scan is steered by a Euclidean bound derived from sp_thres; the pattern must be bit-exact."""
+    P, src, tgt, init = builder(**kw)
+    Q = _rot(25.0, (0.3, 1.0, -0.2))
+    kernel = (Q @ np.diag([0.05, 0.12, 0.02]) @ Q.T).astype(np.float32)
+    T = synth.gt_motion().astype(np.float32)
+    gpu = CvoGPU(params=P)
+    rp, col, val = gpu.compute_association_gpu_non_isotropic(src, tgt, T, kernel)
+    orp, ocol, oval, kinv = oracle.association_non_isotropic(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt),
+                                                             T, kernel)
+    assert np.allclose(kinv @ kernel.astype(np.float64), np.eye(3), atol=1e-4)   # the restated Eigen inverse
+    assert len(ocol) > 100
+    assert np.array_equal(rp, orp)
+    assert np.array_equal(col, ocol)
+    assert np.allclose(val, oval, rtol=2e-6, atol=0)
+
+
+def test_non_isotropic_association_without_a_bound(oracle):
+    """An indefinite kernel has no Euclidean bound: every pair is a candidate, results still match."""
+    P, src, tgt, init = cases.config2(n=400)
+    kernel = np.diag([0.05, -0.08, 0.03]).astype(np.float32)
+    gpu = CvoGPU(params=P)
+    rp, col, val = gpu.compute_association_gpu_non_isotropic(src, tgt, np.eye(4, dtype=np.float32), kernel)
+    orp, ocol, oval, _ = oracle.association_non_isotropic(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt),
+                                                          np.eye(4, dtype=np.float32), kernel)
+    assert np.array_equal(rp, orp) and np.array_equal(col, ocol)
+    assert np.allclose(val, oval, rtol=2e-6, atol=0)

@@ -127,7 +127,7 @@ EXPORTED = [
     "cvo_params_default", "cvo_ctx_create", "cvo_ctx_destroy", "cvo_last_error", "cvo_ctx_stream",
     "cvo_ctx_synchronize", "cvo_cloud_upload", "cvo_cloud_upload_aos192", "cvo_cloud_size", "cvo_cloud_free",
     "cvo_align", "cvo_align_ex", "cvo_align_batch", "cvo_batch_poses_to_device", "cvo_inner_product",
-    "cvo_function_angle", "cvo_association", "cvo_cloud_transformed", "cvo_edge_kernel_matrix", "cvo_debug_last_ell", "cvo_debug_time_scan", "cvo_debug_time_kernels",
+    "cvo_function_angle", "cvo_association", "cvo_association_non_isotropic", "cvo_cloud_transformed", "cvo_edge_kernel_matrix", "cvo_debug_last_ell", "cvo_debug_time_scan", "cvo_debug_time_kernels",
     "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
 ]
 
@@ -171,6 +171,8 @@ def lib():
     L.cvo_function_angle.argtypes = [vp, C.POINTER(cvo_params_t), vp, vp, fp, C.c_float, ip, fp]
     L.cvo_association.argtypes = [vp, C.POINTER(cvo_params_t), vp, vp, fp, C.c_float, C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), fp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.cvo_association_non_isotropic.argtypes = [vp, C.POINTER(cvo_params_t), vp, vp, fp, fp, C.POINTER(C.c_int),
+                                                 C.POINTER(C.c_int), fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cvo_cloud_transformed.argtypes = [vp, vp, fp, C.POINTER(vp)]
     L.cvo_edge_kernel_matrix.argtypes = [vp, C.POINTER(cvo_params_t), vp, vp, C.c_float, ip, fp, C.POINTER(C.c_int), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     L.cvo_debug_last_ell.argtypes = [vp, ip, fp, C.POINTER(C.c_int), C.POINTER(C.c_uint)]

@@ -358,6 +358,24 @@ class CvoGPU:
                                            col.ctypes.data_as(C.POINTER(C.c_int)), _fptr(val), cap, C.byref(nnz)))
         return row_ptr, col[:nnz.value], val[:nnz.value]
 
+    def compute_association_gpu_non_isotropic(self, source, target, T, kernel):
+        """Association under the Mahalanobis kernel d^T kernel^-1 d, as CSR (CvoGPU.cu:1913-1995)."""
+        src, tgt = self._dev(source), self._dev(target)
+        n = src.n
+        p = self.params.to_ctypes()
+        cap = n * min(self.params.nearest_neighbors_max, tgt.n)
+        row_ptr = np.zeros(n + 1, np.int32)
+        col = np.zeros(max(cap, 1), np.int32)
+        val = np.zeros(max(cap, 1), np.float32)
+        nnz = C.c_size_t()
+        Tm = _mat_to_c(T)
+        kcm = np.ascontiguousarray(np.asarray(kernel, np.float32).reshape(3, 3).T).reshape(9)
+        self._check(self.L.cvo_association_non_isotropic(self.ctx, C.byref(p), src.handle, tgt.handle, _fptr(Tm), _fptr(kcm),
+                                                         row_ptr.ctypes.data_as(C.POINTER(C.c_int)),
+                                                         col.ctypes.data_as(C.POINTER(C.c_int)), _fptr(val), cap,
+                                                         C.byref(nnz)))
+        return row_ptr, col[:nnz.value], val[:nnz.value]
+
     # -- multi-frame edge kernel (BinaryStateGPU::update_inner_product, IRLS_State_GPU.cu:43-79) ----
     def transformed(self, cloud, pose_3x4):
         """CvoFrameGPU::transform_pointcloud: a new resident cloud moved by a 3x4 row-major pose."""

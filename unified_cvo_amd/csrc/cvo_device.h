@@ -32,7 +32,11 @@ struct DevParams {
   float stable_thr;
   int use_geo, use_col, use_sem, use_range_ell, use_geotype;
   int trace_dense, trace_every, trace_capacity;
-  int mode;  // 0 = align loop, 1 = single evaluation (inner product / association)
+  int mode;  // 0 = align loop, 1 = single evaluation (inner product / association), 2 = single evaluation with the
+             // non-isotropic kernel (CvoGPU.cu:217-327)
+  float kinv[9];   // mode 2: inverse of the 3x3 kernel matrix, row-major
+  float d2_cull;   // mode 2: squared Euclidean radius beyond which no pair can reach sp_thres (cull only)
+  float s_ell_sq;  // mode 2: s_ell * s_ell kept in float, as that kernel's prologue does
   int T;     // target chunks (of 64) per scan wave: 1, 2, 4 or 8
   int groups_per_block;  // row groups per k_scan block (a multiple of 64)
   // Candidate-list reuse (DESIGN.md "Reusing the candidate list"): the scan runs with the cut-off radius

@@ -391,7 +391,7 @@ struct BatchSetup {
 // Builds descriptors + initial states for a batch and uploads them.
 int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo_cloud* const* sources,
                 const cvo_cloud* const* targets, const float* init_T, const cvo_align_opts_t* opts, int mode,
-                float mode_ell, BatchSetup* S, DevParams* dp_out) {
+                float mode_ell, BatchSetup* S, DevParams* dp_out, const float* kernel_inv_and_cull = nullptr) {
   if (!ctx) return CVO_E_INVALID;
   if (!params || n_pairs <= 0 || !sources || !targets) return fail(ctx, CVO_E_INVALID, "null argument");
   if (params->is_using_kdtree)
@@ -425,6 +425,15 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
 
   DevParams dp = make_dev_params(*params);
   dp.mode = mode;
+  if (mode == 2) {  // non-isotropic kernel: 9 floats of the inverse (row-major) + the squared cull radius
+    for (int q = 0; q < 9; q++) dp.kinv[q] = kernel_inv_and_cull[q];
+    dp.d2_cull = kernel_inv_and_cull[9];
+    dp.s_ell_sq = params->s_ell * params->s_ell;
+    dp.use_geotype = 0;  // CvoGPU.cu:1950-1951
+    // that kernel's prologue keeps s_ell^2 in float (CvoGPU.cu:236, 252)
+    if (params->is_using_semantics)
+      dp.d2_s_thres = (float)(-2.0 * dp.s_ell_sq * (double)std::log(params->sp_thres / (params->s_sigma * params->s_sigma)));
+  }
   dp.T = S->T;
   dp.groups_per_block = S->gpb;
   dp.lean_U = 8;
@@ -554,11 +563,11 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
 }
 
 int run_single_eval(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source, const cvo_cloud* target,
-                    const float Tm[16], float ell, BatchSetup* S) {
+                    const float Tm[16], float ell, BatchSetup* S, const float* kernel_inv_and_cull = nullptr) {
   DevParams dp;
   const cvo_cloud* src[1] = {source};
   const cvo_cloud* tgt[1] = {target};
-  int rc = setup_batch(ctx, params, 1, src, tgt, Tm, nullptr, 1, ell, S, &dp);
+  int rc = setup_batch(ctx, params, 1, src, tgt, Tm, nullptr, kernel_inv_and_cull ? 2 : 1, ell, S, &dp, kernel_inv_and_cull);
   if (rc != CVO_OK) return rc;
   launch_init(ctx, S->geom);
   launch_rebuild(ctx, S->geom);
@@ -1166,24 +1175,15 @@ static int fetch_ell(cvo_ctx* ctx, int pair, std::vector<unsigned>& nz, std::vec
   return CVO_OK;
 }
 
-int cvo_association(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source, const cvo_cloud* target,
-                    const float T[16], float ell, int* row_ptr, int* col, float* val, size_t capacity,
-                    size_t* nnz_out) {
-  if (!ctx || !row_ptr || !T) return fail(ctx, CVO_E_INVALID, "cvo_association: bad argument");
-  if (!source || !target) return fail(ctx, CVO_E_INVALID, "null cloud");
-  if (nnz_out) *nnz_out = 0;
-  if (source->n == 0 || target->n == 0) return CVO_OK;  // CvoGPU.cu:1884-1885
-  BatchSetup S;
-  int rc = run_single_eval(ctx, params, source, target, T, ell, &S);
-  if (rc != CVO_OK) return rc;
+// CSR export of the last single evaluation (gpu_association_to_cpu, CvoGPU_impl.cu:366-427)
+static int export_association(cvo_ctx* ctx, int N, int* row_ptr, int* col, float* val, size_t capacity, size_t* nnz_out) {
   std::vector<unsigned> nz;
   std::vector<float> a;
   std::vector<int> jj;
   unsigned mx = 0;
-  rc = fetch_ell(ctx, 0, nz, a, jj, &mx);
+  int rc = fetch_ell(ctx, 0, nz, a, jj, &mx);
   if (rc != CVO_OK) return rc;
-  const int N = source->n;
-  std::vector<int> sorted_of(N);  // original row -> sorted row (the ELL is stored by sorted row)
+  std::vector<int> sorted_of(N);  // original row -> sorted row (fetch_ell returns sorted rows)
   for (int r = 0; r < N; r++) sorted_of[ctx->last_xorder[r]] = r;
   size_t cnt = 0;
   for (int i = 0; i < N; i++) {
@@ -1201,6 +1201,104 @@ int cvo_association(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
   if (nnz_out) *nnz_out = cnt;
   if (cnt > capacity) return fail(ctx, CVO_E_NOMEM, "association capacity too small");
   return CVO_OK;
+}
+
+int cvo_association(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source, const cvo_cloud* target,
+                    const float T[16], float ell, int* row_ptr, int* col, float* val, size_t capacity,
+                    size_t* nnz_out) {
+  if (!ctx || !row_ptr || !T) return fail(ctx, CVO_E_INVALID, "cvo_association: bad argument");
+  if (!source || !target) return fail(ctx, CVO_E_INVALID, "null cloud");
+  if (nnz_out) *nnz_out = 0;
+  if (source->n == 0 || target->n == 0) return CVO_OK;  // CvoGPU.cu:1884-1885
+  BatchSetup S;
+  int rc = run_single_eval(ctx, params, source, target, T, ell, &S);
+  if (rc != CVO_OK) return rc;
+  return export_association(ctx, source->n, row_ptr, col, val, capacity, nnz_out);
+}
+
+// Eigen 3.3.9 Matrix3f::inverse() (Inverse.h, compute_inverse<..., 3>), as called on the host at CvoGPU.cu:1947:
+// cofactors, det = c00*m00 + (c10*m10 + c20*m20), result = cofactor^T * (1/det), plain float arithmetic.
+// m and out are ROW-major.
+static void inverse3_eigen(const float m[9], float out[9]) {
+  auto M = [&](int i, int j) { return m[3 * i + j]; };
+  auto cof = [&](int i, int j) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return M(i1, j1) * M(i2, j2) - M(i1, j2) * M(i2, j1);
+  };
+  const float c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
+  const float p0 = c0 * M(0, 0), p1 = c1 * M(1, 0), p2 = c2 * M(2, 0);
+  const float det = p0 + (p1 + p2);
+  const float invdet = 1.0f / det;
+  out[0] = c0 * invdet;
+  out[1] = c1 * invdet;
+  out[2] = c2 * invdet;
+  out[3] = cof(0, 1) * invdet;
+  out[4] = cof(1, 1) * invdet;
+  out[5] = cof(2, 1) * invdet;
+  out[6] = cof(0, 2) * invdet;
+  out[7] = cof(1, 2) * invdet;
+  out[8] = cof(2, 2) * invdet;
+}
+
+// smallest eigenvalue of the symmetric part of a 3x3 matrix (cyclic Jacobi, double)
+static double min_eig_sym3(const float a[9]) {
+  double S[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) S[i][j] = 0.5 * ((double)a[3 * i + j] + (double)a[3 * j + i]);
+  for (int sweep = 0; sweep < 30; sweep++) {
+    const double off = S[0][1] * S[0][1] + S[0][2] * S[0][2] + S[1][2] * S[1][2];
+    if (!(off > 1e-30)) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        if (S[p][q] == 0.0) continue;
+        const double th = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
+        const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 3; k++) {  // columns
+          const double kp = S[k][p], kq = S[k][q];
+          S[k][p] = c * kp - sn * kq;
+          S[k][q] = sn * kp + c * kq;
+        }
+        for (int k = 0; k < 3; k++) {  // rows
+          const double pk = S[p][k], qk = S[q][k];
+          S[p][k] = c * pk - sn * qk;
+          S[q][k] = sn * pk + c * qk;
+        }
+      }
+  }
+  return std::min(S[0][0], std::min(S[1][1], S[2][2]));
+}
+
+int cvo_association_non_isotropic(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source,
+                                  const cvo_cloud* target, const float T[16], const float kernel_colmajor[9],
+                                  int* row_ptr, int* col, float* val, size_t capacity, size_t* nnz_out) {
+  if (!ctx || !params || !row_ptr || !T || !kernel_colmajor)
+    return fail(ctx, CVO_E_INVALID, "cvo_association_non_isotropic: bad argument");
+  if (!source || !target) return fail(ctx, CVO_E_INVALID, "null cloud");
+  if (nnz_out) *nnz_out = 0;
+  if (source->n == 0 || target->n == 0) return CVO_OK;  // CvoGPU.cu:1975-1976
+  float km[9], extra[10];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) km[3 * i + j] = kernel_colmajor[3 * j + i];
+  inverse3_eigen(km, extra);
+  // The kernel has no cut-off of its own (CvoGPU.cu:236-238), but a = ck*k*sk can only exceed sp_thres while
+  // k = sigma^2 exp(-d2/2) > sp_thres / (max ck * max sk), i.e. d^T Kinv d < d2m; with lambda = the smallest eigenvalue
+  // of Kinv's symmetric part that bounds |d|^2 < d2m / lambda, which steers the scan (the exact arithmetic then
+  // runs on the survivors only).  No usable bound (indefinite kernel, NaN) => every pair is a candidate.
+  const double sigma2 = (double)params->sigma * params->sigma;
+  const double cmax = params->is_using_intensity ? (double)params->c_sigma * params->c_sigma : 1.0;
+  const double smax = params->is_using_semantics ? (double)params->s_sigma * params->s_sigma : 1.0;
+  const double d2m = -2.0 * std::log((double)params->sp_thres / (sigma2 * cmax * smax));
+  const double lam = min_eig_sym3(extra);
+  double cull = INFINITY;
+  if (params->is_using_geometry && std::isfinite(d2m) && std::isfinite(lam) && lam > 0.0)
+    cull = d2m > 0.0 ? d2m / lam * 1.01 + 1e-12 : 0.0;
+  extra[9] = (float)cull;
+  if (!(extra[9] == extra[9])) extra[9] = INFINITY;
+  BatchSetup S;
+  int rc = run_single_eval(ctx, params, source, target, T, 1.0f, &S, extra);
+  if (rc != CVO_OK) return rc;
+  return export_association(ctx, source->n, row_ptr, col, val, capacity, nnz_out);
 }
 
 int cvo_edge_kernel_matrix(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* frame1, const cvo_cloud* frame2,

@@ -325,6 +325,7 @@ __device__ __forceinline__ RowData make_row(const DevParams& P, const float4 x, 
   const float l = compute_range_ell(ell, a_to_sensor);
   float thr = 1.f;
   if (P.use_geo) thr = (float)(-2.0 * l * l * (double)P.log_geo);
+  if (P.mode == 2) thr = P.d2_cull;  // non-isotropic kernel: no cut-off of its own, this one only steers the scan
   return RowData{x.x, x.y, x.z, l, thr};
 }
 struct Pose {  // the transform applied to the target cloud this iteration (update_tf, CvoGPU.cu:94-112)
@@ -357,7 +358,15 @@ __device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __
   const V3 ytv = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
   const float4 yt = make_float4(ytv.x, ytv.y, ytv.z, 0.f);
   yt_out = yt;
-  if (P.use_geo) {
+  if (P.use_geo && P.mode == 2) {
+    // mahananobis_distance (CvoGPU.cu:152-171): dist = a - b, (dist^T * kernel_inv) * dist; no cut-off (236-238, 279-284)
+    const float d0 = r.x - yt.x, d1 = r.y - yt.y, d2v = r.z - yt.z;
+    const float r0 = dot3_dev(d0, d1, d2v, P.kinv[0], P.kinv[3], P.kinv[6]);
+    const float r1 = dot3_dev(d0, d1, d2v, P.kinv[1], P.kinv[4], P.kinv[7]);
+    const float r2 = dot3_dev(d0, d1, d2v, P.kinv[2], P.kinv[5], P.kinv[8]);
+    const float d2 = dot3_dev(r0, r1, r2, d0, d1, d2v);
+    k = (float)((double)P.sigma2 * exp((double)(-d2) / 2.0));
+  } else if (P.use_geo) {
     const float dx = yt.x - r.x, dy = yt.y - r.y, dz = yt.z - r.z;
     const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
     if (d2 < r.d2_thres)
@@ -393,7 +402,8 @@ __device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __
       }
     }
     if (res < P.d2_s_thres)
-      sk = (float)((double)(P.s_sigma * P.s_sigma) * exp((double)(-res) / (2.0 * P.s_ell * P.s_ell)));
+      sk = P.mode == 2 ? (float)((double)(P.s_sigma * P.s_sigma) * exp((double)(-res) / (2.0 * P.s_ell_sq)))
+                       : (float)((double)(P.s_sigma * P.s_sigma) * exp((double)(-res) / (2.0 * P.s_ell * P.s_ell)));
     else
       return false;
   }
