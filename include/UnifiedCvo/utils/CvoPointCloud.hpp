@@ -21,9 +21,14 @@ class CvoPointCloud {
 
   CvoPointCloud();
   CvoPointCloud(int feature_dimensions, int num_classes);
-  // ASCII .pcd with FIELDS "x y z" or "x y z rgb": the pcl::PointXYZ / pcl::PointXYZRGB constructors
-  // (upstream CvoPointCloud.cpp:569-594, 633-652) applied to what pcl::io::loadPCDFile returns.
-  explicit CvoPointCloud(const std::string& pcd_filename);
+  // A file on disk.  A text file in upstream's own format (CvoPointCloud.cpp:89-148: "N F C" then per point
+  // "x y z f_1..f_F l_1..l_C", points farther than 55 m dropped) is read as upstream's string constructor does.
+  // A file that starts with a PCD header is read as the drivers do with pcl::io::loadPCDFile + the pcl::PointXYZ /
+  // PointXYZRGB / PointXYZI constructors (CvoPointCloud.cpp:569-594, 633-652): ASCII, FIELDS "x y z", "x y z rgb"
+  // or "x y z intensity" (one feature: the cvo_gpu_lidar_lib flavour, FEATURE_DIMENSIONS = 1).
+  explicit CvoPointCloud(const std::string& filename);
+  // upstream CvoPointCloud.cpp:1157-1199: "N F C" then per point "u v idepth f_1..f_F x y z l_1..l_C"; 0 / -1
+  int read_cvo_pointcloud_from_file(const std::string& filename);
 
   static CvoPointCloud from_xyz(const float* xyz, int n);                                // type (1,0), F = 0
   static CvoPointCloud from_xyzrgb(const float* xyz, const unsigned char* rgb, int n);   // type (0,1), F = 5
@@ -48,7 +53,12 @@ class CvoPointCloud {
   int add_point(int index, const Vec3f& xyz, const std::vector<float>& feature, const std::vector<float>& label,
                 const std::vector<float>& geometric_type);
 
-  void write_to_color_pcd(const std::string& name) const;
+  // upstream CvoPointCloud.cpp:1289-1362; PCD files in the layout of pcl::io::savePCDFileASCII (PCL 1.9.1)
+  void write_to_color_pcd(const std::string& name) const;      // PointXYZRGB: r,g,b <- features 2,1,0 as upstream
+  void write_to_pcd(const std::string& name) const;            // PointXYZ
+  void write_to_label_pcd(const std::string& name) const;      // PointXYZL: argmax label (nothing if no classes)
+  void write_to_intensity_pcd(const std::string& name) const;  // PointXYZI: first feature
+  void write_to_txt(const std::string& name) const;            // "N C" header, then xyz line + features/labels line
 
  private:
   int num_points_ = 0;

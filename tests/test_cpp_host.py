@@ -123,3 +123,79 @@ def test_multiframe_edge_driver_matches_python_mirror(tmp_path):
     r = rows["moved"]
     assert (int(r[2]), int(r[4]), int(r[8])) == (nz, k, cs)
     assert float(r[10]) == pytest.approx(st.ell, rel=1e-6)
+
+
+PCIO = os.path.join(HOST, "cvo_pointcloud_io")
+
+
+def _read_pcd(path):
+    lines = open(path).read().splitlines()
+    hdr = {l.split()[0]: l.split()[1:] for l in lines[:11] if l and not l.startswith("#")}
+    data = [l.split() for l in lines[lines.index("DATA ascii") + 1:]]
+    return hdr, data
+
+
+def test_pointcloud_text_format_and_writers(tmp_path):
+    """the upstream text constructor (N F C header, 55 m filter) and the write_to_* family."""
+    rs = np.random.default_rng(3)
+    n, F, C = 40, 5, 19
+    xyz = rs.uniform(-20, 20, (n, 3)).astype(np.float32)
+    xyz[5] = (60, 0, 0)          # dropped: norm > 55
+    xyz[17] = (33, 33, 30.5)     # dropped too (norm 55.7)
+    feat = rs.uniform(0, 1, (n, F)).astype(np.float32)
+    lab = rs.uniform(0, 1, (n, C)).astype(np.float32)
+    src = tmp_path / "cloud_in.txt"
+    with open(src, "w") as f:
+        f.write(f"{n} {F} {C}\n")
+        for i in range(n):
+            f.write(" ".join(repr(float(v)) for v in list(xyz[i]) + list(feat[i]) + list(lab[i])) + "\n")
+    out = subprocess.check_output([PCIO, str(src), str(tmp_path)], text=True).split()
+    kv = dict(zip(out[0::2], out[1::2]))
+    keep = np.linalg.norm(xyz.astype(np.float64), axis=1) <= 55
+    assert int(kv["points"]) == int(keep.sum()) == n - 2
+    assert (int(kv["features"]), int(kv["classes"]), int(kv["geometric_types"])) == (F, C, 0)
+    assert float(kv["sum_xyz"]) == pytest.approx(float(xyz[keep].astype(np.float64).sum()), rel=1e-6)
+    assert float(kv["sum_features"]) == pytest.approx(float(feat[keep].astype(np.float64).sum()), rel=1e-6)
+    assert float(kv["sum_labels"]) == pytest.approx(float(lab[keep].astype(np.float64).sum()), rel=1e-6)
+
+    hdr, data = _read_pcd(tmp_path / "xyz.pcd")
+    assert hdr["FIELDS"] == ["x", "y", "z"] and hdr["POINTS"] == [str(n - 2)] and len(data) == n - 2
+    assert np.allclose(np.array(data, np.float64), xyz[keep], rtol=1e-6)
+    hdr, data = _read_pcd(tmp_path / "label.pcd")
+    assert hdr["FIELDS"] == ["x", "y", "z", "label"]
+    assert [int(d[3]) for d in data] == list(np.argmax(lab[keep], axis=1))
+    hdr, data = _read_pcd(tmp_path / "intensity.pcd")
+    assert hdr["FIELDS"] == ["x", "y", "z", "intensity"]
+    assert np.allclose([float(d[3]) for d in data], feat[keep][:, 0], rtol=1e-6)
+    hdr, data = _read_pcd(tmp_path / "color.pcd")
+    packed = np.array([int(d[3]) for d in data], np.uint64)
+    q = lambda v: np.minimum(255, (v.astype(np.float32) * np.float32(255)).astype(np.int32))  # noqa: E731
+    assert np.array_equal((packed >> 16) & 255, q(feat[keep][:, 2]))   # r <- feature 2, as upstream
+    assert np.array_equal(packed & 255, q(feat[keep][:, 0]))           # b <- feature 0
+    txt = open(tmp_path / "cloud.txt").read().split()
+    assert (int(txt[0]), int(txt[1])) == (n - 2, C)                    # upstream's two-number header
+    assert len(txt) == 2 + (n - 2) * (3 + F + C)
+
+    # the intensity PCD read back: one feature = the cvo_gpu_lidar_lib flavour
+    (tmp_path / "again").mkdir()
+    out2 = subprocess.check_output([PCIO, str(tmp_path / "intensity.pcd"), str(tmp_path / "again")], text=True).split()
+    kv2 = dict(zip(out2[0::2], out2[1::2]))
+    assert (int(kv2["points"]), int(kv2["features"]), int(kv2["classes"])) == (n - 2, 1, 0)
+    assert float(kv2["sum_features"]) == pytest.approx(float(feat[keep][:, 0].astype(np.float64).sum()), rel=1e-5)
+
+
+def test_pointcloud_raw_image_format(tmp_path):
+    """read_cvo_pointcloud_from_file: "u v idepth features xyz labels" per point, no distance filter."""
+    n, F, C = 7, 5, 3
+    rs = np.random.default_rng(4)
+    rows = rs.uniform(0, 100, (n, 3 + F + 3 + C))
+    src = tmp_path / "raw.txt"
+    with open(src, "w") as f:
+        f.write(f"{n} {F} {C}\n")
+        for r in rows:
+            f.write(" ".join(f"{v:.6f}" for v in r) + "\n")
+    out = subprocess.check_output([PCIO, "--raw", str(src), str(tmp_path)], text=True).split()
+    kv = dict(zip(out[0::2], out[1::2]))
+    assert (int(kv["points"]), int(kv["features"]), int(kv["classes"])) == (n, F, C)
+    assert float(kv["sum_xyz"]) == pytest.approx(rows[:, 3 + F:3 + F + 3].sum(), rel=1e-5)
+    assert float(kv["sum_features"]) == pytest.approx(rows[:, 3:3 + F].sum(), rel=1e-5)

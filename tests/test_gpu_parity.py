@@ -473,3 +473,20 @@ def test_non_isotropic_association_without_a_bound(oracle):
                                                           np.eye(4, dtype=np.float32), kernel)
     assert np.array_equal(rp, orp) and np.array_equal(col, ocol)
     assert np.allclose(val, oval, rtol=2e-6, atol=0)
+
+
+def test_lidar_flavour_single_feature(oracle):
+    """cvo_gpu_lidar_lib (FEATURE_DIMENSIONS = 1): clouds with one intensity channel; the backend pads features to
+    five zeros, which leaves every colour distance unchanged."""
+    P = cases.load_params("intensity_gpu")
+    src, fsrc, tgt, ftgt, _, _ = synth.colour_pair(1500, 3)
+    geo = np.tile(np.array([[0.0, 1.0]], np.float32), (1500, 1))
+    a = CvoPointCloud.from_arrays(src, fsrc[:, :1], None, geo)
+    b = CvoPointCloud.from_arrays(tgt, ftgt[:, :1], None, geo)
+    assert a.num_features() == 1
+    _single_iteration(oracle, P, a, b, np.eye(4, dtype=np.float32))
+    g = CvoGPU(params=P).align(a, b, np.eye(4), max_iterations=60)
+    o = oracle.align(oracle.params_from(P), _ocloud(oracle, a), _ocloud(oracle, b), np.eye(4, dtype=np.float32),
+                     max_iterations=60)
+    assert g.iterations == o["iterations"] == 60
+    assert cases.max_abs_diff(g.transform, o["transform"]) < 1e-6
