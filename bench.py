@@ -13,6 +13,7 @@ the timed region (the PCIe-inclusive number is printed to stderr and recorded in
 `value`).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -119,6 +120,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The harness holds ~10^5 live Python objects (clouds, ctypes arrays); a generation-2 garbage collection in the
+    # middle of a step costs ~35 ms of pure interpreter time.  Collect now and park what exists.
+    gc.collect()
+    gc.freeze()
     for _ in range(args.warmup):
         step()
     fence()

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -909,8 +910,10 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   if (!init_T || !out_T) return fail(ctx, CVO_E_INVALID, "null transform pointer");
   BatchSetup S;
   DevParams dp;
+  const auto t_host0 = std::chrono::steady_clock::now();
   int rc = setup_batch(ctx, params, n_pairs, sources, targets, init_T, opts, 0, 0.f, &S, &dp);
   if (rc != CVO_OK) return rc;
+  const auto t_host1 = std::chrono::steady_clock::now();
 
   const int max_iter = dp.max_iter;
   int U = (opts && opts->iters_per_launch > 0) ? opts->iters_per_launch : 16;
@@ -977,6 +980,9 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     bool all_done = false;
     int ch = 0;
     int n_lean_launch = 0, n_full_launch = 0;
+    double t_launch = 0, t_wait = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     for (; ch < chunk_cap && !all_done; ch++) {
       const int slot = ch & 1;
       for (int g = 0; g < G; g++) {
@@ -985,7 +991,9 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
         if (use_graph) {
           rc = get_graph(g, v);
           if (rc != CVO_OK) return rc;
+          const auto tl = now();
           HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g][v], geom[g].stream));
+          t_launch += ms_since(tl);
         } else {
           launch_chunk(ctx, geom[g], U, v == 1, lean_U);
           HIP_TRY(ctx, hipGetLastError());
@@ -1000,7 +1008,9 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       // keep one chunk of speculation in flight: inspect the chunk before this one
       if (ch >= 1) {
         const int ws = (ch - 1) & 1;
+        const auto tw = now();
         for (int g = 0; g < G; g++) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_chk[ws][g]));
+        t_wait += ms_since(tw);
         all_done = true;
         for (int p = 0; p < n_pairs; p++) all_done = all_done && ctx->h_status[ws][p] != 0;
         for (int g = 0; g < G; g++) {
@@ -1012,6 +1022,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       }
     }
     ctx->last_chunks = ch;
+    if (getenv("CVO_VERBOSE")) fprintf(stderr, "[cvo] host loop: %.2f ms in hipGraphLaunch, %.2f ms waiting for the device\n", t_launch, t_wait);
     ctx->last_lean_launches = n_lean_launch;
     ctx->last_full_launches = n_full_launch;
     if (!all_done) {  // the in-flight chunk may have finished the stragglers; otherwise report it
@@ -1030,8 +1041,13 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_states.data(), ctx->d_states, sizeof(PairState) * (size_t)n_pairs,
                               hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const auto t_host2 = std::chrono::steady_clock::now();
   float ms = 0;
   HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+  if (getenv("CVO_VERBOSE"))
+    fprintf(stderr, "[cvo] host: setup %.2f ms, enqueue + wait %.2f ms\n",
+            std::chrono::duration<double, std::milli>(t_host1 - t_host0).count(),
+            std::chrono::duration<double, std::milli>(t_host2 - t_host1).count());
   for (int p = 0; p < n_pairs; p++)
     if (ctx->h_status[0][p] == 3 || ctx->h_status[1][p] == 3)
       return fail(ctx, CVO_E_HIP, "cvo_align_batch: device-side barrier timed out");
