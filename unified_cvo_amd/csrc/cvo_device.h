@@ -49,14 +49,19 @@ struct DevParams {
 
 // Running state of one frame pair; lives in HBM, only touched by one thread of k_step.
 struct PairState {
-  float R[9], T[3];        // running pose (row-major R), CvoGPU.cu:1363-1364
-  float Rinv[9], Tinv[3];  // transform applied to the target cloud this iteration
+  // ---- what every block of the per-iteration kernels reads before it does anything (one scalar-load burst) ----
+  int status;      // 0 running, 1 finished
+  int rebuild;     // the candidate lists are stale: k_prep / k_scan / k_list rebuild them, everybody else waits
+  int n_ovf;       // rows on the overflow list of k_assoc_dense (filled by k_list, reset by k_prep)
+  int K;           // num_neighbors
   float ell;
-  int K;  // num_neighbors
-  int k;  // iteration counter
-  int status;  // 0 running, 1 finished
-  int ret;
+  int epoch;       // k_coeff launches this pair completed (generation of its last-block counter)
+  int k;           // iteration counter
   int iterations;
+  float Rinv[9], Tinv[3];  // transform applied to the target cloud this iteration
+  // ---- the rest of the scalar state ----
+  float R[9], T[3];        // running pose (row-major R), CvoGPU.cu:1363-1364
+  int ret;
   float step;
   float omega[3], v[3];
   unsigned nnz, max_nnz;
@@ -68,14 +73,11 @@ struct PairState {
   unsigned long long ncand_total;  // candidate pairs evaluated exactly, summed over the iterations (statistics)
   int n_trace;
   float out_T[16];  // column-major [R^T | -R^T T]
-  // candidate-list reuse: pose / ell the current bitmap was built with, its skin, and whether the kernels
-  // of the coming iteration have to rebuild it
+  // candidate-list reuse: pose / ell the current bitmap was built with and its skin
   float Rb[9], Tb[3];
   float ell_build, skin;
-  int rebuild, n_builds;
-  int want_full, n_stalls;
-  int epoch, pad_epoch;  // k_coeff launches this pair completed (generation of its last-block counter)
-   // host hint: this pair needs the graph with per-iteration rebuild / dense kernels
+  int n_builds;
+  int want_full, n_stalls;  // host hint: this pair needs the graph with per-iteration rebuild / dense kernels
   // A_sparsity_indicator_ell_update FIFOs (CvoGPU.cu:1167-1285): bookkeeping here, storage below
   int s_head, s_size, e_head, e_size;
   float s_sum, e_sum;
@@ -91,54 +93,55 @@ struct PairState {
 // space so that 4-row groups and 64-target chunks are spatially compact and whole tiles can be
 // rejected by a bounding-box test; k_assoc maps candidates back and restores ascending original j.
 struct PairDesc {
-  int N, M, Mpad, nchunks, nslices, rbw, nblk_assoc, nblk_coeff;
-  // flow_part / cnt_part hold nblk_assoc row-block partials followed by DENSE_BLOCKS partials of k_assoc_dense  // rbw: 32-bit words of slice bits per row
+  // ---- read by the per-iteration kernels (k_assoc, k_coeff): kept together at the front ----
+  int N, M, nblk_assoc, nblk_coeff;
+  // k_list orders the rows of every 256-row window by candidate count; POSITION = index in that order
+  int* cand_cnt;   // [N] candidates of the row at each position
+  void* cand_j;    // [ASSOC_CAP][N] cached candidate lists by position (original target index, ascending), u16 or i32
+  float4* xp4;     // [N] source xyz of the row at each position
+  int* ip;         // [N] ORIGINAL index of the row at each position
+  const float4* y4;   // target xyz (initial cloud), ORIGINAL index
+  float* ell_a;               // ELL kernel matrix values, [K_max][N], indexed by POSITION
+  int* ell_j;                 // ELL column indices (ORIGINAL j, ascending), [K_max][N]
+  unsigned* nnz_row;          // nonzeros[N], by position
+  double* flow_part;          // [nblk_assoc + DENSE_BLOCKS][8]: omega(3), v(3), sum a, pad (row blocks, then k_assoc_dense)
+  unsigned long long* cnt_part;  // [nblk_assoc + DENSE_BLOCKS][4]: nnz, max, candidates, overflow rows
+  double* coef_part;          // [nblk_coeff][4]: B C D E
+  int* done;        // [1] k_coeff: blocks that stored their partials (monotonic; the last one runs the update)
+  const float4* xfeat;
+  const float4* yfeat;
+  const float4* xlabel;
+  const float4* ylabel;
+  const float2* xgeo;
+  const float2* ygeo;
+  // ---- rebuild kernels, update, exports ----
+  int Mpad, nchunks, nslices, rbw;  // rbw: 32-bit words of slice bits per row
   int NG;     // row groups of ROWS_PER_GROUP sorted rows
   int NGpad;  // NG rounded up for the coarse test (pad groups have empty boxes)
   float cx, cy, cz;  // centre subtracted in the cull arithmetic only
   float ymax;        // largest |y0| of the target cloud (bounds how far a pose change moves any target)
   const float4* x4;   // source xyz, ORIGINAL index
   const float4* xs4;  // source xyz, SORTED order (coalesced row reads)
-  const float4* xfeat;
-  const float4* xlabel;
-  const float2* xgeo;
   const int* xorder;
-  const float4* y4;   // target xyz (initial cloud), ORIGINAL index
   const float4* ys4;  // target xyz (initial cloud), SORTED order
-  const float4* yfeat;
-  const float4* ylabel;
-  const float2* ygeo;
   const int* yorder;
   float4* ycull;  // SORTED: {y~x, y~y, y~z, |y~|^2}, y~ = yt - centre; pads are {0,0,0,+inf}
   float4* xcull;  // SORTED: {-2x~x, -2x~y, -2x~z, thres_i + margin_i - |x~|^2}
-  // k_list orders the rows of every 256-row window by candidate count; POSITION = index in that order
-  int* cand_cnt;   // [N] candidates of the row at each position
   int* rowperm;    // [N] position -> sorted row
-  float4* xp4;     // [N] source xyz of the row at each position
-  int* ip;         // [N] ORIGINAL index of the row at each position
-  void* cand_j;    // [ASSOC_CAP][N] cached candidate lists by position (original target index, ascending), u16 or i32
   float4* gbox;   // [NGpad][2]: AABB of each sorted row group, grown by the group's cut-off radius
   float4* cellbox;  // [NGpad/16][2]: AABB of each cell of 16 row groups (level 1 of the scan)
   float4* sbox;   // [nslices][2]: AABB of each scan slice (T chunks)
   unsigned long long* masks;  // [nslices][N sorted rows][T] candidate bit masks; a row's T words of a slice are
                               // valid iff that slice's bit is set in the row's rowbits (never memset)
   unsigned* rowbits;          // [N sorted rows][rbw]: bit s set <=> the row has candidates in scan slice s;
-                              // set by k_scan (returnless atomic OR), cleared by k_assoc
+                              // set by k_scan (returnless atomic OR), cleared by k_prep on a rebuild
   unsigned long long* tile_count;  // [1]: fine tiles executed so far this call (statistics)
-  int* ovf_rows;   // [N]: sorted rows with more candidates than a list holds (handled by k_assoc_dense)
-  int* ovf_count;  // [1]: how many; reset by k_prep when the bitmap is rebuilt
-  float* ell_a;               // ELL kernel matrix values, [K_max][N], indexed by POSITION
-  int* ell_j;                 // ELL column indices (ORIGINAL j, ascending), [K_max][N]
-  unsigned* nnz_row;          // nonzeros[N], SORTED row index
-  double* flow_part;          // [nblk_assoc][8]: omega(3), v(3), sum a, pad
-  unsigned long long* cnt_part;  // [nblk_assoc][4]: nnz, max, candidates, overflow rows
-  double* coef_part;          // [nblk_coeff][4]: B C D E
+  int* ovf_rows;   // [N]: positions of rows with more candidates than a list holds (handled by k_assoc_dense)
   PairState* st;
   cvo_trace_t* trace;
   int* status_out;  // mirror of st->status for cheap host polling
   int* want_out;    // mirror of st->want_full
   int* gate;        // [1] blocks of k_list that finished the current rebuild (the last one validates the list)
-  int* done;        // [1] k_coeff: blocks that stored their partials (monotonic; the last one runs the update)
 };
 
 constexpr int ROWS_PER_GROUP = 4;

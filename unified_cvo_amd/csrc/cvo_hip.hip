@@ -40,7 +40,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, tile_count, ovf_rows, ovf_count, gate, done, cand_cnt, rowperm, xp4, ip, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, tile_count, ovf_rows, gate, done, cand_cnt, rowperm, xp4, ip, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -135,7 +135,6 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.rowbits = take(sizeof(unsigned) * (size_t)(N + 4) * rbw_max);
   L.tile_count = take(sizeof(unsigned long long));
   L.ovf_rows = take(sizeof(int) * (size_t)N);
-  L.ovf_count = take(sizeof(int));
   L.gate = take(sizeof(int));
   L.done = take(sizeof(int));
   L.cand_cnt = take(sizeof(int) * (size_t)N);
@@ -311,7 +310,7 @@ void launch_list(hipStream_t s, bool idx16, int N, int n_pairs, const PairDesc* 
 }
 
 void launch_assoc(hipStream_t s, bool idx16, bool general, int nblk, int n_pairs, const PairDesc* descs,
-                  const DevParams* dp, const int* st, int lean) {
+                  const DevParams* dp, const PairState* st, int lean) {
   const dim3 blk(ASSOC_THREADS), grid = row_grid(nblk, n_pairs);
   if (idx16) {
     if (general)
@@ -359,10 +358,10 @@ void launch_rebuild(cvo_ctx* c, const LaunchGeom& g) {
 void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags) {
   const PairDesc* descs = c->d_descs + g.p0;
   const int* st = c->d_status + g.p0;
-  launch_assoc(g.stream, g.idx16, g.general, g.nba, g.n_pairs, descs, c->d_params, st, lean ? 1 : 0);
+  launch_assoc(g.stream, g.idx16, g.general, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, lean ? 1 : 0);
   if (!lean) launch_dense(g.stream, g.general, g.n_pairs, descs, c->d_params, st);
-  hipLaunchKernelGGL(k_coeff, row_grid(g.nba, g.n_pairs), dim3(ASSOC_THREADS), 0, g.stream, descs, c->d_params, st,
-                     flags | (lean ? 1 : 0), g.nba, g.n_pairs);
+  hipLaunchKernelGGL(k_coeff, row_grid(g.nba, g.n_pairs), dim3(ASSOC_THREADS), 0, g.stream, descs, c->d_params,
+                     c->d_states + g.p0, flags | (lean ? 1 : 0), g.nba, g.n_pairs);
 }
 
 // A chunk of U iterations.  Full: every iteration can rebuild its candidate list and serve overflow rows.
@@ -489,7 +488,6 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.rowbits = (unsigned*)(base + S->L.rowbits);
     D.tile_count = (unsigned long long*)(base + S->L.tile_count);
     D.ovf_rows = (int*)(base + S->L.ovf_rows);
-    D.ovf_count = (int*)(base + S->L.ovf_count);
     D.cand_cnt = (int*)(base + S->L.cand_cnt);
     D.rowperm = (int*)(base + S->L.rowperm);
     D.xp4 = (float4*)(base + S->L.xp4);
@@ -524,7 +522,6 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     // the slice bits must start clean (they are self-cleaning afterwards)
     HIP_TRY(ctx, hipMemsetAsync(D.rowbits, 0, sizeof(unsigned) * (size_t)(S->N + 4) * S->d.rbw_max, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.tile_count, 0, sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(D.ovf_count, 0, sizeof(int), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.gate, 0, sizeof(int), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.done, 0, sizeof(int), ctx->stream));
   }
@@ -1401,10 +1398,10 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
         const int p0 = (int)((long)n_pairs * g / G), p1 = (int)((long)n_pairs * (g + 1) / G);
         if (which == 0)
           launch_assoc(ctx->stream, idx16, general, nba, p1 - p0, ctx->d_descs + p0, ctx->d_params,
-                       ctx->d_status + p0, 2);
+                       ctx->d_states + p0, 2);
         else
           hipLaunchKernelGGL(k_coeff, row_grid(nba, p1 - p0), dim3(ASSOC_THREADS), 0, ctx->stream,
-                             ctx->d_descs + p0, ctx->d_params, ctx->d_status + p0, 8 | 2, nba, p1 - p0);
+                             ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0, 8 | 2, nba, p1 - p0);
       }
     };
     sweep();  // warm-up

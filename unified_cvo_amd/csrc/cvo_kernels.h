@@ -531,7 +531,7 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
     if (cnt_all > ASSOC_CAP) {
       // more candidates than a list holds (dense regime, e.g. rows sitting on K_max): k_assoc_dense
       // evaluates these rows against all targets, 64 at a time
-      const int slot = atomicAdd(D->ovf_count, 1);
+      const int slot = atomicAdd(&D->st->n_ovf, 1);
       D->ovf_rows[slot] = pos;
     } else {
       const unsigned* rb = D->rowbits + (size_t)rr * rbw;
@@ -686,20 +686,37 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
 template <typename IdxT, int ASSOC_CAP, bool GENERAL>
 __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restrict__ descs,
                                                           const DevParams* __restrict__ Pp,
-                                                          const int* __restrict__ status, int lean, int nblk,
+                                                          const PairState* __restrict__ states, int lean, int nblk,
                                                           int n_pairs) {
   PairBlock pb;
   if (!pair_block(nblk, n_pairs, pb)) return;
-  const bool replay = (lean & 2) != 0;  // cvo_debug_time_kernels: re-run on the state the last call left behind
-  if (!replay && status[pb.pair] != 0) return;
   const PairDesc* __restrict__ D = descs + pb.pair;
+  const PairState* __restrict__ st = states + pb.pair;  // == D->st, without the dependent pointer load
+  // everything the prologue branches on, requested in one burst of scalar loads (a chain of dependent ~0.5 us
+  // round trips in front of every block is what this latency-bound kernel can least afford)
+  const int status_v = st->status, rebuild_v = st->rebuild, n_ovf_v = st->n_ovf;
+  const DevParams P = *Pp;
+  {
+    // ... including what the row loop needs first: the empty asm keeps these loads above the early exits, so they
+    // are all in flight together instead of one round trip after each branch
+    const int n = D->N, k = st->K;
+    const int* a0 = D->cand_cnt;
+    const void* a1 = D->cand_j;
+    const float4* a2 = D->xp4;
+    const float4* a3 = D->y4;
+    const float* a4 = D->ell_a;
+    const float e = st->ell, r0 = st->Rinv[0], t0 = st->Tinv[0];
+    asm volatile("" ::"s"(n), "s"(k), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e), "s"(r0), "s"(t0), "s"(P.sp_thres),
+                 "s"(P.log_geo));
+  }
+  const bool replay = (lean & 2) != 0;  // cvo_debug_time_kernels: re-run on the state the last call left behind
+  if (!replay && status_v != 0) return;
   // lean graph (no rebuild / dense kernels inside the iteration): a pair whose list has expired, or that has
   // rows for k_assoc_dense, does not advance; it waits for the next rebuild opportunity / for the host to
   // switch its group to the full graph (k_coeff skips it too and tells the host)
-  if ((lean & 1) && (D->st->rebuild || *D->ovf_count > 0)) return;
-  const DevParams P = *Pp;
+  if ((lean & 1) && (rebuild_v || n_ovf_v > 0)) return;
   __shared__ AssocShared S;
-  assoc_phase<IdxT, ASSOC_CAP, GENERAL>(P, D, D->st, S, pb.bx);
+  assoc_phase<IdxT, ASSOC_CAP, GENERAL>(P, D, st, S, pb.bx);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -719,7 +736,7 @@ __global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict_
   const int N = D->N, M = D->M;
   const int K = st->K;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n_ovf = *D->ovf_count;
+  const int n_ovf = st->n_ovf;
   double red[7] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long nnz_sum = 0;
   unsigned nnz_max = 0;
@@ -1170,7 +1187,7 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
           const float rel = step_move / radius;
           s = P.skin_frac * fminf(fmaxf(1.5f * sqrtf(rel), 0.05f), 0.5f);
           const float s_lean = fmaxf(s, 1.3f * (float)P.lean_U * rel);
-          if (s_lean <= 0.5f && *D->ovf_count == 0) {
+          if (s_lean <= 0.5f && st->n_ovf == 0) {
             s = s_lean;
             want_full = 0;
           } else if (!(s >= 2.f * rel)) {
@@ -1183,7 +1200,7 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
         if (!dry) *D->want_out = want_full;
         st->n_builds = INIT ? 1 : st->n_builds + 1;
         st->rebuild = 1;  // cleared by k_list once bitmap and lists are current
-      } else if (st->want_full && *D->ovf_count == 0 &&
+      } else if (st->want_full && st->n_ovf == 0 &&
                  moved + 1.3f * (float)P.lean_U * step_move <= st->skin) {
         st->want_full = 0;  // the motion has slowed down enough for the lean graph
         if (!dry) *D->want_out = 0;
@@ -1224,18 +1241,32 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
 // flags: bit 0 = lean graph, the rest see update_body.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restrict__ descs,
-                                                         const DevParams* __restrict__ Pp,
-                                                         const int* __restrict__ status, int flags, int nblk,
-                                                         int n_pairs) {
+                                                         const DevParams* __restrict__ Pp, PairState* states, int flags,
+                                                         int nblk, int n_pairs) {
   PairBlock pb;
   if (!pair_block(nblk, n_pairs, pb)) return;
-  const bool replay = (flags & 8) != 0;  // cvo_debug_time_kernels: same work, nothing written back
-  if (!replay && status[pb.pair] != 0) return;
   const PairDesc* __restrict__ D = descs + pb.pair;
-  PairState* const st = D->st;
+  PairState* const st = states + pb.pair;  // == D->st, without the dependent pointer load
+  // The state as this launch found it, through a read-only view so that the loads are scalar (only the block that
+  // finishes last writes the state, after every block has read it); one burst together with what the row loop
+  // needs first, see k_assoc.
+  const PairState* __restrict__ st_in = states + pb.pair;
+  const int status_v = st_in->status, rebuild_v = st_in->rebuild, ovf = st_in->n_ovf;
+  {
+    const int n = D->N, nb = D->nblk_assoc, ep = st_in->epoch;
+    const double* a0 = D->flow_part;
+    const unsigned* a1 = D->nnz_row;
+    const float4* a2 = D->xp4;
+    const float* a3 = D->ell_a;
+    const int* a4 = D->ell_j;
+    const float4* a5 = D->y4;
+    const float e = st_in->ell, r0 = st_in->Rinv[0], t0 = st_in->Tinv[0];
+    asm volatile("" ::"s"(n), "s"(nb), "s"(ep), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(e), "s"(r0), "s"(t0));
+  }
+  const bool replay = (flags & 8) != 0;  // cvo_debug_time_kernels: same work, nothing written back
+  if (!replay && status_v != 0) return;
   if (flags & 1) {
-    const int ovf = *D->ovf_count;
-    if (st->rebuild || ovf > 0) {  // waiting, see k_assoc; tell the host which graph this pair needs
+    if (rebuild_v || ovf > 0) {  // waiting, see k_assoc; tell the host which graph this pair needs
       if (pb.bx == 0 && threadIdx.x == 0) {
         st->n_stalls++;
         if (ovf > 0) {
@@ -1248,7 +1279,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
   }
   const DevParams P = *Pp;
   if (P.mode != 0) return;
-  const int epoch = st->epoch;  // launches of this kernel the pair has completed (bumped by the updating block)
+  const int epoch = st_in->epoch;  // launches of this kernel the pair has completed (bumped by the updating block)
   __shared__ union {
     CoeffShared c;
     UpdateShared u;
@@ -1260,7 +1291,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     twist[c] = S.c.M.omega[c];
     twist[3 + c] = S.c.M.v[c];
   }
-  coeff_rows<true>(P, D, st, S.c, pb.bx);
+  coeff_rows<true>(P, D, st_in, S.c, pb.bx);
   __syncthreads();  // (its release waits for this block's coherent partial stores)
   if (threadIdx.x == 0) {
     const int done = __hip_atomic_fetch_add(D->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1363,7 +1394,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
   const int rs = (blockIdx.x - ntb) * PREP_THREADS + tid;
   if (rs >= D->NGpad * ROWS_PER_GROUP) return;  // whole waves drop out together (NGpad*4 is a multiple of 256)
   const float ell = st->ell;  // == st->ell_build: a rebuild always uses the current lengthscale
-  if (rs == 0) *D->ovf_count = 0;  // k_list refills the overflow list of k_assoc_dense
+  if (rs == 0) D->st->n_ovf = 0;  // k_list refills the overflow list of k_assoc_dense
   const float skin = st->skin;
   float ux = 0, uy = 0, uz = 0, cw = -INF, rad = 0;
   float lox = INF, loy = INF, loz = INF, hix = -INF, hiy = -INF, hiz = -INF;
