@@ -973,21 +973,26 @@ struct UpdateShared {
 template <bool INIT, bool COH>
 __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, const DevParams& P, int flags,
                                             int n_flow_parts, UpdateShared& U, const float* twist,
-                                            unsigned* preloaded_hot) {
+                                            const unsigned* preloaded_hot) {
   PairState* const gst = D->st;
   const bool trio_follows = INIT || (flags & 2) != 0;
   const bool dry = (flags & 8) != 0;  // timing replay: compute everything, write nothing back
   const int horizon = flags >> 8;
   double* const s_c = U.c;
   unsigned long long* const s_n = U.n;
-  unsigned* const s_hot = preloaded_hot ? preloaded_hot : U.hot;
+  unsigned* const s_hot = U.hot;
   const int tid = threadIdx.x;
   const bool act = tid < 64;
 
   // the scalar part of the state is staged through LDS: one coalesced burst in, one out, instead of
   // dozens of dependent global accesses from a single lane
-  if (act && !preloaded_hot)
+  static_assert(HOT_DWORDS <= 128, "two dwords per lane of the first wave cover the scalar state");
+  if (act && preloaded_hot) {  // the caller read the state into registers while it waited for something else
+    s_hot[tid] = preloaded_hot[0];
+    if (tid + 64 < HOT_DWORDS) s_hot[tid + 64] = preloaded_hot[1];
+  } else if (act) {
     for (int q = tid; q < HOT_DWORDS; q += 64) s_hot[q] = reinterpret_cast<const unsigned*>(gst)[q];
+  }
   PairState* const st = reinterpret_cast<PairState*>(s_hot);
   float* const sq = gst->sq;
   float* const eq = gst->eq;
@@ -1292,6 +1297,12 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     twist[3 + c] = S.c.M.v[c];
   }
   coeff_rows<true>(P, D, st_in, S.c, pb.bx);
+  // the scalar state, for whichever block turns out to be the last one: in flight while the counter round trip runs
+  unsigned hot_regs[2] = {0u, 0u};
+  if (threadIdx.x < 64) {
+    hot_regs[0] = reinterpret_cast<const unsigned*>(st)[threadIdx.x];
+    if (threadIdx.x + 64 < HOT_DWORDS) hot_regs[1] = reinterpret_cast<const unsigned*>(st)[threadIdx.x + 64];
+  }
   __syncthreads();  // (its release waits for this block's coherent partial stores)
   if (threadIdx.x == 0) {
     const int done = __hip_atomic_fetch_add(D->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1299,7 +1310,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
   }
   __syncthreads();
   if (!s_last) return;
-  update_body<false, true>(D, P, flags | 4, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, S.u, twist, nullptr);
+  update_body<false, true>(D, P, flags | 4, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, S.u, twist, hot_regs);
 }
 
 // ------------------------------------------------------------------------------------------
