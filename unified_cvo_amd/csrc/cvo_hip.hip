@@ -1401,7 +1401,7 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
                        ctx->d_states + p0, 2);
         else
           hipLaunchKernelGGL(k_coeff, row_grid(nba, p1 - p0), dim3(ASSOC_THREADS), 0, ctx->stream,
-                             ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0, 8 | 2, nba, p1 - p0);
+                             ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0, 8 | 2 | (getenv("CVO_COEFF_NO_UPDATE") ? 16 : 0), nba, p1 - p0);
       }
     };
     sweep();  // warm-up

@@ -1309,7 +1309,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     s_last = replay ? (done % nblk == nblk - 1) : (done == (epoch + 1) * nblk - 1);
   }
   __syncthreads();
-  if (!s_last) return;
+  if (!s_last || (flags & 16)) return;  // (bit 4: cost breakdown of cvo_debug_time_kernels, coefficient phase only)
   update_body<false, true>(D, P, flags | 4, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, S.u, twist, hot_regs);
 }
 
