@@ -519,7 +519,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
       st.ell = opts->ell0;
       st.K = opts->K0;
     }
-    // the slice bits must start clean (they are self-cleaning afterwards)
+    // the slice bits start clean (k_prep clears a row's bits again before every rebuild)
     HIP_TRY(ctx, hipMemsetAsync(D.rowbits, 0, sizeof(unsigned) * (size_t)(S->N + 4) * S->d.rbw_max, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.tile_count, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.gate, 0, sizeof(int), ctx->stream));
