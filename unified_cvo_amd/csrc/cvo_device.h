@@ -94,7 +94,7 @@ struct PairState {
 // rejected by a bounding-box test; k_assoc maps candidates back and restores ascending original j.
 struct PairDesc {
   // ---- read by the per-iteration kernels (k_assoc, k_coeff): kept together at the front ----
-  int N, M, nblk_assoc, nblk_coeff;
+  int N, M, nblk_assoc, nblk_coeff;  // nblk_coeff = nblk_assoc * csplit partials of the coefficient phase
   // k_list orders the rows of every 256-row window by candidate count; POSITION = index in that order
   int* cand_cnt;   // [N] candidates of the row at each position
   void* cand_j;    // [ASSOC_CAP][N] cached candidate lists by position (original target index, ascending), u16 or i32
@@ -106,8 +106,9 @@ struct PairDesc {
   unsigned* nnz_row;          // nonzeros[N], by position
   double* flow_part;          // [nblk_assoc + DENSE_BLOCKS][8]: omega(3), v(3), sum a, pad (row blocks, then k_assoc_dense)
   unsigned long long* cnt_part;  // [nblk_assoc + DENSE_BLOCKS][4]: nnz, max, candidates, overflow rows
-  double* coef_part;          // [nblk_coeff][4]: B C D E
+  double* coef_part;          // [nblk_assoc * COEFF_SPLIT_MAX][4]: B C D E
   int* done;        // [1] k_coeff: blocks that stored their partials (monotonic; the last one runs the update)
+  int csplit, pad_csplit;  // k_coeff: blocks per row block; block q of a row block takes the ELL slots s = q (mod csplit)
   const float4* xfeat;
   const float4* yfeat;
   const float4* xlabel;
@@ -135,6 +136,7 @@ struct PairDesc {
                               // valid iff that slice's bit is set in the row's rowbits (never memset)
   unsigned* rowbits;          // [N sorted rows][rbw]: bit s set <=> the row has candidates in scan slice s;
                               // set by k_scan (returnless atomic OR), cleared by k_prep on a rebuild
+  int* row_cnt;               // [N sorted rows]: candidates of the row in the bitmap (k_prep zeroes, k_scan adds)
   unsigned long long* tile_count;  // [1]: fine tiles executed so far this call (statistics)
   int* ovf_rows;   // [N]: positions of rows with more candidates than a list holds (handled by k_assoc_dense)
   PairState* st;
@@ -144,6 +146,7 @@ struct PairDesc {
   int* gate;        // [1] blocks of k_list that finished the current rebuild (the last one validates the list)
 };
 
+constexpr int COEFF_SPLIT_MAX = 8;
 constexpr int ROWS_PER_GROUP = 4;
 constexpr int DENSE_BLOCKS = 64;  // k_assoc_dense blocks per pair (4 waves each, one overflow row per wave at a time)
 

@@ -40,7 +40,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, tile_count, ovf_rows, gate, done, cand_cnt, rowperm, xp4, ip, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, gate, done, cand_cnt, rowperm, xp4, ip, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -87,7 +87,7 @@ struct cvo_ctx {
   int last_pairs = 0;
   int last_N = 0, last_M = 0, last_Kmax = 0;
   DevParams last_params{};
-  int last_gx = 0, last_gy = 0;
+  int last_gx = 0, last_gy = 0, last_csplit = 1;
   std::vector<int> last_xorder;  // pair 0's source order: sorted row -> original row
   int last_groups = 1;           // sub-batches (streams) of the last call
   PairLayout last_layout{};
@@ -133,6 +133,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.sbox = take(sizeof(float4) * 2 * (size_t)nchunks);
   L.masks = take(sizeof(unsigned long long) * ((size_t)N + 8) * nchunks);
   L.rowbits = take(sizeof(unsigned) * (size_t)(N + 4) * rbw_max);
+  L.row_cnt = take(sizeof(int) * (size_t)N);
   L.tile_count = take(sizeof(unsigned long long));
   L.ovf_rows = take(sizeof(int) * (size_t)N);
   L.gate = take(sizeof(int));
@@ -147,7 +148,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.nnz_row = take(sizeof(unsigned) * (size_t)N);
   L.flow_part = take(sizeof(double) * 8 * (size_t)(nba + DENSE_BLOCKS));
   L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)(nba + DENSE_BLOCKS));
-  L.coef_part = take(sizeof(double) * 4 * (size_t)nbc);
+  L.coef_part = take(sizeof(double) * 4 * (size_t)nbc * COEFF_SPLIT_MAX);
   L.trace = take(sizeof(cvo_trace_t) * (size_t)std::max(trace_capacity, 0));
   L.total = off;
   d->Mpad = Mpad;
@@ -214,6 +215,12 @@ int ensure_workspace(cvo_ctx* c, int n_pairs, size_t bytes_per_pair) {
     drop_graphs(c);
   }
   return CVO_OK;
+}
+
+int coeff_split(int n) {
+  int s = 1;
+  while (s < COEFF_SPLIT_MAX && (long)n * (2 * s) <= 8192) s *= 2;
+  return s;
 }
 
 DevParams make_dev_params(const cvo_params_t& p) {
@@ -333,7 +340,7 @@ void launch_dense(hipStream_t s, bool general, int n_pairs, const PairDesc* desc
 }
 
 struct LaunchGeom {
-  int n_pairs, p0, T, gx, gy, nba, nbc, npb, N;
+  int n_pairs, p0, T, gx, gy, nba, nbc, npb, N, csplit;
   bool idx16, general;
   hipStream_t stream;
 };
@@ -360,8 +367,8 @@ void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags) {
   const int* st = c->d_status + g.p0;
   launch_assoc(g.stream, g.idx16, g.general, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, lean ? 1 : 0);
   if (!lean) launch_dense(g.stream, g.general, g.n_pairs, descs, c->d_params, st);
-  hipLaunchKernelGGL(k_coeff, row_grid(g.nba, g.n_pairs), dim3(ASSOC_THREADS), 0, g.stream, descs, c->d_params,
-                     c->d_states + g.p0, flags | (lean ? 1 : 0), g.nba, g.n_pairs);
+  hipLaunchKernelGGL(k_coeff, row_grid(g.nba * g.csplit, g.n_pairs), dim3(ASSOC_THREADS), 0, g.stream, descs, c->d_params,
+                     c->d_states + g.p0, flags | (lean ? 1 : 0), g.nba | (g.csplit << 16), g.n_pairs);
 }
 
 // A chunk of U iterations.  Full: every iteration can rebuild its candidate list and serve overflow rows.
@@ -460,7 +467,10 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.nslices = S->d.Mpad / (64 * S->T);
     D.rbw = (int)align_up((size_t)(S->d.Mpad / (64 * S->T) + 31) / 32, 4);
     D.nblk_assoc = S->d.nblk_assoc;
-    D.nblk_coeff = S->d.nblk_coeff;
+    // coefficient phase: small clouds get several blocks per row block (see coeff_rows); a function of the pair's own
+    // size only, so that a pair is reduced in the same order whether it is solved alone or inside a batch
+    D.csplit = coeff_split(X->n);
+    D.nblk_coeff = S->d.nblk_assoc * D.csplit;
     D.NG = (X->n + ROWS_PER_GROUP - 1) / ROWS_PER_GROUP;
     D.NGpad = S->d.NGpad;
     D.ymax = Y->rmax;
@@ -486,6 +496,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.sbox = (float4*)(base + S->L.sbox);
     D.masks = (unsigned long long*)(base + S->L.masks);
     D.rowbits = (unsigned*)(base + S->L.rowbits);
+    D.row_cnt = (int*)(base + S->L.row_cnt);
     D.tile_count = (unsigned long long*)(base + S->L.tile_count);
     D.ovf_rows = (int*)(base + S->L.ovf_rows);
     D.cand_cnt = (int*)(base + S->L.cand_cnt);
@@ -543,6 +554,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.gy = S->gy;
   S->geom.nba = S->d.nblk_assoc;
   S->geom.N = N;
+  S->geom.csplit = 1;
+  for (int p = 0; p < n_pairs; p++) S->geom.csplit = std::max(S->geom.csplit, coeff_split(sources[p]->n));
   S->geom.nbc = S->d.nblk_coeff;
   S->geom.npb = S->d.Mpad / PREP_THREADS + (S->d.NGpad * ROWS_PER_GROUP + PREP_THREADS - 1) / PREP_THREADS;
   S->geom.idx16 = M < 65536;
@@ -554,6 +567,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   ctx->last_M = M;
   ctx->last_Kmax = Kmax;
   ctx->last_params = dp;
+  ctx->last_csplit = S->geom.csplit;
   ctx->last_gx = S->gx;
   ctx->last_gy = S->gy;
   ctx->last_layout = S->L;
@@ -947,7 +961,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       key.gx = S.gx;
       key.gy = S.gy;
       key.nba = S.d.nblk_assoc;
-      key.nbc = S.d.nblk_coeff;
+      key.nbc = S.d.nblk_coeff * 64 + S.geom.csplit;
       key.npb = S.geom.npb;
       key.idx16 = S.geom.idx16 ? 1 : 0;
       key.general = S.geom.general ? 1 : 0;
@@ -1400,8 +1414,9 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
           launch_assoc(ctx->stream, idx16, general, nba, p1 - p0, ctx->d_descs + p0, ctx->d_params,
                        ctx->d_states + p0, 2);
         else
-          hipLaunchKernelGGL(k_coeff, row_grid(nba, p1 - p0), dim3(ASSOC_THREADS), 0, ctx->stream,
-                             ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0, 8 | 2 | (getenv("CVO_COEFF_NO_UPDATE") ? 16 : 0), nba, p1 - p0);
+          hipLaunchKernelGGL(k_coeff, row_grid(nba * ctx->last_csplit, p1 - p0), dim3(ASSOC_THREADS), 0, ctx->stream,
+                             ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0,
+                             8 | 2 | (getenv("CVO_COEFF_NO_UPDATE") ? 16 : 0), nba | (ctx->last_csplit << 16), p1 - p0);
       }
     };
     sweep();  // warm-up

@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
   // (lane q = u*T+t <-> row u, chunk t) and rows that are neighbours in space share cache lines
   CVO_GLOBAL unsigned long long* mask_lane = masks + (size_t)slice * N * T + lane;
   CVO_GLOBAL unsigned* rowbits_lane = rowbits + (size_t)(lane / T) * rbw + (slice >> 5);
+  CVO_GLOBAL int* rowcnt_lane = (CVO_GLOBAL int*)D->row_cnt + (lane / T);
 
   // Two-level cull.  Level 1: lane l tests the box of row cell c (64 rows that the k-d ordering made a
   // compact block) against the slice box -> m1.  Level 2: four overlapping cells at a time, lane l tests
@@ -299,10 +300,22 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
         unsigned rowsel = 0;
 #pragma unroll
         for (int u = 0; u < RG; u++) rowsel |= mu[u] ? (((1u << T) - 1u) << (u * T)) : 0u;
+        // candidates of each row in this slice: scalar popcounts of the ballot masks, handed to the row's first lane
+        int row_pc = 0;
+#pragma unroll
+        for (int u = 0; u < RG; u++) {
+          int c = 0;
+#pragma unroll
+          for (int t = 0; t < T; t++) c += __builtin_popcountll(mm[u][t]);
+          row_pc = (lane == u * T) ? c : row_pc;
+        }
         if (lane < RG * T && ((rowsel >> lane) & 1u)) {
           mask_lane[(size_t)r * T] = ((unsigned long long)hi << 32) | lo;
-          if ((lane % T) == 0)  // tells k_assoc that this (row, slice) has valid mask words
+          if ((lane % T) == 0) {
+            // tells k_list that this (row, slice) has valid mask words, and how many candidates they add to the row
             __hip_atomic_fetch_or(rowbits_lane + (size_t)r * rbw, slice_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(rowcnt_lane + r, row_pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
     }
@@ -478,41 +491,25 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
   const int T = Pp->T;
   const int rbw = D->rbw;
   __shared__ IdxT s_list[LIST_THREADS * ASSOC_STRIDE];
-  __shared__ int s_key[LIST_THREADS];
+  __shared__ __attribute__((aligned(16))) int s_key[LIST_THREADS];
   __shared__ int s_row[LIST_THREADS];
   const int tid = threadIdx.x;
   const int w0row = pb.bx * LIST_THREADS;
   // ---- candidates of row w0row + tid
   int ncand = ASSOC_CAP + 2;  // rows past N sort behind every real row
-  if (w0row + tid < N) {
-    const int r = w0row + tid;
-    const unsigned* rb = D->rowbits + (size_t)r * rbw;
-    ncand = 0;
-    for (int w0 = 0; w0 < rbw; w0 += 4) {  // rbw is a multiple of 4 (one 16-byte load covers 128 slices)
-      const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
-      if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
-      const unsigned bw[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        unsigned f = bw[q];
-        while (f) {
-          const int sl = (w0 + q) * 32 + __builtin_ctz(f);
-          f &= f - 1;
-          const unsigned long long* mw = D->masks + ((size_t)sl * N + r) * T;
-          for (int t = 0; t < T; t++) ncand += __builtin_popcountll(mw[t]);
-        }
-      }
-    }
-  }
+  if (w0row + tid < N) ncand = D->row_cnt[w0row + tid];  // accumulated by k_scan's emission
   // ---- stable rank by min(count, CAP + 1): every thread counts the keys that sort before its own
   s_key[tid] = (w0row + tid < N) ? min(ncand, ASSOC_CAP + 1) : ASSOC_CAP + 2;  // overflow rows last, pad rows behind them
   __syncthreads();
   {
     const int mine = s_key[tid];
     int rank = 0;
-    for (int t = 0; t < LIST_THREADS; t++) {
-      const int o = s_key[t];
-      rank += (o < mine || (o == mine && t < tid)) ? 1 : 0;
+    for (int t = 0; t < LIST_THREADS; t += 4) {  // wave-uniform 16-byte LDS reads (broadcast)
+      const int4 o = *reinterpret_cast<const int4*>(&s_key[t]);
+      rank += (o.x < mine || (o.x == mine && t < tid)) ? 1 : 0;
+      rank += (o.y < mine || (o.y == mine && t + 1 < tid)) ? 1 : 0;
+      rank += (o.z < mine || (o.z == mine && t + 2 < tid)) ? 1 : 0;
+      rank += (o.w < mine || (o.w == mine && t + 3 < tid)) ? 1 : 0;
     }
     s_row[rank] = tid | (ncand << 8);  // position `rank` of the window holds row tid (ncand <= ~M < 2^23)
   }
@@ -568,18 +565,17 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
         for (int u = 0; u < 4; u++)
           if (k0 + u < cnt) list[k0 + u] = (IdxT)jj[u];
       }
-      // ascending original j (the order of the reference's first-K truncation and float accumulation)
-      for (int k = 1; k < cnt; k++) {
-        const int j = (int)list[k];
-        int q = k;
-        while (q > 0 && (int)list[q - 1] > j) {
-          list[q] = list[q - 1];
-          q--;
-        }
-        list[q] = (IdxT)j;
-      }
+      // ascending original j (the order of the reference's first-K truncation and float accumulation): every entry
+      // is written straight to its rank (the indices of a row are distinct); cnt^2 independent LDS reads instead of
+      // an insertion sort's chain of dependent shifts
       IdxT* out = reinterpret_cast<IdxT*>(D->cand_j);
-      for (int k = 0; k < cnt; k++) out[(size_t)k * N + pos] = list[k];
+      for (int k = 0; k < cnt; k++) {
+        const int j = (int)list[k];
+        int rank = 0;
+#pragma unroll 4
+        for (int m2 = 0; m2 < cnt; m2++) rank += ((int)list[m2] < j) ? 1 : 0;
+        out[(size_t)rank * N + pos] = (IdxT)j;
+      }
     }
   }
   // The block that finishes last validates the list: every block has read `rebuild` by then, and the
@@ -905,7 +901,7 @@ __device__ __forceinline__ void coeff_entry(const XiMats& M, const float4 x, flo
 // Rows of this block.  COH: the block partial is read by another block of the same launch.
 template <bool COH>
 __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* __restrict__ D, const PairState* st,
-                                           CoeffShared& S, const int bx) {
+                                           CoeffShared& S, const int bx, const int q, const int nsplit) {
   const int N = D->N;
   const int i = bx * ASSOC_THREADS + threadIdx.x;  // position (see k_list)
   double Bi = 0, Ci = 0, Di = 0, Ei = 0;
@@ -920,20 +916,24 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
       }
       const float temp_coef = (float)(1 / (2.0 * temp_ell * temp_ell));
       const Pose pose = load_pose(st);
-      // software pipeline: entry s+1's index / value / target are in flight while entry s is evaluated
-      int idx_n = D->ell_j[i];
-      float a_n = D->ell_a[i];
-      float4 y_n = D->y4[idx_n];
-      for (unsigned s = 0; s < nnz; s++) {
-        const float A_ij = a_n;
-        const float4 y0 = y_n;
-        if (s + 1 < nnz) {
-          idx_n = D->ell_j[(size_t)(s + 1) * N + i];
-          a_n = D->ell_a[(size_t)(s + 1) * N + i];
-          y_n = D->y4[idx_n];
+      // this block's share of the row: slots q, q + nsplit, ...  (small clouds whose rows sit on K_max would
+      // otherwise leave the chip to a handful of waves walking hundreds of entries each).  Software pipeline: the
+      // next entry's index / value / target are in flight while the current one is evaluated.
+      if ((unsigned)q < nnz) {
+        int idx_n = D->ell_j[(size_t)q * N + i];
+        float a_n = D->ell_a[(size_t)q * N + i];
+        float4 y_n = D->y4[idx_n];
+        for (unsigned s = (unsigned)q; s < nnz; s += (unsigned)nsplit) {
+          const float A_ij = a_n;
+          const float4 y0 = y_n;
+          if (s + nsplit < nnz) {
+            idx_n = D->ell_j[(size_t)(s + nsplit) * N + i];
+            a_n = D->ell_a[(size_t)(s + nsplit) * N + i];
+            y_n = D->y4[idx_n];
+          }
+          const V3 yy = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
+          coeff_entry(S.M, x, temp_coef, yy, A_ij, Bi, Ci, Di, Ei);
         }
-        const V3 yy = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
-        coeff_entry(S.M, x, temp_coef, yy, A_ij, Bi, Ci, Di, Ei);
       }
     }
   }
@@ -950,7 +950,7 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
     double t = S.red[0][c];
 #pragma unroll
     for (int w = 1; w < NW; w++) t += S.red[w][c];
-    st_x<COH>(D->coef_part + (size_t)bx * 4 + c, t);
+    st_x<COH>(D->coef_part + ((size_t)bx * nsplit + q) * 4 + c, t);
   }
 }
 
@@ -1248,9 +1248,16 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
 __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restrict__ descs,
                                                          const DevParams* __restrict__ Pp, PairState* states, int flags,
                                                          int nblk, int n_pairs) {
+  // grid: per pair nblk row blocks x launch_split slices of the ELL slots; a pair uses csplit <= launch_split of them
+  const int launch_split = nblk >> 16;
+  nblk &= 0xffff;
   PairBlock pb;
-  if (!pair_block(nblk, n_pairs, pb)) return;
+  if (!pair_block(nblk * launch_split, n_pairs, pb)) return;
   const PairDesc* __restrict__ D = descs + pb.pair;
+  const int csplit = D->csplit;
+  const int cq = pb.bx % launch_split;
+  pb.bx /= launch_split;
+  if (cq >= csplit) return;
   PairState* const st = states + pb.pair;  // == D->st, without the dependent pointer load
   // The state as this launch found it, through a read-only view so that the loads are scalar (only the block that
   // finishes last writes the state, after every block has read it); one burst together with what the row loop
@@ -1272,7 +1279,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
   if (!replay && status_v != 0) return;
   if (flags & 1) {
     if (rebuild_v || ovf > 0) {  // waiting, see k_assoc; tell the host which graph this pair needs
-      if (pb.bx == 0 && threadIdx.x == 0) {
+      if (pb.bx == 0 && cq == 0 && threadIdx.x == 0) {
         st->n_stalls++;
         if (ovf > 0) {
           st->want_full = 1;
@@ -1296,7 +1303,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     twist[c] = S.c.M.omega[c];
     twist[3 + c] = S.c.M.v[c];
   }
-  coeff_rows<true>(P, D, st_in, S.c, pb.bx);
+  coeff_rows<true>(P, D, st_in, S.c, pb.bx, cq, csplit);
   // the scalar state, for whichever block turns out to be the last one: in flight while the counter round trip runs
   unsigned hot_regs[2] = {0u, 0u};
   if (threadIdx.x < 64) {
@@ -1306,7 +1313,8 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
   __syncthreads();  // (its release waits for this block's coherent partial stores)
   if (threadIdx.x == 0) {
     const int done = __hip_atomic_fetch_add(D->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = replay ? (done % nblk == nblk - 1) : (done == (epoch + 1) * nblk - 1);
+    const int nwork = nblk * csplit;  // blocks of this pair that store a partial
+    s_last = replay ? (done % nwork == nwork - 1) : (done == (epoch + 1) * nwork - 1);
   }
   __syncthreads();
   if (!s_last || (flags & 16)) return;  // (bit 4: cost breakdown of cvo_debug_time_kernels, coefficient phase only)
@@ -1430,7 +1438,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
     lox = hix = ux;
     loy = hiy = uy;
     loz = hiz = uz;
-    // the bitmap is rebuilt from scratch: drop this row's slice bits (k_scan runs after this kernel)
+    // the bitmap is rebuilt from scratch: drop this row's slice bits and candidate count (k_scan runs after this kernel)
+    D->row_cnt[rs] = 0;
     unsigned* rb = D->rowbits + (size_t)rs * D->rbw;
     for (int w0 = 0; w0 < D->rbw; w0 += 4) *reinterpret_cast<uint4*>(rb + w0) = make_uint4(0, 0, 0, 0);
   }
