@@ -215,6 +215,18 @@ def main():
                 "sample": f"first {o['iterations']} optimiser iterations of pair 0 ({n}x{n}) with the CPU oracle "
                           f"(dense scan, OpenMP over rows), extrapolated to the {mean_iters:.0f} iterations of a full align()",
             }
+            # "best-effort CPU" (SURVEY.md 8(d)): the same oracle with a uniform grid over the targets instead of the dense
+            # scan (the reference's own CPU code uses a kd-tree); its cost falls as ell decays, so it runs the whole align()
+            po.set_grid(True)
+            try:
+                og = po.align(op, ox, oy, inits[0])
+            finally:
+                po.set_grid(False)
+            cpu_baseline["best_effort"] = {
+                "value": 1.0 / max(og["seconds"], 1e-9), "unit": "align/s", "cores": threads,
+                "ms_per_iter": og["seconds"] * 1e3 / max(og["iterations"], 1),
+                "sample": f"one full align() of pair 0 ({og['iterations']} iterations) with the oracle's uniform-grid variant "
+                          f"(identical results, tests/test_oracle_numpy.py)"}
             # cross-check of the measured batch against the oracle on the same sample
             g = gpu.align(src[0], tgt[0], inits[0], max_iterations=it)
             d = float(np.max(np.abs(g.transform - o["transform"])))

@@ -250,11 +250,119 @@ inline unsigned se_row_blocked(const OracleParams& P, const CloudView& X, int i,
   return num_inds;
 }
 
+// ---- "best-effort CPU" variant: a uniform grid over the transformed targets ------------------
+// The reference's own CPU code searches neighbours with a kd-tree (Cvo.cpp:368-381, CvoGPU.cpp:115-125); so that the
+// GPU is not only timed against a dense scan, the oracle can also generate each row's candidates from the grid cells
+// its cut-off sphere touches.  Candidates are visited in ascending j and go through the same pair_value(), so the
+// result is identical to se_row_literal (checked in tests/test_oracle_numpy.py); only the time differs.
+static int g_use_grid = 0;
+
+struct TargetGrid {
+  double ox, oy, oz, inv_cell;
+  int nx, ny, nz;
+  std::vector<int> start;  // CSR over cells
+  std::vector<int> items;  // target indices, ascending inside a cell (stable counting sort)
+  int cell_of(double v, double o, int n) const {
+    int c = (int)std::floor((v - o) * inv_cell);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+  }
+};
+
+static bool build_grid(const CloudView& Y, double cell, TargetGrid& G) {
+  if (!(cell > 0) || Y.n == 0) return false;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int j = 0; j < Y.n; j++)
+    for (int c = 0; c < 3; c++) {
+      const double v = Y.p(j)[c];
+      if (!(v == v) || std::isinf(v)) return false;
+      lo[c] = std::min(lo[c], v);
+      hi[c] = std::max(hi[c], v);
+    }
+  double ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+  while ((ext[0] / cell + 1) * (ext[1] / cell + 1) * (ext[2] / cell + 1) > 4e6) cell *= 2;  // bound the cell count
+  G.ox = lo[0];
+  G.oy = lo[1];
+  G.oz = lo[2];
+  G.inv_cell = 1.0 / cell;
+  G.nx = (int)(ext[0] / cell) + 1;
+  G.ny = (int)(ext[1] / cell) + 1;
+  G.nz = (int)(ext[2] / cell) + 1;
+  const size_t nc = (size_t)G.nx * G.ny * G.nz;
+  G.start.assign(nc + 1, 0);
+  std::vector<int> cell_of(Y.n);
+  for (int j = 0; j < Y.n; j++) {
+    const int c = (G.cell_of(Y.p(j)[2], G.oz, G.nz) * G.ny + G.cell_of(Y.p(j)[1], G.oy, G.ny)) * G.nx +
+                  G.cell_of(Y.p(j)[0], G.ox, G.nx);
+    cell_of[j] = c;
+    G.start[c + 1]++;
+  }
+  for (size_t c = 0; c < nc; c++) G.start[c + 1] += G.start[c];
+  G.items.resize(Y.n);
+  std::vector<int> fill(G.start.begin(), G.start.end() - 1);
+  for (int j = 0; j < Y.n; j++) G.items[fill[cell_of[j]]++] = j;
+  return true;
+}
+
+inline unsigned se_row_grid(const OracleParams& P, const CloudView& X, int i, const CloudView& Y, const TargetGrid& G,
+                            int K, float ell, float* mat_row, int* ind_row, std::vector<int>& cand) {
+  RowConsts rc = row_consts(P, X.p(i), ell);
+  // every j with (float) d2 < d2_thres lies within this radius of x_i (1e-5 relative + absolute slack for the float
+  // evaluation of d2)
+  const double r = std::sqrt(std::max((double)rc.d2_thres, 0.0)) * (1.0 + 1e-5) + 1e-6;
+  const float* x = X.p(i);
+  const int x0 = G.cell_of(x[0] - r, G.ox, G.nx), x1 = G.cell_of(x[0] + r, G.ox, G.nx);
+  const int y0 = G.cell_of(x[1] - r, G.oy, G.ny), y1 = G.cell_of(x[1] + r, G.oy, G.ny);
+  const int z0 = G.cell_of(x[2] - r, G.oz, G.nz), z1 = G.cell_of(x[2] + r, G.oz, G.nz);
+  cand.clear();
+  for (int cz = z0; cz <= z1; cz++)
+    for (int cy = y0; cy <= y1; cy++) {
+      const size_t row = ((size_t)cz * G.ny + cy) * G.nx;
+      cand.insert(cand.end(), G.items.begin() + G.start[row + x0], G.items.begin() + G.start[row + x1 + 1]);
+    }
+  std::sort(cand.begin(), cand.end());  // ascending j: the reference's truncation / accumulation order
+  unsigned num_inds = 0;
+  for (int j : cand) {
+    if (num_inds == (unsigned)K) break;
+    float a;
+    if (!pair_value(P, rc, X, i, Y, j, &a)) continue;
+    if (a > P.sp_thres) {
+      mat_row[num_inds] = a;
+      ind_row[num_inds] = j;
+      num_inds++;
+    }
+  }
+  return num_inds;
+}
+
 // se_kernel (CvoGPU.cu:648-683) + reset_state_at_new_iter (CvoState.cu:143-157): rows are
 // written from slot 0; slot nnz holds ind = -1, mat = 0 when nnz < K (what memset leaves).
 void se_kernel_impl(const OracleParams& P, const CloudView& X, const CloudView& Y, int K, float ell,
                     float* mat, int* ind, unsigned* nonzeros, bool literal) {
   const int n = X.n, m = Y.n;
+  if (g_use_grid && !literal && P.is_using_geometry && n > 0 && m > 0) {
+    // cell = the largest cut-off radius of any row: at most 3 x 3 x 3 cells per query
+    double rmax = 0;
+    for (int i = 0; i < n; i++) rmax = std::max(rmax, (double)row_consts(P, X.p(i), ell).d2_thres);
+    TargetGrid G;
+    if (rmax > 0 && build_grid(Y, std::sqrt(rmax), G)) {
+#pragma omp parallel
+      {
+        std::vector<int> cand;
+#pragma omp for schedule(dynamic, 64)
+        for (int i = 0; i < n; i++) {
+          float* mr = mat + (size_t)i * K;
+          int* ir = ind + (size_t)i * K;
+          unsigned nn = se_row_grid(P, X, i, Y, G, K, ell, mr, ir, cand);
+          if ((int)nn < K) {
+            ir[nn] = -1;
+            mr[nn] = 0;
+          }
+          nonzeros[i] = nn;
+        }
+      }
+      return;
+    }
+  }
   std::vector<float> yx, yy, yz;
   const bool blocked = !literal && P.is_using_geometry;
   if (blocked) {
@@ -1146,6 +1254,9 @@ int oracle_association_non_isotropic(const OracleParams* p, const OracleCloud* x
   row_ptr[X.n] = cnt;
   return cnt;
 }
+
+void oracle_set_grid(int on) { g_use_grid = on != 0; }
+int oracle_get_grid(void) { return g_use_grid; }
 
 int oracle_num_threads(void) {
 #ifdef _OPENMP

@@ -111,6 +111,11 @@ int oracle_association_non_isotropic(const OracleParams* p, const OracleCloud* x
                                      const float T_colmajor[16], const float kernel_colmajor[9], int* row_ptr,
                                      int* col, float* val, float* kernel_inv_rowmajor_out);
 
+/* 1: se_kernel generates each row's candidates from a uniform grid over the targets ("best-effort CPU" timing
+ * variant, identical results); 0 (default): dense scan as the reference's GPU kernel does it. */
+void oracle_set_grid(int on);
+int oracle_get_grid(void);
+
 int oracle_num_threads(void);
 void oracle_set_num_threads(int n);
 

@@ -91,6 +91,8 @@ def lib():
     L.oracle_function_angle.restype = C.c_float
     L.oracle_association.argtypes = [pp, cp, cp, fp, C.c_float, ip, ip, fp]
     L.oracle_association.restype = C.c_int
+    L.oracle_set_grid.argtypes = [C.c_int]
+    L.oracle_set_grid.restype = None
     L.oracle_num_threads.restype = C.c_int
     L.oracle_set_num_threads.argtypes = [C.c_int]
     L.oracle_set_num_threads.restype = None
@@ -267,6 +269,10 @@ def association_non_isotropic(p, x, y, T, kernel):
                                                  row_ptr.ctypes.data_as(C.POINTER(C.c_int)),
                                                  col.ctypes.data_as(C.POINTER(C.c_int)), _f(val), _f(kinv))
     return row_ptr, col[:cnt], val[:cnt], kinv.reshape(3, 3)
+
+
+def set_grid(on):
+    lib().oracle_set_grid(1 if on else 0)
 
 
 def num_threads():

@@ -161,3 +161,25 @@ def test_transform_pose_vec_matches_float64(oracle):
     # identity pose reproduces the input exactly (the edge kernel relies on it)
     I = np.hstack([np.eye(3), np.zeros((3, 1))])
     assert np.array_equal(oracle.transform_pose_vec(I, xyz), xyz)
+
+
+def test_grid_variant_is_identical_to_the_dense_scan(oracle):
+    """The "best-effort CPU" timing variant (uniform grid over the targets) must reproduce the dense scan bit for bit:
+    same ELL pattern and values in one iteration, same pose after a short trajectory."""
+    import cases
+    for builder, kw in ((cases.config2, dict(n=1500)), (cases.config3, dict(n=900)), (cases.config4, dict(n=800))):
+        P, src, tgt, init = builder(**kw)
+        op = oracle.params_from(P)
+        X, Y = oracle.Cloud.from_pointcloud(src), oracle.Cloud.from_pointcloud(tgt)
+        try:
+            oracle.set_grid(False)
+            a = oracle.iteration(op, X, Y, init[:3, :3], init[:3, 3], P.ell_init, P.nearest_neighbors_max, want_ell=True)
+            ta = oracle.align(op, X, Y, init, max_iterations=40)
+            oracle.set_grid(True)
+            b = oracle.iteration(op, X, Y, init[:3, :3], init[:3, 3], P.ell_init, P.nearest_neighbors_max, want_ell=True)
+            tb = oracle.align(op, X, Y, init, max_iterations=40)
+        finally:
+            oracle.set_grid(False)
+        assert np.array_equal(a["nonzeros"], b["nonzeros"]) and int(a["nonzeros"].sum()) > 0
+        assert np.array_equal(a["ind"], b["ind"]) and np.array_equal(a["mat"], b["mat"])
+        assert np.array_equal(ta["transform"], tb["transform"])
