@@ -219,11 +219,17 @@ def main():
             # scan (the reference's own CPU code uses a kd-tree); its cost falls as ell decays, so it runs the whole align()
             po.set_grid(True)
             try:
-                og = po.align(op, ox, oy, inits[0])
+                og, og_threads = None, threads
+                for t in sorted({min(4, threads), threads}):  # its serial parts stop scaling at a few threads
+                    po.set_num_threads(t)
+                    cand = po.align(op, ox, oy, inits[0])
+                    if og is None or cand["seconds"] < og["seconds"]:
+                        og, og_threads = cand, t
             finally:
                 po.set_grid(False)
+                po.set_num_threads(threads)
             cpu_baseline["best_effort"] = {
-                "value": 1.0 / max(og["seconds"], 1e-9), "unit": "align/s", "cores": threads,
+                "value": 1.0 / max(og["seconds"], 1e-9), "unit": "align/s", "cores": og_threads,
                 "ms_per_iter": og["seconds"] * 1e3 / max(og["iterations"], 1),
                 "sample": f"one full align() of pair 0 ({og['iterations']} iterations) with the oracle's uniform-grid variant "
                           f"(identical results, tests/test_oracle_numpy.py)"}
