@@ -506,6 +506,20 @@ template <bool WAVE>
 __device__ inline float select_step(double B, double C, double D, double E, float min_step, float max_step) {
   const double DMAX = 1.7976931348623157e308;
   double p_coef[4] = {4.0 * E, 3.0 * D, 2.0 * C, B};
+  {
+    // Exact shortcut for the common end game (the loop spends most of its iterations clamped at min_step): if the cubic
+    // changes sign between 0 and min_step it has a real root there, so the smallest admissible root - whichever it is -
+    // lies below min_step and the clamp returns min_step; no root has to be computed.  Signs are only trusted clear of
+    // the rounding noise of the Horner evaluation, and only where cubic_roots would not have given up (finite monic
+    // coefficients); everything else takes the full solve below.
+    const double ms = (double)min_step;
+    const double a0 = fabs(p_coef[0]), a1 = fabs(p_coef[1]), a2 = fabs(p_coef[2]), a3 = fabs(p_coef[3]);
+    if (min_step > 0.f && min_step <= max_step && a0 >= 1e-200 && a0 <= 1e100 && a1 <= 1e100 && a2 <= 1e100 && a3 <= 1e100) {
+      const double fm = ((p_coef[0] * ms + p_coef[1]) * ms + p_coef[2]) * ms + p_coef[3];
+      const double noise = 3.6e-15 * (((a0 * ms + a1) * ms + a2) * ms + a3);  // 16 eps times the magnitude sum
+      if ((p_coef[3] > 0.0 && fm < -noise) || (p_coef[3] < 0.0 && fm > noise)) return min_step;
+    }
+  }
   double re[3], im[3];
   if (WAVE)
     cubic_roots_wave(p_coef, re, im);  // all lanes of the wave are here
