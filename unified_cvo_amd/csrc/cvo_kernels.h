@@ -916,6 +916,17 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
       }
       const float temp_coef = (float)(1 / (2.0 * temp_ell * temp_ell));
       const Pose pose = load_pose(st);
+      // The 42 floats of the twist matrices are the same for every lane: read out of LDS once and pinned to scalar
+      // registers (the compiler cannot know LDS contents are wave-uniform and would keep them in ~40 VGPRs, which
+      // costs this latency-bound kernel three of its seven waves per SIMD)
+      XiMats Mu;
+      {
+        const float* src = reinterpret_cast<const float*>(&S.M);
+        float* dst = reinterpret_cast<float*>(&Mu);
+#pragma unroll
+        for (int q = 0; q < (int)(sizeof(XiMats) / sizeof(float)); q++)
+          dst[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(src[q])));
+      }
       // this block's share of the row: slots q, q + nsplit, ...  (small clouds whose rows sit on K_max would
       // otherwise leave the chip to a handful of waves walking hundreds of entries each).  Software pipeline: the
       // next entry's index / value / target are in flight while the current one is evaluated.
@@ -932,7 +943,7 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
             y_n = D->y4[idx_n];
           }
           const V3 yy = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
-          coeff_entry(S.M, x, temp_coef, yy, A_ij, Bi, Ci, Di, Ei);
+          coeff_entry(Mu, x, temp_coef, yy, A_ij, Bi, Ci, Di, Ei);
         }
       }
     }
@@ -1234,9 +1245,10 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
                                                const int* __restrict__ status, int flags) {
   if (!INIT && status[blockIdx.x] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.x;
+  if (!INIT && (flags & 1) && (D->st->rebuild || D->st->n_ovf > 0)) return;  // lean graph: the pair is waiting (k_assoc)
   const DevParams P = *Pp;
   __shared__ UpdateShared U;
-  update_body<INIT, false>(D, P, flags, D->nblk_assoc + DENSE_BLOCKS, U, nullptr, nullptr);
+  update_body<INIT, false>(D, P, flags, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, U, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
