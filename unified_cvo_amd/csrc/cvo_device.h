@@ -45,6 +45,7 @@ struct DevParams {
   float skin_frac;
   float rebuild_shrink;  // rebuild when ell < rebuild_shrink * ell_build (the lists would be (1/shrink)^3 too long)
   int lean_U;            // iterations between two rebuild opportunities in the lean graph
+  int dbg;  // EXPERIMENT
 };
 
 // Running state of one frame pair; lives in HBM, only touched by one thread of k_step.

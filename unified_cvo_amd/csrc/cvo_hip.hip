@@ -260,6 +260,8 @@ DevParams make_dev_params(const cvo_params_t& p) {
   d.skin_frac = 0.1f;
   d.rebuild_shrink = 0.9f;
   if (const char* e = getenv("CVO_SKIN")) d.skin_frac = std::max(0.f, (float)atof(e));
+  d.dbg = 0;
+  if (const char* e = getenv("CVO_DBG")) d.dbg = atoi(e);  // EXPERIMENT
   if (const char* e = getenv("CVO_SHRINK")) d.rebuild_shrink = std::min(0.99f, std::max(0.f, (float)atof(e)));
   return d;
 }
@@ -1427,6 +1429,40 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipEventElapsedTime(&out[which], ctx->ev_start, ctx->ev_stop));
     out[which] /= (float)(reps * G);
+  }
+  if (dp.dbg & 8) {  // EXPERIMENT
+    static unsigned long long h[2][8192][4];
+    HIP_TRY(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_t), sizeof(h)));
+    const int np = n_pairs - (int)((long)n_pairs * (G - 1) / G);
+    for (int which = 0; which < 2; which++) {
+      const int nb = std::min(4096, 8 * ((np + 7) / 8) * nba * (which ? ctx->last_csplit : 1));
+      unsigned long long t0min = ~0ull, tend = 0;
+      double sum[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+      int cnt = 0;
+      for (int b = 0; b < nb; b++) {
+        if (!h[which][b][0] || !h[which][b][3]) continue;
+        t0min = std::min(t0min, h[which][b][0]);
+        tend = std::max(tend, h[which][b][3]);
+        for (int q = 0; q < 3; q++) {
+          const double d = (double)(long long)(h[which][b][q + 1] - h[which][b][q]);
+          sum[q] += d;
+          mx[q] = std::max(mx[q], d);
+        }
+        cnt++;
+      }
+      double st_first = 0, st_last = 0;
+      for (int b = 0; b < nb; b++)
+        if (h[which][b][0]) st_last = std::max(st_last, (double)(h[which][b][0] - t0min));
+      fprintf(stderr, "[dbg] %s: blocks %d span %.0f ticks, last block starts at %.0f; phases avg %.0f %.0f %.0f max %.0f %.0f %.0f\n",
+              which ? "k_coeff" : "k_assoc", cnt, (double)(tend - t0min), st_last, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt,
+              mx[0], mx[1], mx[2]);
+      (void)st_first;
+      if (which)
+        for (int p = 0; p < std::min(np, 3); p++)
+          fprintf(stderr, "[dbg]   pair %d update block: start->counter %.0f, update %.0f ticks\n", p,
+                  (double)(long long)(h[1][4096 + p][1] - h[1][4096 + p][0]),
+                  (double)(long long)(h[1][4096 + p][2] - h[1][4096 + p][1]));
+    }
   }
   *ms_assoc = out[0];
   *ms_coeff = out[1];

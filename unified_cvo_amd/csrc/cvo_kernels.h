@@ -29,20 +29,45 @@
 
 namespace cvo_dev {
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-  return v;
+// Wave-wide reductions on the DPP cross-lane paths (no LDS traffic, unlike ds_bpermute shuffles): a butterfly
+// inside every row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row results
+// through scalar registers.  Every lane takes part and every lane gets the result; the order of the
+// additions is fixed.
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-  return v;
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = dpp_i32<CTRL>(__double2loint(v)), hi = dpp_i32<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_f64<DPP_XOR1>(v);
+  v += dpp_f64<DPP_XOR2>(v);
+  v += dpp_f64<DPP_HALF_MIRROR>(v);
+  v += dpp_f64<DPP_MIRROR>(v);
+  return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {  // (the caller's sum fits 32 bits)
+  v += (unsigned)dpp_i32<DPP_XOR1>((int)v);
+  v += (unsigned)dpp_i32<DPP_XOR2>((int)v);
+  v += (unsigned)dpp_i32<DPP_HALF_MIRROR>((int)v);
+  v += (unsigned)dpp_i32<DPP_MIRROR>((int)v);
+  return (unsigned)(__builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) +
+                    __builtin_amdgcn_readlane((int)v, 32) + __builtin_amdgcn_readlane((int)v, 48));
 }
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_down((int)v, o));
-  return v;
+  v = max(v, (unsigned)dpp_i32<DPP_XOR1>((int)v));
+  v = max(v, (unsigned)dpp_i32<DPP_XOR2>((int)v));
+  v = max(v, (unsigned)dpp_i32<DPP_HALF_MIRROR>((int)v));
+  v = max(v, (unsigned)dpp_i32<DPP_MIRROR>((int)v));
+  return max(max((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 16)),
+             max((unsigned)__builtin_amdgcn_readlane((int)v, 32), (unsigned)__builtin_amdgcn_readlane((int)v, 48)));
 }
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
@@ -595,6 +620,7 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
 // Association phase: ordered association + flow, one thread per (sorted) source row, over the cached
 // candidate list.
 // ------------------------------------------------------------------------------------------
+__device__ unsigned long long g_dbg_t[2][8192][4];  // EXPERIMENT: phase timestamps
 struct AssocShared {
   double red[ASSOC_THREADS / 64][8];
   unsigned long long cnt[ASSOC_THREADS / 64][4];
@@ -609,6 +635,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
   RowAcc A;
   unsigned long long ncand = 0;
   unsigned overflowed = 0;
+  unsigned long long tt1 = 0, tt2 = 0;
   if (pos < N) {
     const int cnt = D->cand_cnt[pos];
     ncand = (unsigned long long)cnt;
@@ -624,6 +651,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
       // flight while the current one is evaluated
       int j1 = cnt > 0 ? (int)cj[0] : 0;
       int j2 = cnt > 1 ? (int)cj[N] : 0;
+      tt1 = __builtin_readcyclecounter();
       float4 y1 = D->y4[j1];
       for (int k = 0; k < cnt && A.nnz < (unsigned)K; k++) {
         const int j = j1;
@@ -634,7 +662,12 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
         visit_pair<GENERAL>(P, D, pose, i, pos, N, r, pxe, j, ycur, A);
       }
       D->nnz_row[pos] = A.nnz;
+      tt2 = __builtin_readcyclecounter();
     }
+  }
+  if ((P.dbg & 8) && threadIdx.x == 0) {
+    g_dbg_t[0][blockIdx.x & 8191][1] = tt1;
+    g_dbg_t[0][blockIdx.x & 8191][2] = tt2;
   }
   // per-row (omega_i / c, v_i / d) cast to double, then reduced in double (CvoGPU.cu:784-787, 824-825)
   double red[7] = {(double)(A.o0 / P.c), (double)(A.o1 / P.c), (double)(A.o2 / P.c), (double)(A.v0 / P.d),
@@ -643,10 +676,10 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int c = 0; c < 7; c++) red[c] = wave_sum(red[c]);
-  const unsigned long long nn = wave_sum_u64(A.nnz);
+  const unsigned long long nn = wave_sum_u32(A.nnz);  // 64 rows x K_max
   const unsigned mx = wave_max_u32(A.nnz);
-  const unsigned long long nc = wave_sum_u64(ncand);
-  const unsigned long long nov = wave_sum_u64(overflowed);
+  const unsigned long long nc = wave_sum_u32((unsigned)min(ncand, 0x3ffffffull));
+  const unsigned long long nov = (unsigned long long)__builtin_popcountll(__ballot(overflowed != 0));
   if (lane == 0) {
 #pragma unroll
     for (int c = 0; c < 7; c++) S.red[wave][c] = red[c];
@@ -684,6 +717,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
                                                           const DevParams* __restrict__ Pp,
                                                           const PairState* __restrict__ states, int lean, int nblk,
                                                           int n_pairs) {
+  const unsigned long long tt0 = __builtin_readcyclecounter();
   PairBlock pb;
   if (!pair_block(nblk, n_pairs, pb)) return;
   const PairDesc* __restrict__ D = descs + pb.pair;
@@ -713,6 +747,10 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
   if ((lean & 1) && (rebuild_v || n_ovf_v > 0)) return;
   __shared__ AssocShared S;
   assoc_phase<IdxT, ASSOC_CAP, GENERAL>(P, D, st, S, pb.bx);
+  if ((P.dbg & 8) && threadIdx.x == 0) {
+    g_dbg_t[0][blockIdx.x & 8191][0] = tt0;
+    g_dbg_t[0][blockIdx.x & 8191][3] = __builtin_readcyclecounter();
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1260,6 +1298,7 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
 __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restrict__ descs,
                                                          const DevParams* __restrict__ Pp, PairState* states, int flags,
                                                          int nblk, int n_pairs) {
+  const unsigned long long tt0 = __builtin_readcyclecounter();
   // grid: per pair nblk row blocks x launch_split slices of the ELL slots; a pair uses csplit <= launch_split of them
   const int launch_split = nblk >> 16;
   nblk &= 0xffff;
@@ -1315,7 +1354,9 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     twist[c] = S.c.M.omega[c];
     twist[3 + c] = S.c.M.v[c];
   }
+  const unsigned long long tt1 = __builtin_readcyclecounter();
   coeff_rows<true>(P, D, st_in, S.c, pb.bx, cq, csplit);
+  const unsigned long long tt2 = __builtin_readcyclecounter();
   // the scalar state, for whichever block turns out to be the last one: in flight while the counter round trip runs
   unsigned hot_regs[2] = {0u, 0u};
   if (threadIdx.x < 64) {
@@ -1329,8 +1370,20 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     s_last = replay ? (done % nwork == nwork - 1) : (done == (epoch + 1) * nwork - 1);
   }
   __syncthreads();
+  const unsigned long long tt3 = __builtin_readcyclecounter();
+  if ((P.dbg & 8) && threadIdx.x == 0) {
+    g_dbg_t[1][blockIdx.x & 4095][0] = tt0;
+    g_dbg_t[1][blockIdx.x & 4095][1] = tt1;
+    g_dbg_t[1][blockIdx.x & 4095][2] = tt2;
+    g_dbg_t[1][blockIdx.x & 4095][3] = tt3;
+  }
   if (!s_last || (flags & 16)) return;  // (bit 4: cost breakdown of cvo_debug_time_kernels, coefficient phase only)
   update_body<false, true>(D, P, flags | 4, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, S.u, twist, hot_regs);
+  if ((P.dbg & 8) && threadIdx.x == 0) {
+    g_dbg_t[1][4096 + pb.pair][0] = tt0;
+    g_dbg_t[1][4096 + pb.pair][1] = tt3;
+    g_dbg_t[1][4096 + pb.pair][2] = __builtin_readcyclecounter();
+  }
 }
 
 // ------------------------------------------------------------------------------------------
