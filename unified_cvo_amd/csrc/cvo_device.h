@@ -84,6 +84,9 @@ struct PairState {
   float s_sum, e_sum;
   // ---- everything above is the "hot" prefix k_update stages through LDS ----
   float sq[IND_CAP], eq[IND_CAP];
+  // the normalised twist of the iteration and the matrices of compute_step_size_xi (XiMats), written by the last
+  // block of the association launch, read by every block of k_coeff
+  float xi[48];
 };
 
 // Everything a kernel needs to know about one frame pair.
@@ -145,6 +148,7 @@ struct PairDesc {
   int* status_out;  // mirror of st->status for cheap host polling
   int* want_out;    // mirror of st->want_full
   int* gate;        // [1] blocks of k_list that finished the current rebuild (the last one validates the list)
+  int* gate_flow;   // [1] blocks of k_assoc / k_assoc_dense that stored their flow partial (the last one reduces them)
 };
 
 constexpr int COEFF_SPLIT_MAX = 8;
@@ -518,7 +522,7 @@ __device__ inline float select_step(double B, double C, double D, double E, floa
     if (min_step > 0.f && min_step <= max_step && a0 >= 1e-200 && a0 <= 1e100 && a1 <= 1e100 && a2 <= 1e100 && a3 <= 1e100) {
       const double fm = ((p_coef[0] * ms + p_coef[1]) * ms + p_coef[2]) * ms + p_coef[3];
       const double noise = 3.6e-15 * (((a0 * ms + a1) * ms + a2) * ms + a3);  // 16 eps times the magnitude sum
-      if ((p_coef[3] > 0.0 && fm < -noise) || (p_coef[3] < 0.0 && fm > noise)) return min_step;
+      if ((p_coef[3] > 0.0 && fm < -noise) || (p_coef[3] < 0.0 && fm > noise)) return -min_step;  // EXPERIMENT: sign marks the shortcut
     }
   }
   double re[3], im[3];

@@ -40,7 +40,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, gate, done, cand_cnt, rowperm, xp4, ip, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, gate, gate_flow, done, cand_cnt, rowperm, xp4, ip, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -137,6 +137,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.tile_count = take(sizeof(unsigned long long));
   L.ovf_rows = take(sizeof(int) * (size_t)N);
   L.gate = take(sizeof(int));
+  L.gate_flow = take(sizeof(int));
   L.done = take(sizeof(int));
   L.cand_cnt = take(sizeof(int) * (size_t)N);
   L.rowperm = take(sizeof(int) * (size_t)N);
@@ -517,6 +518,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.status_out = ctx->d_status + p;
     D.want_out = ctx->d_status + ctx->cap_pairs + p;
     D.gate = (int*)(base + S->L.gate);
+    D.gate_flow = (int*)(base + S->L.gate_flow);
     D.done = (int*)(base + S->L.done);
 
     PairState& st = ctx->h_states[p];
@@ -536,6 +538,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     HIP_TRY(ctx, hipMemsetAsync(D.rowbits, 0, sizeof(unsigned) * (size_t)(S->N + 4) * S->d.rbw_max, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.tile_count, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.gate, 0, sizeof(int), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(D.gate_flow, 0, sizeof(int), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.done, 0, sizeof(int), ctx->stream));
   }
   // the blocks of k_assoc beyond a smaller pair's N still write their (zero) partials, but the
@@ -1457,6 +1460,20 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
               which ? "k_coeff" : "k_assoc", cnt, (double)(tend - t0min), st_last, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt,
               mx[0], mx[1], mx[2]);
       (void)st_first;
+      if (which) {
+        static unsigned long long u[8192][8];
+        HIP_TRY(ctx, hipMemcpyFromSymbol(u, HIP_SYMBOL(g_dbg_u), sizeof(u)));
+        double su[5] = {0, 0, 0, 0, 0};
+        for (int b = 0; b < nb; b++)
+          for (int q = 0; q < 5; q++) su[q] += (double)u[b][q];
+fprintf(stderr, "[dbg]   first (dry) update %.0f\n", (double)u[4097][0]);
+        fprintf(stderr, "[dbg]   tail marks (from w2): before exp %.0f, after exp %.0f, before log %.0f, after log %.0f, after indicator %.0f, before update_tf %.0f, before status %.0f\n", (double)u[4098][0], (double)u[4098][1], (double)u[4098][2], (double)u[4098][3], (double)u[4098][4], (double)u[4098][5], (double)u[4098][6]);
+        fprintf(stderr, "[dbg]   step shortcut taken %llu of %llu updates\n", u[4099][0], u[4099][1]);
+        fprintf(stderr, "[dbg]   real loop: update %.0f ticks avg, its block start->counter %.0f avg over %llu\n", (double)u[4100][0] / (double)u[4100][1], (double)u[4100][2] / (double)u[4100][1], u[4100][1]);
+        fprintf(stderr, "[dbg]   update: partial loads %.0f, cubic %.0f, scalar tail %.0f\n", (double)u[4096][0], (double)u[4096][1], (double)u[4096][2]);
+                fprintf(stderr, "[dbg]   twist: prologue %.0f, loads %.0f, reduce %.0f, normalise+head %.0f, mats %.0f\n", su[0] / nb,
+                su[1] / nb, su[2] / nb, su[3] / nb, su[4] / nb);
+      }
       if (which)
         for (int p = 0; p < std::min(np, 3); p++)
           fprintf(stderr, "[dbg]   pair %d update block: start->counter %.0f, update %.0f ticks\n", p,

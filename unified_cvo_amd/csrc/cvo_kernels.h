@@ -616,11 +616,75 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
   }
 }
 
+// thrust::reduce of omega_gpu / v_gpu (CvoGPU.cu:824-825) from the association block partials, Eigen's
+// normalize() and the matrices of compute_step_size_xi: once per pair and iteration, by one wave of the block of
+// the association launch that stores its partial last (k_assoc in the lean graph, k_assoc_dense in the full one).
+// Lane l owns component (l & 7) of blocks l>>3, l>>3 + 8, ... (independent loads, all in flight), the eight
+// groups meet through DPP / ds_swizzle; the order of the additions is fixed.  k_coeff reads the 42 floats with
+// scalar loads in its first burst (they used to be reduced again by every one of its blocks: ~3 us of
+// dependent round trips in front of each row loop and a hot spot of 150 readers per cache line).
+static_assert(sizeof(XiMats) <= 48 * sizeof(float), "PairState::xi holds an XiMats");
+template <bool COH>
+__device__ __forceinline__ double coeff_twist_load(const PairDesc* __restrict__ D, int nparts) {
+  const int lane = threadIdx.x & 63;
+  const double* __restrict__ src = D->flow_part + (lane & 7);
+  double acc = 0;
+  // sixteen loads per round, all issued before the first addition (79 row blocks = one round); slots past the
+  // end re-read the last one and add zero
+  for (int b = lane >> 3; b < nparts; b += 128) {
+    double p[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) p[u] = ld_x<COH>(src + (size_t)min(b + 8 * u, nparts - 1) * 8);
+#pragma unroll
+    for (int u = 0; u < 16; u++) acc += (b + 8 * u < nparts) ? p[u] : 0.0;
+  }
+  return acc;
+}
+__device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, int nparts) {
+  double acc = coeff_twist_load<true>(D, nparts);
+  acc += dpp_f64<0x128>(acc);  // row_ror:8 : groups g and g ^ 1
+  acc += __shfl_xor(acc, 16);
+  acc += __shfl_xor(acc, 32);
+  float ov[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) ov[q] = (float)lane_f64(acc, q);
+  float z = 0;  // Eigen normalize(): z = squaredNorm(); if (z > 0) *this /= sqrt(z)
+#pragma unroll
+  for (int q = 0; q < 6; q++) z = z + ov[q] * ov[q];
+  if (z > 0) {
+    const float sq = sqrtf(z);
+#pragma unroll
+    for (int q = 0; q < 6; q++) ov[q] = ov[q] / sq;
+  }
+  XiMats M;
+  xi_mats(ov, ov + 3, M);
+  if ((threadIdx.x & 63) == 0) {
+    const float* mv = reinterpret_cast<const float*>(&M);
+    float* dst = D->st->xi;
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(XiMats) / sizeof(float)); q++) dst[q] = mv[q];
+  }
+}
+// The flow partial of this block is stored; the block that finds it was the last one of its pair reduces them.
+// Every thread of the block calls this.
+__device__ __forceinline__ void flow_gate(const PairDesc* __restrict__ D, int nblocks, int nparts) {
+  __shared__ int s_flow_last;
+  __syncthreads();  // (its release waits for this block's coherent partial stores)
+  if (threadIdx.x == 0) {
+    const int done = __hip_atomic_fetch_add(D->gate_flow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_flow_last = (done == nblocks - 1) ? 1 : 0;
+    if (done == nblocks - 1) __hip_atomic_store(D->gate_flow, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (s_flow_last && threadIdx.x < 64) twist_finalize(D, nparts);
+}
+
 // ------------------------------------------------------------------------------------------
 // Association phase: ordered association + flow, one thread per (sorted) source row, over the cached
 // candidate list.
 // ------------------------------------------------------------------------------------------
-__device__ unsigned long long g_dbg_t[2][8192][4];  // EXPERIMENT: phase timestamps
+__device__ unsigned long long g_dbg_t[2][8192][4];
+__device__ unsigned long long g_dbg_u[8192][8];  // EXPERIMENT: phase timestamps
 struct AssocShared {
   double red[ASSOC_THREADS / 64][8];
   unsigned long long cnt[ASSOC_THREADS / 64][4];
@@ -637,6 +701,9 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
   unsigned overflowed = 0;
   unsigned long long tt1 = 0, tt2 = 0;
   if (pos < N) {
+    // the first two list slots are requested together with the count (they exist whatever the count is)
+    const int j1s = (int)(reinterpret_cast<const IdxT*>(D->cand_j) + pos)[0];
+    const int j2s = (int)(reinterpret_cast<const IdxT*>(D->cand_j) + pos)[N];
     const int cnt = D->cand_cnt[pos];
     ncand = (unsigned long long)cnt;
     overflowed = cnt > ASSOC_CAP ? 1u : 0u;
@@ -649,8 +716,8 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
       const IdxT* cj = reinterpret_cast<const IdxT*>(D->cand_j) + pos;
       // exact evaluation in ascending original j; index and coordinates of the next candidates are in
       // flight while the current one is evaluated
-      int j1 = cnt > 0 ? (int)cj[0] : 0;
-      int j2 = cnt > 1 ? (int)cj[N] : 0;
+      int j1 = cnt > 0 ? j1s : 0;
+      int j2 = cnt > 1 ? j2s : 0;
       tt1 = __builtin_readcyclecounter();
       float4 y1 = D->y4[j1];
       for (int k = 0; k < cnt && A.nnz < (unsigned)K; k++) {
@@ -694,7 +761,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
     double t = S.red[0][c];
 #pragma unroll
     for (int w = 1; w < NW; w++) t += S.red[w][c];
-    D->flow_part[(size_t)bx * 8 + c] = t;
+    st_x<true>(D->flow_part + (size_t)bx * 8 + c, t);  // read by another block of this launch (flow_gate)
   } else if (threadIdx.x == 8) {
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
@@ -747,6 +814,8 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
   if ((lean & 1) && (rebuild_v || n_ovf_v > 0)) return;
   __shared__ AssocShared S;
   assoc_phase<IdxT, ASSOC_CAP, GENERAL>(P, D, st, S, pb.bx);
+  // lean graph: nothing else adds to the flow, the twist of the iteration can be finished here
+  if ((lean & 3) && P.mode == 0) flow_gate(D, nblk, nblk);  // (bit 1: the timing replay includes it)
   if ((P.dbg & 8) && threadIdx.x == 0) {
     g_dbg_t[0][blockIdx.x & 8191][0] = tt0;
     g_dbg_t[0][blockIdx.x & 8191][3] = __builtin_readcyclecounter();
@@ -848,7 +917,7 @@ __global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict_
   const size_t slot = (size_t)D->nblk_assoc + blockIdx.x;
   if (threadIdx.x < 7) {
     const int c = threadIdx.x;
-    D->flow_part[slot * 8 + c] = ((s_red[0][c] + s_red[1][c]) + s_red[2][c]) + s_red[3][c];
+    st_x<true>(D->flow_part + slot * 8 + c, ((s_red[0][c] + s_red[1][c]) + s_red[2][c]) + s_red[3][c]);
   } else if (threadIdx.x == 8) {
     unsigned long long* cp = D->cnt_part + slot * 4;
     cp[0] = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
@@ -856,6 +925,8 @@ __global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict_
     cp[2] = 0;
     cp[3] = 0;
   }
+  // full graph: the twist of the iteration from the partials of k_assoc (an earlier launch) and of this kernel
+  if (P.mode == 0) flow_gate(D, DENSE_BLOCKS, D->nblk_assoc + DENSE_BLOCKS);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -863,44 +934,8 @@ __global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict_
 // thread per row position, blocks of ASSOC_THREADS rows.
 // ------------------------------------------------------------------------------------------
 struct CoeffShared {
-  double ov[6];
-  XiMats M;
   double red[ASSOC_THREADS / 64][4];
-  double part[ASSOC_THREADS / 8][8];
 };
-
-// thrust::reduce of omega_gpu / v_gpu (CvoGPU.cu:824-825) from the association block partials: thread t owns
-// component (t & 7) of blocks t>>3, t>>3 + 16, ... (all loads in flight), then a fixed-order finish.
-template <bool COH>
-__device__ __forceinline__ void coeff_twist(const PairDesc* __restrict__ D, CoeffShared& S, int nparts) {
-  constexpr int NGRP = ASSOC_THREADS / 8;
-  {
-    const int c = threadIdx.x & 7;
-    double acc = 0;
-    for (int b = threadIdx.x >> 3; b < nparts; b += NGRP) acc += ld_x<COH>(D->flow_part + (size_t)b * 8 + c);
-    S.part[threadIdx.x >> 3][c] = acc;
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    double t = 0;
-#pragma unroll 8
-    for (int g = 0; g < NGRP; g++) t += S.part[g][threadIdx.x];
-    S.ov[threadIdx.x] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float ov[6];
-    for (int c = 0; c < 6; c++) ov[c] = (float)S.ov[c];
-    float z = 0;  // Eigen normalize(): z = squaredNorm(); if (z > 0) *this /= sqrt(z)
-    for (int c = 0; c < 6; c++) z = z + ov[c] * ov[c];
-    if (z > 0) {
-      const float sq = sqrtf(z);
-      for (int c = 0; c < 6; c++) ov[c] = ov[c] / sq;
-    }
-    xi_mats(ov, ov + 3, S.M);
-  }
-  __syncthreads();
-}
 
 // one nonzero (i, j): compute_step_size_xi for target j (CvoGPU.cu:974-986) + compute_step_size_poly_coeff
 // (CvoGPU.cu:1053-1078); yy is the transformed target
@@ -936,54 +971,49 @@ __device__ __forceinline__ void coeff_entry(const XiMats& M, const float4 x, flo
                         1 / 24.0 * beta_ij * beta_ij * beta_ij * beta_ij);
 }
 
-// Rows of this block.  COH: the block partial is read by another block of the same launch.
+// Rows of this block, in two steps so that the first loads of the row loop (count -> first ELL entry -> its target:
+// three dependent round trips) are in flight while the twist is reduced.
+struct CoeffRowHead {
+  unsigned nnz;
+  float4 x;
+  int idx_n;
+  float a_n;
+  float4 y_n;
+};
+// COH: the block partial is read by another block of the same launch.
 template <bool COH>
 __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* __restrict__ D, const PairState* st,
-                                           CoeffShared& S, const int bx, const int q, const int nsplit) {
+                                           CoeffShared& S, const XiMats& Mu, const CoeffRowHead& h, const int bx,
+                                           const int q, const int nsplit) {
   const int N = D->N;
-  const int i = bx * ASSOC_THREADS + threadIdx.x;  // position (see k_list)
+  const int i = bx * ASSOC_THREADS + threadIdx.x;
   double Bi = 0, Ci = 0, Di = 0, Ei = 0;
-  if (i < N) {
-    const unsigned nnz = D->nnz_row[i];
-    if (nnz) {
-      const float4 x = D->xp4[i];
-      float temp_ell = st->ell;
-      if (P.use_range_ell) {
-        const float d2_sqrt = sqrtf(dot3_dev(x.x, x.y, x.z, x.x, x.y, x.z));
-        temp_ell = compute_range_ell(temp_ell, d2_sqrt);
+  // this block's share of the row: slots q, q + nsplit, ...  (small clouds whose rows sit on K_max would
+  // otherwise leave the chip to a handful of waves walking hundreds of entries each).  Software pipeline: the
+  // next entry's index / value / target are in flight while the current one is evaluated.
+  const unsigned nnz = h.nnz;
+  if ((unsigned)q < nnz) {
+    const float4 x = h.x;
+    float temp_ell = st->ell;
+    if (P.use_range_ell) {
+      const float d2_sqrt = sqrtf(dot3_dev(x.x, x.y, x.z, x.x, x.y, x.z));
+      temp_ell = compute_range_ell(temp_ell, d2_sqrt);
+    }
+    const float temp_coef = (float)(1 / (2.0 * temp_ell * temp_ell));
+    const Pose pose = load_pose(st);
+    int idx_n = h.idx_n;
+    float a_n = h.a_n;
+    float4 y_n = h.y_n;
+    for (unsigned s = (unsigned)q; s < nnz; s += (unsigned)nsplit) {
+      const float A_ij = a_n;
+      const float4 y0 = y_n;
+      if (s + nsplit < nnz) {
+        idx_n = D->ell_j[(size_t)(s + nsplit) * N + i];
+        a_n = D->ell_a[(size_t)(s + nsplit) * N + i];
+        y_n = D->y4[idx_n];
       }
-      const float temp_coef = (float)(1 / (2.0 * temp_ell * temp_ell));
-      const Pose pose = load_pose(st);
-      // The 42 floats of the twist matrices are the same for every lane: read out of LDS once and pinned to scalar
-      // registers (the compiler cannot know LDS contents are wave-uniform and would keep them in ~40 VGPRs, which
-      // costs this latency-bound kernel three of its seven waves per SIMD)
-      XiMats Mu;
-      {
-        const float* src = reinterpret_cast<const float*>(&S.M);
-        float* dst = reinterpret_cast<float*>(&Mu);
-#pragma unroll
-        for (int q = 0; q < (int)(sizeof(XiMats) / sizeof(float)); q++)
-          dst[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(src[q])));
-      }
-      // this block's share of the row: slots q, q + nsplit, ...  (small clouds whose rows sit on K_max would
-      // otherwise leave the chip to a handful of waves walking hundreds of entries each).  Software pipeline: the
-      // next entry's index / value / target are in flight while the current one is evaluated.
-      if ((unsigned)q < nnz) {
-        int idx_n = D->ell_j[(size_t)q * N + i];
-        float a_n = D->ell_a[(size_t)q * N + i];
-        float4 y_n = D->y4[idx_n];
-        for (unsigned s = (unsigned)q; s < nnz; s += (unsigned)nsplit) {
-          const float A_ij = a_n;
-          const float4 y0 = y_n;
-          if (s + nsplit < nnz) {
-            idx_n = D->ell_j[(size_t)(s + nsplit) * N + i];
-            a_n = D->ell_a[(size_t)(s + nsplit) * N + i];
-            y_n = D->y4[idx_n];
-          }
-          const V3 yy = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
-          coeff_entry(Mu, x, temp_coef, yy, A_ij, Bi, Ci, Di, Ei);
-        }
-      }
+      const V3 yy = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
+      coeff_entry(Mu, x, temp_coef, yy, A_ij, Bi, Ci, Di, Ei);
     }
   }
   double red[4] = {Bi, Ci, Di, Ei};
@@ -1014,16 +1044,48 @@ struct UpdateShared {
   unsigned hot[HOT_DWORDS];
 };
 
+// What the update reads from the pair descriptor, requested in one burst of scalar loads (k_coeff issues it while
+// the last-block counter is on its way): every field first touched in the middle of the serial tail would be
+// another cold round trip there.
+struct UpdDesc {
+  PairState* st;
+  const double* coef_part;
+  const double* flow_part;
+  const unsigned long long* cnt_part;
+  cvo_trace_t* trace;
+  int* status_out;
+  int* want_out;
+  int nblk_coeff, N, M;
+  float ymax;
+};
+__device__ __forceinline__ UpdDesc load_upd_desc(const PairDesc* __restrict__ D) {
+  UpdDesc u;
+  u.st = D->st;
+  u.coef_part = D->coef_part;
+  u.flow_part = D->flow_part;
+  u.cnt_part = D->cnt_part;
+  u.trace = D->trace;
+  u.status_out = D->status_out;
+  u.want_out = D->want_out;
+  u.nblk_coeff = D->nblk_coeff;
+  u.N = D->N;
+  u.M = D->M;
+  u.ymax = D->ymax;
+  asm volatile("" ::"s"(u.st), "s"(u.coef_part), "s"(u.flow_part), "s"(u.cnt_part), "s"(u.trace), "s"(u.status_out),
+               "s"(u.want_out), "s"(u.nblk_coeff), "s"(u.N), "s"(u.M), "s"(u.ymax));
+  return u;
+}
+
 // Executed by the first wave of the calling block (the other threads only take part in the barriers).
 // flags: bit 1 = the rebuild kernels run right after this iteration, bit 2 = called from k_coeff, bit 3 = replay for
 // timing (nothing is written back), bits 8.. = how many
 // iterations the list has to survive without another rebuild opportunity (0 in the full graph).  n_flow_parts: association partials to
 // sum (the lean graph has no k_assoc_dense, so its slots are not read).
 template <bool INIT, bool COH>
-__device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, const DevParams& P, int flags,
+__device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P, int flags,
                                             int n_flow_parts, UpdateShared& U, const float* twist,
                                             const unsigned* preloaded_hot) {
-  PairState* const gst = D->st;
+  PairState* const gst = D.st;
   const bool trio_follows = INIT || (flags & 2) != 0;
   const bool dry = (flags & 8) != 0;  // timing replay: compute everything, write nothing back
   const int horizon = flags >> 8;
@@ -1049,7 +1111,7 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
     // The four thrust::reduce of compute_step_size (CvoGPU.cu:1118-1121) and the nonzero / max counts
     // (SparseKernelMat.cu:37-46, CvoGPU.cu:1518): lane l owns component (l & 3) of blocks l>>2, l>>2 + 16, ...
     // so all loads are in flight at once; a fixed xor-shuffle tree finishes (deterministic order).
-    const int nba = n_flow_parts, nbc = D->nblk_coeff;
+    const int nba = n_flow_parts, nbc = D.nblk_coeff;
     const int c = tid & 3;
     double s = 0;
     if (P.mode == 0) {
@@ -1059,18 +1121,24 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
 #pragma unroll
         for (int u = 0; u < 8; u++) {
           const int b = b0 + 16 * u;
-          v[u] = b < nbc ? ld_x<COH>(D->coef_part + (size_t)b * 4 + c) : 0.0;
+          v[u] = b < nbc ? ld_x<COH>(D.coef_part + (size_t)b * 4 + c) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) s += v[u];
       }
     } else if (c == 0) {
-      for (int b = tid >> 2; b < nba; b += 16) s += D->flow_part[(size_t)b * 8 + 6];
+      for (int b = tid >> 2; b < nba; b += 16) s += D.flow_part[(size_t)b * 8 + 6];
     }
     unsigned long long q = 0;  // (written by the association kernel(s), i.e. before this launch: plain loads)
-    for (int b = tid >> 2; b < nba; b += 16) {
-      const unsigned long long v = D->cnt_part[(size_t)b * 4 + c];
-      q = (c == 1) ? max(q, v) : q + v;
+    for (int b0 = tid >> 2; b0 < nba; b0 += 128) {
+      unsigned long long v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int b = b0 + 16 * u;
+        v[u] = b < nba ? D.cnt_part[(size_t)b * 4 + c] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) q = (c == 1) ? max(q, v[u]) : q + v[u];
     }
 #pragma unroll
     for (int o = 4; o < 64; o <<= 1) {
@@ -1087,6 +1155,11 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
   // the step of this iteration: the cubic's real roots are searched on three lanes side by side
   float step_w = 0.f;
   if (!INIT && act && P.mode == 0) step_w = select_step<true>(s_c[0], s_c[1], s_c[2], s_c[3], P.min_step, P.max_step);
+  if (step_w < 0.f) {
+    step_w = -step_w;
+    if ((P.dbg & 8) && tid == 0 && !dry) atomicAdd(&g_dbg_u[4099][0], 1ull);
+  }
+  if ((P.dbg & 8) && tid == 0 && !dry && !INIT) atomicAdd(&g_dbg_u[4099][1], 1ull);
   if (tid == 0) {
     int done = 0;
     if (twist) {  // k_coeff: every block derived the same normalised twist
@@ -1151,7 +1224,7 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
           for (int q = 0; q < 9; q++) st->R[q] = R[q] = Rn[q];
           for (int q = 0; q < 3; q++) st->T[q] = T[q] = Tn[q];
           dist = se3_log_norm(dR, dT);  // CvoGPU.cu:1473-1476
-          const float ip_curr = (float)((double)nnz / sqrt((double)D->N * (double)D->M));  // 1486
+          const float ip_curr = (float)((double)nnz / sqrt((double)D.N * (double)D.M));  // 1486
           const bool need_decay_ell = dry ? false : indicator_update(st, sq, eq, ip_curr, P.window, P.stable_thr);
           if (dist < (double)P.eps_2) {  // CvoGPU.cu:1505-1508
             done = 1;
@@ -1172,9 +1245,9 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
         }
         st->dist = dist;
         // optional per-iteration trace (the reference's is_logging history files, CvoGPU.cu:1495-1503)
-        if (!dry && D->trace && st->n_trace < P.trace_capacity &&
+        if (!dry && D.trace && st->n_trace < P.trace_capacity &&
             (k < P.trace_dense || (P.trace_every > 0 && k % P.trace_every == 0))) {
-          cvo_trace_t* tr = D->trace + st->n_trace;
+          cvo_trace_t* tr = D.trace + st->n_trace;
           tr->k = k;
           tr->K = K_used;
           tr->ell = ell_used;
@@ -1218,7 +1291,7 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
         dt1 += b * b;
         tn += Ti[q] * Ti[q];
       }
-      const float ymax = D->ymax;
+      const float ymax = D.ymax;
       const float slack = 1e-5f * (ymax + sqrtf(tn) + 1.f);  // rounding of the two transform evaluations
       const float moved = (sqrtf(dr) * ymax + sqrtf(dt)) * 1.001f + slack;
       const float step_move = sqrtf(dr1) * ymax + sqrtf(dt1);  // bound on what this iteration alone moved
@@ -1251,13 +1324,13 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
         if (!(s == s)) s = 0.f;
         st->skin = s * radius;
         st->want_full = want_full;
-        if (!dry) *D->want_out = want_full;
+        if (!dry) *D.want_out = want_full;
         st->n_builds = INIT ? 1 : st->n_builds + 1;
         st->rebuild = 1;  // cleared by k_list once bitmap and lists are current
       } else if (st->want_full && st->n_ovf == 0 &&
                  moved + 1.3f * (float)P.lean_U * step_move <= st->skin) {
         st->want_full = 0;  // the motion has slowed down enough for the lean graph
-        if (!dry) *D->want_out = 0;
+        if (!dry) *D.want_out = 0;
       }
     }
     for (int q = 0; q < 9; q++) st->Rinv[q] = Ri[q];
@@ -1270,7 +1343,7 @@ __device__ __forceinline__ void update_body(const PairDesc* __restrict__ D, cons
     st->out_T[15] = 1;
     if (done && !dry) {
       st->status = 1;
-      *D->status_out = 1;
+      *D.status_out = 1;
     }
   }
   __syncthreads();
@@ -1286,7 +1359,8 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
   if (!INIT && (flags & 1) && (D->st->rebuild || D->st->n_ovf > 0)) return;  // lean graph: the pair is waiting (k_assoc)
   const DevParams P = *Pp;
   __shared__ UpdateShared U;
-  update_body<INIT, false>(D, P, flags, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, U, nullptr, nullptr);
+  update_body<INIT, false>(load_upd_desc(D), P, flags, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, U, nullptr,
+                           nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1348,14 +1422,38 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     UpdateShared u;
   } S;
   __shared__ int s_last;
-  coeff_twist<false>(D, S.c, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS);
+  // head of the row loop (count, coordinates, first ELL entry - requested before the count is known, used only
+  // if it exists - and that entry's target)
+  CoeffRowHead head;
+  const int N_ = D->N, pos_ = pb.bx * ASSOC_THREADS + threadIdx.x;
+  head.nnz = 0;
+  head.x = make_float4(0.f, 0.f, 0.f, 0.f);
+  head.idx_n = 0;
+  head.a_n = 0.f;
+  head.y_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pos_ < N_) {
+    head.nnz = D->nnz_row[pos_];
+    head.x = D->xp4[pos_];
+    if (cq < P.K_max) {
+      head.idx_n = D->ell_j[(size_t)cq * N_ + pos_];
+      head.a_n = D->ell_a[(size_t)cq * N_ + pos_];
+    }
+  }
+  // the twist and its matrices (twist_finalize): wave-uniform scalar loads
+  XiMats Mu;
+  {
+    float* mu = reinterpret_cast<float*>(&Mu);
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(XiMats) / sizeof(float)); q++) mu[q] = st_in->xi[q];
+  }
+  if ((unsigned)cq < head.nnz) head.y_n = D->y4[head.idx_n];
   float twist[6];
   for (int c = 0; c < 3; c++) {
-    twist[c] = S.c.M.omega[c];
-    twist[3 + c] = S.c.M.v[c];
+    twist[c] = Mu.omega[c];
+    twist[3 + c] = Mu.v[c];
   }
   const unsigned long long tt1 = __builtin_readcyclecounter();
-  coeff_rows<true>(P, D, st_in, S.c, pb.bx, cq, csplit);
+  coeff_rows<true>(P, D, st_in, S.c, Mu, head, pb.bx, cq, csplit);
   const unsigned long long tt2 = __builtin_readcyclecounter();
   // the scalar state, for whichever block turns out to be the last one: in flight while the counter round trip runs
   unsigned hot_regs[2] = {0u, 0u};
@@ -1363,6 +1461,8 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     hot_regs[0] = reinterpret_cast<const unsigned*>(st)[threadIdx.x];
     if (threadIdx.x + 64 < HOT_DWORDS) hot_regs[1] = reinterpret_cast<const unsigned*>(st)[threadIdx.x + 64];
   }
+  const UpdDesc upd = load_upd_desc(D);
+  const int n_flow_upd = (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS;
   __syncthreads();  // (its release waits for this block's coherent partial stores)
   if (threadIdx.x == 0) {
     const int done = __hip_atomic_fetch_add(D->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1378,7 +1478,17 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     g_dbg_t[1][blockIdx.x & 4095][3] = tt3;
   }
   if (!s_last || (flags & 16)) return;  // (bit 4: cost breakdown of cvo_debug_time_kernels, coefficient phase only)
-  update_body<false, true>(D, P, flags | 4, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, S.u, twist, hot_regs);
+  if (P.dbg & 16) {
+    update_body<false, true>(upd, P, flags | 4 | 8, n_flow_upd, S.u, twist, hot_regs);
+    __syncthreads();
+    if (threadIdx.x == 0) g_dbg_u[4097][0] = __builtin_readcyclecounter() - tt3;
+  }
+  update_body<false, true>(upd, P, flags | 4, n_flow_upd, S.u, twist, hot_regs);
+  if ((P.dbg & 8) && threadIdx.x == 0 && !replay) {
+    atomicAdd(&g_dbg_u[4100][0], (unsigned long long)(__builtin_readcyclecounter() - tt3));
+    atomicAdd(&g_dbg_u[4100][1], 1ull);
+    atomicAdd(&g_dbg_u[4100][2], (unsigned long long)(tt3 - tt0));
+  }
   if ((P.dbg & 8) && threadIdx.x == 0) {
     g_dbg_t[1][4096 + pb.pair][0] = tt0;
     g_dbg_t[1][4096 + pb.pair][1] = tt3;
