@@ -23,7 +23,7 @@ HIPCC_FLAGS = [
     "-ffp-contract=off",  # only the explicit fmaf() calls fuse (DESIGN.md "Numerics")
     # kernel arguments arrive in SGPRs with the wave instead of behind a first scalar-load round trip (the
     # per-iteration kernels are latency bound; the compiler keeps a fallback prologue for older firmware)
-    "-mllvm", "-amdgpu-kernarg-preload-count=8",
+    "-mllvm", "-amdgpu-kernarg-preload-count=12",
     "-Wall",
     "-Wextra",
     "-Wno-unused-parameter",

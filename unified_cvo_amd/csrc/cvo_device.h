@@ -45,7 +45,7 @@ struct DevParams {
   float skin_frac;
   float rebuild_shrink;  // rebuild when ell < rebuild_shrink * ell_build (the lists would be (1/shrink)^3 too long)
   int lean_U;            // iterations between two rebuild opportunities in the lean graph
-  int dbg;  // EXPERIMENT
+  int phase_ticks;  // CVO_PHASE_TICKS: leave per-block phase timestamps (g_phase_ticks) for cvo_debug_time_kernels
 };
 
 // Running state of one frame pair; lives in HBM, only touched by one thread of k_step.
@@ -96,6 +96,24 @@ struct PairState {
 // upload (xorder / yorder map sorted position -> original index).  k_scan works entirely in sorted
 // space so that 4-row groups and 64-target chunks are spatially compact and whole tiles can be
 // rejected by a bounding-box test; k_assoc maps candidates back and restores ascending original j.
+struct EllEntry {
+  float a;
+  int j;
+};
+
+// The row arrays of the per-iteration kernels open every pair's workspace, at offsets that depend only on the
+// launch-wide padded row count: a block computes their addresses from kernel arguments (arena of the launch's
+// first pair, stride between pairs, padded rows) and requests its rows together with the descriptor and the
+// state, instead of one cold round trip later (every kernel starts with an invalidated L2 on this multi-die part).
+//   cand_cnt int[Np] | ip int[Np] | nnz_row u32[Np] | pad | xp4 float4[Np] | cand_j 128 B x Np | ell [K_max][N]
+constexpr int ROW_PAD = 256;
+__host__ __device__ inline size_t row_off_cand_cnt(int) { return 0; }
+__host__ __device__ inline size_t row_off_ip(int Np) { return (size_t)4 * Np; }
+__host__ __device__ inline size_t row_off_nnz(int Np) { return (size_t)8 * Np; }
+__host__ __device__ inline size_t row_off_xp4(int Np) { return (size_t)16 * Np; }
+__host__ __device__ inline size_t row_off_cand_j(int Np) { return (size_t)32 * Np; }
+__host__ __device__ inline size_t row_off_ell(int Np) { return (size_t)160 * Np; }
+
 struct PairDesc {
   // ---- read by the per-iteration kernels (k_assoc, k_coeff): kept together at the front ----
   int N, M, nblk_assoc, nblk_coeff;  // nblk_coeff = nblk_assoc * csplit partials of the coefficient phase
@@ -105,8 +123,7 @@ struct PairDesc {
   float4* xp4;     // [N] source xyz of the row at each position
   int* ip;         // [N] ORIGINAL index of the row at each position
   const float4* y4;   // target xyz (initial cloud), ORIGINAL index
-  float* ell_a;               // ELL kernel matrix values, [K_max][N], indexed by POSITION
-  int* ell_j;                 // ELL column indices (ORIGINAL j, ascending), [K_max][N]
+  EllEntry* ell;              // ELL kernel matrix [K_max][N] by POSITION: value + column (ORIGINAL j, ascending in a row)
   unsigned* nnz_row;          // nonzeros[N], by position
   double* flow_part;          // [nblk_assoc + DENSE_BLOCKS][8]: omega(3), v(3), sum a, pad (row blocks, then k_assoc_dense)
   unsigned long long* cnt_part;  // [nblk_assoc + DENSE_BLOCKS][4]: nnz, max, candidates, overflow rows
@@ -522,7 +539,7 @@ __device__ inline float select_step(double B, double C, double D, double E, floa
     if (min_step > 0.f && min_step <= max_step && a0 >= 1e-200 && a0 <= 1e100 && a1 <= 1e100 && a2 <= 1e100 && a3 <= 1e100) {
       const double fm = ((p_coef[0] * ms + p_coef[1]) * ms + p_coef[2]) * ms + p_coef[3];
       const double noise = 3.6e-15 * (((a0 * ms + a1) * ms + a2) * ms + a3);  // 16 eps times the magnitude sum
-      if ((p_coef[3] > 0.0 && fm < -noise) || (p_coef[3] < 0.0 && fm > noise)) return -min_step;  // EXPERIMENT: sign marks the shortcut
+      if ((p_coef[3] > 0.0 && fm < -noise) || (p_coef[3] < 0.0 && fm > noise)) return min_step;
     }
   }
   double re[3], im[3];
@@ -642,8 +659,10 @@ __device__ inline double se3_log_norm(const double R[9], const double t[3]) {
 }
 
 // A_sparsity_indicator_ell_update (CvoGPU.cu:1167-1285), FIFOs as ring buffers.
+// e_front / s_front: eq[st->e_head] / sq[st->s_head] as they were on entry, read ahead by the caller (two dependent
+// cold loads in the middle of the serial tail otherwise; the pushes below never touch the heads, window + 1 < IND_CAP)
 __device__ inline bool indicator_update(PairState* st, float* sq, float* eq, float indicator, int queue_len,
-                                        float thr) {
+                                        float thr, float e_front, float s_front) {
   bool decrease = false;
   auto s_push = [&](float x) {
     sq[(st->s_head + st->s_size) % IND_CAP] = x;
@@ -668,13 +687,13 @@ __device__ inline bool indicator_update(PairState* st, float* sq, float* eq, flo
       st->s_sum = 0;
       st->e_sum = 0;
     } else {
-      float ef = eq[st->e_head];
+      float ef = e_front;
       st->e_sum -= ef;
       st->s_sum += ef;
       s_push(ef);
       st->e_head = (st->e_head + 1) % IND_CAP;
       st->e_size--;
-      st->s_sum -= sq[st->s_head];
+      st->s_sum -= s_front;
       st->s_head = (st->s_head + 1) % IND_CAP;
       st->s_size--;
       e_push(indicator);

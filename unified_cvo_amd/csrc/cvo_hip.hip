@@ -40,15 +40,19 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, gate, gate_flow, done, cand_cnt, rowperm, xp4, ip, cand_j, ell_a, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, gate, gate_flow, done, cand_cnt, rowperm, xp4, ip, cand_j, ell, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
 struct GraphKey {
   int n_pairs = 0, p0 = 0, T = 0, gx = 0, gy = 0, nba = 0, nbc = 0, npb = 0, idx16 = 0, general = 0, U = 0;
+  const void* arena = nullptr;  // kernel arguments of the row-block kernels (ArenaArg)
+  unsigned stride256 = 0;
+  int Npad = 0;
   bool operator==(const GraphKey& o) const {
     return n_pairs == o.n_pairs && p0 == o.p0 && T == o.T && gx == o.gx && gy == o.gy && nba == o.nba &&
-           nbc == o.nbc && npb == o.npb && idx16 == o.idx16 && general == o.general && U == o.U;
+           nbc == o.nbc && npb == o.npb && idx16 == o.idx16 && general == o.general && U == o.U && arena == o.arena &&
+           stride256 == o.stride256 && Npad == o.Npad;
   }
 };
 
@@ -88,6 +92,8 @@ struct cvo_ctx {
   int last_N = 0, last_M = 0, last_Kmax = 0;
   DevParams last_params{};
   int last_gx = 0, last_gy = 0, last_csplit = 1;
+  unsigned last_stride256 = 0;
+  int last_Npad = 0;
   std::vector<int> last_xorder;  // pair 0's source order: sorted row -> original row
   int last_groups = 1;           // sub-batches (streams) of the last call
   PairLayout last_layout{};
@@ -108,7 +114,7 @@ int fail(cvo_ctx* ctx, int code, const std::string& msg) {
   } while (0)
 
 struct Dims {
-  int Mpad, nchunks, rbw_max, nblk_assoc, nblk_coeff, NG, NGpad;
+  int Mpad, nchunks, rbw_max, nblk_assoc, nblk_coeff, NG, NGpad, Npad;
 };
 
 PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
@@ -120,7 +126,15 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   const int NG = (N + ROWS_PER_GROUP - 1) / ROWS_PER_GROUP;
   const int NGpad = (int)align_up((size_t)NG, 64) + 64;
   PairLayout L{};
-  size_t off = 0;
+  // the row arrays of the per-iteration kernels first, at the fixed offsets of cvo_device.h (row_off_*)
+  const int Npad = (int)align_up((size_t)N, ROW_PAD);
+  L.cand_cnt = row_off_cand_cnt(Npad);
+  L.ip = row_off_ip(Npad);
+  L.nnz_row = row_off_nnz(Npad);
+  L.xp4 = row_off_xp4(Npad);
+  L.cand_j = row_off_cand_j(Npad);  // ASSOC_CAP16 x u16 == ASSOC_CAP32 x i32 == 128 bytes per row
+  L.ell = row_off_ell(Npad);
+  size_t off = align_up(L.ell + sizeof(EllEntry) * (size_t)Npad * Kmax, 256);
   auto take = [&](size_t bytes) {
     size_t o = off;
     off = align_up(off + bytes, 256);
@@ -139,14 +153,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.gate = take(sizeof(int));
   L.gate_flow = take(sizeof(int));
   L.done = take(sizeof(int));
-  L.cand_cnt = take(sizeof(int) * (size_t)N);
   L.rowperm = take(sizeof(int) * (size_t)N);
-  L.xp4 = take(sizeof(float4) * (size_t)N);
-  L.ip = take(sizeof(int) * (size_t)N);
-  L.cand_j = take((size_t)128 * (size_t)N);  // ASSOC_CAP16 x u16 == ASSOC_CAP32 x i32 == 128 bytes per row
-  L.ell_a = take(sizeof(float) * (size_t)N * Kmax);
-  L.ell_j = take(sizeof(int) * (size_t)N * Kmax);
-  L.nnz_row = take(sizeof(unsigned) * (size_t)N);
   L.flow_part = take(sizeof(double) * 8 * (size_t)(nba + DENSE_BLOCKS));
   L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)(nba + DENSE_BLOCKS));
   L.coef_part = take(sizeof(double) * 4 * (size_t)nbc * COEFF_SPLIT_MAX);
@@ -159,6 +166,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   d->nblk_coeff = nbc;
   d->NG = NG;
   d->NGpad = NGpad;
+  d->Npad = Npad;
   return L;
 }
 
@@ -261,8 +269,7 @@ DevParams make_dev_params(const cvo_params_t& p) {
   d.skin_frac = 0.1f;
   d.rebuild_shrink = 0.9f;
   if (const char* e = getenv("CVO_SKIN")) d.skin_frac = std::max(0.f, (float)atof(e));
-  d.dbg = 0;
-  if (const char* e = getenv("CVO_DBG")) d.dbg = atoi(e);  // EXPERIMENT
+  d.phase_ticks = getenv("CVO_PHASE_TICKS") ? 1 : 0;
   if (const char* e = getenv("CVO_SHRINK")) d.rebuild_shrink = std::min(0.99f, std::max(0.f, (float)atof(e)));
   return d;
 }
@@ -319,20 +326,39 @@ void launch_list(hipStream_t s, bool idx16, int N, int n_pairs, const PairDesc* 
     hipLaunchKernelGGL((k_list<int, ASSOC_CAP32>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
 }
 
+// Where the workspaces of a launch's pairs are (kernel arguments of the row-block kernels, see row_off_*)
+struct ArenaArg {
+  const char* base;    // workspace of the launch's first pair
+  unsigned stride256;  // bytes / 256 between consecutive pairs
+  int Npad;
+};
+
 void launch_assoc(hipStream_t s, bool idx16, bool general, int nblk, int n_pairs, const PairDesc* descs,
-                  const DevParams* dp, const PairState* st, int lean) {
+                  const DevParams* dp, const PairState* st, const ArenaArg& A, int lean) {
   const dim3 blk(ASSOC_THREADS), grid = row_grid(nblk, n_pairs);
+  const int packed = (lean & 0xf) | (nblk << 4) | (int)((unsigned)n_pairs << 20);  // (ensure_workspace bounds both)
   if (idx16) {
     if (general)
-      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, true>), grid, blk, 0, s, descs, dp, st, lean, nblk, n_pairs);
+      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, true>), grid, blk, 0, s, descs, dp, st, A.base, packed,
+                         A.stride256, A.Npad);
     else
-      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, false>), grid, blk, 0, s, descs, dp, st, lean, nblk, n_pairs);
+      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, false>), grid, blk, 0, s, descs, dp, st, A.base, packed,
+                         A.stride256, A.Npad);
   } else {
     if (general)
-      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, true>), grid, blk, 0, s, descs, dp, st, lean, nblk, n_pairs);
+      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, true>), grid, blk, 0, s, descs, dp, st, A.base, packed, A.stride256,
+                         A.Npad);
     else
-      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, false>), grid, blk, 0, s, descs, dp, st, lean, nblk, n_pairs);
+      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, false>), grid, blk, 0, s, descs, dp, st, A.base, packed, A.stride256,
+                         A.Npad);
   }
+}
+
+void launch_coeff(hipStream_t s, int nblk, int split, int n_pairs, const PairDesc* descs, const DevParams* dp,
+                  PairState* st, const ArenaArg& A, int flags) {
+  const int packed = nblk | (split << 16) | (int)((unsigned)n_pairs << 20);
+  hipLaunchKernelGGL(k_coeff, row_grid(nblk * split, n_pairs), dim3(ASSOC_THREADS), 0, s, descs, dp, st, A.base, flags, packed,
+                     A.stride256, A.Npad);
 }
 
 void launch_dense(hipStream_t s, bool general, int n_pairs, const PairDesc* descs, const DevParams* dp, const int* st) {
@@ -346,6 +372,7 @@ struct LaunchGeom {
   int n_pairs, p0, T, gx, gy, nba, nbc, npb, N, csplit;
   bool idx16, general;
   hipStream_t stream;
+  ArenaArg arena;  // of pair p0
 };
 
 void launch_init(cvo_ctx* c, const LaunchGeom& g) {
@@ -368,10 +395,9 @@ void launch_rebuild(cvo_ctx* c, const LaunchGeom& g) {
 void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags) {
   const PairDesc* descs = c->d_descs + g.p0;
   const int* st = c->d_status + g.p0;
-  launch_assoc(g.stream, g.idx16, g.general, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, lean ? 1 : 0);
+  launch_assoc(g.stream, g.idx16, g.general, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, lean ? 1 : 0);
   if (!lean) launch_dense(g.stream, g.general, g.n_pairs, descs, c->d_params, st);
-  hipLaunchKernelGGL(k_coeff, row_grid(g.nba * g.csplit, g.n_pairs), dim3(ASSOC_THREADS), 0, g.stream, descs, c->d_params,
-                     c->d_states + g.p0, flags | (lean ? 1 : 0), g.nba | (g.csplit << 16), g.n_pairs);
+  launch_coeff(g.stream, g.nba, g.csplit, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0));
 }
 
 // A chunk of U iterations.  Full: every iteration can rebuild its candidate list and serve overflow rows.
@@ -431,6 +457,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->G = n_pairs >= 32 ? 4 : (n_pairs >= 8 ? 2 : 1);
   if (const char* e = getenv("CVO_STREAMS")) S->G = std::max(1, std::min(atoi(e), (int)cvo_ctx::MAX_GROUPS));
   S->G = std::min(S->G, n_pairs);
+  if ((n_pairs + S->G - 1) / S->G > 4095 || S->d.nblk_assoc > 65535)
+    return fail(ctx, CVO_E_INVALID, "batch too large for one call: at most 4095 pairs per stream and 8388480 source points per cloud");
   choose_scan_config((n_pairs + S->G - 1) / S->G, S->d.NG, S->d.Mpad, &S->T, &S->gpb);
 
   DevParams dp = make_dev_params(*params);
@@ -507,8 +535,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.xp4 = (float4*)(base + S->L.xp4);
     D.ip = (int*)(base + S->L.ip);
     D.cand_j = (void*)(base + S->L.cand_j);
-    D.ell_a = (float*)(base + S->L.ell_a);
-    D.ell_j = (int*)(base + S->L.ell_j);
+    D.ell = (EllEntry*)(base + S->L.ell);
     D.nnz_row = (unsigned*)(base + S->L.nnz_row);
     D.flow_part = (double*)(base + S->L.flow_part);
     D.cnt_part = (unsigned long long*)(base + S->L.cnt_part);
@@ -559,6 +586,9 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.gy = S->gy;
   S->geom.nba = S->d.nblk_assoc;
   S->geom.N = N;
+  S->geom.arena.base = ctx->arena;
+  S->geom.arena.stride256 = (unsigned)(S->L.total >> 8);
+  S->geom.arena.Npad = S->d.Npad;
   S->geom.csplit = 1;
   for (int p = 0; p < n_pairs; p++) S->geom.csplit = std::max(S->geom.csplit, coeff_split(sources[p]->n));
   S->geom.nbc = S->d.nblk_coeff;
@@ -573,6 +603,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   ctx->last_Kmax = Kmax;
   ctx->last_params = dp;
   ctx->last_csplit = S->geom.csplit;
+  ctx->last_stride256 = S->geom.arena.stride256;
+  ctx->last_Npad = S->geom.arena.Npad;
   ctx->last_gx = S->gx;
   ctx->last_gy = S->gy;
   ctx->last_layout = S->L;
@@ -945,6 +977,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     geom[g] = S.geom;
     geom[g].p0 = p0;
     geom[g].n_pairs = p1 - p0;
+    geom[g].arena.base = S.geom.arena.base + S.L.total * (size_t)p0;
     geom[g].stream = ctx->gstream[g];
   }
 
@@ -971,6 +1004,9 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       key.idx16 = S.geom.idx16 ? 1 : 0;
       key.general = S.geom.general ? 1 : 0;
       key.U = U * 256 + lean_U;
+      key.arena = geom[g].arena.base;
+      key.stride256 = geom[g].arena.stride256;
+      key.Npad = geom[g].arena.Npad;
       if (ctx->graph_exec[g][v] && ctx->graph_key[g][v] == key) return CVO_OK;
       if (ctx->graph_exec[g][v]) {
         (void)hipGraphExecDestroy(ctx->graph_exec[g][v]);
@@ -1188,8 +1224,12 @@ static int fetch_ell(cvo_ctx* ctx, int pair, std::vector<unsigned>& nz, std::vec
   std::vector<float> ap((size_t)mx * N);
   std::vector<int> jp((size_t)mx * N);
   if (mx) {
-    HIP_TRY(ctx, hipMemcpy(ap.data(), D.ell_a, sizeof(float) * (size_t)mx * N, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(jp.data(), D.ell_j, sizeof(int) * (size_t)mx * N, hipMemcpyDeviceToHost));
+    std::vector<EllEntry> ep((size_t)mx * N);
+    HIP_TRY(ctx, hipMemcpy(ep.data(), D.ell, sizeof(EllEntry) * (size_t)mx * N, hipMemcpyDeviceToHost));
+    for (size_t q = 0; q < ep.size(); q++) {
+      ap[q] = ep[q].a;
+      jp[q] = ep[q].j;
+    }
   }
   nz.assign(N, 0);
   a.assign((size_t)mx * N, 0.f);
@@ -1415,13 +1455,13 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
     auto sweep = [&]() {
       for (int g = 0; g < G; g++) {
         const int p0 = (int)((long)n_pairs * g / G), p1 = (int)((long)n_pairs * (g + 1) / G);
+        const ArenaArg A{ctx->arena + ((size_t)ctx->last_stride256 << 8) * (size_t)p0, ctx->last_stride256, ctx->last_Npad};
         if (which == 0)
-          launch_assoc(ctx->stream, idx16, general, nba, p1 - p0, ctx->d_descs + p0, ctx->d_params,
-                       ctx->d_states + p0, 2);
+          launch_assoc(ctx->stream, idx16, general, nba, p1 - p0, ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0, A,
+                       2);
         else
-          hipLaunchKernelGGL(k_coeff, row_grid(nba * ctx->last_csplit, p1 - p0), dim3(ASSOC_THREADS), 0, ctx->stream,
-                             ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0,
-                             8 | 2 | (getenv("CVO_COEFF_NO_UPDATE") ? 16 : 0), nba | (ctx->last_csplit << 16), p1 - p0);
+          launch_coeff(ctx->stream, nba, ctx->last_csplit, p1 - p0, ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0,
+                       A, 8 | 2 | (getenv("CVO_COEFF_NO_UPDATE") ? 16 : 0));
       }
     };
     sweep();  // warm-up
@@ -1433,19 +1473,16 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
     HIP_TRY(ctx, hipEventElapsedTime(&out[which], ctx->ev_start, ctx->ev_stop));
     out[which] /= (float)(reps * G);
   }
-  if (dp.dbg & 8) {  // EXPERIMENT
+  if (dp.phase_ticks) {  // where the blocks of the last sub-batch's launches spent their time (see g_phase_ticks)
     static unsigned long long h[2][8192][4];
-    HIP_TRY(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_t), sizeof(h)));
+    HIP_TRY(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_ticks), sizeof(h)));
     const int np = n_pairs - (int)((long)n_pairs * (G - 1) / G);
     for (int which = 0; which < 2; which++) {
       const int nb = std::min(4096, 8 * ((np + 7) / 8) * nba * (which ? ctx->last_csplit : 1));
-      unsigned long long t0min = ~0ull, tend = 0;
       double sum[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
       int cnt = 0;
       for (int b = 0; b < nb; b++) {
         if (!h[which][b][0] || !h[which][b][3]) continue;
-        t0min = std::min(t0min, h[which][b][0]);
-        tend = std::max(tend, h[which][b][3]);
         for (int q = 0; q < 3; q++) {
           const double d = (double)(long long)(h[which][b][q + 1] - h[which][b][q]);
           sum[q] += d;
@@ -1453,30 +1490,13 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
         }
         cnt++;
       }
-      double st_first = 0, st_last = 0;
-      for (int b = 0; b < nb; b++)
-        if (h[which][b][0]) st_last = std::max(st_last, (double)(h[which][b][0] - t0min));
-      fprintf(stderr, "[dbg] %s: blocks %d span %.0f ticks, last block starts at %.0f; phases avg %.0f %.0f %.0f max %.0f %.0f %.0f\n",
-              which ? "k_coeff" : "k_assoc", cnt, (double)(tend - t0min), st_last, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt,
-              mx[0], mx[1], mx[2]);
-      (void)st_first;
-      if (which) {
-        static unsigned long long u[8192][8];
-        HIP_TRY(ctx, hipMemcpyFromSymbol(u, HIP_SYMBOL(g_dbg_u), sizeof(u)));
-        double su[5] = {0, 0, 0, 0, 0};
-        for (int b = 0; b < nb; b++)
-          for (int q = 0; q < 5; q++) su[q] += (double)u[b][q];
-fprintf(stderr, "[dbg]   first (dry) update %.0f\n", (double)u[4097][0]);
-        fprintf(stderr, "[dbg]   tail marks (from w2): before exp %.0f, after exp %.0f, before log %.0f, after log %.0f, after indicator %.0f, before update_tf %.0f, before status %.0f\n", (double)u[4098][0], (double)u[4098][1], (double)u[4098][2], (double)u[4098][3], (double)u[4098][4], (double)u[4098][5], (double)u[4098][6]);
-        fprintf(stderr, "[dbg]   step shortcut taken %llu of %llu updates\n", u[4099][0], u[4099][1]);
-        fprintf(stderr, "[dbg]   real loop: update %.0f ticks avg, its block start->counter %.0f avg over %llu\n", (double)u[4100][0] / (double)u[4100][1], (double)u[4100][2] / (double)u[4100][1], u[4100][1]);
-        fprintf(stderr, "[dbg]   update: partial loads %.0f, cubic %.0f, scalar tail %.0f\n", (double)u[4096][0], (double)u[4096][1], (double)u[4096][2]);
-                fprintf(stderr, "[dbg]   twist: prologue %.0f, loads %.0f, reduce %.0f, normalise+head %.0f, mats %.0f\n", su[0] / nb,
-                su[1] / nb, su[2] / nb, su[3] / nb, su[4] / nb);
-      }
+      if (!cnt) continue;
+      fprintf(stderr, "[cvo] %s: %d blocks; ticks (avg / max) %s %.0f / %.0f, row loop %.0f / %.0f, %s %.0f / %.0f\n",
+              which ? "k_coeff" : "k_assoc", cnt, which ? "prologue + twist" : "prologue", sum[0] / cnt, mx[0], sum[1] / cnt,
+              mx[1], which ? "reduction + counter" : "reduction + flow gate", sum[2] / cnt, mx[2]);
       if (which)
         for (int p = 0; p < std::min(np, 3); p++)
-          fprintf(stderr, "[dbg]   pair %d update block: start->counter %.0f, update %.0f ticks\n", p,
+          fprintf(stderr, "[cvo]   pair %d, updating block: entry -> counter %.0f, update %.0f ticks\n", p,
                   (double)(long long)(h[1][4096 + p][1] - h[1][4096 + p][0]),
                   (double)(long long)(h[1][4096 + p][2] - h[1][4096 + p][1]));
     }

@@ -473,8 +473,7 @@ __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* _
   float4 yt;
   if (!eval_pair<GENERAL>(P, D, pose, i, r, j, y0, a, yt)) return;
   if (a > P.sp_thres) {
-    D->ell_a[(size_t)A.nnz * N + pos] = a;
-    D->ell_j[(size_t)A.nnz * N + pos] = j;
+    D->ell[(size_t)A.nnz * N + pos] = EllEntry{a, j};
     A.nnz++;
     const V3 pye{yt.x, yt.y, yt.z};
     const V3 cr = cross_dev(pxe, pye);
@@ -683,8 +682,17 @@ __device__ __forceinline__ void flow_gate(const PairDesc* __restrict__ D, int nb
 // Association phase: ordered association + flow, one thread per (sorted) source row, over the cached
 // candidate list.
 // ------------------------------------------------------------------------------------------
-__device__ unsigned long long g_dbg_t[2][8192][4];
-__device__ unsigned long long g_dbg_u[8192][8];  // EXPERIMENT: phase timestamps
+// CVO_PHASE_TICKS=1: thread 0 of every block of k_assoc [0] / k_coeff [1] leaves four s_memtime stamps (entry, row loop
+// start, row loop end, exit; for k_coeff: entry, rows start, rows end, counter), and the updating block of pair p its
+// entry / counter / exit at [1][4096 + p].  Only differences inside a block mean anything (the counters of
+// different XCDs are not aligned).  Printed by cvo_debug_time_kernels.
+__device__ unsigned long long g_phase_ticks[2][8192][4];
+// What a row needs first, requested from kernel-argument addresses (see row_off_* in cvo_device.h) before the
+// descriptor has arrived.
+struct AssocRowHead {
+  int cnt, ip, j1;
+  float4 x;
+};
 struct AssocShared {
   double red[ASSOC_THREADS / 64][8];
   unsigned long long cnt[ASSOC_THREADS / 64][4];
@@ -692,7 +700,7 @@ struct AssocShared {
 
 template <typename IdxT, int ASSOC_CAP, bool GENERAL>
 __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* __restrict__ D, const PairState* st,
-                                            AssocShared& S, const int bx) {
+                                            AssocShared& S, const int bx, const AssocRowHead& head) {
   const int N = D->N;
   const int pos = bx * ASSOC_THREADS + threadIdx.x;  // position in k_list's count-ordered row windows
   const int K = st->K;
@@ -701,15 +709,14 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
   unsigned overflowed = 0;
   unsigned long long tt1 = 0, tt2 = 0;
   if (pos < N) {
-    // the first two list slots are requested together with the count (they exist whatever the count is)
-    const int j1s = (int)(reinterpret_cast<const IdxT*>(D->cand_j) + pos)[0];
+    const int j1s = head.j1;  // (the first list slot exists whatever the count is)
     const int j2s = (int)(reinterpret_cast<const IdxT*>(D->cand_j) + pos)[N];
-    const int cnt = D->cand_cnt[pos];
+    const int cnt = head.cnt;
     ncand = (unsigned long long)cnt;
     overflowed = cnt > ASSOC_CAP ? 1u : 0u;
     if (!overflowed) {
-      const int i = D->ip[pos];
-      const float4 x = D->xp4[pos];
+      const int i = head.ip;
+      const float4 x = head.x;
       const RowData r = make_row(P, x, st->ell);
       const V3 pxe{x.x, x.y, x.z};
       const Pose pose = load_pose(st);
@@ -732,9 +739,9 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
       tt2 = __builtin_readcyclecounter();
     }
   }
-  if ((P.dbg & 8) && threadIdx.x == 0) {
-    g_dbg_t[0][blockIdx.x & 8191][1] = tt1;
-    g_dbg_t[0][blockIdx.x & 8191][2] = tt2;
+  if (P.phase_ticks && threadIdx.x == 0) {
+    g_phase_ticks[0][blockIdx.x & 8191][1] = tt1;
+    g_phase_ticks[0][blockIdx.x & 8191][2] = tt2;
   }
   // per-row (omega_i / c, v_i / d) cast to double, then reduced in double (CvoGPU.cu:784-787, 824-825)
   double red[7] = {(double)(A.o0 / P.c), (double)(A.o1 / P.c), (double)(A.o2 / P.c), (double)(A.v0 / P.d),
@@ -782,13 +789,25 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
 template <typename IdxT, int ASSOC_CAP, bool GENERAL>
 __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restrict__ descs,
                                                           const DevParams* __restrict__ Pp,
-                                                          const PairState* __restrict__ states, int lean, int nblk,
-                                                          int n_pairs) {
+                                                          const PairState* __restrict__ states,
+                                                          const char* __restrict__ arena, int lean_nblk_pairs,
+                                                          unsigned stride256, int Npad) {
   const unsigned long long tt0 = __builtin_readcyclecounter();
+  // one packed argument keeps everything inside the preloaded kernel-argument registers
+  const int lean = lean_nblk_pairs & 0xf, nblk = (lean_nblk_pairs >> 4) & 0xffff, n_pairs = (int)((unsigned)lean_nblk_pairs >> 20);
   PairBlock pb;
   if (!pair_block(nblk, n_pairs, pb)) return;
   const PairDesc* __restrict__ D = descs + pb.pair;
   const PairState* __restrict__ st = states + pb.pair;  // == D->st, without the dependent pointer load
+  AssocRowHead head;
+  {
+    const char* wb = arena + (size_t)pb.pair * ((size_t)stride256 << 8);
+    const int pos = pb.bx * ASSOC_THREADS + threadIdx.x;  // < Npad; values of rows >= N are never used
+    head.cnt = reinterpret_cast<const int*>(wb + row_off_cand_cnt(Npad))[pos];
+    head.ip = reinterpret_cast<const int*>(wb + row_off_ip(Npad))[pos];
+    head.j1 = (int)reinterpret_cast<const IdxT*>(wb + row_off_cand_j(Npad))[pos];
+    head.x = reinterpret_cast<const float4*>(wb + row_off_xp4(Npad))[pos];
+  }
   // everything the prologue branches on, requested in one burst of scalar loads (a chain of dependent ~0.5 us
   // round trips in front of every block is what this latency-bound kernel can least afford)
   const int status_v = st->status, rebuild_v = st->rebuild, n_ovf_v = st->n_ovf;
@@ -801,7 +820,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
     const void* a1 = D->cand_j;
     const float4* a2 = D->xp4;
     const float4* a3 = D->y4;
-    const float* a4 = D->ell_a;
+    const EllEntry* a4 = D->ell;
     const float e = st->ell, r0 = st->Rinv[0], t0 = st->Tinv[0];
     asm volatile("" ::"s"(n), "s"(k), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e), "s"(r0), "s"(t0), "s"(P.sp_thres),
                  "s"(P.log_geo));
@@ -813,12 +832,12 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
   // switch its group to the full graph (k_coeff skips it too and tells the host)
   if ((lean & 1) && (rebuild_v || n_ovf_v > 0)) return;
   __shared__ AssocShared S;
-  assoc_phase<IdxT, ASSOC_CAP, GENERAL>(P, D, st, S, pb.bx);
+  assoc_phase<IdxT, ASSOC_CAP, GENERAL>(P, D, st, S, pb.bx, head);
   // lean graph: nothing else adds to the flow, the twist of the iteration can be finished here
   if ((lean & 3) && P.mode == 0) flow_gate(D, nblk, nblk);  // (bit 1: the timing replay includes it)
-  if ((P.dbg & 8) && threadIdx.x == 0) {
-    g_dbg_t[0][blockIdx.x & 8191][0] = tt0;
-    g_dbg_t[0][blockIdx.x & 8191][3] = __builtin_readcyclecounter();
+  if (P.phase_ticks && threadIdx.x == 0) {
+    g_phase_ticks[0][blockIdx.x & 8191][0] = tt0;
+    g_phase_ticks[0][blockIdx.x & 8191][3] = __builtin_readcyclecounter();
   }
 }
 
@@ -868,8 +887,7 @@ __global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict_
         const unsigned rank = nnz + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         const bool keep = ok && rank < (unsigned)K;  // `if (num_inds == num_neighbors) break;`
         if (keep) {
-          D->ell_a[(size_t)rank * N + r_sorted] = a;
-          D->ell_j[(size_t)rank * N + r_sorted] = j;
+          D->ell[(size_t)rank * N + r_sorted] = EllEntry{a, j};
         }
         // flow terms of this lane's pair (CvoGPU.cu:767-769)
         const V3 pye{yt.x, yt.y, yt.z};
@@ -1008,8 +1026,9 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
       const float A_ij = a_n;
       const float4 y0 = y_n;
       if (s + nsplit < nnz) {
-        idx_n = D->ell_j[(size_t)(s + nsplit) * N + i];
-        a_n = D->ell_a[(size_t)(s + nsplit) * N + i];
+        const EllEntry e = D->ell[(size_t)(s + nsplit) * N + i];
+        idx_n = e.j;
+        a_n = e.a;
         y_n = D->y4[idx_n];
       }
       const V3 yy = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
@@ -1152,14 +1171,15 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     }
   }
   __syncthreads();
+  // fronts of the indicator FIFOs (HBM), on their way while the step is computed
+  float e_front = 0.f, s_front = 0.f;
+  if (!INIT && tid == 0) {
+    e_front = eq[st->e_head];
+    s_front = sq[st->s_head];
+  }
   // the step of this iteration: the cubic's real roots are searched on three lanes side by side
   float step_w = 0.f;
   if (!INIT && act && P.mode == 0) step_w = select_step<true>(s_c[0], s_c[1], s_c[2], s_c[3], P.min_step, P.max_step);
-  if (step_w < 0.f) {
-    step_w = -step_w;
-    if ((P.dbg & 8) && tid == 0 && !dry) atomicAdd(&g_dbg_u[4099][0], 1ull);
-  }
-  if ((P.dbg & 8) && tid == 0 && !dry && !INIT) atomicAdd(&g_dbg_u[4099][1], 1ull);
   if (tid == 0) {
     int done = 0;
     if (twist) {  // k_coeff: every block derived the same normalised twist
@@ -1225,7 +1245,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
           for (int q = 0; q < 3; q++) st->T[q] = T[q] = Tn[q];
           dist = se3_log_norm(dR, dT);  // CvoGPU.cu:1473-1476
           const float ip_curr = (float)((double)nnz / sqrt((double)D.N * (double)D.M));  // 1486
-          const bool need_decay_ell = dry ? false : indicator_update(st, sq, eq, ip_curr, P.window, P.stable_thr);
+          const bool need_decay_ell = dry ? false : indicator_update(st, sq, eq, ip_curr, P.window, P.stable_thr, e_front, s_front);
           if (dist < (double)P.eps_2) {  // CvoGPU.cu:1505-1508
             done = 1;
             st->iterations = k;
@@ -1370,18 +1390,33 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
 // flags: bit 0 = lean graph, the rest see update_body.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restrict__ descs,
-                                                         const DevParams* __restrict__ Pp, PairState* states, int flags,
-                                                         int nblk, int n_pairs) {
+                                                         const DevParams* __restrict__ Pp, PairState* states,
+                                                         const char* __restrict__ arena, int flags, int nblk_split_pairs,
+                                                         unsigned stride256, int Npad) {
   const unsigned long long tt0 = __builtin_readcyclecounter();
   // grid: per pair nblk row blocks x launch_split slices of the ELL slots; a pair uses csplit <= launch_split of them
-  const int launch_split = nblk >> 16;
-  nblk &= 0xffff;
+  const int nblk = nblk_split_pairs & 0xffff, launch_split = (nblk_split_pairs >> 16) & 0xf,
+            n_pairs = (int)((unsigned)nblk_split_pairs >> 20);
   PairBlock pb;
   if (!pair_block(nblk * launch_split, n_pairs, pb)) return;
   const PairDesc* __restrict__ D = descs + pb.pair;
-  const int csplit = D->csplit;
   const int cq = pb.bx % launch_split;
   pb.bx /= launch_split;
+  // head of the row loop, from kernel-argument addresses (row_off_*): count, coordinates and the first ELL entry
+  // of this block's slice - requested before the count is known, used only if it exists
+  CoeffRowHead head;
+  {
+    const char* wb = arena + (size_t)pb.pair * ((size_t)stride256 << 8);
+    const int pos = pb.bx * ASSOC_THREADS + threadIdx.x;  // < Npad; values of rows >= N are never used
+    head.nnz = reinterpret_cast<const unsigned*>(wb + row_off_nnz(Npad))[pos];
+    head.x = reinterpret_cast<const float4*>(wb + row_off_xp4(Npad))[pos];
+    EllEntry e{0.f, 0};
+    if (cq == 0) e = reinterpret_cast<const EllEntry*>(wb + row_off_ell(Npad))[pos];
+    head.idx_n = e.j;
+    head.a_n = e.a;
+    head.y_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int csplit = D->csplit;
   if (cq >= csplit) return;
   PairState* const st = states + pb.pair;  // == D->st, without the dependent pointer load
   // The state as this launch found it, through a read-only view so that the loads are scalar (only the block that
@@ -1394,8 +1429,8 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     const double* a0 = D->flow_part;
     const unsigned* a1 = D->nnz_row;
     const float4* a2 = D->xp4;
-    const float* a3 = D->ell_a;
-    const int* a4 = D->ell_j;
+    const EllEntry* a3 = D->ell;
+    const int a4 = D->M;
     const float4* a5 = D->y4;
     const float e = st_in->ell, r0 = st_in->Rinv[0], t0 = st_in->Tinv[0];
     asm volatile("" ::"s"(n), "s"(nb), "s"(ep), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(e), "s"(r0), "s"(t0));
@@ -1422,22 +1457,12 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     UpdateShared u;
   } S;
   __shared__ int s_last;
-  // head of the row loop (count, coordinates, first ELL entry - requested before the count is known, used only
-  // if it exists - and that entry's target)
-  CoeffRowHead head;
   const int N_ = D->N, pos_ = pb.bx * ASSOC_THREADS + threadIdx.x;
-  head.nnz = 0;
-  head.x = make_float4(0.f, 0.f, 0.f, 0.f);
-  head.idx_n = 0;
-  head.a_n = 0.f;
-  head.y_n = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (pos_ < N_) {
-    head.nnz = D->nnz_row[pos_];
-    head.x = D->xp4[pos_];
-    if (cq < P.K_max) {
-      head.idx_n = D->ell_j[(size_t)cq * N_ + pos_];
-      head.a_n = D->ell_a[(size_t)cq * N_ + pos_];
-    }
+  if (pos_ >= N_) head.nnz = 0;
+  if (cq > 0 && (unsigned)cq < head.nnz) {  // (small clouds only: the slices of a row beyond the first)
+    const EllEntry e = D->ell[(size_t)cq * N_ + pos_];
+    head.idx_n = e.j;
+    head.a_n = e.a;
   }
   // the twist and its matrices (twist_finalize): wave-uniform scalar loads
   XiMats Mu;
@@ -1471,28 +1496,18 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
   }
   __syncthreads();
   const unsigned long long tt3 = __builtin_readcyclecounter();
-  if ((P.dbg & 8) && threadIdx.x == 0) {
-    g_dbg_t[1][blockIdx.x & 4095][0] = tt0;
-    g_dbg_t[1][blockIdx.x & 4095][1] = tt1;
-    g_dbg_t[1][blockIdx.x & 4095][2] = tt2;
-    g_dbg_t[1][blockIdx.x & 4095][3] = tt3;
+  if (P.phase_ticks && threadIdx.x == 0) {
+    g_phase_ticks[1][blockIdx.x & 4095][0] = tt0;
+    g_phase_ticks[1][blockIdx.x & 4095][1] = tt1;
+    g_phase_ticks[1][blockIdx.x & 4095][2] = tt2;
+    g_phase_ticks[1][blockIdx.x & 4095][3] = tt3;
   }
   if (!s_last || (flags & 16)) return;  // (bit 4: cost breakdown of cvo_debug_time_kernels, coefficient phase only)
-  if (P.dbg & 16) {
-    update_body<false, true>(upd, P, flags | 4 | 8, n_flow_upd, S.u, twist, hot_regs);
-    __syncthreads();
-    if (threadIdx.x == 0) g_dbg_u[4097][0] = __builtin_readcyclecounter() - tt3;
-  }
   update_body<false, true>(upd, P, flags | 4, n_flow_upd, S.u, twist, hot_regs);
-  if ((P.dbg & 8) && threadIdx.x == 0 && !replay) {
-    atomicAdd(&g_dbg_u[4100][0], (unsigned long long)(__builtin_readcyclecounter() - tt3));
-    atomicAdd(&g_dbg_u[4100][1], 1ull);
-    atomicAdd(&g_dbg_u[4100][2], (unsigned long long)(tt3 - tt0));
-  }
-  if ((P.dbg & 8) && threadIdx.x == 0) {
-    g_dbg_t[1][4096 + pb.pair][0] = tt0;
-    g_dbg_t[1][4096 + pb.pair][1] = tt3;
-    g_dbg_t[1][4096 + pb.pair][2] = __builtin_readcyclecounter();
+  if (P.phase_ticks && threadIdx.x == 0) {
+    g_phase_ticks[1][4096 + pb.pair][0] = tt0;
+    g_phase_ticks[1][4096 + pb.pair][1] = tt3;
+    g_phase_ticks[1][4096 + pb.pair][2] = __builtin_readcyclecounter();
   }
 }
 
