@@ -25,6 +25,7 @@ import numpy as np
 # queues by default, and sharing a queue serialises two of our sub-batches (measured: 0.37 s instead of
 # 0.25 s per step under torchrun).  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("CVO_KERNEL_CLOCK", "1")  # per-pair kernel durations inside the timed loop (roofline.avg_launch_ms)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -149,13 +150,25 @@ def main():
         # cached candidate lists) and k_coeff (pass 2: K4+K5, plus the scalar update in its last block); k_scan only
         # runs when a pair's candidate list has expired.  k_coeff holds the largest share of GPU time.
         tiles, rpt, tpt = gpu.debug_scan_stats()        # over the last measured step (all pairs, all list builds)
+        # Durations of the two per-iteration kernels INSIDE the timed loop (last measured step): every block reports its
+        # entry on the device's constant-rate counter, the block that finishes a pair's work closes the interval
+        # (CVO_KERNEL_CLOCK, rate calibrated against HIP events) - first block in to last block out, per pair and launch,
+        # i.e. what rocprofv3 --kernel-trace --stats averages for the same launches.  The launches sit inside hipGraphs,
+        # where HIP events cannot be timed; the HIP-event figures below are replays of the same launches alone on the GPU.
+        try:
+            assoc_ms, coeff_ms, clocked = gpu.debug_kernel_clock()
+        except Exception:  # CVO_KERNEL_CLOCK=0: fall back to the replayed launches below
+            assoc_ms = coeff_ms = None
+            clocked = 0
         builds, iters_total, cand_evals = gpu.debug_list_builds()
         n_groups, ppl = gpu.debug_last_geometry()       # the batch runs as n_groups sub-batches of ppl pairs
         # Kernel times depend on the optimiser state (lists shrink as ell decays): replay them on the state half way
         # through the trajectory, which is close to the average over the run that rocprofv3 --stats reports.
         mid_iters = max(1, int(mean_iters) // 2)
         gpu.align_batch(src, tgt, inits, max_iterations=mid_iters)
-        assoc_ms, coeff_ms = gpu.debug_time_kernels(20)  # avg per launch (ppl pairs)
+        assoc_alone_ms, coeff_alone_ms = gpu.debug_time_kernels(20)
+        if not clocked:
+            assoc_ms, coeff_ms = assoc_alone_ms, coeff_alone_ms
         scan_ms = gpu.debug_time_scan(20)
         bytes_pass = (n * 12 + n * 12) * ppl            # one pass over one iteration's inputs, geometric payload
         pair_tests_iter = 2.0 * float(n) * float(n)     # two passes over N x M per iteration and pair
@@ -173,19 +186,23 @@ def main():
             except Exception:
                 traffic = {}
 
-        def kernel_entry(name, ms, share):
+        def kernel_entry(name, ms, share, alone_ms=None):
             gbs = bytes_pass / (ms * 1e-3) / 1e9
-            return {"kernel": name, "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6),
-                    "avg_launch_ms": round(ms, 5), "launches_per_iteration_and_subbatch": share,
-                    "traffic": traffic.get(name.split("::")[-1])}
+            e = {"kernel": name, "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6),
+                 "avg_launch_ms": round(ms, 5), "launches_per_iteration_and_subbatch": share,
+                 "traffic": traffic.get(name.split("::")[-1])}
+            if alone_ms is not None:
+                e["alone_on_gpu_launch_ms"] = round(alone_ms, 5)
+            return e
 
-        dom = kernel_entry("cvo_dev::k_coeff", coeff_ms, 1.0)
+        dom = kernel_entry("cvo_dev::k_coeff", coeff_ms, 1.0, coeff_alone_ms)
         roofline = {
             "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["frac"], "traffic": dom["traffic"],
             "algorithmic_bytes_per_launch": bytes_pass, "avg_launch_ms": dom["avg_launch_ms"],
+            "alone_on_gpu_launch_ms": dom["alone_on_gpu_launch_ms"], "launches_clocked": int(clocked),
             "pairs_per_launch": ppl, "sub_batches": n_groups, "timed_at_iteration": mid_iters,
-            "other_kernels": [kernel_entry("cvo_dev::k_assoc", assoc_ms, 1.0),
+            "other_kernels": [kernel_entry("cvo_dev::k_assoc", assoc_ms, 1.0, assoc_alone_ms),
                               kernel_entry("cvo_dev::k_scan", scan_ms, round(builds / max(iters_total, 1), 5))],
             # The path is an all-pairs accumulation with O(N+M) compulsory bytes: HBM is not the binding roof
             # (SURVEY.md 8(d)).  The VALU view: algorithmic pair tests per second of the whole job against the FP32
@@ -253,8 +270,8 @@ def main():
         h2d_rate = (2 * n * 16 * 1.0) * B / max(t_h2d, 1e-9) / 1e9
         log(f"[bench] inputs: generated in {t_gen:.2f}s, uploaded in {t_h2d:.3f}s ({h2d_rate:.2f} GB/s incl. host packing); "
             f"PCIe-inclusive rate = {aligns / (elapsed + args.steps * t_h2d):.2f} align/s")
-        log(f"[bench] loop {loop_s:.3f}s/step on rank 0; per launch of {ppl} pairs: k_assoc {assoc_ms*1e3:.1f} us, "
-            f"k_coeff {coeff_ms*1e3:.1f} us, k_scan {scan_ms*1e3:.1f} us (runs in {100.0*builds/max(iters_total,1):.1f}% of the "
+        log(f"[bench] loop {loop_s:.4f}s/step on rank 0; per launch of {ppl} pairs: k_assoc {assoc_ms*1e3:.1f} us "
+            f"({assoc_alone_ms*1e3:.1f} alone on the GPU), k_coeff {coeff_ms*1e3:.1f} us ({coeff_alone_ms*1e3:.1f} alone), k_scan {scan_ms*1e3:.1f} us (runs in {100.0*builds/max(iters_total,1):.1f}% of the "
             f"iterations); {pair_rate/1e12:.1f} T algorithmic pair-tests/s, {100*executed_frac:.3f}% of them executed")
         assert int(stat.abs().sum().item()) == 0, "some align() returned -1"
         print(json.dumps(out), flush=True)

@@ -234,6 +234,13 @@ int cvo_debug_scan_stats(cvo_ctx* ctx, unsigned long long* tiles, int* rows_per_
  * `reps` times, on the state the last call left behind and without writing anything back; timed with HIP events on
  * the context's stream.  *ms_* = average milliseconds per launch (of pairs_per_group pairs). */
 int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_coeff);
+/* Kernel durations inside the optimiser loop itself.  With CVO_KERNEL_CLOCK set in the environment when the context is
+ * created, the first block of a pair in k_assoc (lean graph) / k_coeff stamps its entry on the device's constant-rate counter
+ * (s_memrealtime) and the block that finishes the pair's work in the launch (twist reduction / update) closes the
+ * interval; the per-pair sums are part of the state.  Returns the averages of the last align call in ms - first
+ * block in to last block out per pair and launch, the quantity rocprofv3 --kernel-trace --stats averages per launch -
+ * and the number of k_coeff intervals behind them.  The counter's rate is calibrated against HIP events. */
+int cvo_debug_kernel_clock(cvo_ctx* ctx, float* ms_assoc, float* ms_coeff, unsigned long long* launches);
 /* Candidate-list reuse of the last align call, summed over the pairs: how many times the candidate bitmap was
  * (re)built by k_scan, the optimiser iterations run, and the candidate pairs k_assoc evaluated exactly. */
 int cvo_debug_list_builds(cvo_ctx* ctx, unsigned long long* builds, unsigned long long* iterations,

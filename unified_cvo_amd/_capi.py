@@ -128,6 +128,7 @@ EXPORTED = [
     "cvo_ctx_synchronize", "cvo_cloud_upload", "cvo_cloud_upload_aos192", "cvo_cloud_size", "cvo_cloud_free",
     "cvo_align", "cvo_align_ex", "cvo_align_batch", "cvo_batch_poses_to_device", "cvo_inner_product",
     "cvo_function_angle", "cvo_association", "cvo_association_non_isotropic", "cvo_cloud_transformed", "cvo_edge_kernel_matrix", "cvo_debug_last_ell", "cvo_debug_time_scan", "cvo_debug_time_kernels",
+    "cvo_debug_kernel_clock",
     "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
 ]
 
@@ -178,6 +179,7 @@ def lib():
     L.cvo_debug_last_ell.argtypes = [vp, ip, fp, C.POINTER(C.c_int), C.POINTER(C.c_uint)]
     L.cvo_debug_time_scan.argtypes = [vp, ip, fp]
     L.cvo_debug_time_kernels.argtypes = [vp, ip, fp, fp]
+    L.cvo_debug_kernel_clock.argtypes = [vp, fp, fp, C.POINTER(C.c_ulonglong)]
     L.cvo_debug_last_candidates.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.cvo_debug_list_builds.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.cvo_debug_last_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]

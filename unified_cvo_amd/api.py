@@ -421,6 +421,13 @@ class CvoGPU:
         self._check(self.L.cvo_debug_time_kernels(self.ctx, reps, C.byref(a), C.byref(c)))
         return a.value, c.value
 
+    def debug_kernel_clock(self):
+        """(k_assoc ms, k_coeff ms, intervals): average duration per pair and launch inside the last align call's
+        optimiser loop, from the device clock (needs CVO_KERNEL_CLOCK=1 in the environment at context creation)."""
+        a, c, n = C.c_float(), C.c_float(), C.c_ulonglong()
+        self._check(self.L.cvo_debug_kernel_clock(self.ctx, C.byref(a), C.byref(c), C.byref(n)))
+        return a.value, c.value, n.value
+
     def debug_last_geometry(self):
         """(sub-batches of the last call, pairs per sub-batch): the k_scan launches a profiler sees."""
         g, p = C.c_int(), C.c_int()

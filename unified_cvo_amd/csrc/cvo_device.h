@@ -45,6 +45,7 @@ struct DevParams {
   float skin_frac;
   float rebuild_shrink;  // rebuild when ell < rebuild_shrink * ell_build (the lists would be (1/shrink)^3 too long)
   int lean_U;            // iterations between two rebuild opportunities in the lean graph
+  int kernel_clock;  // CVO_KERNEL_CLOCK: accumulate per-pair kernel durations in PairState::clk_*
   int phase_ticks;  // CVO_PHASE_TICKS: leave per-block phase timestamps (g_phase_ticks) for cvo_debug_time_kernels
 };
 
@@ -82,11 +83,17 @@ struct PairState {
   // A_sparsity_indicator_ell_update FIFOs (CvoGPU.cu:1167-1285): bookkeeping here, storage below
   int s_head, s_size, e_head, e_size;
   float s_sum, e_sum;
+  // CVO_KERNEL_CLOCK: ticks of the s_memrealtime counter between the entry of a pair's first block and the exit of the
+  // block that finishes the pair's work in the launch, [0] k_assoc (lean graph; its last interval is left in
+  // clk_last_assoc by the flow gate and added by the update) / [1] k_coeff, summed over clk_n iterations
+  unsigned clk_last_assoc, clk_n[2], clk_pad;
+  unsigned long long clk_sum[2];
   // ---- everything above is the "hot" prefix k_update stages through LDS ----
   float sq[IND_CAP], eq[IND_CAP];
   // the normalised twist of the iteration and the matrices of compute_step_size_xi (XiMats), written by the last
   // block of the association launch, read by every block of k_coeff
   float xi[48];
+  unsigned long long clk_start[2];  // CVO_KERNEL_CLOCK: entry stamp of the pair's first block in the running launch
 };
 
 // Everything a kernel needs to know about one frame pair.

@@ -92,6 +92,7 @@ struct cvo_ctx {
   int last_N = 0, last_M = 0, last_Kmax = 0;
   DevParams last_params{};
   int last_gx = 0, last_gy = 0, last_csplit = 1;
+  double clock_ms_per_tick = 0.0;  // s_memrealtime, calibrated on first use (cvo_debug_kernel_clock)
   unsigned last_stride256 = 0;
   int last_Npad = 0;
   std::vector<int> last_xorder;  // pair 0's source order: sorted row -> original row
@@ -270,6 +271,7 @@ DevParams make_dev_params(const cvo_params_t& p) {
   d.rebuild_shrink = 0.9f;
   if (const char* e = getenv("CVO_SKIN")) d.skin_frac = std::max(0.f, (float)atof(e));
   d.phase_ticks = getenv("CVO_PHASE_TICKS") ? 1 : 0;
+  d.kernel_clock = (getenv("CVO_KERNEL_CLOCK") && atoi(getenv("CVO_KERNEL_CLOCK")) != 0) ? 1 : 0;
   if (const char* e = getenv("CVO_SHRINK")) d.rebuild_shrink = std::min(0.99f, std::max(0.f, (float)atof(e)));
   return d;
 }
@@ -1503,6 +1505,35 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
   }
   *ms_assoc = out[0];
   *ms_coeff = out[1];
+  return CVO_OK;
+}
+
+int cvo_debug_kernel_clock(cvo_ctx* ctx, float* ms_assoc, float* ms_coeff, unsigned long long* launches) {
+  if (!ctx || ctx->last_pairs < 1 || !ms_assoc || !ms_coeff)
+    return fail(ctx, CVO_E_INVALID, "cvo_debug_kernel_clock: bad argument");
+  if (!ctx->last_params.kernel_clock) return fail(ctx, CVO_E_INVALID, "cvo_debug_kernel_clock: the last call ran without CVO_KERNEL_CLOCK");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->clock_ms_per_tick <= 0.0) {  // the counter's rate, against HIP events around a kernel that waits 1e6 ticks
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    for (int rep = 0; rep < 2; rep++) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+      hipLaunchKernelGGL(k_hold, dim3(1), dim3(64), 0, ctx->stream, 1000000ull);
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    }
+    ctx->clock_ms_per_tick = (double)ms / 1e6;
+  }
+  double sum[2] = {0, 0}, n[2] = {0, 0};
+  for (int p = 0; p < ctx->last_pairs; p++)
+    for (int w = 0; w < 2; w++) {
+      sum[w] += (double)ctx->h_states[p].clk_sum[w];
+      n[w] += (double)ctx->h_states[p].clk_n[w];
+    }
+  *ms_assoc = n[0] > 0 ? (float)(sum[0] / n[0] * ctx->clock_ms_per_tick) : 0.f;
+  *ms_coeff = n[1] > 0 ? (float)(sum[1] / n[1] * ctx->clock_ms_per_tick) : 0.f;
+  if (launches) *launches = (unsigned long long)n[1];
   return CVO_OK;
 }
 

@@ -666,7 +666,7 @@ __device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, i
 }
 // The flow partial of this block is stored; the block that finds it was the last one of its pair reduces them.
 // Every thread of the block calls this.
-__device__ __forceinline__ void flow_gate(const PairDesc* __restrict__ D, int nblocks, int nparts) {
+__device__ __forceinline__ bool flow_gate(const PairDesc* __restrict__ D, int nblocks, int nparts) {
   __shared__ int s_flow_last;
   __syncthreads();  // (its release waits for this block's coherent partial stores)
   if (threadIdx.x == 0) {
@@ -676,6 +676,7 @@ __device__ __forceinline__ void flow_gate(const PairDesc* __restrict__ D, int nb
   }
   __syncthreads();
   if (s_flow_last && threadIdx.x < 64) twist_finalize(D, nparts);
+  return s_flow_last != 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -687,6 +688,22 @@ __device__ __forceinline__ void flow_gate(const PairDesc* __restrict__ D, int nb
 // entry / counter / exit at [1][4096 + p].  Only differences inside a block mean anything (the counters of
 // different XCDs are not aligned).  Printed by cvo_debug_time_kernels.
 __device__ unsigned long long g_phase_ticks[2][8192][4];
+
+// CVO_KERNEL_CLOCK (see PairState::clk_*): the first block of pair p stamps its entry (blocks are dispatched in
+// order, so it is the pair's earliest or close to it; an atomic minimum over all blocks would serialise 79 atomics per
+// pair on one address), the block that finishes the pair's work in the launch (flow gate / update) closes the interval.
+__device__ __forceinline__ void pair_clock_begin(bool on, PairState* st, int which) {
+  if (on && threadIdx.x == 0) st_x<true>(&st->clk_start[which], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+// t0: the stamp, read (coherently) by the caller before it waited for its last-block counter - the pair's first block
+// is long past its entry by then, and the load stays off the serial tail
+__device__ __forceinline__ unsigned long long pair_clock_peek(bool on, const PairState* st, int which) {
+  return (on && threadIdx.x == 0) ? ld_x<true>(&st->clk_start[which]) : 0ull;
+}
+__device__ __forceinline__ unsigned pair_clock_ticks(unsigned long long t0) {
+  const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+  return (t0 != 0ull && t0 <= t1) ? (unsigned)min(t1 - t0, 0xffffffffull) : 0u;
+}
 // What a row needs first, requested from kernel-argument addresses (see row_off_* in cvo_device.h) before the
 // descriptor has arrived.
 struct AssocRowHead {
@@ -831,10 +848,15 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
   // rows for k_assoc_dense, does not advance; it waits for the next rebuild opportunity / for the host to
   // switch its group to the full graph (k_coeff skips it too and tells the host)
   if ((lean & 1) && (rebuild_v || n_ovf_v > 0)) return;
+  pair_clock_begin(P.kernel_clock && lean == 1 && pb.bx == 0, const_cast<PairState*>(st), 0);
   __shared__ AssocShared S;
   assoc_phase<IdxT, ASSOC_CAP, GENERAL>(P, D, st, S, pb.bx, head);
   // lean graph: nothing else adds to the flow, the twist of the iteration can be finished here
-  if ((lean & 3) && P.mode == 0) flow_gate(D, nblk, nblk);  // (bit 1: the timing replay includes it)
+  if ((lean & 3) && P.mode == 0) {  // (bit 1: the timing replay includes it)
+    const unsigned long long clk0 = pair_clock_peek(P.kernel_clock && lean == 1, st, 0);
+    const bool last = flow_gate(D, nblk, nblk);
+    if (last && threadIdx.x == 0 && clk0) D->st->clk_last_assoc = pair_clock_ticks(clk0);  // added up by the update
+  }
   if (P.phase_ticks && threadIdx.x == 0) {
     g_phase_ticks[0][blockIdx.x & 8191][0] = tt0;
     g_phase_ticks[0][blockIdx.x & 8191][3] = __builtin_readcyclecounter();
@@ -1103,7 +1125,7 @@ __device__ __forceinline__ UpdDesc load_upd_desc(const PairDesc* __restrict__ D)
 template <bool INIT, bool COH>
 __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P, int flags,
                                             int n_flow_parts, UpdateShared& U, const float* twist,
-                                            const unsigned* preloaded_hot) {
+                                            const unsigned* preloaded_hot, unsigned long long clk0 = 0ull) {
   PairState* const gst = D.st;
   const bool trio_follows = INIT || (flags & 2) != 0;
   const bool dry = (flags & 8) != 0;  // timing replay: compute everything, write nothing back
@@ -1361,6 +1383,15 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     }
     st->out_T[3] = st->out_T[7] = st->out_T[11] = 0;
     st->out_T[15] = 1;
+    if (clk0 && !dry) {  // CVO_KERNEL_CLOCK (k_coeff): this launch's interval and the association's, see PairState
+      if (st->clk_last_assoc) {
+        st->clk_sum[0] += st->clk_last_assoc;
+        st->clk_n[0]++;
+        st->clk_last_assoc = 0;
+      }
+      st->clk_sum[1] += pair_clock_ticks(clk0);
+      st->clk_n[1]++;
+    }
     if (done && !dry) {
       st->status = 1;
       *D.status_out = 1;
@@ -1451,6 +1482,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
   }
   const DevParams P = *Pp;
   if (P.mode != 0) return;
+  pair_clock_begin(P.kernel_clock && !replay && pb.bx == 0 && cq == 0, st, 1);
   const int epoch = st_in->epoch;  // launches of this kernel the pair has completed (bumped by the updating block)
   __shared__ union {
     CoeffShared c;
@@ -1486,6 +1518,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     hot_regs[0] = reinterpret_cast<const unsigned*>(st)[threadIdx.x];
     if (threadIdx.x + 64 < HOT_DWORDS) hot_regs[1] = reinterpret_cast<const unsigned*>(st)[threadIdx.x + 64];
   }
+  const unsigned long long clk0 = pair_clock_peek(P.kernel_clock && !replay, st, 1);
   const UpdDesc upd = load_upd_desc(D);
   const int n_flow_upd = (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS;
   __syncthreads();  // (its release waits for this block's coherent partial stores)
@@ -1503,12 +1536,18 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     g_phase_ticks[1][blockIdx.x & 4095][3] = tt3;
   }
   if (!s_last || (flags & 16)) return;  // (bit 4: cost breakdown of cvo_debug_time_kernels, coefficient phase only)
-  update_body<false, true>(upd, P, flags | 4, n_flow_upd, S.u, twist, hot_regs);
+  update_body<false, true>(upd, P, flags | 4, n_flow_upd, S.u, twist, hot_regs, clk0);
   if (P.phase_ticks && threadIdx.x == 0) {
     g_phase_ticks[1][4096 + pb.pair][0] = tt0;
     g_phase_ticks[1][4096 + pb.pair][1] = tt3;
     g_phase_ticks[1][4096 + pb.pair][2] = __builtin_readcyclecounter();
   }
+}
+
+// Waits for `ticks` of the s_memrealtime counter (cvo_debug_kernel_clock calibrates the counter's rate with it).
+__global__ void k_hold(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
 // ------------------------------------------------------------------------------------------
