@@ -7,3 +7,6 @@ P, src, tgt, init = cases.config1()
 gpu = CvoGPU(params=P)
 g = gpu.align(src, tgt, init, max_iterations=300)
 print(g.iterations, g.seconds)
+g = gpu.align(src, tgt, init, max_iterations=1000)
+print(g.iterations, g.seconds, "us/iter", 1e6 * g.seconds / g.iterations)
+print("builds, iterations, candidates:", gpu.debug_list_builds())

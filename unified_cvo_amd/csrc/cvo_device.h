@@ -80,6 +80,7 @@ struct PairState {
   float ell_build, skin;
   int n_builds;
   int want_full, n_stalls;  // host hint: this pair needs the graph with per-iteration rebuild / dense kernels
+  int all_dense, pad_dense;  // dense regime: every row is served by k_assoc_dense, no lists (see update_body)
   // A_sparsity_indicator_ell_update FIFOs (CvoGPU.cu:1167-1285): bookkeeping here, storage below
   int s_head, s_size, e_head, e_size;
   float s_sum, e_sum;
@@ -175,9 +176,10 @@ struct PairDesc {
   int* gate_flow;   // [1] blocks of k_assoc / k_assoc_dense that stored their flow partial (the last one reduces them)
 };
 
-constexpr int COEFF_SPLIT_MAX = 8;
+constexpr int COEFF_SPLIT_MAX = 32;
 constexpr int ROWS_PER_GROUP = 4;
-constexpr int DENSE_BLOCKS = 64;  // k_assoc_dense blocks per pair (4 waves each, one overflow row per wave at a time)
+constexpr int DENSE_BLOCKS = 64;  // k_assoc_dense blocks per pair (one overflow row per wave at a time)
+// (4 waves per block; 8 for small clouds, where the dense regime sends every row here: see launch_dense)
 
 // ---- arithmetic conventions (DESIGN.md "Numerics") ------------------------------------------
 __device__ __forceinline__ float dot3_dev(float a0, float a1, float a2, float b0, float b1, float b2) {

@@ -229,7 +229,9 @@ int ensure_workspace(cvo_ctx* c, int n_pairs, size_t bytes_per_pair) {
 
 int coeff_split(int n) {
   int s = 1;
-  while (s < COEFF_SPLIT_MAX && (long)n * (2 * s) <= 8192) s *= 2;
+  while (s < 8 && (long)n * (2 * s) <= 8192) s *= 2;
+  // tiny clouds (the dense regime walks hundreds of entries per row): a few more slices as long as the launch stays small
+  while (s >= 8 && s < COEFF_SPLIT_MAX && (long)n * (2 * s) <= 32768) s *= 2;
   return s;
 }
 
@@ -358,16 +360,25 @@ void launch_assoc(hipStream_t s, bool idx16, bool general, int nblk, int n_pairs
 
 void launch_coeff(hipStream_t s, int nblk, int split, int n_pairs, const PairDesc* descs, const DevParams* dp,
                   PairState* st, const ArenaArg& A, int flags) {
-  const int packed = nblk | (split << 16) | (int)((unsigned)n_pairs << 20);
+  const int packed = nblk | (split << 14) | (int)((unsigned)n_pairs << 20);  // 14 + 6 + 12 bits
   hipLaunchKernelGGL(k_coeff, row_grid(nblk * split, n_pairs), dim3(ASSOC_THREADS), 0, s, descs, dp, st, A.base, flags, packed,
                      A.stride256, A.Npad);
 }
 
-void launch_dense(hipStream_t s, bool general, int n_pairs, const PairDesc* descs, const DevParams* dp, const int* st) {
-  if (general)
-    hipLaunchKernelGGL(k_assoc_dense<true>, dim3(DENSE_BLOCKS, n_pairs), dim3(256), 0, s, descs, dp, st);
-  else
-    hipLaunchKernelGGL(k_assoc_dense<false>, dim3(DENSE_BLOCKS, n_pairs), dim3(256), 0, s, descs, dp, st);
+void launch_dense(hipStream_t s, bool general, int N, int n_pairs, const PairDesc* descs, const DevParams* dp, const int* st) {
+  // small clouds can have every row here (dense regime): twice the waves; large ones mostly launch it for nothing
+  const dim3 grid(DENSE_BLOCKS, n_pairs);
+  if (N <= 4096) {
+    if (general)
+      hipLaunchKernelGGL((k_assoc_dense<true, 8>), grid, dim3(512), 0, s, descs, dp, st);
+    else
+      hipLaunchKernelGGL((k_assoc_dense<false, 8>), grid, dim3(512), 0, s, descs, dp, st);
+  } else {
+    if (general)
+      hipLaunchKernelGGL((k_assoc_dense<true, 4>), grid, dim3(256), 0, s, descs, dp, st);
+    else
+      hipLaunchKernelGGL((k_assoc_dense<false, 4>), grid, dim3(256), 0, s, descs, dp, st);
+  }
 }
 
 struct LaunchGeom {
@@ -398,7 +409,7 @@ void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags) {
   const PairDesc* descs = c->d_descs + g.p0;
   const int* st = c->d_status + g.p0;
   launch_assoc(g.stream, g.idx16, g.general, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, lean ? 1 : 0);
-  if (!lean) launch_dense(g.stream, g.general, g.n_pairs, descs, c->d_params, st);
+  if (!lean) launch_dense(g.stream, g.general, g.N, g.n_pairs, descs, c->d_params, st);
   launch_coeff(g.stream, g.nba, g.csplit, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0));
 }
 
@@ -459,8 +470,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->G = n_pairs >= 32 ? 4 : (n_pairs >= 8 ? 2 : 1);
   if (const char* e = getenv("CVO_STREAMS")) S->G = std::max(1, std::min(atoi(e), (int)cvo_ctx::MAX_GROUPS));
   S->G = std::min(S->G, n_pairs);
-  if ((n_pairs + S->G - 1) / S->G > 4095 || S->d.nblk_assoc > 65535)
-    return fail(ctx, CVO_E_INVALID, "batch too large for one call: at most 4095 pairs per stream and 8388480 source points per cloud");
+  if ((n_pairs + S->G - 1) / S->G > 4095 || S->d.nblk_assoc > 16383)
+    return fail(ctx, CVO_E_INVALID, "batch too large for one call: at most 4095 pairs per stream and 2097024 source points per cloud");
   choose_scan_config((n_pairs + S->G - 1) / S->G, S->d.NG, S->d.Mpad, &S->T, &S->gpb);
 
   DevParams dp = make_dev_params(*params);

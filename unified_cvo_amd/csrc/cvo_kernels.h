@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
   if (!force && status[blockIdx.z] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.z;
   if (!force && !D->st->rebuild) return;  // the bitmap of an earlier iteration is still a superset
+  if (!force && D->st->all_dense) return;  // dense regime: k_list sends every row to k_assoc_dense, no bitmap needed
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int slice = blockIdx.x * 4 + wave;
@@ -521,7 +522,10 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
   const int w0row = pb.bx * LIST_THREADS;
   // ---- candidates of row w0row + tid
   int ncand = ASSOC_CAP + 2;  // rows past N sort behind every real row
-  if (w0row + tid < N) ncand = D->row_cnt[w0row + tid];  // accumulated by k_scan's emission
+  if (w0row + tid < N) {  // accumulated by k_scan's emission; dense regime: every row takes the overflow path
+    const int rc = D->row_cnt[w0row + tid];
+    ncand = D->st->all_dense ? ASSOC_CAP + 1 : rc;
+  }
   // ---- stable rank by min(count, CAP + 1): every thread counts the keys that sort before its own
   s_key[tid] = (w0row + tid < N) ? min(ncand, ASSOC_CAP + 1) : ASSOC_CAP + 2;  // overflow rows last, pad rows behind them
   __syncthreads();
@@ -870,8 +874,8 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
 // ELL slot in ascending j (so the first-K truncation and its early exit are exact), and the float flow
 // accumulation of compute_flow_gpu_no_eigen is replayed serially in lane (= j) order with v_readlane.
 // ------------------------------------------------------------------------------------------
-template <bool GENERAL>
-__global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
+template <bool GENERAL, int DENSE_WAVES>
+__global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
                                                      const int* __restrict__ status) {
   if (status[blockIdx.y] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.y;
@@ -881,55 +885,85 @@ __global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict_
   const int K = st->K;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n_ovf = st->n_ovf;
+  __shared__ float2 s_hits[DENSE_WAVES][128][6];  // per wave: the hits of one step, compacted ({flow term, value} per component)
   double red[7] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long nnz_sum = 0;
   unsigned nnz_max = 0;
   if (n_ovf > 0) {
     const Pose pose = load_pose(st);
-    for (int q = blockIdx.x * 4 + wave; q < n_ovf; q += DENSE_BLOCKS * 4) {
+    for (int q = blockIdx.x * DENSE_WAVES + wave; q < n_ovf; q += DENSE_BLOCKS * DENSE_WAVES) {
       const int r_sorted = D->ovf_rows[q];  // a position of k_list's ordering (all per-row outputs are stored by position)
       const int i = D->ip[r_sorted];
       const float4 x = D->xp4[r_sorted];
       const RowData r = make_row(P, x, st->ell);
       const V3 pxe{x.x, x.y, x.z};
-      float o0 = 0, o1 = 0, o2 = 0, v0 = 0, v1 = 0, v2 = 0;
-      double asum = 0;
       unsigned nnz = 0;
-      for (int j0 = 0; j0 < M && nnz < (unsigned)K; j0 += 64) {
-        const int j = j0 + lane;
-        float a = 0.f;
-        float4 yt = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool ok = false;
-        if (j < M) {
-          const float4 y0 = D->y4[j];
-          ok = eval_pair<GENERAL>(P, D, pose, i, r, j, y0, a, yt) && (a > P.sp_thres);
+      // Two chunks of 64 targets per step: their (independent) evaluations overlap in the pipeline; if the first one
+      // already fills the row, the second was evaluated for nothing.  Hits are compacted into LDS in ascending j
+      // (slot = rank inside the step), then lanes 0..5 replay the reference's ordered float accumulation, one
+      // component each (one LDS read + one FMA per hit and lane; lane 6 carries the double sum of the values).
+      float acc = 0.f;   // lanes 0..2: omega_i, lanes 3..5: v_i  (CvoGPU.cu:779-780)
+      double asum = 0;   // lane 6
+      for (int j0 = 0; j0 < M && nnz < (unsigned)K; j0 += 128) {
+        float a[2] = {0.f, 0.f};
+        float4 yt[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        bool ok[2] = {false, false};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int j = j0 + 64 * h + lane;
+          if (j < M) {
+            const float4 y0 = D->y4[j];
+            ok[h] = eval_pair<GENERAL>(P, D, pose, i, r, j, y0, a[h], yt[h]) && (a[h] > P.sp_thres);
+          }
         }
-        const unsigned long long m = __ballot(ok);
-        if (!m) continue;
-        const unsigned rank = nnz + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        const bool keep = ok && rank < (unsigned)K;  // `if (num_inds == num_neighbors) break;`
-        if (keep) {
-          D->ell[(size_t)rank * N + r_sorted] = EllEntry{a, j};
+        int nstaged = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const unsigned long long m = __ballot(ok[h]);
+          const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          const unsigned rank = nnz + below;
+          const bool keep = ok[h] && rank < (unsigned)K;  // `if (num_inds == num_neighbors) break;`
+          if (keep) {
+            D->ell[(size_t)rank * N + r_sorted] = EllEntry{a[h], j0 + 64 * h + lane};
+            // flow terms of this lane's pair (CvoGPU.cu:767-769)
+            const V3 pye{yt[h].x, yt[h].y, yt[h].z};
+            const V3 cr = cross_dev(pxe, pye);
+            float2* slot = s_hits[wave][nstaged + (int)below];
+            slot[0] = make_float2(cr.x, a[h]);
+            slot[1] = make_float2(cr.y, a[h]);
+            slot[2] = make_float2(cr.z, a[h]);
+            slot[3] = make_float2(pye.x - pxe.x, a[h]);
+            slot[4] = make_float2(pye.y - pxe.y, a[h]);
+            slot[5] = make_float2(pye.z - pxe.z, a[h]);
+          }
+          const int nkeep = __builtin_popcountll(__ballot(keep));
+          nnz += (unsigned)nkeep;
+          nstaged += nkeep;
         }
-        // flow terms of this lane's pair (CvoGPU.cu:767-769)
-        const V3 pye{yt.x, yt.y, yt.z};
-        const V3 cr = cross_dev(pxe, pye);
-        const float dx = pye.x - pxe.x, dy = pye.y - pxe.y, dz = pye.z - pxe.z;
-        unsigned long long mk = __ballot(keep);
-        nnz += (unsigned)__builtin_popcountll(mk);
-        while (mk) {  // ascending j: the reference's float accumulation order (CvoGPU.cu:779-780)
-          const int l = __builtin_ctzll(mk);
-          mk &= mk - 1;
-          const float al = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), l));
-          o0 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cr.x), l)), al, o0);
-          o1 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cr.y), l)), al, o1);
-          o2 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cr.z), l)), al, o2);
-          v0 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dx), l)), al, v0);
-          v1 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dy), l)), al, v1);
-          v2 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dz), l)), al, v2);
-          asum += (double)al;
+        __builtin_amdgcn_wave_barrier();  // (same wave wrote the slots: LDS operations of a wave complete in order)
+        const int c = lane < 6 ? lane : 0;
+        int k = 0;
+        for (; k + 4 <= nstaged; k += 4) {
+          const float2 e0 = s_hits[wave][k][c], e1 = s_hits[wave][k + 1][c], e2 = s_hits[wave][k + 2][c],
+                       e3 = s_hits[wave][k + 3][c];
+          acc = __builtin_fmaf(e0.x, e0.y, acc);
+          acc = __builtin_fmaf(e1.x, e1.y, acc);
+          acc = __builtin_fmaf(e2.x, e2.y, acc);
+          acc = __builtin_fmaf(e3.x, e3.y, acc);
+          asum += (double)e0.y;
+          asum += (double)e1.y;
+          asum += (double)e2.y;
+          asum += (double)e3.y;
         }
+        for (; k < nstaged; k++) {
+          const float2 e = s_hits[wave][k][c];
+          acc = __builtin_fmaf(e.x, e.y, acc);
+          asum += (double)e.y;
+        }
+        __builtin_amdgcn_wave_barrier();
       }
+      const float o0 = __shfl(acc, 0), o1 = __shfl(acc, 1), o2 = __shfl(acc, 2);
+      const float v0 = __shfl(acc, 3), v1 = __shfl(acc, 4), v2 = __shfl(acc, 5);
       if (lane == 0) {
         D->nnz_row[r_sorted] = nnz;
         red[0] += (double)(o0 / P.c);
@@ -945,8 +979,8 @@ __global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict_
     }
   }
   // block partials are always written (zeros when there was nothing to do): k_coeff / k_update sum them
-  __shared__ double s_red[4][8];
-  __shared__ unsigned long long s_cnt[4][2];
+  __shared__ double s_red[DENSE_WAVES][8];
+  __shared__ unsigned long long s_cnt[DENSE_WAVES][2];
   if (lane == 0) {
 #pragma unroll
     for (int c = 0; c < 7; c++) s_red[wave][c] = red[c];
@@ -957,11 +991,20 @@ __global__ __launch_bounds__(256) void k_assoc_dense(const PairDesc* __restrict_
   const size_t slot = (size_t)D->nblk_assoc + blockIdx.x;
   if (threadIdx.x < 7) {
     const int c = threadIdx.x;
-    st_x<true>(D->flow_part + slot * 8 + c, ((s_red[0][c] + s_red[1][c]) + s_red[2][c]) + s_red[3][c]);
+    double t = s_red[0][c];
+#pragma unroll
+    for (int w = 1; w < DENSE_WAVES; w++) t += s_red[w][c];
+    st_x<true>(D->flow_part + slot * 8 + c, t);
   } else if (threadIdx.x == 8) {
     unsigned long long* cp = D->cnt_part + slot * 4;
-    cp[0] = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
-    cp[1] = max(max(s_cnt[0][1], s_cnt[1][1]), max(s_cnt[2][1], s_cnt[3][1]));
+    unsigned long long c0 = 0, c1 = 0;
+#pragma unroll
+    for (int w = 0; w < DENSE_WAVES; w++) {
+      c0 += s_cnt[w][0];
+      c1 = max(c1, s_cnt[w][1]);
+    }
+    cp[0] = c0;
+    cp[1] = c1;
     cp[2] = 0;
     cp[3] = 0;
   }
@@ -1342,6 +1385,20 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
                      ell_next < P.rebuild_shrink * st->ell_build;
       // ... or would expire before the next rebuild opportunity of the lean graph
       if (trio_follows && horizon > 0 && !(moved + 1.25f * (float)horizon * step_move <= st->skin)) rebuild = true;
+      // Dense regime (rows sitting on K_max, e.g. the first iterations of an outdoor pair at a large ell): when most
+      // rows overflow their lists anyway, lists are pointless - every row goes to k_assoc_dense (the reference's
+      // literal ordered scan), nothing is rebuilt while that lasts, and the pair returns to lists once the rows have
+      // thinned out (mean nonzeros per row below 12, far from the 32 / 64 a list holds).
+      if (!INIT && P.mode == 0) {
+        const bool was = st->all_dense != 0;
+        const bool now = was ? (unsigned long long)st->nnz >= 12ull * (unsigned long long)D.N : 2 * st->n_ovf > D.N;
+        if (now != was) {
+          st->all_dense = now ? 1 : 0;
+          rebuild = true;
+        } else if (now) {
+          rebuild = false;
+        }
+      }
       if (rebuild) {
         for (int q = 0; q < 9; q++) st->Rb[q] = Ri[q];
         for (int q = 0; q < 3; q++) st->Tb[q] = Ti[q];
@@ -1352,7 +1409,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         // too much (fast motion) or rows overflow their lists, ask the host for the full graph.
         int want_full = 1;
         float s = 0.f;
-        if (!INIT && P.mode == 0 && P.use_geo && radius > 0.f && P.skin_frac > 0.f) {
+        if (!INIT && P.mode == 0 && P.use_geo && radius > 0.f && P.skin_frac > 0.f && !st->all_dense) {
           const float rel = step_move / radius;
           s = P.skin_frac * fminf(fmaxf(1.5f * sqrtf(rel), 0.05f), 0.5f);
           const float s_lean = fmaxf(s, 1.3f * (float)P.lean_U * rel);
@@ -1426,7 +1483,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
                                                          unsigned stride256, int Npad) {
   const unsigned long long tt0 = __builtin_readcyclecounter();
   // grid: per pair nblk row blocks x launch_split slices of the ELL slots; a pair uses csplit <= launch_split of them
-  const int nblk = nblk_split_pairs & 0xffff, launch_split = (nblk_split_pairs >> 16) & 0xf,
+  const int nblk = nblk_split_pairs & 0x3fff, launch_split = (nblk_split_pairs >> 14) & 0x3f,
             n_pairs = (int)((unsigned)nblk_split_pairs >> 20);
   PairBlock pb;
   if (!pair_block(nblk * launch_split, n_pairs, pb)) return;
@@ -1572,6 +1629,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
   const PairDesc* __restrict__ D = descs + blockIdx.y;
   const PairState* st = D->st;
   if (!st->rebuild) return;  // k_update: the bitmap of an earlier iteration still covers this one
+  if (st->all_dense) {  // dense regime: no operands to prepare, only the overflow list to reset for k_list
+    if (blockIdx.x == 0 && threadIdx.x == 0) D->st->n_ovf = 0;
+    return;
+  }
   const DevParams P = *Pp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float INF = __builtin_inff();
