@@ -102,8 +102,8 @@ def main():
     host_clouds = [(q[1], q[2]) for q in pairs]
     t_gen = time.time() - t_up
     t_up = time.time()
-    src = [gpu.upload(a) for a, _ in host_clouds]
-    tgt = [gpu.upload(b) for _, b in host_clouds]
+    both = gpu.upload_many([a for a, _ in host_clouds] + [b for _, b in host_clouds], threads=available_cpus())
+    src, tgt = both[:len(host_clouds)], both[len(host_clouds):]
     t_h2d = time.time() - t_up
     inits = [q[3] for q in pairs]
     pose_buf = torch.zeros(hi - lo, 16, dtype=torch.float32, device=dev)
@@ -268,7 +268,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         h2d_rate = (2 * n * 16 * 1.0) * B / max(t_h2d, 1e-9) / 1e9
-        log(f"[bench] inputs: generated in {t_gen:.2f}s, uploaded in {t_h2d:.3f}s ({h2d_rate:.2f} GB/s incl. host packing); "
+        log(f"[bench] inputs: generated in {t_gen:.2f}s, uploaded in {t_h2d:.3f}s ({h2d_rate:.2f} GB/s incl. host-side k-d ordering on {available_cpus()} threads); "
             f"PCIe-inclusive rate = {aligns / (elapsed + args.steps * t_h2d):.2f} align/s")
         log(f"[bench] loop {loop_s:.4f}s/step on rank 0; per launch of {ppl} pairs: k_assoc {assoc_ms*1e3:.1f} us "
             f"({assoc_alone_ms*1e3:.1f} alone on the GPU), k_coeff {coeff_ms*1e3:.1f} us ({coeff_alone_ms*1e3:.1f} alone), k_scan {scan_ms*1e3:.1f} us (runs in {100.0*builds/max(iters_total,1):.1f}% of the "

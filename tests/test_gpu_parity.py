@@ -412,6 +412,16 @@ def test_kernel_clock_and_phase_stamps_do_not_change_results(monkeypatch):
         gpu2.debug_kernel_clock()
 
 
+def test_upload_many_matches_single_uploads():
+    P, src, tgt, init = cases.config2(n=1500)
+    gpu = CvoGPU(params=P)
+    a = gpu.align(src, tgt, init, max_iterations=60)
+    ds = gpu.upload_many([src, tgt, src, tgt], threads=4)
+    b = gpu.align(ds[0], ds[1], init, max_iterations=60)
+    c = gpu.align(ds[2], ds[3], init, max_iterations=60)
+    assert np.array_equal(a.transform, b.transform) and np.array_equal(a.transform, c.transform)
+
+
 def test_dense_regime_switches_both_ways(oracle):
     """Config 1 starts with nearly every row on K_max (all rows served by k_assoc_dense, lists never rebuilt) and
     thins out later: the list builds stay a handful, and the trajectory is the oracle's (test_config1_* cover the

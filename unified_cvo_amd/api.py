@@ -5,6 +5,7 @@ This is the harness used by tests/ and bench.py; the C++ veneer with the same na
 include/UnifiedCvo/.  All compute happens in libcvo_hip.so on the GPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -251,6 +252,22 @@ class CvoGPU:
 
     def upload(self, pc):
         return DeviceCloud(self, pc)
+
+    def upload_many(self, clouds, threads=None):
+        """Uploads a list of clouds from a thread pool: cvo_cloud_upload is self-contained (host-side k-d ordering, one
+        allocation, one copy) and releases the GIL, so the ordering of different clouds runs on different cores."""
+        from concurrent.futures import ThreadPoolExecutor
+        clouds = list(clouds)
+        if threads is None:
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                threads = os.cpu_count() or 1
+        threads = max(1, min(int(threads), len(clouds), 32))
+        if threads == 1:
+            return [self.upload(c) for c in clouds]
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            return list(ex.map(self.upload, clouds))
 
     def _dev(self, pc):
         return pc if isinstance(pc, DeviceCloud) else DeviceCloud(self, pc)
