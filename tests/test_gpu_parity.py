@@ -412,6 +412,21 @@ def test_kernel_clock_and_phase_stamps_do_not_change_results(monkeypatch):
         gpu2.debug_kernel_clock()
 
 
+@pytest.mark.parametrize("env", [{}, {"CVO_NO_DENSE_REGIME": "1"}, {"CVO_NO_LEAN": "1"}])
+def test_config1_is_reproducible_run_to_run(monkeypatch, env):
+    """The demo pair stops on an accidentally small step: one flipped bit anywhere changes its iteration
+    count, so repeated runs expose any cross-block race of the last-block patterns (flow gate, update) - the version
+    without a vmcnt wait in front of the counters failed one run in three on the list + overflow path."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    P, src, tgt, init = cases.config1()
+    gpu = CvoGPU(params=P)
+    runs = [gpu.align(src, tgt, init) for _ in range(6)]
+    assert len({r.iterations for r in runs}) == 1
+    assert all(np.array_equal(r.transform, runs[0].transform) for r in runs)
+    assert runs[0].iterations == 6661
+
+
 def test_upload_many_matches_single_uploads():
     P, src, tgt, init = cases.config2(n=1500)
     gpu = CvoGPU(params=P)

@@ -45,6 +45,9 @@ struct DevParams {
   float skin_frac;
   float rebuild_shrink;  // rebuild when ell < rebuild_shrink * ell_build (the lists would be (1/shrink)^3 too long)
   int lean_U;            // iterations between two rebuild opportunities in the lean graph
+  float skin_min, skin_max;  // clamp of the skin (fractions of the cut-off radius) before skin_frac
+  int dense_regime;      // 0: never switch a pair to the all-rows-dense regime (CVO_NO_DENSE_REGIME)
+  float lean_skin;       // skin of the lean graph in units of (lean_U x the motion of one iteration)
   int kernel_clock;  // CVO_KERNEL_CLOCK: accumulate per-pair kernel durations in PairState::clk_*
   int phase_ticks;  // CVO_PHASE_TICKS: leave per-block phase timestamps (g_phase_ticks) for cvo_debug_time_kernels
 };
@@ -80,7 +83,9 @@ struct PairState {
   float ell_build, skin;
   int n_builds;
   int want_full, n_stalls;  // host hint: this pair needs the graph with per-iteration rebuild / dense kernels
-  int all_dense, pad_dense;  // dense regime: every row is served by k_assoc_dense, no lists (see update_body)
+  int all_dense;
+  float skin_scale;  // backs the skin off while rows overflow their lists (see update_body)
+  // all_dense = dense regime: every row is served by k_assoc_dense, no lists (see update_body)
   // A_sparsity_indicator_ell_update FIFOs (CvoGPU.cu:1167-1285): bookkeeping here, storage below
   int s_head, s_size, e_head, e_size;
   float s_sum, e_sum;

@@ -269,7 +269,14 @@ DevParams make_dev_params(const cvo_params_t& p) {
   d.use_sem = p.is_using_semantics != 0;
   d.use_range_ell = p.is_using_range_ell != 0;
   d.use_geotype = p.is_using_geometric_type != 0;
-  d.skin_frac = 0.1f;
+  d.skin_frac = 1.0f;
+  d.lean_skin = 1.3f;
+  d.dense_regime = getenv("CVO_NO_DENSE_REGIME") ? 0 : 1;
+  d.skin_min = 0.05f;
+  d.skin_max = 0.25f;
+  if (const char* e = getenv("CVO_SKIN_MIN")) d.skin_min = std::max(0.f, (float)atof(e));
+  if (const char* e = getenv("CVO_SKIN_MAX")) d.skin_max = std::max(d.skin_min, (float)atof(e));
+  if (const char* e = getenv("CVO_LEAN_SKIN")) d.lean_skin = std::max(1.3f, (float)atof(e));
   d.rebuild_shrink = 0.9f;
   if (const char* e = getenv("CVO_SKIN")) d.skin_frac = std::max(0.f, (float)atof(e));
   d.phase_ticks = getenv("CVO_PHASE_TICKS") ? 1 : 0;

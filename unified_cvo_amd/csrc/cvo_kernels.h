@@ -672,7 +672,11 @@ __device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, i
 // Every thread of the block calls this.
 __device__ __forceinline__ bool flow_gate(const PairDesc* __restrict__ D, int nblocks, int nparts) {
   __shared__ int s_flow_last;
-  __syncthreads();  // (its release waits for this block's coherent partial stores)
+  // this block's partial must have reached the L2 before its counter increment can be seen: the barrier alone only
+  // orders LDS traffic (the compiler emits no vmcnt wait for it), and a store and an atomic of one wave to
+  // different addresses are not ordered on their way to memory
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (threadIdx.x == 0) {
     const int done = __hip_atomic_fetch_add(D->gate_flow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_flow_last = (done == nblocks - 1) ? 1 : 0;
@@ -1389,7 +1393,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
       // rows overflow their lists anyway, lists are pointless - every row goes to k_assoc_dense (the reference's
       // literal ordered scan), nothing is rebuilt while that lasts, and the pair returns to lists once the rows have
       // thinned out (mean nonzeros per row below 12, far from the 32 / 64 a list holds).
-      if (!INIT && P.mode == 0) {
+      if (!INIT && P.mode == 0 && P.dense_regime) {
         const bool was = st->all_dense != 0;
         const bool now = was ? (unsigned long long)st->nnz >= 12ull * (unsigned long long)D.N : 2 * st->n_ovf > D.N;
         if (now != was) {
@@ -1409,10 +1413,16 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         // too much (fast motion) or rows overflow their lists, ask the host for the full graph.
         int want_full = 1;
         float s = 0.f;
+        // rows that overflow their lists fall back to the literal scan over all targets (k_assoc_dense): fine for a few
+        // rows or a small cloud, ruinous if a generous skin pushes many rows of a large one over the edge - the skin
+        // backs off by halves while the last build left overflow rows and recovers slowly afterwards
+        if (INIT) st->skin_scale = 1.f;
+        else if (st->n_ovf > 0 && !st->all_dense) st->skin_scale = fmaxf(0.5f * st->skin_scale, 1.f / 64.f);
+        else st->skin_scale = fminf(1.f, 1.1f * st->skin_scale);
         if (!INIT && P.mode == 0 && P.use_geo && radius > 0.f && P.skin_frac > 0.f && !st->all_dense) {
           const float rel = step_move / radius;
-          s = P.skin_frac * fminf(fmaxf(1.5f * sqrtf(rel), 0.05f), 0.5f);
-          const float s_lean = fmaxf(s, 1.3f * (float)P.lean_U * rel);
+          s = st->skin_scale * P.skin_frac * fminf(fmaxf(1.5f * sqrtf(rel), P.skin_min), P.skin_max);
+          const float s_lean = fmaxf(s, P.lean_skin * (float)P.lean_U * rel);
           if (s_lean <= 0.5f && st->n_ovf == 0) {
             s = s_lean;
             want_full = 0;
@@ -1427,7 +1437,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         st->n_builds = INIT ? 1 : st->n_builds + 1;
         st->rebuild = 1;  // cleared by k_list once bitmap and lists are current
       } else if (st->want_full && st->n_ovf == 0 &&
-                 moved + 1.3f * (float)P.lean_U * step_move <= st->skin) {
+                 moved + fminf(P.lean_skin, 1.3f) * (float)P.lean_U * step_move <= st->skin) {
         st->want_full = 0;  // the motion has slowed down enough for the lean graph
         if (!dry) *D.want_out = 0;
       }
@@ -1578,7 +1588,8 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
   const unsigned long long clk0 = pair_clock_peek(P.kernel_clock && !replay, st, 1);
   const UpdDesc upd = load_upd_desc(D);
   const int n_flow_upd = (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS;
-  __syncthreads();  // (its release waits for this block's coherent partial stores)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partial stores before the counter, see flow_gate
+  __syncthreads();
   if (threadIdx.x == 0) {
     const int done = __hip_atomic_fetch_add(D->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int nwork = nblk * csplit;  // blocks of this pair that store a partial
