@@ -269,7 +269,7 @@ DevParams make_dev_params(const cvo_params_t& p) {
   d.use_sem = p.is_using_semantics != 0;
   d.use_range_ell = p.is_using_range_ell != 0;
   d.use_geotype = p.is_using_geometric_type != 0;
-  d.skin_frac = 1.0f;
+  d.skin_frac = 2.0f;
   d.lean_skin = 1.3f;
   d.dense_regime = getenv("CVO_NO_DENSE_REGIME") ? 0 : 1;
   d.skin_min = 0.05f;
