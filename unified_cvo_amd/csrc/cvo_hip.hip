@@ -1090,6 +1090,11 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
           for (int p = geom[g].p0; p < geom[g].p0 + geom[g].n_pairs; p++)
             want_full = want_full || (ctx->h_status[ws][p] == 0 && ctx->h_status[ws][ctx->cap_pairs + p] != 0);
           lean_next[g] = allow_lean && !want_full;
+          if (getenv("CVO_VERBOSE") && atoi(getenv("CVO_VERBOSE")) >= 2 && ch < 12) {
+            int nw = 0;
+            for (int p = geom[g].p0; p < geom[g].p0 + geom[g].n_pairs; p++) nw += ctx->h_status[ws][ctx->cap_pairs + p] != 0;
+            fprintf(stderr, "[cvo] after chunk %d group %d: %d of %d pairs ask for the full graph\n", ch - 1, g, nw, geom[g].n_pairs);
+          }
         }
       }
     }
