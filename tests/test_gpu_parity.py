@@ -427,6 +427,37 @@ def test_config1_is_reproducible_run_to_run(monkeypatch, env):
     assert runs[0].iterations == 6661
 
 
+def test_contexts_and_clouds_release_device_memory():
+    """Twenty context / cloud / align cycles leave the free device memory where it was (a 64-pair workspace is
+    an 8-pair workspace alone is ~100 MB
+    per cycle: a leak would show at once; scripts/leak_check.py prints the curve)."""
+    import gc
+    import torch
+    P, src, tgt, init = cases.config2(n=4000)
+
+    def cycle():
+        gpu = CvoGPU(params=P)
+        ds, dt = gpu.upload(src), gpu.upload(tgt)
+        r = gpu.align_batch([ds] * 8, [dt] * 8, [init] * 8, max_iterations=40)
+        ds.free()
+        dt.free()
+        gpu.close() if hasattr(gpu, "close") else None
+        del gpu, ds, dt
+        gc.collect()
+        return r[0].transform
+
+    first = cycle()
+    for _ in range(4):  # (the HIP runtime grows its own pools in 64 MiB steps during the first cycles)
+        cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        assert np.array_equal(cycle(), first)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 200 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 20 cycles"
+
+
 def test_upload_many_matches_single_uploads():
     P, src, tgt, init = cases.config2(n=1500)
     gpu = CvoGPU(params=P)
