@@ -710,7 +710,9 @@ __device__ __forceinline__ unsigned long long pair_clock_peek(bool on, const Pai
 }
 __device__ __forceinline__ unsigned pair_clock_ticks(unsigned long long t0) {
   const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
-  return (t0 != 0ull && t0 <= t1) ? (unsigned)min(t1 - t0, 0xffffffffull) : 0u;
+  // (a stamp left over from an earlier launch - the first block of this one has not run yet - would show up as an
+  // interval of many milliseconds: dropped)
+  return (t0 != 0ull && t0 <= t1 && t1 - t0 < 400000ull) ? (unsigned)(t1 - t0) : 0u;
 }
 // What a row needs first, requested from kernel-argument addresses (see row_off_* in cvo_device.h) before the
 // descriptor has arrived.
@@ -1456,8 +1458,11 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         st->clk_n[0]++;
         st->clk_last_assoc = 0;
       }
-      st->clk_sum[1] += pair_clock_ticks(clk0);
-      st->clk_n[1]++;
+      const unsigned dt_coeff = pair_clock_ticks(clk0);
+      if (dt_coeff) {
+        st->clk_sum[1] += dt_coeff;
+        st->clk_n[1]++;
+      }
     }
     if (done && !dry) {
       st->status = 1;
