@@ -223,12 +223,15 @@ def main():
             ox, oy = po.Cloud.from_pointcloud(host_clouds[0][0]), po.Cloud.from_pointcloud(host_clouds[0][1])
             it = min(args.cpu_iters, P.MAX_ITER)
             po.align(op, ox, oy, inits[0], max_iterations=5)  # warm-up (page-in, thread pool)
+            po.scan_seconds(reset=True)
             o = po.align(op, ox, oy, inits[0], max_iterations=it)
+            scan_share = po.scan_seconds(reset=True) / max(o["seconds"], 1e-12)
             sec_per_iter = o["seconds"] / max(o["iterations"], 1)
             cpu_value = 1.0 / (sec_per_iter * mean_iters)
             cpu_baseline = {
                 "value": cpu_value, "unit": "align/s", "cores": threads, "kind": "port",
                 "ms_per_iter": sec_per_iter * 1e3,
+                "scan_share": round(scan_share, 4),  # the K2 (association scan) share of the CPU time
                 "sample": f"first {o['iterations']} optimiser iterations of pair 0 ({n}x{n}) with the CPU oracle "
                           f"(dense scan, OpenMP over rows), extrapolated to the {mean_iters:.0f} iterations of a full align()",
             }
@@ -239,7 +242,9 @@ def main():
                 og, og_threads = None, threads
                 for t in sorted({min(4, threads), threads}):  # its serial parts stop scaling at a few threads
                     po.set_num_threads(t)
+                    po.scan_seconds(reset=True)
                     cand = po.align(op, ox, oy, inits[0])
+                    cand["scan_share"] = po.scan_seconds(reset=True) / max(cand["seconds"], 1e-12)
                     if og is None or cand["seconds"] < og["seconds"]:
                         og, og_threads = cand, t
             finally:
@@ -247,6 +252,7 @@ def main():
                 po.set_num_threads(threads)
             cpu_baseline["best_effort"] = {
                 "value": 1.0 / max(og["seconds"], 1e-9), "unit": "align/s", "cores": og_threads,
+                "scan_share": round(og["scan_share"], 4),
                 "ms_per_iter": og["seconds"] * 1e3 / max(og["iterations"], 1),
                 "sample": f"one full align() of pair 0 ({og['iterations']} iterations) with the oracle's uniform-grid variant "
                           f"(identical results, tests/test_oracle_numpy.py)"}

@@ -256,6 +256,7 @@ inline unsigned se_row_blocked(const OracleParams& P, const CloudView& X, int i,
 // its cut-off sphere touches.  Candidates are visited in ascending j and go through the same pair_value(), so the
 // result is identical to se_row_literal (checked in tests/test_oracle_numpy.py); only the time differs.
 static int g_use_grid = 0;
+static double g_scan_seconds = 0;  // time spent in se_kernel (the association scan) since the last reset: bench.py's per-stage split
 
 struct TargetGrid {
   double ox, oy, oz, inv_cell;
@@ -891,7 +892,11 @@ IterResult iterate(const OracleParams& P, const CloudView& X, const CloudView& Y
     ws.ind.resize((size_t)n * K);
   }
   ws.nonzeros.resize(n);
-  se_kernel_impl(P, X, Y, K, ell, ws.mat.data(), ws.ind.data(), ws.nonzeros.data(), false);  // 1419
+  {
+    const auto ts = std::chrono::steady_clock::now();
+    se_kernel_impl(P, X, Y, K, ell, ws.mat.data(), ws.ind.data(), ws.nonzeros.data(), false);  // 1419
+    g_scan_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
+  }
   unsigned nnz = 0, mx = 0;  // compute_nonzeros SparseKernelMat.cu:37-46; max_element CvoGPU.cu:1518
   for (int i = 0; i < n; i++) {
     nnz += ws.nonzeros[i];
@@ -1256,6 +1261,11 @@ int oracle_association_non_isotropic(const OracleParams* p, const OracleCloud* x
 }
 
 void oracle_set_grid(int on) { g_use_grid = on != 0; }
+double oracle_scan_seconds(int reset) {
+  const double v = g_scan_seconds;
+  if (reset) g_scan_seconds = 0;
+  return v;
+}
 int oracle_get_grid(void) { return g_use_grid; }
 
 int oracle_num_threads(void) {

@@ -115,6 +115,9 @@ int oracle_association_non_isotropic(const OracleParams* p, const OracleCloud* x
  * variant, identical results); 0 (default): dense scan as the reference's GPU kernel does it. */
 void oracle_set_grid(int on);
 int oracle_get_grid(void);
+/* Seconds spent in the association scan (se_kernel) by oracle_align / oracle_iteration since the last reset:
+ * the K2 share of the CPU baseline. */
+double oracle_scan_seconds(int reset);
 
 int oracle_num_threads(void);
 void oracle_set_num_threads(int n);

@@ -93,6 +93,8 @@ def lib():
     L.oracle_association.restype = C.c_int
     L.oracle_set_grid.argtypes = [C.c_int]
     L.oracle_set_grid.restype = None
+    L.oracle_scan_seconds.argtypes = [C.c_int]
+    L.oracle_scan_seconds.restype = C.c_double
     L.oracle_num_threads.restype = C.c_int
     L.oracle_set_num_threads.argtypes = [C.c_int]
     L.oracle_set_num_threads.restype = None
@@ -269,6 +271,11 @@ def association_non_isotropic(p, x, y, T, kernel):
                                                  row_ptr.ctypes.data_as(C.POINTER(C.c_int)),
                                                  col.ctypes.data_as(C.POINTER(C.c_int)), _f(val), _f(kinv))
     return row_ptr, col[:cnt], val[:cnt], kinv.reshape(3, 3)
+
+
+def scan_seconds(reset=True):
+    """Seconds the oracle spent in the association scan (se_kernel) since the last reset."""
+    return float(lib().oracle_scan_seconds(1 if reset else 0))
 
 
 def set_grid(on):
