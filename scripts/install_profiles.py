@@ -1,0 +1,29 @@
+"""Copies the outputs of scripts/profile_round.sh (gpurun_out/r1b) into profiles/<round> and refreshes
+profiles/kernel_traffic.json from the PMC passes.  Usage: install_profiles.py [round, default r1]"""
+import csv, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "r1b") + "/"
+dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r1") + "/"
+os.makedirs(dst, exist_ok=True)
+for f in ("bench_kernel_stats.csv", "configs.json"):
+    shutil.copy(src + f, dst + f)
+for f in ("bench_n1.json", "bench_under_rocprof.json"):
+    line = open(src + f).read().strip().splitlines()[-1]
+    json.dump(json.loads(line), open(dst + f, "w"), indent=1)
+raw = json.load(open(src + "pmc_summary_raw.json"))
+raw.pop("cvo_dev::k_hold", None)
+cmd = ("rocprofv3 --pmc <counters> --output-format csv -- python bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline (one pass "
+       "per counter group, no trace domains; every launch covers one sub-batch of 16 pairs x 10k x 10k; averages over all launches "
+       "of the run, including the early-exit launches of k_prep / k_scan / k_list / k_assoc_dense in iterations that do not rebuild; "
+       "summarised on the GPU box by scripts/summarize_pmc.py)")
+json.dump({"command": cmd, "kernels": raw}, open(dst + "pmc_summary.json", "w"), indent=0)
+def hbm(k):
+    return int((2 * raw[k]["FETCH_SIZE"]["avg_per_launch"] + raw[k]["WRITE_SIZE"]["avg_per_launch"]) * 1024)
+kt = json.load(open(os.path.join(ROOT, "profiles", "kernel_traffic.json")))
+kt["hbm_bytes_per_launch"] = {"k_coeff": hbm("cvo_dev::k_coeff"), "k_assoc": hbm("cvo_dev::k_assoc<unsigned short, 64, false>"),
+                              "k_scan": hbm("cvo_dev::k_scan<2>")}
+json.dump(kt, open(os.path.join(ROOT, "profiles", "kernel_traffic.json"), "w"), indent=1)
+d = json.load(open(dst + "bench_n1.json"))
+print("value", d["value"], "ms/step", d["ms_per_step"], "k_coeff", d["roofline"]["avg_launch_ms"], "k_assoc", d["roofline"]["other_kernels"][0]["avg_launch_ms"])
+for row in list(csv.DictReader(open(dst + "bench_kernel_stats.csv")))[:5]:
+    print(row["Name"][:50], row["Calls"], row["AverageNs"])
