@@ -35,6 +35,30 @@
 #include <omp.h>
 #endif
 
+// ---- build-time convention switches (oracle/Makefile: variants; tests/test_oracle_conventions.py) -------------
+// The default build fixes the conventions listed above.  Because no reference build exists to pin them, the
+// oracle can be rebuilt under the other plausible choices and the tests show that the results the north_star
+// promises (discrete decisions over the well-conditioned prefix, final pose to 1e-4 / 2e-4) do not depend on them:
+//   -DORACLE_FMA_NONE          no contraction anywhere: every FMAF(a, b, c) is a rounded product plus a rounded sum
+//   -ffp-contract=fast         ("all") the explicit FMAFs stay and the compiler also fuses the host-side expressions
+//   -DORACLE_SUM_ALT           3-term reductions associate the other way: (a0 + a1) + a2 where the default has
+//                              a0 + (a1 + a2), and vice versa
+#if defined(ORACLE_FMA_NONE)
+static inline float FMAF(float a, float b, float c) {
+  volatile float p = a * b;  // (volatile: the product is rounded even when the file is built with contraction on)
+  return p + c;
+}
+#else
+static inline float FMAF(float a, float b, float c) { return std::fmaf(a, b, c); }
+#endif
+#if defined(ORACLE_SUM_ALT)
+#define SUM3(a0, a1, a2) (((a0) + (a1)) + (a2))
+#define SUM3L(a0, a1, a2) ((a0) + ((a1) + (a2)))
+#else
+#define SUM3(a0, a1, a2) ((a0) + ((a1) + (a2)))
+#define SUM3L(a0, a1, a2) (((a0) + (a1)) + (a2))
+#endif
+
 namespace {
 
 constexpr int FD = ORACLE_FEATURE_DIMENSIONS;
@@ -44,10 +68,14 @@ constexpr int NC = ORACLE_NUM_CLASSES;
 
 // Eigen fixed-size 3-term dot product compiled for the device: a0*b0 + (a1*b1 + a2*b2).
 inline float dot3_dev(float a0, float a1, float a2, float b0, float b1, float b2) {
-  return std::fmaf(a0, b0, std::fmaf(a1, b1, a2 * b2));
+#if defined(ORACLE_SUM_ALT)
+  return FMAF(a2, b2, FMAF(a1, b1, a0 * b0));  // (a0*b0 + a1*b1) + a2*b2
+#else
+  return FMAF(a0, b0, FMAF(a1, b1, a2 * b2));
+#endif
 }
 // a*b - c*d on the device.
-inline float dop_dev(float a, float b, float c, float d) { return std::fmaf(a, b, -(c * d)); }
+inline float dop_dev(float a, float b, float c, float d) { return FMAF(a, b, -(c * d)); }
 
 struct V3 {
   float x, y, z;
@@ -81,25 +109,25 @@ inline V3 matvec_dev(const M3& a, const V3& v) {
 // squared_dist(const T&, const T&), gpu_utils.cuh:72-78 (device)
 inline float squared_dist_xyz(const float* a, const float* b) {
   float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
-  return std::fmaf(dz, dz, std::fmaf(dy, dy, dx * dx));
+  return FMAF(dz, dz, FMAF(dy, dy, dx * dx));
 }
 // squared_dist(const T*, const T*, int), gpu_utils.cuh:33-41 (device)
 inline float squared_dist_n(const float* a, const float* b, int dim) {
   float result = 0;
   for (int i = 0; i < dim; i++) {
     float tmp = a[i] - b[i];
-    result = std::fmaf(tmp, tmp, result);
+    result = FMAF(tmp, tmp, result);
   }
   return result;
 }
 inline float square_norm_n(const float* a, int dim) {  // gpu_utils.cuh:96-104
   float result = 0;
-  for (int j = 0; j < dim; j++) result = std::fmaf(a[j], a[j], result);
+  for (int j = 0; j < dim; j++) result = FMAF(a[j], a[j], result);
   return result;
 }
 inline float dot_n(const float* a, const float* b, int dim) {  // gpu_utils.cuh:23-30
   float result = 0;
-  for (int i = 0; i < dim; i++) result = std::fmaf(a[i], b[i], result);
+  for (int i = 0; i < dim; i++) result = FMAF(a[i], b[i], result);
   return result;
 }
 // compute_geometric_type_ip, CvoGPU.cu:203-215
@@ -140,7 +168,7 @@ inline RowConsts row_consts(const OracleParams& P, const float* pa, float ell) {
   r.c_sigma2 = P.c_sigma * P.c_sigma;
   r.s_ell = P.s_ell;
   r.s_sigma2 = P.s_sigma * P.s_sigma;
-  float a_to_sensor = std::sqrt(std::fmaf(pa[2], pa[2], std::fmaf(pa[1], pa[1], pa[0] * pa[0])));
+  float a_to_sensor = std::sqrt(FMAF(pa[2], pa[2], FMAF(pa[1], pa[1], pa[0] * pa[0])));
   r.l = compute_range_ell(ell, a_to_sensor);
   r.d2_thres = 1;
   r.d2_c_thres = 1;
@@ -229,7 +257,7 @@ inline unsigned se_row_blocked(const OracleParams& P, const CloudView& X, int i,
     int any = 0;
     for (int t = 0; t < jn; t++) {
       float dx = yx[j0 + t] - ax, dy = yy[j0 + t] - ay, dz = yz[j0 + t] - az;
-      float d2 = std::fmaf(dz, dz, std::fmaf(dy, dy, dx * dx));
+      float d2 = FMAF(dz, dz, FMAF(dy, dy, dx * dx));
       unsigned char h = d2 < thr;
       hit[t] = h;
       any |= h;
@@ -397,7 +425,7 @@ void update_tf_impl(const float R[9], const float T[3], float Ri[9], float Ti[3]
   for (int i = 0; i < 3; i++) {
     // (-R_inv) * T, Eigen 3-term product a0 + (a1 + a2) on the host (unfused)
     float a0 = (-Ri[3 * i + 0]) * T[0], a1 = (-Ri[3 * i + 1]) * T[1], a2 = (-Ri[3 * i + 2]) * T[2];
-    Ti[i] = a0 + (a1 + a2);
+    Ti[i] = SUM3(a0, a1, a2);
   }
 }
 
@@ -430,12 +458,12 @@ FlowOut compute_flow_impl(const OracleParams& P, const CloudView& X, const Cloud
       V3 cr = cross_dev(pxe, pye);
       float dx = pye.x - pxe.x, dy = pye.y - pxe.y, dz = pye.z - pxe.z;
       float a = mat[(size_t)i * K + j];
-      o0 = std::fmaf(cr.x, a, o0);
-      o1 = std::fmaf(cr.y, a, o1);
-      o2 = std::fmaf(cr.z, a, o2);
-      v0 = std::fmaf(dx, a, v0);
-      v1 = std::fmaf(dy, a, v1);
-      v2 = std::fmaf(dz, a, v2);
+      o0 = FMAF(cr.x, a, o0);
+      o1 = FMAF(cr.y, a, o1);
+      o2 = FMAF(cr.z, a, o2);
+      v0 = FMAF(dx, a, v0);
+      v1 = FMAF(dy, a, v1);
+      v2 = FMAF(dz, a, v2);
     }
     om[3 * (size_t)i + 0] = (double)(o0 / P.c);
     om[3 * (size_t)i + 1] = (double)(o1 / P.c);
@@ -501,7 +529,7 @@ inline XiZ xi_point(const XiMats& M, const float omega[3], const float v[3], con
   r.xi4z = {a.x + M.m3v.x, a.y + M.m3v.y, a.z + M.m3v.z};
   r.normxiz2 = dot3_dev(r.xiz.x, r.xiz.y, r.xiz.z, r.xiz.x, r.xiz.y, r.xiz.z);
   r.xiz_dot_xi2z = -dot3_dev(r.xiz.x, r.xiz.y, r.xiz.z, r.xi2z.x, r.xi2z.y, r.xi2z.z);
-  r.epsil_const = std::fmaf(2.0f, dot3_dev(r.xiz.x, r.xiz.y, r.xiz.z, r.xi3z.x, r.xi3z.y, r.xi3z.z),
+  r.epsil_const = FMAF(2.0f, dot3_dev(r.xiz.x, r.xiz.y, r.xiz.z, r.xi3z.x, r.xi3z.y, r.xi3z.z),
                             dot3_dev(r.xi2z.x, r.xi2z.y, r.xi2z.z, r.xi2z.x, r.xi2z.y, r.xi2z.z));
   return r;
 }
@@ -544,10 +572,10 @@ Coefs poly_coeff_impl(const OracleParams& P, const CloudView& X, const CloudView
       Bi += bi;
       double ci = (double)A_ij * ((double)gamma_ij + (double)(beta_ij * beta_ij) / 2.0);
       Ci += ci;
-      double di = (double)A_ij * ((double)std::fmaf(beta_ij, gamma_ij, delta_ij) +
+      double di = (double)A_ij * ((double)FMAF(beta_ij, gamma_ij, delta_ij) +
                                   (double)(beta_ij * beta_ij * beta_ij) / 6.0);
       Di += di;
-      double ei = (double)A_ij * ((double)std::fmaf(beta_ij, delta_ij, epsil_ij) +
+      double ei = (double)A_ij * ((double)FMAF(beta_ij, delta_ij, epsil_ij) +
                                   1 / 2.0 * beta_ij * beta_ij * gamma_ij + 1 / 2.0 * gamma_ij * gamma_ij +
                                   1 / 24.0 * beta_ij * beta_ij * beta_ij * beta_ij);
       Ei += ei;
@@ -728,7 +756,7 @@ float select_step_impl(double B, double C, double D, double E, float min_step, f
 void exp_sek3_impl(const float xi[6], float dt, float out[12]) {
   const float TOLERANCE = 1e-6f;  // LieGroup.cpp:9
   float w0 = xi[0], w1 = xi[1], w2 = xi[2];
-  float theta = std::sqrt(w0 * w0 + (w1 * w1 + w2 * w2));
+  float theta = std::sqrt(SUM3(w0 * w0, w1 * w1, w2 * w2));
   float R[3][3], Jl[3][3];
   const float I[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   if (theta < TOLERANCE) {
@@ -742,7 +770,7 @@ void exp_sek3_impl(const float xi[6], float dt, float out[12]) {
     float oneMinusCosTheta2 = (1 - ctheta) / (theta2);
     float A2[3][3];
     for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) A2[i][j] = A[i][0] * A[0][j] + (A[i][1] * A[1][j] + A[i][2] * A[2][j]);
+      for (int j = 0; j < 3; j++) A2[i][j] = SUM3(A[i][0] * A[0][j], A[i][1] * A[1][j], A[i][2] * A[2][j]);
     float s1 = stheta / theta;
     float s3 = (dt * theta - stheta) / (theta2 * theta);
     for (int i = 0; i < 3; i++)
@@ -753,7 +781,7 @@ void exp_sek3_impl(const float xi[6], float dt, float out[12]) {
   }
   for (int i = 0; i < 3; i++) {
     for (int j = 0; j < 3; j++) out[4 * i + j] = R[i][j];
-    out[4 * i + 3] = Jl[i][0] * xi[3] + (Jl[i][1] * xi[4] + Jl[i][2] * xi[5]);
+    out[4 * i + 3] = SUM3(Jl[i][0] * xi[3], Jl[i][1] * xi[4], Jl[i][2] * xi[5]);
   }
 }
 
@@ -803,7 +831,7 @@ double se3_log_norm_impl(const double R[9], const double t[3]) {
   double O[3][3] = {{0, -om[2], om[1]}, {om[2], 0, -om[0]}, {-om[1], om[0], 0}};
   double O2[3][3];
   for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) O2[i][j] = O[i][0] * O[0][j] + O[i][1] * O[1][j] + O[i][2] * O[2][j];
+    for (int j = 0; j < 3; j++) O2[i][j] = SUM3L(O[i][0] * O[0][j], O[i][1] * O[1][j], O[i][2] * O[2][j]);
   double coef;
   if (std::fabs(theta) < eps) {
     coef = 1.0 / 12.0;
@@ -813,11 +841,9 @@ double se3_log_norm_impl(const double R[9], const double t[3]) {
   }
   double u[3];
   for (int i = 0; i < 3; i++) {
-    u[i] = 0;
-    for (int j = 0; j < 3; j++) {
-      double Vinv = (i == j ? 1.0 : 0.0) - 0.5 * O[i][j] + coef * O2[i][j];
-      u[i] += Vinv * t[j];
-    }
+    double Vinv[3];
+    for (int j = 0; j < 3; j++) Vinv[j] = (i == j ? 1.0 : 0.0) - 0.5 * O[i][j] + coef * O2[i][j];
+    u[i] = SUM3L(Vinv[0] * t[0], Vinv[1] * t[1], Vinv[2] * t[2]);
   }
   double s = 0;
   for (int i = 0; i < 3; i++) s += u[i] * u[i];
@@ -873,6 +899,13 @@ struct Workspace {
   std::vector<float> mat;
   std::vector<int> ind;
   std::vector<unsigned> nonzeros;
+  // literal_buffers: mat / ind are the reference's persistent rows x nearest_neighbors_max device buffers
+  // (CvoState.cu:74-83), cleared over their first rows * num_neighbors entries at the top of every iteration
+  // (reset_state_at_new_iter -> clear_SparseKernelMat(A, num_neighbors), CvoState.cu:143-146,
+  // SparseKernelMat.cu:87-95) and written with row stride num_neighbors (CvoGPU.cu:577-578).  Only the association
+  // export of align() can tell the difference (it may read them with another stride, see export_align_association).
+  bool literal_buffers = false;
+  int K_alloc = 0;
 };
 
 // One pass of the loop body of align_impl, CvoGPU.cu:1387-1531, up to (not including) the
@@ -887,7 +920,14 @@ IterResult iterate(const OracleParams& P, const CloudView& X, const CloudView& Y
   for (int j = 0; j < m; j++) transform_point(Ri, Ti, Y0.p(j), &ws.yt[3 * (size_t)j]);  // 1404
   CloudView Y = Y0;
   Y.xyz = ws.yt.data();
-  if (ws.mat.size() < (size_t)n * K) {
+  if (ws.literal_buffers) {
+    if (ws.mat.size() != (size_t)n * ws.K_alloc) {  // cudaMalloc'ed, first cleared by iteration 0 (K == K_alloc there)
+      ws.mat.assign((size_t)n * ws.K_alloc, 0.0f);
+      ws.ind.assign((size_t)n * ws.K_alloc, -1);
+    }
+    std::fill(ws.mat.begin(), ws.mat.begin() + (size_t)n * K, 0.0f);
+    std::fill(ws.ind.begin(), ws.ind.begin() + (size_t)n * K, -1);
+  } else if (ws.mat.size() < (size_t)n * K) {
     ws.mat.resize((size_t)n * K);
     ws.ind.resize((size_t)n * K);
   }
@@ -923,11 +963,11 @@ IterResult iterate(const OracleParams& P, const CloudView& X, const CloudView& Y
   }
   auto norm3d = [](const float* a) {
     double x = a[0], y = a[1], z = a[2];
-    return std::sqrt(x * x + (y * y + z * z));
+    return std::sqrt(SUM3(x * x, y * y, z * z));
   };
   IterResult res{0, 0};
   if (norm3d(f.omega) < P.eps && norm3d(f.v) < P.eps) {  // 1454-1458
-    auto norm3f = [](const float* a) { return std::sqrt(a[0] * a[0] + (a[1] * a[1] + a[2] * a[2])); };
+    auto norm3f = [](const float* a) { return std::sqrt(SUM3(a[0] * a[0], a[1] * a[1], a[2] * a[2])); };
     if (norm3f(f.omega) < 1e-8 && norm3f(f.v) < 1e-8) res.ret = -1;
     res.status = 1;
     if (tr) {
@@ -948,8 +988,8 @@ IterResult iterate(const OracleParams& P, const CloudView& X, const CloudView& Y
   float Tn[3], Rn[9];
   for (int i = 0; i < 3; i++) {
     double r0 = R[3 * i + 0], r1 = R[3 * i + 1], r2 = R[3 * i + 2];
-    Tn[i] = (float)((r0 * dT[0] + (r1 * dT[1] + r2 * dT[2])) + (double)T[i]);
-    for (int j = 0; j < 3; j++) Rn[3 * i + j] = (float)(r0 * dR[0 + j] + (r1 * dR[3 + j] + r2 * dR[6 + j]));
+    Tn[i] = (float)(SUM3(r0 * dT[0], r1 * dT[1], r2 * dT[2]) + (double)T[i]);
+    for (int j = 0; j < 3; j++) Rn[3 * i + j] = (float)SUM3(r0 * dR[0 + j], r1 * dR[3 + j], r2 * dR[6 + j]);
   }
   std::memcpy(R, Rn, sizeof(Rn));
   std::memcpy(T, Tn, sizeof(Tn));
@@ -1005,7 +1045,7 @@ void oracle_transform_pose_vec(const float pose12[12], int n, const float* xyz_i
   for (int i = 0; i < n; i++) {
     const float x = xyz_in[3 * i], y = xyz_in[3 * i + 1], z = xyz_in[3 * i + 2];
     for (int r = 0; r < 3; r++)
-      xyz_out[3 * i + r] = std::fmaf(T[4 * r], x, T[4 * r + 1] * y) + std::fmaf(T[4 * r + 2], z, T[4 * r + 3]);
+      xyz_out[3 * i + r] = FMAF(T[4 * r], x, T[4 * r + 1] * y) + FMAF(T[4 * r + 2], z, T[4 * r + 3]);
   }
 }
 void oracle_se_kernel(const OracleParams* p, const OracleCloud* x, const OracleCloud* y, int K, float ell,
@@ -1038,9 +1078,10 @@ int oracle_iteration(const OracleParams* p, const OracleCloud* x, const OracleCl
 }
 
 // CvoGPU::align + align_impl, CvoGPU.cu:1338-1632
-int oracle_align(const OracleParams* p, const OracleCloud* x, const OracleCloud* y, const float init[16],
+static int align_core(const OracleParams* p, const OracleCloud* x, const OracleCloud* y, const float init[16],
                  float out[16], int* iterations, OracleTrace* trace, int max_trace, int trace_dense,
-                 int trace_every, int* n_trace, double* seconds, int max_iter_override) {
+                 int trace_every, int* n_trace, double* seconds, int max_iter_override, OracleAssociation* assoc) {
+  if (assoc) assoc->n_pairs = assoc->n_source_inliers = assoc->K_used = assoc->K_final = assoc->overflow = 0;
   if (n_trace) *n_trace = 0;
   if (iterations) *iterations = 0;
   if (x->n == 0 || y->n == 0) return 0;  // CvoGPU.cu:1614-1617: transform untouched
@@ -1058,13 +1099,19 @@ int oracle_align(const OracleParams* p, const OracleCloud* x, const OracleCloud*
   int num_neighbors = P.nearest_neighbors_max;
   int max_iter = max_iter_override > 0 ? std::min(max_iter_override, P.MAX_ITER) : P.MAX_ITER;
   Workspace ws;
+  ws.literal_buffers = assoc != nullptr;
+  ws.K_alloc = P.nearest_neighbors_max;
   int k = 0;
   int nt = 0;
+  int K_used = num_neighbors;
+  unsigned last_nnz = 0;
   for (; k < max_iter; k++) {
     OracleTrace tr;
     std::memset(&tr, 0, sizeof(tr));
     tr.k = k;
+    K_used = num_neighbors;
     IterResult r = iterate(P, X, Y0, R, T, ell, num_neighbors, ws, &tr);
+    last_nnz = tr.nnz;
     bool rec = trace && nt < max_trace && (k < trace_dense || (trace_every > 0 && k % trace_every == 0));
     if (rec) trace[nt++] = tr;
     if (r.status == 1) {
@@ -1084,8 +1131,51 @@ int oracle_align(const OracleParams* p, const OracleCloud* x, const OracleCloud*
   if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
   if (iterations) *iterations = k;
   if (n_trace) *n_trace = nt;
+  // if (params.is_exporting_association && association_mat) gpu_association_to_cpu(A_host, ..., num_neighbors),
+  // CvoGPU.cu:1552-1556 -> CvoGPU_impl.cu:366-427.  Literal, including its stride: `cols` is the value num_neighbors
+  // has AFTER the loop.  When the loop ended through a `break` that is the stride the matrix was written with; when it
+  // ran out of iterations, num_neighbors was already advanced for an iteration that never ran (CvoGPU.cu:1529), and the
+  // row-major buffers are read with a stride they were not written with (whatever that yields is what upstream
+  // returns; entries beyond rows * K_used are leftovers of earlier iterations).  source_inliers / target_inliers /
+  // the pairs of a row are reported in row order (upstream fills them from an OpenMP loop, order unspecified).
+  if (assoc && k > 0) {
+    assoc->K_used = K_used;
+    assoc->K_final = num_neighbors;
+    const int rows = X.n, cols = num_neighbors;
+    if (last_nnz != 0) {
+      for (int i = 0; i < rows; i++) {
+        if (ws.nonzeros[i] == 0) continue;
+        if (assoc->source_inliers && assoc->n_source_inliers < assoc->cap_rows) assoc->source_inliers[assoc->n_source_inliers] = i;
+        assoc->n_source_inliers++;
+        for (int j = 0; j < cols; j++) {
+          const size_t f = (size_t)i * cols + j;
+          if (ws.ind[f] == -1) break;
+          if (assoc->n_pairs < assoc->cap_pairs) {
+            assoc->row[assoc->n_pairs] = i;
+            assoc->col[assoc->n_pairs] = ws.ind[f];
+            assoc->val[assoc->n_pairs] = ws.mat[f];
+          } else {
+            assoc->overflow = 1;
+          }
+          assoc->n_pairs++;
+        }
+      }
+    }
+  }
   mat4_from_RT_inverse(R, T, out);
   return ret;
+}
+
+int oracle_align(const OracleParams* p, const OracleCloud* x, const OracleCloud* y, const float init[16],
+                 float out[16], int* iterations, OracleTrace* trace, int max_trace, int trace_dense,
+                 int trace_every, int* n_trace, double* seconds, int max_iter_override) {
+  return align_core(p, x, y, init, out, iterations, trace, max_trace, trace_dense, trace_every, n_trace, seconds,
+                    max_iter_override, nullptr);
+}
+
+int oracle_align_association(const OracleParams* p, const OracleCloud* x, const OracleCloud* y, const float init[16],
+                             float out[16], int* iterations, int max_iter_override, OracleAssociation* assoc) {
+  return align_core(p, x, y, init, out, iterations, nullptr, 0, 0, 0, nullptr, nullptr, max_iter_override, assoc);
 }
 
 // inner_product_impl + A_sum, CvoGPU.cu:1719-1778, SparseKernelMat.cu:62-68.  The float
@@ -1173,7 +1263,7 @@ static void inverse3_eigen(const float m[9], float out[9]) {
   };
   const float c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
   const float p0 = c0 * M(0, 0), p1 = c1 * M(1, 0), p2 = c2 * M(2, 0);
-  const float det = p0 + (p1 + p2);
+  const float det = SUM3(p0, p1, p2);
   const float invdet = 1.0f / det;
   out[0] = c0 * invdet;  // result.row(0) = cofactors_col0 * invdet
   out[1] = c1 * invdet;

@@ -93,6 +93,23 @@ int oracle_align(const OracleParams* p, const OracleCloud* x, const OracleCloud*
                  OracleTrace* trace, int max_trace, int trace_dense, int trace_every, int* n_trace,
                  double* seconds, int max_iter_override);
 
+/* align() with is_exporting_association: the Association the reference fills after the loop (CvoGPU.cu:1552-1556 ->
+ * gpu_association_to_cpu, CvoGPU_impl.cu:366-427) from the kernel matrix of the LAST EXECUTED iteration, read with the
+ * stride num_neighbors has after the loop.  Pairs as (row, col, val) triplets in row order; caller-owned arrays. */
+typedef struct OracleAssociation {
+  int cap_pairs, cap_rows;   /* capacities of row/col/val and of source_inliers */
+  int* row;
+  int* col;
+  float* val;
+  int* source_inliers;       /* may be NULL */
+  int n_pairs, n_source_inliers;
+  int K_used, K_final;       /* stride the matrix was written with / read with */
+  int overflow;              /* 1: more pairs than cap_pairs (n_pairs still counts them) */
+} OracleAssociation;
+int oracle_align_association(const OracleParams* p, const OracleCloud* x, const OracleCloud* y,
+                             const float init_colmajor[16], float out_colmajor[16], int* iterations,
+                             int max_iter_override, OracleAssociation* assoc);
+
 float oracle_inner_product(const OracleParams* p, const OracleCloud* x, const OracleCloud* y,
                            const float T_colmajor[16], float ell);
 float oracle_function_angle(const OracleParams* p, const OracleCloud* x, const OracleCloud* y,

@@ -58,7 +58,53 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
-    L = C.CDLL(LIB_PATH)
+    _lib = _bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+VARIANT_FMA = ("dev", "none", "all")
+VARIANT_SUM = ("def", "alt")
+
+
+def build_variants():
+    """The same source under the other plausible floating-point conventions (oracle/Makefile, target `variants`)."""
+    subprocess.check_call(["make", "-C", HERE, "-s", "-j4", "variants"])
+
+
+class variant:
+    """Context manager: every pyoracle call inside runs on the oracle built with the given conventions.
+    fma: 'dev' (default build) | 'none' | 'all';  sum3: 'def' | 'alt'  (see oracle/Makefile)."""
+    _cache = {}
+
+    def __init__(self, fma="dev", sum3="def"):
+        assert fma in VARIANT_FMA and sum3 in VARIANT_SUM
+        self.key = f"{fma}_{sum3}"
+
+    def __enter__(self):
+        global _lib
+        if self.key not in variant._cache:
+            path = os.path.join(HERE, "_variants", f"libcvo_oracle_{self.key}.so")
+            srcs = [os.path.join(HERE, f) for f in ("cvo_oracle.cpp", "cvo_oracle.h", "Makefile")]
+            if not os.path.exists(path) or any(os.path.getmtime(q) > os.path.getmtime(path) for q in srcs):
+                build_variants()
+            variant._cache[self.key] = _bind(C.CDLL(path))
+        self.prev = lib()
+        _lib = variant._cache[self.key]
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
+
+
+class OracleAssociation(C.Structure):
+    _fields_ = [("cap_pairs", C.c_int), ("cap_rows", C.c_int), ("row", C.POINTER(C.c_int)), ("col", C.POINTER(C.c_int)),
+                ("val", C.POINTER(C.c_float)), ("source_inliers", C.POINTER(C.c_int)), ("n_pairs", C.c_int),
+                ("n_source_inliers", C.c_int), ("K_used", C.c_int), ("K_final", C.c_int), ("overflow", C.c_int)]
+
+
+def _bind(L):
     dp, fp, ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)
     pp, cp, tp = C.POINTER(OracleParams), C.POINTER(OracleCloud), C.POINTER(OracleTrace)
     L.oracle_cubic_roots.argtypes = [dp, dp, dp]
@@ -98,7 +144,8 @@ def lib():
     L.oracle_num_threads.restype = C.c_int
     L.oracle_set_num_threads.argtypes = [C.c_int]
     L.oracle_set_num_threads.restype = None
-    _lib = L
+    L.oracle_align_association.argtypes = [pp, cp, cp, fp, fp, ip, C.c_int, C.POINTER(OracleAssociation)]
+    L.oracle_align_association.restype = C.c_int
     return L
 
 
@@ -235,6 +282,27 @@ def align(p, x, y, init, trace_capacity=0, trace_dense=0, trace_every=0, max_ite
                              C.byref(nt), C.byref(secs), max_iterations)
     return dict(ret=ret, transform=out.reshape(4, 4).T.copy(), iterations=iters.value,
                 trace=[tr[i] for i in range(nt.value)], seconds=secs.value)
+
+
+def align_association(p, x, y, init, max_iterations=0):
+    """align() with is_exporting_association (CvoGPU.cu:1552-1556): the pose plus the exported Association as
+    (row, col, val) triplets in row order, the source inliers, and the two strides (written / read)."""
+    out = np.zeros(16, np.float32)
+    iters = C.c_int(0)
+    cap = x.n * min(p.nearest_neighbors_max, max(y.n, 1)) + 1
+    row, col = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    val = np.zeros(cap, np.float32)
+    inl = np.zeros(x.n + 1, np.int32)
+    ipt = C.POINTER(C.c_int)
+    A = OracleAssociation(cap, x.n + 1, row.ctypes.data_as(ipt), col.ctypes.data_as(ipt), _f(val), inl.ctypes.data_as(ipt),
+                          0, 0, 0, 0, 0)
+    ret = lib().oracle_align_association(C.byref(p), C.byref(x.c), C.byref(y.c), _f(_cm(init)), _f(out), C.byref(iters),
+                                         max_iterations, C.byref(A))
+    assert not A.overflow
+    n = A.n_pairs
+    return dict(ret=ret, transform=out.reshape(4, 4).T.copy(), iterations=iters.value, row=row[:n].copy(),
+                col=col[:n].copy(), val=val[:n].copy(), source_inliers=inl[:A.n_source_inliers].copy(),
+                K_used=A.K_used, K_final=A.K_final)
 
 
 def inner_product(p, x, y, T, ell):
