@@ -37,6 +37,7 @@ extern "C" {
 #define CVO_E_HIP (-3)
 #define CVO_E_NOMEM (-4)
 #define CVO_E_UNSUPPORTED (-5)
+#define CVO_E_VERIFY (-6) /* CVO_VERIFY_LISTS=1: a row derived from the cached candidate lists differed from the literal scan */
 
 /* Layout-identical to cvo::CvoParams (include/UnifiedCvo/cvo/CvoParams.hpp:12-73): same
  * members, same order, same types, so a reference build can pass &params unchanged. */
@@ -180,6 +181,20 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
  * round trip). */
 int cvo_batch_poses_to_device(cvo_ctx* ctx, void* dst_device, int n_pairs);
 
+/* ---- the Association align() exports (CvoGPU.cu:1552-1556 -> gpu_association_to_cpu, CvoGPU_impl.cu:366-427) -------
+ * What `align(..., Association*)` returns when params.is_exporting_association is set: the kernel matrix of the LAST
+ * EXECUTED iteration of the loop (pose before that iteration's update, that iteration's ell and num_neighbors), of
+ * pair `pair` of the last cvo_align / cvo_align_ex / cvo_align_batch call on this context.  CSR as cvo_association:
+ * row_ptr n_source + 1 ints; col / val up to `capacity` entries (NULL / 0 to size: CVO_E_NOMEM with *nnz_out set).
+ * Stride: upstream reads its row-major buffers with the value num_neighbors has AFTER the loop.  After a `break`
+ * (eps / eps_2) that is the stride they were written with.  When the loop ran out of iterations num_neighbors had
+ * already been advanced (CvoGPU.cu:1529) and, if it changed, the buffers are read with another stride than they were
+ * written with; that re-striding is reproduced here wherever it stays inside the part of the buffer the last iteration
+ * defined (new stride <= old stride); beyond it upstream returns leftovers of earlier iterations, here the row ends
+ * (see DESIGN.md "Association export").  *stride_written / *stride_read (optional) report the two values. */
+int cvo_align_association(cvo_ctx* ctx, int pair, int* row_ptr, int* col, float* val, size_t capacity, size_t* nnz_out,
+                          int* stride_written, int* stride_read);
+
 /* ---- inner_product_gpu / function_angle (CvoGPU.cu:1780-1873) ------------------------ */
 int cvo_inner_product(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source,
                       const cvo_cloud* target, const float T[16], float ell, float* out);
@@ -247,6 +262,14 @@ int cvo_debug_list_builds(cvo_ctx* ctx, unsigned long long* builds, unsigned lon
                           unsigned long long* candidate_evaluations);
 /* Number of candidate pairs in the bitmap the last iteration used (superset of nnz). */
 int cvo_debug_last_candidates(cvo_ctx* ctx, unsigned long long* out);
+/* Runs the device's scalar restatements of the reference's host-side maths (cubic roots of poly_solver_order3,
+ * the step selection of compute_step_size, Exp_SEK3, ||SE3 log||, update_tf, the indicator windows) on caller-supplied
+ * inputs, so that the device code itself can be pinned against numpy / scipy.  ops and layouts: k_scalar_math in
+ * unified_cvo_amd/csrc/cvo_kernels.h.  in / out: host arrays of 16 doubles per item (op 7: one item of 2 + n / n). */
+int cvo_debug_scalar_math(cvo_ctx* ctx, int op, int n, const double* in, double* out);
+/* CVO_VERIFY_LISTS=1 (environment, read when a call starts): rows k_verify re-derived with the literal scan during the
+ * last align call, summed over pairs and iterations (0 when the check was off). */
+int cvo_debug_verified_rows(cvo_ctx* ctx, unsigned long long* rows);
 const char* cvo_version(void);
 
 #ifdef __cplusplus

@@ -134,6 +134,28 @@ def test_trajectory_prefix(oracle, builder, kw, n_it):
     assert cases.max_abs_diff(g.transform, o["transform"]) <= 1e-6
 
 
+@pytest.mark.parametrize("builder,n_it", [(cases.config3, 220), (cases.config4, 220), (cases.config2, 220)])
+def test_trajectory_prefix_full_size_10k(oracle, builder, n_it):
+    """BASELINE.json configs 3 / 4 (and the 10k geometric shape of config 5) at their FULL size: every iteration of a
+    220-iteration prefix - the fast first iterations with their list rebuilds, then the lean graph - must take the
+    oracle's integer decisions (K, nnz, max_nnz, ell) and follow its twist / coefficients / pose."""
+    P, src, tgt, init = builder(n=10000)
+    g, o = _prefix(oracle, P, src, tgt, init, n_it)
+    for a, b in zip(g.trace, o["trace"]):
+        _cmp_trace(a, b)
+    assert cases.max_abs_diff(g.transform, o["transform"]) <= 1e-6
+
+
+def test_final_pose_config4_full_size(oracle):
+    """Config 4 at 10k x 10k to its own dist < eps_2 stop (~300 iterations): same stop iteration, pose to 1e-4."""
+    P, src, tgt, init = cases.config4(n=10000)
+    g = CvoGPU(params=P).align(src, tgt, init)
+    o = oracle.align(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt), init)
+    assert g.ret == o["ret"] == 0 and g.iterations < P.MAX_ITER
+    assert abs(g.iterations - o["iterations"]) <= 2
+    assert cases.max_abs_diff(g.transform, o["transform"]) <= TOL_POSE
+
+
 def test_final_pose_config2_clamped(oracle):
     P, src, tgt, init = cases.config2(n=2000)
     gpu = CvoGPU(params=P)
@@ -296,6 +318,47 @@ def test_batch_equals_individual_aligns():
         one = CvoGPU(params=P).align(s, t, init, max_iterations=400)
         assert r.iterations == one.iterations == 400
         assert np.array_equal(r.transform, one.transform)
+
+
+def _ragged(builder, k, n_lo, n_hi, seed):
+    rs = np.random.default_rng(seed)
+    out = []
+    for p in range(k):
+        n = int(rs.integers(n_lo, n_hi))
+        P, a, b, init = builder(n=n, pair_id=p)
+        if p % 3 == 1:  # ragged: fewer source rows than targets, and the other way round
+            xs, fs, ls, gs = a.device_arrays()
+            cut = int(n * 0.7)
+            a = CvoPointCloud.from_arrays(xs[:cut], None if fs is None else fs[:cut], None if ls is None else ls[:cut], gs[:cut])
+        elif p % 3 == 2:
+            xt, ft, lt, gt = b.device_arrays()
+            cut = int(n * 0.8)
+            b = CvoPointCloud.from_arrays(xt[:cut], None if ft is None else ft[:cut], None if lt is None else lt[:cut], gt[:cut])
+        out.append((P, a, b, init))
+    return out
+
+
+@pytest.mark.parametrize("builder,n_it", [(cases.config3, 260), (cases.config4, 10000)])
+def test_batch_of_32_general_pairs_equals_individual_aligns(builder, n_it):
+    """The GENERAL (colour / semantic) instantiation under four concurrent sub-batch streams and the lean graph: 32
+    ragged pairs solved as one batch give bit-identical poses, iteration counts and final ell / K to 32 separate
+    cvo_align calls (config 4 runs to its own eps_2 stops, which differ from pair to pair)."""
+    pairs = _ragged(builder, 32, 1200, 3200, seed=42)
+    P = pairs[0][0]
+    gpu = CvoGPU(params=P)
+    res = gpu.align_batch([p[1] for p in pairs], [p[2] for p in pairs], [p[3] for p in pairs], max_iterations=n_it)
+    n_groups, _ = gpu.debug_last_geometry()
+    assert n_groups == 4
+    solo = CvoGPU(params=P)
+    its = set()
+    for (Pp, s_, t_, init), r in zip(pairs, res):
+        one = solo.align(s_, t_, init, max_iterations=n_it)
+        assert (r.iterations, r.ret, r.final_ell, r.final_num_neighbors) == (one.iterations, one.ret, one.final_ell,
+                                                                             one.final_num_neighbors)
+        assert np.array_equal(r.transform, one.transform)
+        its.add(r.iterations)
+    if builder is cases.config4:
+        assert len(its) > 4 and max(its) < 10000     # really ended by eps_2, at different iterations
 
 
 def test_determinism_full_size():
@@ -583,7 +646,7 @@ def test_lidar_flavour_single_feature(oracle):
     assert cases.max_abs_diff(g.transform, o["transform"]) < 1e-6
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("CVO_FUZZ_SEEDS", "12"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CVO_FUZZ_SEEDS", "48"))))
 def test_randomised_trajectories(oracle, seed):
     """Randomised sizes / parameters / initial guesses: every recorded iteration (counts, ell, K, twist, B..E, step,
     pose) must follow the oracle through list rebuilds, waits, ordered truncation and the overflow path."""
@@ -591,6 +654,9 @@ def test_randomised_trajectories(oracle, seed):
     kind = seed % 3
     n = int(rs.integers(150, 1800))
     m = int(rs.integers(150, 1800))
+    if seed % 8 == 7:  # a few at BASELINE scale (up to 10k x 10k, ragged)
+        n = int(rs.integers(4000, 10001))
+        m = int(rs.integers(4000, 10001))
     if kind == 0:
         P = cases.load_params("geometric_gpu")
         src, tgt, _ = synth.geometric_pair(n, seed, m=m)

@@ -1,0 +1,339 @@
+"""GPU tests of the API surface round 1 left untested, and of the device code pinned WITHOUT the oracle:
+
+  * the 192-byte AoS route (pcl_PointCloud_to_gpu, CvoGPU_impl.cu:287-362) == the SoA route, bit for bit;
+  * the Association align() exports (CvoGPU.cu:1552-1556 + CvoGPU_impl.cu:366-427): the LAST EXECUTED iteration's matrix;
+  * the device's scalar maths (cubic, step selection, Exp_SEK3, ||SE3 log||, update_tf, indicator windows) against
+    numpy / scipy directly (cvo_debug_scalar_math) - not against the oracle, which shares text with the device code;
+  * CVO_VERIFY_LISTS=1: the device-side self-check of the candidate-list reuse at full size;
+  * argument validation of the public override fields.
+"""
+import collections
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+import cases
+import np_reference as npr
+from unified_cvo_amd import (CvoGPU, CvoPointCloud, CvoError, synth, cvo_points_from_pointcloud, CVO_POINT_DTYPE)
+
+pytestmark = pytest.mark.gpu
+
+
+def _ocloud(oracle, pc):
+    return oracle.Cloud.from_pointcloud(pc)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 192-byte AoS records
+# ---------------------------------------------------------------------------------------------------------------
+def test_cvo_point_layout_is_192_bytes():
+    assert CVO_POINT_DTYPE.itemsize == 192
+    off = {n: CVO_POINT_DTYPE.fields[n][1] for n in CVO_POINT_DTYPE.names}
+    assert (off["xyz"], off["rgba"], off["features"], off["label"], off["label_distribution"], off["geometric_type"],
+            off["normal"], off["covariance"], off["cov_eigenvalues"]) == (0, 16, 20, 40, 44, 120, 128, 140, 176)
+
+
+def test_aos192_upload_matches_soa_route_and_oracle(oracle):
+    """pcl::PointCloud<CvoPoint> overloads: the AoS record IS the wire format.  Records are built in numpy at the
+    offsets of PointSegmentedDistribution.hpp:17-99 (with garbage in every field the kernels must not read)."""
+    P, src, tgt, init = cases.config4(n=2000)
+    gpu = CvoGPU(params=P)
+    rs = np.random.default_rng(3)
+    recs = []
+    for pc in (src, tgt):
+        r = cvo_points_from_pointcloud(pc)
+        r["pad_w"] = rs.normal(size=r.shape[0])        # never read
+        r["normal"] = rs.normal(size=(r.shape[0], 3))
+        r["covariance"] = rs.normal(size=(r.shape[0], 9))
+        r["cov_eigenvalues"] = rs.normal(size=(r.shape[0], 3))
+        r["label"] = rs.integers(0, 19, r.shape[0])
+        recs.append(r)
+    a_src, a_tgt = gpu.upload_aos192(recs[0]), gpu.upload_aos192(recs[1])
+    n_it = 120
+    g_aos = gpu.align(a_src, a_tgt, init, max_iterations=n_it, trace_capacity=n_it, trace_dense=n_it)
+    g_soa = gpu.align(src, tgt, init, max_iterations=n_it, trace_capacity=n_it, trace_dense=n_it)
+    assert g_aos.iterations == g_soa.iterations == n_it
+    assert np.array_equal(g_aos.transform, g_soa.transform)
+    for a, b in zip(g_aos.trace, g_soa.trace):
+        assert (a.K, a.nnz, a.max_nnz, a.B, a.C, a.D, a.E) == (b.K, b.nnz, b.max_nnz, b.B, b.C, b.D, b.E)
+    ip_a = gpu.inner_product_gpu(a_src, a_tgt, init, 0.2)
+    assert ip_a == gpu.inner_product_gpu(src, tgt, init, 0.2)
+    assert gpu.function_angle(a_src, a_tgt, init, 0.2, False) == gpu.function_angle(src, tgt, init, 0.2, False)
+    o = oracle.align(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt), init, max_iterations=n_it)
+    assert cases.max_abs_diff(g_aos.transform, o["transform"]) <= 1e-6
+    assert ip_a == pytest.approx(oracle.inner_product(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt), init, 0.2),
+                                 rel=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# align(..., Association*)
+# ---------------------------------------------------------------------------------------------------------------
+def _assoc_triplets(row_ptr, col, val):
+    rows = np.repeat(np.arange(len(row_ptr) - 1), np.diff(row_ptr))
+    return rows.astype(np.int32), col, val
+
+
+def _check_association(oracle, P, src, tgt, init, expect_same_stride=None):
+    gpu = CvoGPU(params=P)
+    g = gpu.align(src, tgt, init)
+    rp, col, val, kw, kr = gpu.align_association(src.num_points())
+    o = oracle.align_association(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt), init)
+    assert g.iterations == o["iterations"] and g.ret == o["ret"]
+    assert (kw, kr) == (o["K_used"], o["K_final"])
+    if expect_same_stride is not None:
+        assert (kw == kr) == expect_same_stride
+    rows, c, v = _assoc_triplets(rp, col, val)
+    assert np.array_equal(rows, o["row"]) and np.array_equal(c, o["col"])
+    assert np.allclose(v, o["val"], rtol=2e-7, atol=0)
+    inl = np.nonzero(np.diff(rp) > 0)[0]
+    assert np.array_equal(inl, o["source_inliers"][:len(inl)]) or kw != kr
+    return g, o, (rp, col, val, kw, kr)
+
+
+def test_align_association_after_eps2_break(oracle):
+    """Config 4 stops through dist < eps_2: the exported matrix is the one of the last executed iteration (built at
+    the pose BEFORE its update, with that iteration's ell and K) - not a fresh evaluation at the final pose."""
+    P, src, tgt, init = cases.config4(n=2000)
+    P.is_exporting_association = 1
+    g, o, (rp, col, val, kw, kr) = _check_association(oracle, P, src, tgt, init, expect_same_stride=True)
+    assert g.iterations < P.MAX_ITER and len(col) > 1000
+    # and it is NOT what round 1 exported (re-evaluation at the final pose with K_max and the decayed ell)
+    gpu = CvoGPU(params=P)
+    rp2, col2, val2 = gpu.compute_association_gpu(src, tgt, np.linalg.inv(g.transform), g.final_ell)
+    assert not (len(col2) == len(col) and np.array_equal(col2, col) and np.array_equal(val2, val))
+
+
+def test_align_association_after_max_iter(oracle):
+    """The loop runs out of iterations: num_neighbors was already advanced for an iteration that never ran
+    (CvoGPU.cu:1529) and upstream reads the buffers with that stride."""
+    P, src, tgt, init = cases.config2(n=1500)
+    P.is_exporting_association = 1
+    P.MAX_ITER = 300
+    _check_association(oracle, P, src, tgt, init)
+    for max_iter in (1, 2, 3, 7):       # early cut-offs: K drops from K_max to 1.2 * max_nnz -> stride_read < stride_written
+        P.MAX_ITER = max_iter
+        g, o, (rp, col, val, kw, kr) = _check_association(oracle, P, src, tgt, init)
+        if max_iter == 1:
+            assert kw == P.nearest_neighbors_max and kr < kw
+
+
+def test_align_association_empty(oracle):
+    P, src, tgt, init = cases.config2(n=300)
+    P.is_exporting_association = 1
+    far = CvoPointCloud.from_xyz(tgt.positions() + np.float32(100.0))
+    gpu = CvoGPU(params=P)
+    g = gpu.align(src, far, init)
+    rp, col, val, kw, kr = gpu.align_association(300)
+    assert g.ret == -1 and len(col) == 0 and not rp.any()
+    gpu.inner_product_gpu(src, tgt, init, 0.3)
+    with pytest.raises(CvoError):          # the last call was not an align
+        gpu.align_association(300)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# device scalar maths vs numpy / scipy
+# ---------------------------------------------------------------------------------------------------------------
+def _roots_match(dev, ref, tol):
+    dev = sorted(dev, key=lambda z: (round(z.real, 9), z.imag))
+    used = [False] * 3
+    for z in dev:
+        d = [abs(z - w) if not used[i] else np.inf for i, w in enumerate(ref)]
+        i = int(np.argmin(d))
+        if d[i] > tol * max(1.0, abs(ref[i])):
+            return False
+        used[i] = True
+    return True
+
+
+@pytest.mark.parametrize("op", [0, 1])
+def test_device_cubic_roots_vs_numpy(op):
+    """poly_solver_order3 (LieGroup.cpp:309-325: companion-matrix eigenvalues): both device variants - the scalar solver
+    and the three-lane search the update uses - against numpy.roots (LAPACK)."""
+    rs = np.random.default_rng(17)
+    coefs = []
+    for _ in range(300):
+        s = 10.0 ** rs.uniform(-3, 3, 4)
+        coefs.append(rs.normal(size=4) * s)
+    for r in ([1, 2, 3], [-0.5, 1e-4, 40.0], [1e-5, 2e-5, 5.0], [2, 2, -1], [0.3, 0.3, 0.3]):   # real, incl. repeated
+        coefs.append(np.poly(r) * rs.uniform(0.5, 2))
+    for re, im in ((0.1, 2.0), (-3.0, 1e-3), (5.0, 40.0)):                                      # complex pairs
+        coefs.append(np.real(np.poly([rs.normal(), complex(re, im), complex(re, -im)])))
+    coefs = np.array(coefs)
+    gpu = CvoGPU()
+    out = gpu.debug_scalar_math(op, coefs)
+    bad = 0
+    for c, o in zip(coefs, out):
+        dev = [complex(o[q], o[3 + q]) for q in range(3)]
+        ref = np.roots(c)
+        # relative residual of every device root (robust for ill-conditioned clusters), then root matching
+        for z in dev:
+            res = abs(np.polyval(c, z))
+            scale = sum(abs(ck) * abs(z) ** (3 - k) for k, ck in enumerate(c))
+            assert res <= 1e-9 * max(scale, 1e-300), (c, z, res, scale)
+        bad += 0 if _roots_match(dev, ref, 1e-6) else 1
+    assert bad <= 2          # (clustered roots: numpy itself is only good to ~sqrt(eps) there)
+    # both device variants return identical roots
+    assert np.array_equal(out[:, :6], gpu.debug_scalar_math(1 - op, coefs)[:, :6])
+
+
+@pytest.mark.parametrize("op", [2, 3])
+def test_device_step_selection_vs_numpy(op):
+    """compute_step_size's host half (CvoGPU.cu:1122-1158): smallest root with positive real part and |imag| < 1e-5,
+    clamped; "no admissible root -> max_step" (the overwrite quirk).  Includes the device's min_step shortcut."""
+    rs = np.random.default_rng(23)
+    items = []
+    for _ in range(400):
+        B, Cc, D, E = rs.normal(size=4) * 10.0 ** rs.uniform(-2, 5, 4)
+        items.append([B, Cc, D, E, 10.0 ** rs.uniform(-6, -3), 10.0 ** rs.uniform(-2, 0)])
+    # end-game shapes of the real loop: tiny positive root below min_step
+    for _ in range(100):
+        r0 = 10.0 ** rs.uniform(-7, -3)
+        c = np.poly([r0, -abs(rs.normal()) - 0.05, abs(rs.normal()) + 0.06]) * rs.uniform(1e2, 1e6)
+        items.append([c[3], c[2] / 2, c[1] / 3, c[0] / 4, 1e-4, 0.8])
+    items.append([1.0, 1.0, 1.0, 1.0, 1e-4, 0.8])      # no positive root at all -> max_step
+    items.append([-1.0, 0.0, 0.0, 0.0, 1e-4, 0.8])     # degenerate leading coefficient (NaN roots) -> max_step
+    items = np.array(items)
+    out = CvoGPU().debug_scalar_math(op, items)[:, 0]
+    n_short = 0
+    for it, s in zip(items, out):
+        B, Cc, D, E, mn, mx = it
+        mn32, mx32 = float(np.float32(mn)), float(np.float32(mx))
+        with np.errstate(all="ignore"):
+            ref = npr.step_from_coeffs(B, Cc, D, E, mn32, mx32) if E != 0 else mx32
+        ref32 = float(np.float32(ref))
+        if s == pytest.approx(ref32, rel=1e-5):
+            n_short += s == np.float32(mn32)
+            continue
+        # a root within rounding of a clamp or of the |imag| < 1e-5 rule may legitimately fall either side
+        r = np.roots([4 * E, 3 * D, 2 * Cc, B])
+        near_rule = any(abs(abs(z.imag) - 1e-5) < 1e-7 or abs(z.real) < 1e-12 for z in r)
+        assert near_rule, (it, s, ref32, r)
+    assert n_short > 50
+
+
+def test_device_exp_sek3_vs_scipy():
+    """Exp_SEK3 (LieGroup.cpp:244-274) == expm of the 4x4 twist times dt; theta < 1e-6 -> R = I, translation = v."""
+    rs = np.random.default_rng(5)
+    items = []
+    for _ in range(200):
+        xi = rs.normal(size=6)
+        xi /= np.linalg.norm(xi)
+        items.append(list(xi) + [10.0 ** rs.uniform(-5, 0)])
+    items.append([0, 0, 0, 0.6, 0.0, 0.8, 0.01])           # pure translation: Jl = I, NOT dt * I
+    items.append([1e-8, 0, 0, 0.6, 0.0, 0.8, 0.5])
+    out = CvoGPU().debug_scalar_math(4, np.array(items))[:, :12].reshape(-1, 3, 4)
+    for it, o in zip(items, out):
+        w, v, dt = np.array(it[:3]), np.array(it[3:6]), it[6]
+        if np.linalg.norm(np.float32(w)) < 1e-6:
+            assert np.allclose(o[:, :3], np.eye(3)) and np.allclose(o[:, 3], np.float32(v))
+            continue
+        X = np.zeros((4, 4))
+        X[:3, :3] = npr.hat(w)
+        X[:3, 3] = v
+        E = scipy.linalg.expm(X * dt)
+        assert np.allclose(o[:, :3], E[:3, :3], atol=3e-7), (it, o, E)
+        assert np.allclose(o[:, 3], E[:3, 3], atol=3e-7 + 2e-6 * dt)   # (1 - cos)/theta^2 in float at tiny dt * theta
+
+
+def test_device_se3_log_norm_vs_scipy():
+    """|| Sophus::SE3d(dRT).log() || (CvoGPU.cu:1473-1476) == norm of the (u, omega) coordinates of logm."""
+    rs = np.random.default_rng(9)
+    items = []
+    for _ in range(200):
+        w = rs.normal(size=3)
+        w *= 10.0 ** rs.uniform(-7, 0.4) / np.linalg.norm(w)
+        t = rs.normal(size=3) * 10.0 ** rs.uniform(-6, 0)
+        R = scipy.linalg.expm(npr.hat(w))
+        items.append(list(R.reshape(9)) + list(t))
+    items.append(list(np.eye(3).reshape(9)) + [0.0, 0.0, 0.0])
+    items.append(list(np.eye(3).reshape(9)) + [3e-5, -4e-5, 0.0])
+    out = CvoGPU().debug_scalar_math(5, np.array(items))[:, 0]
+    for it, o in zip(items, out):
+        ref = npr._se3_log_norm(np.array(it[:9]).reshape(3, 3), np.array(it[9:12]))
+        assert o == pytest.approx(ref, rel=1e-7, abs=1e-12), (it, o, ref)
+
+
+def test_device_update_tf_vs_numpy():
+    rs = np.random.default_rng(2)
+    items = []
+    for _ in range(50):
+        R = scipy.linalg.expm(npr.hat(rs.normal(size=3))).astype(np.float32)
+        items.append(list(R.reshape(9)) + list(rs.normal(size=3).astype(np.float32) * 5))
+    out = CvoGPU().debug_scalar_math(6, np.array(items))
+    for it, o in zip(items, out):
+        R, T = np.array(it[:9]).reshape(3, 3), np.array(it[9:12])
+        assert np.array_equal(o[:9].reshape(3, 3), R.T)              # transform = [R^T | -R^T T]  (CvoGPU.cu:94-112)
+        assert np.allclose(o[9:12], -R.T @ T, atol=2e-6)
+
+
+@pytest.mark.parametrize("window,thr", [(15, 0.2), (10, 0.001), (3, 0.05), (1, 0.5)])
+def test_device_indicator_windows_vs_deque(window, thr):
+    """The ring-buffer restatement of A_sparsity_indicator_ell_update that the update kernel runs, against the deque
+    version written from the reference text (np_reference.IndicatorWindows): the literal three-`if` control flow."""
+    rs = np.random.default_rng(window)
+    seq = np.concatenate([rs.uniform(0.5, 1.5, 40), np.full(60, 1.0) + rs.normal(0, 1e-4, 60), rs.uniform(0.2, 3.0, 80),
+                          np.linspace(2.0, 1.0, 120)]).astype(np.float32)
+    dev = CvoGPU().debug_scalar_math(7, np.concatenate([[window, thr], seq.astype(np.float64)]))
+    ref = npr.IndicatorWindows(window, thr)
+    want = np.array([1.0 if ref.push(x) else 0.0 for x in seq])
+    assert np.array_equal(dev, want)
+    assert want.sum() >= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CVO_VERIFY_LISTS: the list-reuse argument checked on the device at full size
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,builder,kw,n_it", [
+    ("config2-10k", cases.config2, dict(n=10000), 320),
+    ("config3", cases.config3, dict(n=10000), 320),
+    ("config4", cases.config4, dict(n=10000), 320),
+    ("config2-5k", cases.config2, dict(n=5000), 400),
+    ("config1", cases.config1, {}, 1200),
+])
+def test_verify_lists_full_size(monkeypatch, name, builder, kw, n_it):
+    """Every row of every iteration - including the fast-moving first 30, where lists live for one or two iterations,
+    and the lean graph's waits - re-derived with the literal scan and compared bit for bit on the device."""
+    P, src, tgt, init = builder(**kw)
+    ref = CvoGPU(params=P).align(src, tgt, init, max_iterations=n_it)
+    monkeypatch.setenv("CVO_VERIFY_LISTS", "1")
+    gpu = CvoGPU(params=P)
+    g = gpu.align(src, tgt, init, max_iterations=n_it)      # raises CvoError(CVO_E_VERIFY) on any mismatch
+    assert g.iterations == ref.iterations and np.array_equal(g.transform, ref.transform)
+    assert gpu.debug_verified_rows() == g.iterations * src.num_points() + (0 if g.iterations == n_it else src.num_points())
+    builds, iters, _ = gpu.debug_list_builds()
+    assert builds < iters                                    # lists really were reused while being verified
+
+
+def test_verify_lists_catches_a_broken_skin(monkeypatch):
+    """The check is not vacuous: with the motion bound disabled (CVO_DEBUG_NO_MOTION_BOUND: lists are never rebuilt for
+    motion) the first fast iterations lose pairs and the call fails with CVO_E_VERIFY."""
+    P, src, tgt, init = cases.config2(n=3000)
+    monkeypatch.setenv("CVO_VERIFY_LISTS", "1")
+    monkeypatch.setenv("CVO_DEBUG_NO_MOTION_BOUND", "1")
+    with pytest.raises(CvoError, match="CVO_VERIFY_LISTS"):
+        CvoGPU(params=P).align(src, tgt, init, max_iterations=60)
+
+
+def test_verify_lists_batch(monkeypatch):
+    monkeypatch.setenv("CVO_VERIFY_LISTS", "1")
+    pairs = [cases.config2(n=3000, pair_id=p) for p in range(6)] + [cases.config2(n=1200, pair_id=9, m=2100)]
+    gpu = CvoGPU(params=pairs[0][0])
+    res = gpu.align_batch([p[1] for p in pairs], [p[2] for p in pairs], [p[3] for p in pairs], max_iterations=250)
+    assert all(r.iterations == 250 for r in res)
+    assert gpu.debug_verified_rows() == 250 * sum(p[1].num_points() for p in pairs)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# argument validation
+# ---------------------------------------------------------------------------------------------------------------
+def test_override_state_is_validated():
+    """K0 beyond nearest_neighbors_max would write past the ELL: rejected, like a non-positive / NaN ell0."""
+    P, src, tgt, init = cases.config2(n=300)
+    P.nearest_neighbors_max = 16
+    gpu = CvoGPU(params=P)
+    for bad in (dict(K0=17), dict(K0=0), dict(K0=-3), dict(ell0=0.0), dict(ell0=-1.0), dict(ell0=float("nan")),
+                dict(ell0=float("inf"))):
+        with pytest.raises(CvoError):
+            gpu.align(src, tgt, init, max_iterations=2, **bad)
+    assert gpu.align(src, tgt, init, max_iterations=2, K0=16, ell0=0.3).iterations == 2

@@ -4,4 +4,5 @@ Only what the path needs: csrc/ (HIP kernels + the C-ABI of include/cvo_hip.h) a
 mirror of the reference interface (CvoGPU / CvoPointCloud / CvoParams).
 """
 from .params import CvoParams, read_cvo_params_yaml, parse_cvo_yaml_text  # noqa: F401
-from .api import CvoGPU, CvoPointCloud, DeviceCloud, CvoError, AlignResult, CvoFrameGPU, BinaryStateGPU  # noqa: F401
+from .api import (CvoGPU, CvoPointCloud, DeviceCloud, DeviceCloudAoS, CvoError, AlignResult, CvoFrameGPU,  # noqa: F401
+                  BinaryStateGPU, CVO_POINT_DTYPE, cvo_points_from_pointcloud)

@@ -15,6 +15,7 @@ CVO_E_INVALID = -2
 CVO_E_HIP = -3
 CVO_E_NOMEM = -4
 CVO_E_UNSUPPORTED = -5
+CVO_E_VERIFY = -6
 
 
 class cvo_params_t(C.Structure):
@@ -130,6 +131,7 @@ EXPORTED = [
     "cvo_function_angle", "cvo_association", "cvo_association_non_isotropic", "cvo_cloud_transformed", "cvo_edge_kernel_matrix", "cvo_debug_last_ell", "cvo_debug_time_scan", "cvo_debug_time_kernels",
     "cvo_debug_kernel_clock",
     "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
+    "cvo_align_association", "cvo_debug_scalar_math", "cvo_debug_verified_rows",
 ]
 
 _lib = None
@@ -184,6 +186,10 @@ def lib():
     L.cvo_debug_list_builds.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.cvo_debug_last_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cvo_debug_scan_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.cvo_align_association.argtypes = [vp, ip, C.POINTER(C.c_int), C.POINTER(C.c_int), fp, C.c_size_t,
+                                        C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.cvo_debug_scalar_math.argtypes = [vp, ip, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.cvo_debug_verified_rows.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     for name in EXPORTED:
         getattr(L, name)  # AttributeError here = the library does not export what the header declares
     _lib = L

@@ -194,6 +194,53 @@ class DeviceCloud:
             pass
 
 
+class DeviceCloudAoS(DeviceCloud):
+    """A cloud uploaded from the reference's 192-byte AoS records (pcl::PointCloud<CvoPoint>::points, the wire format
+    of pcl_PointCloud_to_gpu, CvoGPU_impl.cu:287-362) through cvo_cloud_upload_aos192."""
+
+    def __init__(self, gpu, records):
+        rec = np.ascontiguousarray(records)
+        assert rec.dtype.itemsize == 192, "CvoPoint is 192 bytes (PointSegmentedDistribution.hpp:17-99)"
+        self.gpu = gpu
+        self.n = int(rec.shape[0])
+        self._keep = rec
+        h = C.c_void_p()
+        gpu._check(gpu.L.cvo_cloud_upload_aos192(gpu.ctx, self.n, rec.ctypes.data_as(C.c_void_p), C.byref(h)))
+        self.handle = h
+
+
+# numpy view of pcl::PointSegmentedDistribution<5, 19> (PointSegmentedDistribution.hpp:17-99): byte offsets as laid out
+# by PCL_ADD_POINT4D / PCL_ADD_RGB and the member order, verified with a layout-identical struct (SURVEY.md 8(a) T1)
+CVO_POINT_DTYPE = np.dtype({
+    "names": ["xyz", "pad_w", "rgba", "features", "label", "label_distribution", "geometric_type", "normal", "covariance",
+              "cov_eigenvalues"],
+    "formats": [(np.float32, 3), np.float32, np.uint32, (np.float32, 5), np.int32, (np.float32, 19), (np.float32, 2),
+                (np.float32, 3), (np.float32, 9), (np.float32, 3)],
+    "offsets": [0, 12, 16, 20, 40, 44, 120, 128, 140, 176],
+    "itemsize": 192,
+})
+
+
+def cvo_points_from_pointcloud(pc):
+    """What CvoPointCloud_to_gpu builds per point (CvoGPU_impl.cu:206-263) as an array of CvoPoint records: xyz,
+    features (+ r, g, b bytes = min(255, f * 255)), label_distribution (+ label = argmax), geometric_type."""
+    xyz, feat, label, geo = pc.device_arrays()
+    n = xyz.shape[0]
+    rec = np.zeros(n, CVO_POINT_DTYPE)
+    rec["xyz"] = xyz
+    rec["pad_w"] = 1.0
+    if feat is not None:
+        rec["features"] = feat
+        rgb = np.minimum(255.0, feat[:, :3] * 255.0).astype(np.uint32)
+        rec["rgba"] = (rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2]
+    if label is not None:
+        rec["label_distribution"] = label
+        rec["label"] = np.argmax(label, axis=1)
+    if geo is not None:
+        rec["geometric_type"] = geo
+    return rec
+
+
 def _mat_to_c(T):
     a = np.ascontiguousarray(np.asarray(T, np.float32).reshape(4, 4).T).reshape(16)
     return a
@@ -269,6 +316,10 @@ class CvoGPU:
         with ThreadPoolExecutor(max_workers=threads) as ex:
             return list(ex.map(self.upload, clouds))
 
+    def upload_aos192(self, records):
+        """pcl_PointCloud_to_gpu: uploads an array of 192-byte CvoPoint records (dtype CVO_POINT_DTYPE)."""
+        return DeviceCloudAoS(self, records)
+
     def _dev(self, pc):
         return pc if isinstance(pc, DeviceCloud) else DeviceCloud(self, pc)
 
@@ -337,6 +388,22 @@ class CvoGPU:
             res.append(AlignResult(infos[i].ret, out[16 * i:16 * i + 16].reshape(4, 4).T.copy(), infos[i], trace))
         self._keepalive = keep
         return res
+
+    def align_association(self, n_source, pair=0, capacity=None):
+        """The Association `align()` exports under is_exporting_association (CvoGPU.cu:1552-1556): CSR of the kernel
+        matrix of the last executed iteration of pair `pair` of the last align call, + (stride_written, stride_read)."""
+        row_ptr = np.zeros(n_source + 1, np.int32)
+        nnz, kw, kr = C.c_size_t(), C.c_int(), C.c_int()
+        ipt = C.POINTER(C.c_int)
+        rc = self.L.cvo_align_association(self.ctx, pair, row_ptr.ctypes.data_as(ipt), None, None, 0, C.byref(nnz),
+                                          C.byref(kw), C.byref(kr))
+        if rc != _capi.CVO_E_NOMEM:
+            self._check(rc)
+        cap = nnz.value if capacity is None else capacity
+        col, val = np.zeros(max(cap, 1), np.int32), np.zeros(max(cap, 1), np.float32)
+        self._check(self.L.cvo_align_association(self.ctx, pair, row_ptr.ctypes.data_as(ipt), col.ctypes.data_as(ipt),
+                                                 _fptr(val), cap, C.byref(nnz), C.byref(kw), C.byref(kr)))
+        return row_ptr, col[:nnz.value], val[:nnz.value], kw.value, kr.value
 
     def poses_to_device(self, dst_ptr, n):
         self._check(self.L.cvo_batch_poses_to_device(self.ctx, C.c_void_p(dst_ptr), n))
@@ -461,6 +528,28 @@ class CvoGPU:
         b, it, ce = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
         self._check(self.L.cvo_debug_list_builds(self.ctx, C.byref(b), C.byref(it), C.byref(ce)))
         return b.value, it.value, ce.value
+
+    def debug_scalar_math(self, op, items):
+        """Runs one of the device's scalar routines (k_scalar_math ops 0-6) on `items` (n x <=16 doubles); returns
+        n x 16 doubles.  op 7 (indicator windows): items = [window, threshold, x_0, ...], returns the n decisions."""
+        dp = C.POINTER(C.c_double)
+        if op == 7:
+            a = np.ascontiguousarray(items, np.float64).reshape(-1)
+            n = a.shape[0] - 2
+            out = np.zeros(n, np.float64)
+        else:
+            it = np.atleast_2d(np.asarray(items, np.float64))
+            n = it.shape[0]
+            a = np.zeros((n, 16), np.float64)
+            a[:, :it.shape[1]] = it
+            out = np.zeros((n, 16), np.float64)
+        self._check(self.L.cvo_debug_scalar_math(self.ctx, op, n, a.ctypes.data_as(dp), out.ctypes.data_as(dp)))
+        return out
+
+    def debug_verified_rows(self):
+        v = C.c_ulonglong()
+        self._check(self.L.cvo_debug_verified_rows(self.ctx, C.byref(v)))
+        return v.value
 
     def debug_last_candidates(self):
         v = C.c_ulonglong()

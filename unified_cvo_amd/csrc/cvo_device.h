@@ -50,6 +50,9 @@ struct DevParams {
   float lean_skin;       // skin of the lean graph in units of (lean_U x the motion of one iteration)
   int kernel_clock;  // CVO_KERNEL_CLOCK: accumulate per-pair kernel durations in PairState::clk_*
   int phase_ticks;  // CVO_PHASE_TICKS: leave per-block phase timestamps (g_phase_ticks) for cvo_debug_time_kernels
+  int verify_lists;  // CVO_VERIFY_LISTS: k_verify re-derives every row with the literal scan after each association
+  int debug_no_motion_bound;  // CVO_DEBUG_NO_MOTION_BOUND (tests only): the update pretends no target ever moves, so
+                              // lists outlive their validity - what CVO_VERIFY_LISTS exists to catch
 };
 
 // Running state of one frame pair; lives in HBM, only touched by one thread of k_step.
@@ -92,7 +95,8 @@ struct PairState {
   // CVO_KERNEL_CLOCK: ticks of the s_memrealtime counter between the entry of a pair's first block and the exit of the
   // block that finishes the pair's work in the launch, [0] k_assoc (lean graph; its last interval is left in
   // clk_last_assoc by the flow gate and added by the update) / [1] k_coeff, summed over clk_n iterations
-  unsigned clk_last_assoc, clk_n[2], clk_pad;
+  unsigned clk_last_assoc, clk_n[2];
+  int K_last;  // num_neighbors of the last EXECUTED iteration: the row stride upstream wrote its A matrix with
   unsigned long long clk_sum[2];
   // ---- everything above is the "hot" prefix k_update stages through LDS ----
   float sq[IND_CAP], eq[IND_CAP];
@@ -100,6 +104,11 @@ struct PairState {
   // block of the association launch, read by every block of k_coeff
   float xi[48];
   unsigned long long clk_start[2];  // CVO_KERNEL_CLOCK: entry stamp of the pair's first block in the running launch
+  // CVO_VERIFY_LISTS: sticky result of k_verify (0 = every row of every iteration matched the literal scan); on the
+  // first mismatch: iteration, row position and what differed (1 = count, 2 = column, 3 = value).  Outside the hot
+  // prefix: written by k_verify's blocks with atomics, never staged by the update.
+  int verify_err, verify_k, verify_pos, verify_what;
+  unsigned long long verify_rows;  // rows checked so far
 };
 
 // Everything a kernel needs to know about one frame pair.

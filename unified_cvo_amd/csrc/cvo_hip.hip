@@ -45,13 +45,13 @@ struct PairLayout {  // byte offsets of one pair's workspace inside the arena
 };
 
 struct GraphKey {
-  int n_pairs = 0, p0 = 0, T = 0, gx = 0, gy = 0, nba = 0, nbc = 0, npb = 0, idx16 = 0, general = 0, U = 0;
+  int n_pairs = 0, p0 = 0, T = 0, gx = 0, gy = 0, nba = 0, nbc = 0, npb = 0, idx16 = 0, general = 0, U = 0, flags = 0;
   const void* arena = nullptr;  // kernel arguments of the row-block kernels (ArenaArg)
   unsigned stride256 = 0;
   int Npad = 0;
   bool operator==(const GraphKey& o) const {
     return n_pairs == o.n_pairs && p0 == o.p0 && T == o.T && gx == o.gx && gy == o.gy && nba == o.nba &&
-           nbc == o.nbc && npb == o.npb && idx16 == o.idx16 && general == o.general && U == o.U && arena == o.arena &&
+           nbc == o.nbc && npb == o.npb && idx16 == o.idx16 && general == o.general && U == o.U && flags == o.flags && arena == o.arena &&
            stride256 == o.stride256 && Npad == o.Npad;
   }
 };
@@ -281,6 +281,8 @@ DevParams make_dev_params(const cvo_params_t& p) {
   if (const char* e = getenv("CVO_SKIN")) d.skin_frac = std::max(0.f, (float)atof(e));
   d.phase_ticks = getenv("CVO_PHASE_TICKS") ? 1 : 0;
   d.kernel_clock = (getenv("CVO_KERNEL_CLOCK") && atoi(getenv("CVO_KERNEL_CLOCK")) != 0) ? 1 : 0;
+  d.verify_lists = (getenv("CVO_VERIFY_LISTS") && atoi(getenv("CVO_VERIFY_LISTS")) != 0) ? 1 : 0;
+  d.debug_no_motion_bound = getenv("CVO_DEBUG_NO_MOTION_BOUND") ? 1 : 0;
   if (const char* e = getenv("CVO_SHRINK")) d.rebuild_shrink = std::min(0.99f, std::max(0.f, (float)atof(e)));
   return d;
 }
@@ -344,32 +346,53 @@ struct ArenaArg {
   int Npad;
 };
 
-void launch_assoc(hipStream_t s, bool idx16, bool general, int nblk, int n_pairs, const PairDesc* descs,
+// instr: the instantiation with time stamps (CVO_KERNEL_CLOCK / CVO_PHASE_TICKS); the production kernels have none
+template <typename IdxT, int CAP, bool GENERAL>
+void launch_assoc_t(hipStream_t s, bool instr, dim3 grid, const PairDesc* descs, const DevParams* dp, const PairState* st,
+                    const ArenaArg& A, int packed) {
+  const dim3 blk(ASSOC_THREADS);
+  if (instr)
+    hipLaunchKernelGGL((k_assoc<IdxT, CAP, GENERAL, true>), grid, blk, 0, s, descs, dp, st, A.base, packed, A.stride256, A.Npad);
+  else
+    hipLaunchKernelGGL((k_assoc<IdxT, CAP, GENERAL, false>), grid, blk, 0, s, descs, dp, st, A.base, packed, A.stride256, A.Npad);
+}
+
+void launch_assoc(hipStream_t s, bool idx16, bool general, bool instr, int nblk, int n_pairs, const PairDesc* descs,
                   const DevParams* dp, const PairState* st, const ArenaArg& A, int lean) {
-  const dim3 blk(ASSOC_THREADS), grid = row_grid(nblk, n_pairs);
+  const dim3 grid = row_grid(nblk, n_pairs);
   const int packed = (lean & 0xf) | (nblk << 4) | (int)((unsigned)n_pairs << 20);  // (ensure_workspace bounds both)
   if (idx16) {
     if (general)
-      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, true>), grid, blk, 0, s, descs, dp, st, A.base, packed,
-                         A.stride256, A.Npad);
+      launch_assoc_t<unsigned short, ASSOC_CAP16, true>(s, instr, grid, descs, dp, st, A, packed);
     else
-      hipLaunchKernelGGL((k_assoc<unsigned short, ASSOC_CAP16, false>), grid, blk, 0, s, descs, dp, st, A.base, packed,
-                         A.stride256, A.Npad);
+      launch_assoc_t<unsigned short, ASSOC_CAP16, false>(s, instr, grid, descs, dp, st, A, packed);
   } else {
     if (general)
-      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, true>), grid, blk, 0, s, descs, dp, st, A.base, packed, A.stride256,
-                         A.Npad);
+      launch_assoc_t<int, ASSOC_CAP32, true>(s, instr, grid, descs, dp, st, A, packed);
     else
-      hipLaunchKernelGGL((k_assoc<int, ASSOC_CAP32, false>), grid, blk, 0, s, descs, dp, st, A.base, packed, A.stride256,
-                         A.Npad);
+      launch_assoc_t<int, ASSOC_CAP32, false>(s, instr, grid, descs, dp, st, A, packed);
   }
 }
 
-void launch_coeff(hipStream_t s, int nblk, int split, int n_pairs, const PairDesc* descs, const DevParams* dp,
+void launch_coeff(hipStream_t s, bool instr, int nblk, int split, int n_pairs, const PairDesc* descs, const DevParams* dp,
                   PairState* st, const ArenaArg& A, int flags) {
   const int packed = nblk | (split << 14) | (int)((unsigned)n_pairs << 20);  // 14 + 6 + 12 bits
-  hipLaunchKernelGGL(k_coeff, row_grid(nblk * split, n_pairs), dim3(ASSOC_THREADS), 0, s, descs, dp, st, A.base, flags, packed,
-                     A.stride256, A.Npad);
+  if (instr)
+    hipLaunchKernelGGL(k_coeff<true>, row_grid(nblk * split, n_pairs), dim3(ASSOC_THREADS), 0, s, descs, dp, st, A.base, flags,
+                       packed, A.stride256, A.Npad);
+  else
+    hipLaunchKernelGGL(k_coeff<false>, row_grid(nblk * split, n_pairs), dim3(ASSOC_THREADS), 0, s, descs, dp, st, A.base, flags,
+                       packed, A.stride256, A.Npad);
+}
+
+// CVO_VERIFY_LISTS: literal re-derivation of every row after the association of an iteration (k_verify)
+void launch_verify(hipStream_t s, bool general, int N, int n_pairs, const PairDesc* descs, const DevParams* dp, const int* st,
+                   int lean) {
+  const dim3 grid((unsigned)std::min((N + 3) / 4, 2048), (unsigned)n_pairs);
+  if (general)
+    hipLaunchKernelGGL(k_verify<true>, grid, dim3(256), 0, s, descs, dp, st, lean);
+  else
+    hipLaunchKernelGGL(k_verify<false>, grid, dim3(256), 0, s, descs, dp, st, lean);
 }
 
 void launch_dense(hipStream_t s, bool general, int N, int n_pairs, const PairDesc* descs, const DevParams* dp, const int* st) {
@@ -390,7 +413,7 @@ void launch_dense(hipStream_t s, bool general, int N, int n_pairs, const PairDes
 
 struct LaunchGeom {
   int n_pairs, p0, T, gx, gy, nba, nbc, npb, N, csplit;
-  bool idx16, general;
+  bool idx16, general, instr, verify;
   hipStream_t stream;
   ArenaArg arena;  // of pair p0
 };
@@ -415,9 +438,10 @@ void launch_rebuild(cvo_ctx* c, const LaunchGeom& g) {
 void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags) {
   const PairDesc* descs = c->d_descs + g.p0;
   const int* st = c->d_status + g.p0;
-  launch_assoc(g.stream, g.idx16, g.general, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, lean ? 1 : 0);
+  launch_assoc(g.stream, g.idx16, g.general, g.instr, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, lean ? 1 : 0);
   if (!lean) launch_dense(g.stream, g.general, g.N, g.n_pairs, descs, c->d_params, st);
-  launch_coeff(g.stream, g.nba, g.csplit, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0));
+  if (g.verify) launch_verify(g.stream, g.general, g.N, g.n_pairs, descs, c->d_params, st, lean ? 1 : 0);
+  launch_coeff(g.stream, g.instr, g.nba, g.csplit, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0));
 }
 
 // A chunk of U iterations.  Full: every iteration can rebuild its candidate list and serve overflow rows.
@@ -455,6 +479,13 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   if (params->nearest_neighbors_max <= 0) return fail(ctx, CVO_E_INVALID, "nearest_neighbors_max must be > 0");
   if (params->indicator_window_size + 1 >= IND_CAP || params->indicator_window_size < 0)
     return fail(ctx, CVO_E_INVALID, "indicator_window_size out of range");
+  if (mode == 0 && opts && opts->override_state) {
+    // the ELL holds nearest_neighbors_max slots per row and the kernels write slot nnz while nnz < K
+    if (opts->K0 < 1 || opts->K0 > params->nearest_neighbors_max)
+      return fail(ctx, CVO_E_INVALID, "cvo_align_opts_t.K0 must lie in [1, nearest_neighbors_max]");
+    if (!(opts->ell0 > 0.f) || !std::isfinite(opts->ell0))
+      return fail(ctx, CVO_E_INVALID, "cvo_align_opts_t.ell0 must be finite and > 0");
+  }
   int N = 0, M = 0;
   for (int p = 0; p < n_pairs; p++) {
     if (!sources[p] || !targets[p]) return fail(ctx, CVO_E_INVALID, "null cloud");
@@ -470,7 +501,23 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   const int Kmax = params->nearest_neighbors_max;
   S->N = N;
   S->M = M;
+  // k_list packs a row's candidate count next to an 8-bit row number; the candidate bitmap of a pair takes
+  // N * M / 8 bytes (DESIGN.md "Data layout"), every pair of a batch sized by the batch maxima
+  if (M >= (1 << 23)) return fail(ctx, CVO_E_INVALID, "target clouds are limited to 8388607 points");
   S->L = make_layout(N, M, Kmax, trace_cap, &S->d);
+  {
+    size_t free_b = 0, total_b = 0;
+    const size_t need = S->L.total * (size_t)n_pairs;
+    if (need > ctx->arena_bytes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b + ctx->arena_bytes) {
+      char msg[320];
+      snprintf(msg, sizeof msg,
+               "workspace of %d pair(s) of %d x %d points needs %.1f GiB (candidate bitmap N*M/8 = %.1f GiB per pair, ELL "
+               "%.1f GiB per pair) but %.1f GiB of device memory are free: split the batch or the clouds",
+               n_pairs, N, M, need / 1073741824.0, (double)N * S->d.Mpad / 8.0 / 1073741824.0,
+               (double)S->d.Npad * Kmax * 8.0 / 1073741824.0, (free_b + ctx->arena_bytes) / 1073741824.0);
+      return fail(ctx, CVO_E_NOMEM, msg);
+    }
+  }
   int rc = ensure_workspace(ctx, n_pairs, S->L.total);
   if (rc != CVO_OK) return rc;
   // sub-batches on separate streams (see cvo_ctx): the scan geometry is chosen for one group's launch
@@ -577,10 +624,11 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     }
     st.ell = mode == 0 ? params->ell_init : mode_ell;  // CvoState.cu:30
     st.K = Kmax;                                        // CvoGPU.cu:1385
-    if (mode == 0 && opts && opts->override_state) {
+    if (mode == 0 && opts && opts->override_state) {  // (validated above)
       st.ell = opts->ell0;
       st.K = opts->K0;
     }
+    st.K_last = st.K;
     // the slice bits start clean (k_prep clears a row's bits again before every rebuild)
     HIP_TRY(ctx, hipMemsetAsync(D.rowbits, 0, sizeof(unsigned) * (size_t)(S->N + 4) * S->d.rbw_max, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D.tile_count, 0, sizeof(unsigned long long), ctx->stream));
@@ -615,6 +663,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.npb = S->d.Mpad / PREP_THREADS + (S->d.NGpad * ROWS_PER_GROUP + PREP_THREADS - 1) / PREP_THREADS;
   S->geom.idx16 = M < 65536;
   S->geom.general = dp.use_col || dp.use_sem || dp.use_geotype;
+  S->geom.instr = dp.kernel_clock || dp.phase_ticks;
+  S->geom.verify = dp.verify_lists != 0;
   ctx->last_xorder = sources[0]->h_order;
   ctx->last_groups = S->G;
   ctx->last_pairs = n_pairs;
@@ -1024,6 +1074,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       key.idx16 = S.geom.idx16 ? 1 : 0;
       key.general = S.geom.general ? 1 : 0;
       key.U = U * 256 + lean_U;
+      key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0);
       key.arena = geom[g].arena.base;
       key.stride256 = geom[g].arena.stride256;
       key.Npad = geom[g].arena.Npad;
@@ -1035,10 +1086,18 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       hipGraph_t gr = nullptr;
       HIP_TRY(ctx, hipStreamBeginCapture(geom[g].stream, hipStreamCaptureModeThreadLocal));
       launch_chunk(ctx, geom[g], U, v == 1, lean_U);
-      HIP_TRY(ctx, hipStreamEndCapture(geom[g].stream, &gr));
-      hipError_t e = hipGraphInstantiate(&ctx->graph_exec[g][v], gr, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(gr);
-      if (e != hipSuccess) return fail(ctx, CVO_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+      // (the capture is always ended, whatever the launches reported: a stream left in capture mode would poison
+      // every later call on this context)
+      const hipError_t e_launch = hipGetLastError();
+      hipError_t e = hipStreamEndCapture(geom[g].stream, &gr);
+      if (e == hipSuccess && e_launch != hipSuccess) e = e_launch;
+      if (e == hipSuccess) e = hipGraphInstantiate(&ctx->graph_exec[g][v], gr, nullptr, nullptr, 0);
+      if (gr) (void)hipGraphDestroy(gr);
+      if (e != hipSuccess) {
+        ctx->graph_exec[g][v] = nullptr;
+        for (int q = 0; q < G; q++) (void)hipStreamSynchronize(geom[q].stream);  // other groups may be in flight
+        return fail(ctx, CVO_E_HIP, std::string("graph capture / instantiate: ") + hipGetErrorString(e));
+      }
       ctx->graph_key[g][v] = key;
       return CVO_OK;
     };
@@ -1125,9 +1184,17 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     fprintf(stderr, "[cvo] host: setup %.2f ms, enqueue + wait %.2f ms\n",
             std::chrono::duration<double, std::milli>(t_host1 - t_host0).count(),
             std::chrono::duration<double, std::milli>(t_host2 - t_host1).count());
-  for (int p = 0; p < n_pairs; p++)
-    if (ctx->h_status[0][p] == 3 || ctx->h_status[1][p] == 3)
-      return fail(ctx, CVO_E_HIP, "cvo_align_batch: device-side barrier timed out");
+  for (int p = 0; p < n_pairs; p++) {  // CVO_VERIFY_LISTS: a row of the list path differed from the literal scan
+    const PairState& st = ctx->h_states[p];
+    if (st.verify_err) {
+      char msg[256];
+      snprintf(msg, sizeof msg,
+               "CVO_VERIFY_LISTS: pair %d, iteration %d, row position %d: the list-derived row differs from the literal "
+               "scan (%s)", p, st.verify_k, st.verify_pos,
+               st.verify_what == 1 ? "nonzero count" : (st.verify_what == 2 ? "column" : "value"));
+      return fail(ctx, CVO_E_VERIFY, msg);
+    }
+  }
   if (getenv("CVO_VERBOSE")) {
     long builds = 0, stalls = 0, its = 0;
     for (int p = 0; p < n_pairs; p++) {
@@ -1457,6 +1524,115 @@ int cvo_debug_last_ell(cvo_ctx* ctx, int K, float* mat, int* ind, unsigned int* 
   return CVO_OK;
 }
 
+// gpu_association_to_cpu(A_host, ..., num_neighbors) at the end of align_impl (CvoGPU.cu:1552-1556, CvoGPU_impl.cu:366-427)
+int cvo_align_association(cvo_ctx* ctx, int pair, int* row_ptr, int* col, float* val, size_t capacity, size_t* nnz_out,
+                          int* stride_written, int* stride_read) {
+  if (!ctx || !row_ptr || pair < 0 || pair >= ctx->last_pairs || ctx->last_params.mode != 0)
+    return fail(ctx, CVO_E_INVALID, "cvo_align_association: no align call to export from");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const PairDesc& D = ctx->h_descs[pair];
+  const PairState& st = ctx->h_states[pair];
+  const int N = D.N;
+  const int Kw = st.K_last, Kr = st.K;  // written with / read with
+  if (stride_written) *stride_written = Kw;
+  if (stride_read) *stride_read = Kr;
+  if (nnz_out) *nnz_out = 0;
+  for (int i = 0; i <= N; i++) row_ptr[i] = 0;
+  const bool executed = (st.status ? st.iterations : st.k) > 0 || st.ret == -1;  // at least one se_kernel ran
+  if (!executed || st.nnz == 0) return CVO_OK;  // `if (association_gpu.nonzero_sum == 0) return;`
+  // the last iteration's matrix by position: count, original row index, entries (slot-major)
+  std::vector<unsigned> nzp(N);
+  std::vector<int> ip(N);
+  HIP_TRY(ctx, hipMemcpy(nzp.data(), D.nnz_row, sizeof(unsigned) * (size_t)N, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(ip.data(), D.ip, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+  unsigned mx = 0;
+  for (int q = 0; q < N; q++) mx = std::max(mx, nzp[q]);
+  std::vector<EllEntry> ep((size_t)mx * N);
+  if (mx) HIP_TRY(ctx, hipMemcpy(ep.data(), D.ell, sizeof(EllEntry) * (size_t)mx * N, hipMemcpyDeviceToHost));
+  std::vector<int> pos_of(N, -1);  // original row -> position
+  for (int q = 0; q < N; q++) {
+    if (ip[q] < 0 || ip[q] >= N) return fail(ctx, CVO_E_HIP, "cvo_align_association: corrupt row index");
+    pos_of[ip[q]] = q;
+  }
+  // the reference's row-major buffer entry at flat index f (row stride Kw), defined for f < N * Kw
+  auto buf = [&](size_t f, int* j, float* a) {
+    const size_t r = f / (size_t)Kw, sidx = f % (size_t)Kw;
+    if (r >= (size_t)N) {  // beyond what the last iteration cleared and wrote: leftovers upstream, the row ends here
+      *j = -1;
+      *a = 0.f;
+      return;
+    }
+    const int q = pos_of[r];
+    if (sidx < nzp[q]) {
+      const EllEntry& e = ep[sidx * (size_t)N + q];
+      *j = e.j;
+      *a = e.a;
+    } else {
+      *j = -1;
+      *a = 0.f;
+    }
+  };
+  size_t cnt = 0;
+  for (int i = 0; i < N; i++) {
+    row_ptr[i] = (int)cnt;
+    if (nzp[pos_of[i]] == 0) continue;  // `if (nonzeros[i] > 0)`
+    for (int c = 0; c < Kr; c++) {
+      int j;
+      float a;
+      buf((size_t)i * Kr + c, &j, &a);
+      if (j == -1) break;
+      if (cnt < capacity && col && val) {
+        col[cnt] = j;
+        val[cnt] = a;
+      }
+      cnt++;
+    }
+  }
+  row_ptr[N] = (int)cnt;
+  if (nnz_out) *nnz_out = cnt;
+  if (cnt > capacity) return fail(ctx, CVO_E_NOMEM, "association capacity too small");
+  return CVO_OK;
+}
+
+int cvo_debug_scalar_math(cvo_ctx* ctx, int op, int n, const double* in, double* out) {
+  if (!ctx || !in || !out || n <= 0 || op < 0 || op > 7) return fail(ctx, CVO_E_INVALID, "cvo_debug_scalar_math: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t n_in = op == 7 ? (size_t)n + 2 : 16 * (size_t)n, n_out = op == 7 ? (size_t)n : 16 * (size_t)n;
+  double *d_in = nullptr, *d_out = nullptr;
+  PairState* d_st = nullptr;
+  int rc = CVO_OK;
+  auto cleanup = [&]() {
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (d_st) (void)hipFree(d_st);
+  };
+  if (hipMalloc(&d_in, sizeof(double) * n_in) != hipSuccess || hipMalloc(&d_out, sizeof(double) * n_out) != hipSuccess ||
+      hipMalloc(&d_st, sizeof(PairState)) != hipSuccess) {
+    cleanup();
+    return fail(ctx, CVO_E_NOMEM, "cvo_debug_scalar_math: hipMalloc failed");
+  }
+  hipError_t e = hipMemcpyAsync(d_in, in, sizeof(double) * n_in, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, sizeof(double) * n_out, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d_st, 0, sizeof(PairState), ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_scalar_math, dim3(op == 7 ? 1 : n), dim3(64), 0, ctx->stream, op, n, d_in, d_out, d_st);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) rc = fail(ctx, CVO_E_HIP, std::string("cvo_debug_scalar_math: ") + hipGetErrorString(e));
+  cleanup();
+  return rc;
+}
+
+int cvo_debug_verified_rows(cvo_ctx* ctx, unsigned long long* rows) {
+  if (!ctx || !rows || ctx->last_pairs < 1) return fail(ctx, CVO_E_INVALID, "cvo_debug_verified_rows: bad argument");
+  unsigned long long t = 0;
+  for (int p = 0; p < ctx->last_pairs; p++) t += ctx->h_states[p].verify_rows;
+  *rows = t;
+  return CVO_OK;
+}
+
 int cvo_debug_last_candidates(cvo_ctx* ctx, unsigned long long* out) {
   if (!ctx || !out || ctx->last_pairs < 1) return fail(ctx, CVO_E_INVALID, "cvo_debug_last_candidates: bad argument");
   *out = ctx->h_states[0].ncand;
@@ -1474,6 +1650,7 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
   const bool idx16 = ctx->last_M < 65536;
   const DevParams& dp = ctx->last_params;
   const bool general = dp.use_col || dp.use_sem || dp.use_geotype;
+  const bool instr = dp.kernel_clock || dp.phase_ticks;
   const int nba = (ctx->last_N + ASSOC_THREADS - 1) / ASSOC_THREADS;
   float out[2] = {0.f, 0.f};
   for (int which = 0; which < 2; which++) {
@@ -1482,10 +1659,10 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
         const int p0 = (int)((long)n_pairs * g / G), p1 = (int)((long)n_pairs * (g + 1) / G);
         const ArenaArg A{ctx->arena + ((size_t)ctx->last_stride256 << 8) * (size_t)p0, ctx->last_stride256, ctx->last_Npad};
         if (which == 0)
-          launch_assoc(ctx->stream, idx16, general, nba, p1 - p0, ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0, A,
+          launch_assoc(ctx->stream, idx16, general, instr, nba, p1 - p0, ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0, A,
                        2);
         else
-          launch_coeff(ctx->stream, nba, ctx->last_csplit, p1 - p0, ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0,
+          launch_coeff(ctx->stream, instr, nba, ctx->last_csplit, p1 - p0, ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0,
                        A, 8 | 2 | (getenv("CVO_COEFF_NO_UPDATE") ? 16 : 0));
       }
     };

@@ -555,9 +555,10 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
     D->ip[pos] = D->xorder[rr];
     if (cnt_all > ASSOC_CAP) {
       // more candidates than a list holds (dense regime, e.g. rows sitting on K_max): k_assoc_dense
-      // evaluates these rows against all targets, 64 at a time
-      const int slot = atomicAdd(&D->st->n_ovf, 1);
-      D->ovf_rows[slot] = pos;
+      // evaluates these rows against all targets, 64 at a time.  Only counted here: the list itself is written in
+      // ascending position order by the block that finishes last (below), so that the order in which
+      // k_assoc_dense's waves accumulate their rows never depends on the arrival order of atomics.
+      atomicAdd(&D->st->n_ovf, 1);
     } else {
       const unsigned* rb = D->rowbits + (size_t)rr * rbw;
       int cnt = 0;  // sorted-space positions of the candidates (the mask words come from L1/L2 this time)
@@ -608,14 +609,42 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
   }
   // The block that finishes last validates the list: every block has read `rebuild` by then, and the
   // kernels of the iteration (stream order) see rebuild == 0 <=> bitmap, lists and overflow list are current.
+  __shared__ int s_last_block;
   __syncthreads();
   if (tid == 0) {
     __threadfence();
     const int done = atomicAdd(D->gate, 1);
-    if (done == nblk - 1) {
-      *D->gate = 0;
-      D->st->rebuild = 0;
+    s_last_block = (done == nblk - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last_block) return;
+  // Overflow list in ascending position order (dense regime: every row overflows, the list is the identity and
+  // k_assoc_dense does not read it).  The counts of the other blocks are read coherently: they were written inside
+  // this launch, possibly on another XCD (each writer fenced before its gate increment).
+  const int n_ovf = __hip_atomic_load(&D->st->n_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (n_ovf > 0 && !D->st->all_dense) {
+    __shared__ int s_wave_cnt[LIST_THREADS / 64];
+    int base = 0;
+    for (int p0 = 0; p0 < N; p0 += LIST_THREADS) {
+      const int p = p0 + tid;
+      const bool ov = p < N && __hip_atomic_load(D->cand_cnt + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > ASSOC_CAP;
+      const unsigned long long m = __ballot(ov);
+      if ((tid & 63) == 0) s_wave_cnt[tid >> 6] = __builtin_popcountll(m);
+      __syncthreads();
+      int off = base, tot = 0;
+#pragma unroll
+      for (int w = 0; w < LIST_THREADS / 64; w++) {
+        off += (w < (tid >> 6)) ? s_wave_cnt[w] : 0;
+        tot += s_wave_cnt[w];
+      }
+      if (ov) D->ovf_rows[off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = p;
+      base += tot;
+      __syncthreads();
     }
+  }
+  if (tid == 0) {
+    *D->gate = 0;
+    D->st->rebuild = 0;
   }
 }
 
@@ -725,7 +754,7 @@ struct AssocShared {
   unsigned long long cnt[ASSOC_THREADS / 64][4];
 };
 
-template <typename IdxT, int ASSOC_CAP, bool GENERAL>
+template <typename IdxT, int ASSOC_CAP, bool GENERAL, bool INSTR>
 __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* __restrict__ D, const PairState* st,
                                             AssocShared& S, const int bx, const AssocRowHead& head) {
   const int N = D->N;
@@ -752,7 +781,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
       // flight while the current one is evaluated
       int j1 = cnt > 0 ? j1s : 0;
       int j2 = cnt > 1 ? j2s : 0;
-      tt1 = __builtin_readcyclecounter();
+      if (INSTR) tt1 = __builtin_readcyclecounter();
       float4 y1 = D->y4[j1];
       for (int k = 0; k < cnt && A.nnz < (unsigned)K; k++) {
         const int j = j1;
@@ -763,10 +792,10 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
         visit_pair<GENERAL>(P, D, pose, i, pos, N, r, pxe, j, ycur, A);
       }
       D->nnz_row[pos] = A.nnz;
-      tt2 = __builtin_readcyclecounter();
+      if (INSTR) tt2 = __builtin_readcyclecounter();
     }
   }
-  if (P.phase_ticks && threadIdx.x == 0) {
+  if (INSTR && P.phase_ticks && threadIdx.x == 0) {
     g_phase_ticks[0][blockIdx.x & 8191][1] = tt1;
     g_phase_ticks[0][blockIdx.x & 8191][2] = tt2;
   }
@@ -813,13 +842,15 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
   }
 }
 
-template <typename IdxT, int ASSOC_CAP, bool GENERAL>
+// INSTR = true is the instrumented instantiation (CVO_KERNEL_CLOCK / CVO_PHASE_TICKS); the production one carries no
+// time stamps at all.
+template <typename IdxT, int ASSOC_CAP, bool GENERAL, bool INSTR>
 __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restrict__ descs,
                                                           const DevParams* __restrict__ Pp,
                                                           const PairState* __restrict__ states,
                                                           const char* __restrict__ arena, int lean_nblk_pairs,
                                                           unsigned stride256, int Npad) {
-  const unsigned long long tt0 = __builtin_readcyclecounter();
+  const unsigned long long tt0 = INSTR ? __builtin_readcyclecounter() : 0ull;
   // one packed argument keeps everything inside the preloaded kernel-argument registers
   const int lean = lean_nblk_pairs & 0xf, nblk = (lean_nblk_pairs >> 4) & 0xffff, n_pairs = (int)((unsigned)lean_nblk_pairs >> 20);
   PairBlock pb;
@@ -858,16 +889,16 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restr
   // rows for k_assoc_dense, does not advance; it waits for the next rebuild opportunity / for the host to
   // switch its group to the full graph (k_coeff skips it too and tells the host)
   if ((lean & 1) && (rebuild_v || n_ovf_v > 0)) return;
-  pair_clock_begin(P.kernel_clock && lean == 1 && pb.bx == 0, const_cast<PairState*>(st), 0);
+  pair_clock_begin(INSTR && P.kernel_clock && lean == 1 && pb.bx == 0, const_cast<PairState*>(st), 0);
   __shared__ AssocShared S;
-  assoc_phase<IdxT, ASSOC_CAP, GENERAL>(P, D, st, S, pb.bx, head);
+  assoc_phase<IdxT, ASSOC_CAP, GENERAL, INSTR>(P, D, st, S, pb.bx, head);
   // lean graph: nothing else adds to the flow, the twist of the iteration can be finished here
   if ((lean & 3) && P.mode == 0) {  // (bit 1: the timing replay includes it)
-    const unsigned long long clk0 = pair_clock_peek(P.kernel_clock && lean == 1, st, 0);
+    const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && lean == 1, st, 0);
     const bool last = flow_gate(D, nblk, nblk);
     if (last && threadIdx.x == 0 && clk0) D->st->clk_last_assoc = pair_clock_ticks(clk0);  // added up by the update
   }
-  if (P.phase_ticks && threadIdx.x == 0) {
+  if (INSTR && P.phase_ticks && threadIdx.x == 0) {
     g_phase_ticks[0][blockIdx.x & 8191][0] = tt0;
     g_phase_ticks[0][blockIdx.x & 8191][3] = __builtin_readcyclecounter();
   }
@@ -891,6 +922,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
   const int K = st->K;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n_ovf = st->n_ovf;
+  const bool all_dense = st->all_dense != 0;
   __shared__ float2 s_hits[DENSE_WAVES][128][6];  // per wave: the hits of one step, compacted ({flow term, value} per component)
   double red[7] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long nnz_sum = 0;
@@ -898,7 +930,8 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
   if (n_ovf > 0) {
     const Pose pose = load_pose(st);
     for (int q = blockIdx.x * DENSE_WAVES + wave; q < n_ovf; q += DENSE_BLOCKS * DENSE_WAVES) {
-      const int r_sorted = D->ovf_rows[q];  // a position of k_list's ordering (all per-row outputs are stored by position)
+      // a position of k_list's ordering (all per-row outputs are stored by position); dense regime: every row
+      const int r_sorted = all_dense ? q : D->ovf_rows[q];
       const int i = D->ip[r_sorted];
       const float4 x = D->xp4[r_sorted];
       const RowData r = make_row(P, x, st->ell);
@@ -1267,6 +1300,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
       st->ncand = s_n[2];
       st->ncand_total += s_n[2];
       st->noverflow = s_n[3];
+      st->K_last = st->K;  // the stride upstream wrote this iteration's A matrix with (gpu_association_to_cpu)
       if (P.mode != 0) {  // single evaluation: A_sum (SparseKernelMat.cu:62-68)
         st->asum = s_c[0];
         done = 1;
@@ -1384,8 +1418,9 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
       }
       const float ymax = D.ymax;
       const float slack = 1e-5f * (ymax + sqrtf(tn) + 1.f);  // rounding of the two transform evaluations
-      const float moved = (sqrtf(dr) * ymax + sqrtf(dt)) * 1.001f + slack;
-      const float step_move = sqrtf(dr1) * ymax + sqrtf(dt1);  // bound on what this iteration alone moved
+      float moved = (sqrtf(dr) * ymax + sqrtf(dt)) * 1.001f + slack;
+      float step_move = sqrtf(dr1) * ymax + sqrtf(dt1);  // bound on what this iteration alone moved
+      if (P.debug_no_motion_bound) moved = step_move = 0.f;  // (tests: a deliberately broken bound, see DevParams)
       // the list is unusable for the coming iteration ...
       bool rebuild = INIT || P.mode != 0 || !(moved <= st->skin) || ell_next > st->ell_build ||
                      ell_next < P.rebuild_shrink * st->ell_build;
@@ -1492,11 +1527,12 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
 // cross blocks inside the launch, hence the coherent stores / loads (st_x / ld_x).
 // flags: bit 0 = lean graph, the rest see update_body.
 // ------------------------------------------------------------------------------------------
+template <bool INSTR>
 __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restrict__ descs,
                                                          const DevParams* __restrict__ Pp, PairState* states,
                                                          const char* __restrict__ arena, int flags, int nblk_split_pairs,
                                                          unsigned stride256, int Npad) {
-  const unsigned long long tt0 = __builtin_readcyclecounter();
+  const unsigned long long tt0 = INSTR ? __builtin_readcyclecounter() : 0ull;
   // grid: per pair nblk row blocks x launch_split slices of the ELL slots; a pair uses csplit <= launch_split of them
   const int nblk = nblk_split_pairs & 0x3fff, launch_split = (nblk_split_pairs >> 14) & 0x3f,
             n_pairs = (int)((unsigned)nblk_split_pairs >> 20);
@@ -1554,7 +1590,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
   }
   const DevParams P = *Pp;
   if (P.mode != 0) return;
-  pair_clock_begin(P.kernel_clock && !replay && pb.bx == 0 && cq == 0, st, 1);
+  pair_clock_begin(INSTR && P.kernel_clock && !replay && pb.bx == 0 && cq == 0, st, 1);
   const int epoch = st_in->epoch;  // launches of this kernel the pair has completed (bumped by the updating block)
   __shared__ union {
     CoeffShared c;
@@ -1581,16 +1617,16 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     twist[c] = Mu.omega[c];
     twist[3 + c] = Mu.v[c];
   }
-  const unsigned long long tt1 = __builtin_readcyclecounter();
+  const unsigned long long tt1 = INSTR ? __builtin_readcyclecounter() : 0ull;
   coeff_rows<true>(P, D, st_in, S.c, Mu, head, pb.bx, cq, csplit);
-  const unsigned long long tt2 = __builtin_readcyclecounter();
+  const unsigned long long tt2 = INSTR ? __builtin_readcyclecounter() : 0ull;
   // the scalar state, for whichever block turns out to be the last one: in flight while the counter round trip runs
   unsigned hot_regs[2] = {0u, 0u};
   if (threadIdx.x < 64) {
     hot_regs[0] = reinterpret_cast<const unsigned*>(st)[threadIdx.x];
     if (threadIdx.x + 64 < HOT_DWORDS) hot_regs[1] = reinterpret_cast<const unsigned*>(st)[threadIdx.x + 64];
   }
-  const unsigned long long clk0 = pair_clock_peek(P.kernel_clock && !replay, st, 1);
+  const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && !replay, st, 1);
   const UpdDesc upd = load_upd_desc(D);
   const int n_flow_upd = (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partial stores before the counter, see flow_gate
@@ -1601,8 +1637,8 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     s_last = replay ? (done % nwork == nwork - 1) : (done == (epoch + 1) * nwork - 1);
   }
   __syncthreads();
-  const unsigned long long tt3 = __builtin_readcyclecounter();
-  if (P.phase_ticks && threadIdx.x == 0) {
+  const unsigned long long tt3 = INSTR ? __builtin_readcyclecounter() : 0ull;
+  if (INSTR && P.phase_ticks && threadIdx.x == 0) {
     g_phase_ticks[1][blockIdx.x & 4095][0] = tt0;
     g_phase_ticks[1][blockIdx.x & 4095][1] = tt1;
     g_phase_ticks[1][blockIdx.x & 4095][2] = tt2;
@@ -1610,10 +1646,141 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
   }
   if (!s_last || (flags & 16)) return;  // (bit 4: cost breakdown of cvo_debug_time_kernels, coefficient phase only)
   update_body<false, true>(upd, P, flags | 4, n_flow_upd, S.u, twist, hot_regs, clk0);
-  if (P.phase_ticks && threadIdx.x == 0) {
+  if (INSTR && P.phase_ticks && threadIdx.x == 0) {
     g_phase_ticks[1][4096 + pb.pair][0] = tt0;
     g_phase_ticks[1][4096 + pb.pair][1] = tt3;
     g_phase_ticks[1][4096 + pb.pair][2] = __builtin_readcyclecounter();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_verify (CVO_VERIFY_LISTS=1): the self-check of the candidate-list reuse.  After the association of an iteration
+// (k_assoc over the cached lists [+ k_assoc_dense]) one wave per row re-derives the row with the reference's literal
+// ordered scan over ALL targets (CvoGPU.cu:522-590) at the pose / ell / K of that iteration and compares it with the
+// row the lists produced: nonzero count, every column, every value bit for bit.  A list that had lost a pair - a skin
+// too small for the motion since the build, a cull that was not conservative - shows up as a missing or shifted entry.
+// The first mismatch of a pair is latched in its state (sticky) and turns the call's return code into CVO_E_VERIFY.
+// Independent of the oracle and of the clouds' size: the tests run it at 10k x 10k over the fast-moving first iterations.
+// ------------------------------------------------------------------------------------------
+template <bool GENERAL>
+__global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
+                                                const int* __restrict__ status, int lean) {
+  if (status[blockIdx.y] != 0) return;
+  const PairDesc* __restrict__ D = descs + blockIdx.y;
+  PairState* st = D->st;
+  if (lean && (st->rebuild || st->n_ovf > 0)) return;  // the pair did not advance in this slot (see k_assoc)
+  const DevParams P = *Pp;
+  const int N = D->N, M = D->M, K = st->K;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const Pose pose = load_pose(st);
+  unsigned checked = 0;
+  for (int pos = blockIdx.x * 4 + wave; pos < N; pos += gridDim.x * 4) {
+    const int i = D->ip[pos];
+    const float4 x = D->xp4[pos];
+    const RowData r = make_row(P, x, st->ell);
+    unsigned nnz = 0;
+    int err = 0;
+    for (int j0 = 0; j0 < M && nnz < (unsigned)K; j0 += 64) {
+      const int j = j0 + lane;
+      float a = 0.f;
+      float4 yt;
+      bool ok = false;
+      if (j < M) ok = eval_pair<GENERAL>(P, D, pose, i, r, j, D->y4[j], a, yt) && (a > P.sp_thres);
+      const unsigned long long m = __ballot(ok);
+      const unsigned rank = nnz + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      const bool keep = ok && rank < (unsigned)K;
+      if (keep) {
+        const EllEntry e = D->ell[(size_t)rank * N + pos];
+        if (e.j != j)
+          err = 2;
+        else if (__float_as_uint(e.a) != __float_as_uint(a))
+          err = 3;
+      }
+      nnz += (unsigned)__builtin_popcountll(__ballot(keep));
+    }
+    if (D->nnz_row[pos] != nnz) err = 1;  // (also catches entries the list path has and the scan does not)
+    if (__ballot(err != 0) != 0ull) {
+      int e = err;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) e = max(e, __shfl_xor(e, o));
+      if (lane == 0 && atomicCAS(&st->verify_err, 0, 1) == 0) {
+        st->verify_k = st->k;
+        st->verify_pos = pos;
+        st->verify_what = (D->nnz_row[pos] != nnz) ? 1 : e;
+      }
+    }
+    checked++;
+  }
+  if (lane == 0 && checked) atomicAdd(&st->verify_rows, (unsigned long long)checked);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scalar_math (cvo_debug_scalar_math): the device's scalar restatements of the reference's host-side maths, run
+// on caller-supplied inputs so that the tests can pin THE DEVICE CODE ITSELF against numpy / scipy (the oracle
+// carries the same text for some of them, so "GPU == oracle" alone only shows that two compilers agree).
+// One wave per item; item q reads in[16 q ..] and writes out[16 q ..].
+//   op 0  cubic_roots            in: p0..p3                      out: re[3], im[3]
+//   op 1  cubic_roots_wave       (the three-lane search used by the update)  same layout
+//   op 2  select_step<false>     in: B, C, D, E, min_step, max_step          out: step
+//   op 3  select_step<true>      same
+//   op 4  exp_sek3               in: xi[6], dt                   out: 3x4 row-major
+//   op 5  se3_log_norm           in: R[9] row-major, t[3]        out: norm
+//   op 6  update_tf              in: R[9], T[3]                  out: Rinv[9], Tinv[3]
+//   op 7  indicator windows      ONE item: in = {window, threshold, x_0 .. x_{n-1}}, out[k] = decision of sample k
+//                                (indicator_update on a scratch PairState, exactly as the update calls it)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_scalar_math(int op, int n, const double* __restrict__ in, double* __restrict__ out,
+                                                    PairState* scratch) {
+  const int lane = threadIdx.x;
+  if (op == 7) {
+    if (blockIdx.x != 0 || lane != 0) return;
+    const int window = (int)in[0];
+    const float thr = (float)in[1];
+    for (int k = 0; k < n; k++) {
+      const float e_front = scratch->eq[scratch->e_head], s_front = scratch->sq[scratch->s_head];
+      out[k] = indicator_update(scratch, scratch->sq, scratch->eq, (float)in[2 + k], window, thr, e_front, s_front) ? 1.0 : 0.0;
+    }
+    return;
+  }
+  const double* a = in + 16 * (size_t)blockIdx.x;
+  double* o = out + 16 * (size_t)blockIdx.x;
+  if (op == 0 || op == 1) {
+    const double coef[4] = {a[0], a[1], a[2], a[3]};
+    double re[3], im[3];
+    if (op == 0)
+      cubic_roots(coef, re, im);
+    else
+      cubic_roots_wave(coef, re, im);
+    if (lane == 0)
+      for (int q = 0; q < 3; q++) {
+        o[q] = re[q];
+        o[3 + q] = im[q];
+      }
+  } else if (op == 2 || op == 3) {
+    const float st = op == 2 ? select_step<false>(a[0], a[1], a[2], a[3], (float)a[4], (float)a[5])
+                             : select_step<true>(a[0], a[1], a[2], a[3], (float)a[4], (float)a[5]);
+    if (lane == 0) o[0] = (double)st;
+  } else if (op == 4) {
+    float xi[6], dt = (float)a[6], res[12];
+    for (int q = 0; q < 6; q++) xi[q] = (float)a[q];
+    exp_sek3(xi, dt, res);
+    if (lane == 0)
+      for (int q = 0; q < 12; q++) o[q] = (double)res[q];
+  } else if (op == 5) {
+    double R[9], t[3];
+    for (int q = 0; q < 9; q++) R[q] = a[q];
+    for (int q = 0; q < 3; q++) t[q] = a[9 + q];
+    const double v = se3_log_norm(R, t);
+    if (lane == 0) o[0] = v;
+  } else if (op == 6) {
+    float R[9], T[3], Ri[9], Ti[3];
+    for (int q = 0; q < 9; q++) R[q] = (float)a[q];
+    for (int q = 0; q < 3; q++) T[q] = (float)a[9 + q];
+    update_tf(R, T, Ri, Ti);
+    if (lane == 0) {
+      for (int q = 0; q < 9; q++) o[q] = (double)Ri[q];
+      for (int q = 0; q < 3; q++) o[9 + q] = (double)Ti[q];
+    }
   }
 }
 
