@@ -84,10 +84,22 @@ def _check_association(oracle, P, src, tgt, init, expect_same_stride=None):
     if expect_same_stride is not None:
         assert (kw == kr) == expect_same_stride
     rows, c, v = _assoc_triplets(rp, col, val)
-    assert np.array_equal(rows, o["row"]) and np.array_equal(c, o["col"])
-    assert np.allclose(v, o["val"], rtol=2e-7, atol=0)
-    inl = np.nonzero(np.diff(rp) > 0)[0]
-    assert np.array_equal(inl, o["source_inliers"][:len(inl)]) or kw != kr
+    orow, ocol, oval = o["row"], o["col"], o["val"]
+    if kr > kw:
+        # The loop ran out of iterations right after num_neighbors GREW: upstream reads rows * kr entries of buffers
+        # whose last iteration defined only the first rows * kw; what lies beyond are leftovers of earlier iterations
+        # (the literal oracle keeps the buffers' history and returns them, the C-ABI ends the row there: DESIGN.md
+        # "Association export").  Rows read entirely inside the defined part must still agree.
+        n = src.num_points()
+        inside = (orow.astype(np.int64) + 1) * kr <= n * kw
+        assert not inside.all() or len(orow) == len(rows)
+        gi = (rows.astype(np.int64) + 1) * kr <= n * kw
+        orow, ocol, oval = orow[inside], ocol[inside], oval[inside]
+        rows, c, v = rows[gi], c[gi], v[gi]
+    assert np.array_equal(rows, orow) and np.array_equal(c, ocol)
+    assert np.allclose(v, oval, rtol=2e-7, atol=0)
+    if kw == kr:
+        assert np.array_equal(np.nonzero(np.diff(rp) > 0)[0], o["source_inliers"])
     return g, o, (rp, col, val, kw, kr)
 
 
