@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--max-iterations", type=int, default=0, help="debug only: cap the optimiser loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=400)
+    ap.add_argument("--no-single-pair", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -176,15 +177,27 @@ def main():
         valu_peak_pairs = FP32_VALU_PEAK_TFLOPS * 1e12 / C_CULL_FLOPS
         executed_tests = float(tiles) * rpt * tpt + 2.0 * float(cand_evals)   # scan tiles + both passes over the lists
         executed_frac = executed_tests / (pair_tests_iter * max(float(iters_total), 1.0))
-        traffic = {}
+        # HBM traffic per launch comes from PMC passes (rocprofv3 --pmc, scripts/profile_round.sh), which cannot run
+        # inside this process: profiles/kernel_traffic.json carries them together with the hash of the kernel sources they
+        # were measured on, and is only reported while that hash matches the library that runs here (else null).
+        traffic, traffic_note = {}, "profiles/kernel_traffic.json missing"
         tpath = os.path.join(ROOT, "profiles", "kernel_traffic.json")
         if os.path.exists(tpath):
             try:
+                from unified_cvo_amd import build as hipbuild
                 tj = json.load(open(tpath))
-                if tj.get("points") == n and tj.get("pairs") == ppl:
+                if tj.get("source_sha") != hipbuild.source_hash():
+                    traffic_note = (f"stale: measured on kernel sources {tj.get('source_sha')}, running {hipbuild.source_hash()} "
+                                    "(re-run scripts/profile_round.sh)")
+                elif tj.get("points") != n or tj.get("pairs") != ppl:
+                    traffic_note = "measured on another workload shape"
+                else:
                     traffic = tj.get("hbm_bytes_per_launch", {})
-            except Exception:
-                traffic = {}
+                    traffic_note = tj.get("source", "")
+            except Exception as e:  # noqa: BLE001
+                traffic_note = f"unreadable: {e}"
+        if not traffic:
+            log(f"[bench] roofline.traffic = null ({traffic_note})")
 
         def kernel_entry(name, ms, share, alone_ms=None):
             gbs = bytes_pass / (ms * 1e-3) / 1e9
@@ -198,7 +211,7 @@ def main():
         dom = kernel_entry("cvo_dev::k_coeff", coeff_ms, 1.0, coeff_alone_ms)
         roofline = {
             "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dom["frac"], "traffic": dom["traffic"],
+            "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_note,
             "algorithmic_bytes_per_launch": bytes_pass, "avg_launch_ms": dom["avg_launch_ms"],
             "alone_on_gpu_launch_ms": dom["alone_on_gpu_launch_ms"], "launches_clocked": int(clocked),
             "pairs_per_launch": ppl, "sub_batches": n_groups, "timed_at_iteration": mid_iters,
@@ -261,6 +274,37 @@ def main():
             d = float(np.max(np.abs(g.transform - o["transform"])))
             log(f"[bench] parity of the sample ({it} iterations): pose max|d| = {d:.2e}")
             cpu_baseline["sample_parity_max_abs"] = d
+        # ---- what a single align() costs (the reference's own use: frame-to-frame tracking, one pair at a time):
+        # BASELINE.json configs 2, 3, 4 and the 10k shape of config 2, one pair in flight, hipEvent time of the loop
+        single_pair = []
+        if world == 1 and args.max_iterations <= 0 and not args.no_single_pair:
+            for name, builder, kw2 in (("config2: 5k x 5k xyz", cases.config2, dict(n=5000)),
+                                       ("config2 shape at 10k x 10k xyz", cases.config2, dict(n=10000)),
+                                       ("config3: 10k x 10k + 5-channel colour", cases.config3, dict(n=10000)),
+                                       ("config4: 10k x 10k + colour + 19-class semantics, warm start", cases.config4, dict(n=10000))):
+                Pc, a_, b_, init_ = builder(**kw2)
+                gsp = CvoGPU(params=Pc, device=local_rank)
+                da, db = gsp.upload(a_), gsp.upload(b_)
+                gsp.align(da, db, init_, max_iterations=50)          # graphs instantiated, workspace allocated
+                best = None
+                for _ in range(3):
+                    r = gsp.align(da, db, init_)
+                    if best is None or r.seconds < best.seconds:
+                        best = r
+                single_pair.append({"config": name, "iterations": best.iterations, "ret": best.ret,
+                                    "align_ms": round(best.seconds * 1e3, 4),
+                                    "ms_per_iter": round(best.seconds * 1e3 / max(best.iterations, 1), 6)})
+                da.free()
+                db.free()
+                gsp.close()
+                log(f"[bench] single pair, {name}: {best.iterations} iterations, {best.seconds*1e3:.2f} ms "
+                    f"({best.seconds*1e6/max(best.iterations,1):.2f} us/iteration)")
+        upload_ms_per_cloud = t_h2d * 1e3 / max(2 * len(host_clouds), 1)
+        pcie_inclusive = {"value": aligns / (elapsed + args.steps * t_h2d), "unit": "align/s",
+                          "upload_ms_per_cloud": round(upload_ms_per_cloud, 4), "upload_threads": available_cpus(),
+                          "note": "every step re-uploads its 2 x pairs_per_gpu clouds (spatial ordering + one H2D copy "
+                                  "per cloud) before solving; `value` above has them resident, as registration_seconds "
+                                  "of the reference excludes its H2D copies"}
         out = {
             "metric": "frame-pair align()/sec, 10k x 10k geometric clouds", "value": value, "unit": "align/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -271,7 +315,8 @@ def main():
                                    f"{mean_iters:.0f} optimiser iterations per align()",
                        "pairs_per_gpu": B, "points": n, "iterations_per_align": mean_iters,
                        "parallelism": f"pairs sharded {B}/GPU over {world} GPU(s); one RCCL all-gather of poses per step"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "single_pair": single_pair,
+            "pcie_inclusive": pcie_inclusive,
         }
         h2d_rate = (2 * n * 16 * 1.0) * B / max(t_h2d, 1e-9) / 1e9
         log(f"[bench] inputs: generated in {t_gen:.2f}s, uploaded in {t_h2d:.3f}s ({h2d_rate:.2f} GB/s incl. host-side k-d ordering on {available_cpus()} threads); "

@@ -1,5 +1,6 @@
 // cvo::CvoGPU over the C-ABI (see include/UnifiedCvo/cvo/CvoGPU.hpp).
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -67,7 +68,65 @@ void fill_association(cvo_ctx* ctx, const cvo_params_t& p, cvo_cloud* s, cvo_clo
   a.target_inliers = a.pairs.col;
 }
 
+// The Association align() exports (upstream CvoGPU.cu:1552-1556 -> gpu_association_to_cpu, CvoGPU_impl.cu:366-427):
+// the kernel matrix of the loop's LAST EXECUTED iteration, which is still resident in the context.
+void fill_align_association(cvo_ctx* ctx, int n_source, int n_target, Association& a) {
+  a.source_inliers.clear();
+  a.target_inliers.clear();
+  a.pairs.rows = n_source;
+  a.pairs.cols = n_target;
+  a.pairs.row_ptr.assign(n_source + 1, 0);
+  size_t nnz = 0;
+  int rc = cvo_align_association(ctx, 0, a.pairs.row_ptr.data(), nullptr, nullptr, 0, &nnz, nullptr, nullptr);
+  if (rc != CVO_E_NOMEM) check(ctx, rc, "cvo_align_association");
+  a.pairs.col.assign(nnz, 0);
+  a.pairs.val.assign(nnz, 0.f);
+  if (nnz)
+    check(ctx, cvo_align_association(ctx, 0, a.pairs.row_ptr.data(), a.pairs.col.data(), a.pairs.val.data(), nnz, &nnz,
+                                     nullptr, nullptr),
+          "cvo_align_association");
+  for (int i = 0; i < n_source; i++)
+    if (a.pairs.row_ptr[i + 1] > a.pairs.row_ptr[i]) a.source_inliers.push_back(i);
+  a.target_inliers = a.pairs.col;
+}
+
 }  // namespace
+
+std::vector<CvoPoint> CvoPointCloud_to_cvo_points(const CvoPointCloud& pc) {
+  const int n = pc.num_points();
+  std::vector<CvoPoint> out((size_t)n);
+  const MatXf& F = pc.features();
+  const MatXf& L = pc.labels();
+  const std::vector<float>& g = pc.geometric_types();
+  for (int i = 0; i < n; i++) {
+    CvoPoint p{};
+    p.x = pc.positions()[i][0];
+    p.y = pc.positions()[i][1];
+    p.z = pc.positions()[i][2];
+    p.data_w = 1.f;
+    if (F.rows() == n)
+      for (int c = 0; c < 5 && c < F.cols(); c++) p.features[c] = F(i, c);
+    if (F.rows() == n && F.cols() >= 3) {  // r, g, b bytes (CvoGPU_impl.cu:229-234)
+      const unsigned r = (unsigned)std::min(255.0, (double)F(i, 0) * 255.0), gg = (unsigned)std::min(255.0, (double)F(i, 1) * 255.0),
+                     b = (unsigned)std::min(255.0, (double)F(i, 2) * 255.0);
+      p.rgba = (r << 16) | (gg << 8) | b;
+    }
+    if (pc.num_classes() > 0 && L.rows() == n) {
+      int best = 0;
+      for (int c = 0; c < pc.num_classes() && c < 19; c++) {
+        p.label_distribution[c] = L(i, c);
+        if (L(i, c) > L(i, best)) best = c;
+      }
+      p.label = best;
+    }
+    if (g.size() >= 2 * (size_t)i + 2) {
+      p.geometric_type[0] = g[2 * (size_t)i];
+      p.geometric_type[1] = g[2 * (size_t)i + 1];
+    }
+    out[(size_t)i] = p;
+  }
+  return out;
+}
 
 CvoGPU::CvoGPU(const std::string& f, int device) {
   std::vector<std::string> warnings;
@@ -99,11 +158,11 @@ int CvoGPU::align(const CvoPointCloud& source_points, const CvoPointCloud& targe
   transform = out;
   if (registration_seconds) *registration_seconds = info.seconds;
   if (params.is_exporting_association && association)  // upstream CvoGPU.cu:1552-1556
-    fill_association(ctx, params, s.h, t.h, out.inverse_rigid(), info.final_ell, *association);
+    fill_align_association(ctx, source_points.num_points(), target_points.num_points(), *association);
   return rc;
 }
 
-int CvoGPU::align(const void* src_pts, int n_source, const void* tgt_pts, int n_target, const Mat4f& init,
+int CvoGPU::align(const CvoPoint* src_pts, int n_source, const CvoPoint* tgt_pts, int n_target, const Mat4f& init,
                   Mat4f& transform, Association* association, double* registration_seconds) const {
   if (n_source == 0 || n_target == 0) return 0;
   DeviceCloud s, t;
@@ -115,9 +174,30 @@ int CvoGPU::align(const void* src_pts, int n_source, const void* tgt_pts, int n_
   check(ctx, rc, "cvo_align");
   transform = out;
   if (registration_seconds) *registration_seconds = info.seconds;
-  if (params.is_exporting_association && association)
-    fill_association(ctx, params, s.h, t.h, out.inverse_rigid(), info.final_ell, *association);
+  if (params.is_exporting_association && association) fill_align_association(ctx, n_source, n_target, *association);
   return rc;
+}
+
+float CvoGPU::inner_product_gpu(const CvoPoint* src_pts, int n_source, const CvoPoint* tgt_pts, int n_target, const Mat4f& T,
+                                float ell) const {
+  if (n_source == 0 || n_target == 0) return 0.f;
+  DeviceCloud s, t;
+  check(ctx, cvo_cloud_upload_aos192(ctx, n_source, src_pts, &s.h), "cvo_cloud_upload_aos192");
+  check(ctx, cvo_cloud_upload_aos192(ctx, n_target, tgt_pts, &t.h), "cvo_cloud_upload_aos192");
+  float v = 0;
+  check(ctx, cvo_inner_product(ctx, &params, s.h, t.h, T.data(), ell, &v), "cvo_inner_product");
+  return v;
+}
+
+float CvoGPU::function_angle(const CvoPoint* src_pts, int n_source, const CvoPoint* tgt_pts, int n_target, const Mat4f& T,
+                             float ell, bool is_approximate) const {
+  if (n_source == 0 || n_target == 0) return 0.f;  // upstream CvoGPU.cu:1855-1857
+  DeviceCloud s, t;
+  check(ctx, cvo_cloud_upload_aos192(ctx, n_source, src_pts, &s.h), "cvo_cloud_upload_aos192");
+  check(ctx, cvo_cloud_upload_aos192(ctx, n_target, tgt_pts, &t.h), "cvo_cloud_upload_aos192");
+  float v = 0;
+  check(ctx, cvo_function_angle(ctx, &params, s.h, t.h, T.data(), ell, is_approximate ? 1 : 0, &v), "cvo_function_angle");
+  return v;
 }
 
 std::vector<int> CvoGPU::align_batch(const std::vector<const CvoPointCloud*>& sources,
@@ -162,8 +242,19 @@ float CvoGPU::inner_product_gpu(const CvoPointCloud& a, const CvoPointCloud& b, 
 float CvoGPU::function_angle(const CvoPointCloud& a, const CvoPointCloud& b, const Mat4f& T, float ell,
                              bool is_approximate, bool is_gpu) const {
   if (a.num_points() == 0 || b.num_points() == 0) return 0.f;
-  if (!is_gpu)  // upstream's is_gpu=false routes to inner_product_cpu (kd-tree, different semantics): out of scope
-    throw std::runtime_error("function_angle(is_gpu=false) is out of scope; see DESIGN.md");
+  if (!is_gpu) {  // upstream CvoGPU.cu:1827-1843: the host inner product in all three places
+    const float fxfz = inner_product_cpu(a, b, T, ell);
+    float fx_norm, fz_norm;
+    if (is_approximate) {
+      fx_norm = std::sqrt((float)a.num_points());
+      fz_norm = std::sqrt((float)b.num_points());
+    } else {
+      const Mat4f I = Mat4f::Identity();
+      fx_norm = std::sqrt(inner_product_cpu(a, a, I, ell));
+      fz_norm = std::sqrt(inner_product_cpu(b, b, I, ell));
+    }
+    return fxfz / (fx_norm * fz_norm);
+  }
   DeviceCloud s, t;
   upload(ctx, a, s);
   upload(ctx, b, t);

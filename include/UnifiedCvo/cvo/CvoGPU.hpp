@@ -1,13 +1,15 @@
 // cvo::CvoGPU for MI355X: the public API of upstream include/UnifiedCvo/cvo/CvoGPU.hpp:49-229 (pairwise
 // overloads) over the C-ABI of cvo_hip.h.  Differences forced by the missing dependencies: Mat4f instead
-// of Eigen::Matrix4f (same 16-float column-major layout), the 192-byte CvoPoint array instead of
-// pcl::PointCloud<CvoPoint>.  The multi-frame overloads (Ceres IRLS) are out of scope.
+// of Eigen::Matrix4f (same 16-float column-major layout; UnifiedCvo/eigen_interop.hpp converts where Eigen exists),
+// an array of the 192-byte CvoPoint record instead of pcl::PointCloud<CvoPoint> (UnifiedCvo/pcl_interop.hpp forwards
+// pcl clouds where PCL exists).  The multi-frame overloads (Ceres IRLS) are out of scope.
 #pragma once
 #include <string>
 #include <vector>
 
 #include "cvo/Association.hpp"
 #include "cvo/CvoParams.hpp"
+#include "utils/CvoPoint.hpp"
 #include "utils/CvoPointCloud.hpp"
 #include "utils/data_type.hpp"
 
@@ -30,8 +32,8 @@ class CvoGPU {
   int align(const CvoPointCloud& source_points, const CvoPointCloud& target_points,
             const Mat4f& T_target_frame_to_source_frame, Mat4f& transform, Association* association = nullptr,
             double* registration_seconds = nullptr) const;
-  // pcl overload: n records of the 192-byte AoS CvoPoint (PointSegmentedDistribution<5,19>).
-  int align(const void* source_cvo_points, int n_source, const void* target_cvo_points, int n_target,
+  // pcl overload (upstream CvoGPU.hpp:91-99): n records of the 192-byte AoS CvoPoint (PointSegmentedDistribution<5,19>).
+  int align(const CvoPoint* source_cvo_points, int n_source, const CvoPoint* target_cvo_points, int n_target,
             const Mat4f& T_target_frame_to_source_frame, Mat4f& transform, Association* association = nullptr,
             double* registration_seconds = nullptr) const;
 
@@ -44,6 +46,16 @@ class CvoGPU {
                        const Mat4f& T_target_frame_to_source_frame, float ell, bool is_approximate = true,
                        bool is_gpu = true) const;
   float inner_product_gpu(const CvoPointCloud& source_points, const CvoPointCloud& target_points,
+                          const Mat4f& T_target_frame_to_source_frame, float ell) const;
+  // pcl overloads (upstream CvoGPU.hpp:167-171, 220-224; CvoGPU.cu:1796-1809, 1848-1873)
+  float function_angle(const CvoPoint* source_cvo_points, int n_source, const CvoPoint* target_cvo_points, int n_target,
+                       const Mat4f& T_target_frame_to_source_frame, float ell, bool is_approximate = true) const;
+  float inner_product_gpu(const CvoPoint* source_cvo_points, int n_source, const CvoPoint* target_cvo_points, int n_target,
+                          const Mat4f& T_target_frame_to_source_frame, float ell) const;
+  // The reference's HOST function of the same name (upstream CvoGPU.cpp:95-213): NOT the function the GPU path
+  // computes - plain ell (no range factor), no neighbour cap, no colour / semantic cut-offs, radius search instead of
+  // the ordered scan - and not a fallback for anything: function_angle(..., is_gpu = false) routes here as upstream's does.
+  float inner_product_cpu(const CvoPointCloud& source_points, const CvoPointCloud& target_points,
                           const Mat4f& T_target_frame_to_source_frame, float ell) const;
   void compute_association_gpu(const CvoPointCloud& source_points, const CvoPointCloud& target_points,
                                const Mat4f& T_target_frame_to_source_frame, float lengthscale,

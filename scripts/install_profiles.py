@@ -1,9 +1,12 @@
-"""Copies the outputs of scripts/profile_round.sh (gpurun_out/r1b) into profiles/<round> and refreshes
-profiles/kernel_traffic.json from the PMC passes.  Usage: install_profiles.py [round, default r1]"""
+"""Copies the outputs of scripts/profile_round.sh (gpurun_out/<round>_prof) into profiles/<round> and refreshes
+profiles/kernel_traffic.json from the PMC passes (keyed on the hash of the kernel sources they were measured on).
+Usage: install_profiles.py [round, default r2]"""
 import csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "r1b") + "/"
-dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r1") + "/"
+sys.path.insert(0, ROOT)
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r2"
+src = os.path.join(ROOT, "gpurun_out", rnd + "_prof") + "/"
+dst = os.path.join(ROOT, "profiles", rnd) + "/"
 os.makedirs(dst, exist_ok=True)
 for f in ("bench_kernel_stats.csv", "configs.json"):
     shutil.copy(src + f, dst + f)
@@ -17,11 +20,15 @@ cmd = ("rocprofv3 --pmc <counters> --output-format csv -- python bench.py --gpus
        "of the run, including the early-exit launches of k_prep / k_scan / k_list / k_assoc_dense in iterations that do not rebuild; "
        "summarised on the GPU box by scripts/summarize_pmc.py)")
 json.dump({"command": cmd, "kernels": raw}, open(dst + "pmc_summary.json", "w"), indent=0)
-def hbm(k):
+def hbm(prefix):
+    k = max((q for q in raw if q.startswith(prefix)), key=lambda q: raw[q]["FETCH_SIZE"]["launches"])  # (template arguments vary)
     return int((2 * raw[k]["FETCH_SIZE"]["avg_per_launch"] + raw[k]["WRITE_SIZE"]["avg_per_launch"]) * 1024)
 kt = json.load(open(os.path.join(ROOT, "profiles", "kernel_traffic.json")))
-kt["hbm_bytes_per_launch"] = {"k_coeff": hbm("cvo_dev::k_coeff"), "k_assoc": hbm("cvo_dev::k_assoc<unsigned short, 64, false>"),
-                              "k_scan": hbm("cvo_dev::k_scan<2>")}
+from unified_cvo_amd import build as hipbuild
+kt["source_sha"] = hipbuild.source_hash()
+kt["source"] = f"profiles/{rnd}/pmc_summary.json (separate --pmc passes for FETCH_SIZE and WRITE_SIZE; average per launch of one 16-pair sub-batch)"
+kt["hbm_bytes_per_launch"] = {"k_coeff": hbm("cvo_dev::k_coeff"), "k_assoc": hbm("cvo_dev::k_assoc<"),
+                              "k_scan": hbm("cvo_dev::k_scan<")}
 json.dump(kt, open(os.path.join(ROOT, "profiles", "kernel_traffic.json"), "w"), indent=1)
 d = json.load(open(dst + "bench_n1.json"))
 print("value", d["value"], "ms/step", d["ms_per_step"], "k_coeff", d["roofline"]["avg_launch_ms"], "k_assoc", d["roofline"]["other_kernels"][0]["avg_launch_ms"])

@@ -231,3 +231,26 @@ def align_loop(P, x, y0, init, max_iterations=0, fx=None, fy=None, lx=None, ly=N
     out[:3, :3] = Rt
     out[:3, 3] = -Rt @ T.astype(np.float64)
     return dict(transform=out, ret=ret, iterations=k, events=events)
+
+
+def inner_product_cpu(P, x, y, T_t2s, ell, fx=None, fy=None, lx=None, ly=None):
+    """CvoGPU::inner_product_cpu (upstream src/cvo/CvoGPU.cpp:95-213), dense: moving points under T^-1, every pair with
+    squared distance below d2_thres = -2 l^2 log(sp_thres / sigma^2) (the nanoflann radius search), plain ell, no
+    neighbour cap, NO cut-off on the colour / semantic kernels, a = ck k sk kept if a > sp_thres; returns sum(a)."""
+    x = x.astype(np.float64)
+    Ti = np.linalg.inv(np.asarray(T_t2s, np.float64))
+    ym = y.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]
+    sp = float(np.float32(P.sp_thres))
+    s2 = float(np.float32(P.sigma)) ** 2
+    d2 = ((x[:, None, :] - ym[None, :, :]) ** 2).sum(-1)
+    near = d2 < -2.0 * ell * ell * np.log(sp / s2)
+    A = np.ones_like(d2)
+    if P.is_using_semantics:
+        d2s = ((lx.astype(np.float64)[:, None, :] - ly.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+        A = A * float(np.float32(P.s_sigma)) ** 2 * np.exp(-d2s / (2.0 * float(np.float32(P.s_ell)) ** 2))
+    if P.is_using_geometry:
+        A = A * s2 * np.exp(-d2 / (2.0 * ell * ell))
+    if P.is_using_intensity:
+        d2c = ((fx.astype(np.float64)[:, None, :] - fy.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+        A = A * float(np.float32(P.c_sigma)) ** 2 * np.exp(-d2c / (2.0 * float(np.float32(P.c_ell)) ** 2))
+    return float(A[near & (A > sp)].sum())

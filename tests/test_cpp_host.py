@@ -125,6 +125,142 @@ def test_multiframe_edge_driver_matches_python_mirror(tmp_path):
     assert float(r[10]) == pytest.approx(st.ell, rel=1e-6)
 
 
+@pytest.mark.gpu
+def test_api_surface_driver(tmp_path):
+    """The rest of the cvo::CvoGPU surface through the C++ veneer: pcl (192-byte CvoPoint array) overloads of align /
+    inner_product_gpu / function_angle, align(..., Association*) = the last executed iteration's matrix,
+    inner_product_cpu and function_angle(is_gpu=false) (the reference's HOST function, against a dense numpy form)."""
+    import np_reference as npr
+    from unified_cvo_amd import CvoGPU, CvoPointCloud
+    surf = os.path.join(HOST, "cvo_api_surface")
+    sx, sr, tx, tr = cases.demo_clouds()
+    _write_pcd(tmp_path / "source.pcd", sx, sr)
+    _write_pcd(tmp_path / "target.pcd", tx, tr)
+    yaml = os.path.join(cases.CONFIGS, "outdoor.yaml")
+    max_iter, ell = 400, 0.9
+    out = subprocess.check_output([surf, str(tmp_path / "source.pcd"), str(tmp_path / "target.pcd"), yaml, str(max_iter),
+                                   str(ell)], text=True)
+    rows = {l.split()[0]: l.split()[1:] for l in out.strip().splitlines()}
+    assert rows["ret"] == ["0", "0"] and rows["aos_equals_soa"] == ["1"]
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        P = read_cvo_params_yaml(yaml)
+    P.MAX_ITER = max_iter
+    P.is_exporting_association = 1
+    src, tgt = CvoPointCloud.from_xyzrgb(sx, sr), CvoPointCloud.from_xyzrgb(tx, tr)
+    gpu = CvoGPU(params=P)
+    g = gpu.align(src, tgt, np.eye(4))
+    T_cpp = np.array([float(v) for v in rows["transform"]], np.float32).reshape(4, 4).T
+    assert np.array_equal(T_cpp, g.transform)
+    rp, col, val, kw, kr = gpu.align_association(src.num_points())
+    a = dict(zip(rows["association"][0::2], rows["association"][1::2]))
+    assert int(a["nnz"]) == len(col) > 100 and int(a["rows"]) == src.num_points() and int(a["cols"]) == tgt.num_points()
+    assert int(a["source_inliers"]) == int((np.diff(rp) > 0).sum()) and int(a["target_inliers"]) == len(col)
+    assert float(a["value_sum"]) == pytest.approx(float(val.astype(np.float64).sum()), rel=1e-7)
+    assert int(a["col_checksum"]) == int((col.astype(np.int64) * (np.arange(len(col)) % 97 + 1)).sum())
+
+    ip = gpu.inner_product_gpu(src, tgt, np.eye(4), ell)
+    assert [np.float32(v) for v in rows["inner_product_gpu"]] == [np.float32(ip)] * 2
+    fa = [gpu.function_angle(src, tgt, np.eye(4), ell, True), gpu.function_angle(src, tgt, np.eye(4), ell, False)]
+    got = [np.float32(v) for v in rows["function_angle_gpu"]]
+    assert got[0] == got[1] == np.float32(fa[0]) and got[2] == got[3] == np.float32(fa[1])
+
+    xs, fs, _, _ = src.device_arrays()
+    xt, ft, _, _ = tgt.device_arrays()
+    ref0 = npr.inner_product_cpu(P, xs, xt, np.eye(4), ell, fs, ft)
+    ref1 = npr.inner_product_cpu(P, xs, xt, np.linalg.inv(g.transform.astype(np.float64)), ell, fs, ft)
+    got = [float(v) for v in rows["inner_product_cpu"]]
+    assert got[0] == pytest.approx(ref0, rel=2e-5) and got[1] == pytest.approx(ref1, rel=2e-5) and ref1 > ref0 > 0
+    fxx = npr.inner_product_cpu(P, xs, xs, np.eye(4), ell, fs, fs)
+    fyy = npr.inner_product_cpu(P, xt, xt, np.eye(4), ell, ft, ft)
+    got = [float(v) for v in rows["function_angle_cpu"]]
+    assert got[0] == pytest.approx(ref0 / np.sqrt(len(xs)) / np.sqrt(len(xt)), rel=2e-5)
+    assert got[1] == pytest.approx(ref0 / np.sqrt(fxx) / np.sqrt(fyy), rel=2e-5)
+
+
+def _write_xyz_pcd(path, xyz):
+    with open(path, "w") as f:
+        f.write("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\n"
+                f"COUNT 1 1 1\nWIDTH {len(xyz)}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {len(xyz)}\nDATA ascii\n")
+        for p in xyz:
+            f.write(f"{p[0]:.9g} {p[1]:.9g} {p[2]:.9g}\n")
+
+
+@pytest.mark.gpu
+def test_sharded_cpp_host_matches_batch(tmp_path):
+    """cvo::CvoGPUSharded (host/cvo_gpu_sharded.cpp): one context + host thread per device, contiguous blocks of pairs,
+    ONE ncclAllGather (RCCL) of the poses and one of the return codes.  On the single GPU of the test box the
+    communicator has one rank; the gathered result must equal cvo_align_batch bit for bit (the C++ path north_star
+    names for the 8-GPU mode; the driver's scaling run uses the Python harness)."""
+    from unified_cvo_amd import CvoGPU, CvoPointCloud, synth
+    shard = os.path.join(HOST, "cvo_align_sharded")
+    yaml = os.path.join(cases.CONFIGS, "geometric_gpu.yaml")
+    pairs, args = [], []
+    for p in range(5):
+        src, tgt, _ = synth.geometric_pair(900 + 150 * p, p)
+        _write_xyz_pcd(tmp_path / f"s{p}.pcd", src)
+        _write_xyz_pcd(tmp_path / f"t{p}.pcd", tgt)
+        args += [str(tmp_path / f"s{p}.pcd"), str(tmp_path / f"t{p}.pcd")]
+        pairs.append((CvoPointCloud.from_xyz(src), CvoPointCloud.from_xyz(tgt)))
+    out = subprocess.check_output([shard, yaml, "250", "1"] + args, text=True)
+    lines = [l.split() for l in out.strip().splitlines()]
+    assert lines[-1][:4] == ["devices", "1", "pairs", "5"]
+    P = cases.load_params("geometric_gpu")
+    P.MAX_ITER = 250
+    res = CvoGPU(params=P).align_batch([a for a, _ in pairs], [b for _, b in pairs], [np.eye(4)] * 5)
+    for p, (l, r) in enumerate(zip(lines[:5], res)):
+        assert l[:6] == ["pair", str(p), "device", "0", "ret", str(r.ret)]
+        T = np.array([float(v) for v in l[7:23]], np.float32).reshape(4, 4).T
+        assert np.array_equal(T, r.transform), p
+
+
+def test_sharded_block_assignment():
+    """pair p -> device p / ceil(n / n_devices): 512 pairs on 8 devices = 64 contiguous pairs per GPU (configs[4])."""
+    per = lambda n, D: (n + D - 1) // D  # noqa: E731
+    assert [p // per(512, 8) for p in (0, 63, 64, 511)] == [0, 0, 1, 7]
+    from unified_cvo_amd import sharding
+    for n, D in ((512, 8), (100, 8), (5, 2), (7, 1)):
+        for r in range(D):
+            lo, hi = sharding.shard_range(n, D, r)
+            assert all(p // per(n, D) == r for p in range(lo, hi))
+
+
+def test_cmake_package_builds_installs_and_is_consumable(tmp_path):
+    """The drop-in packaging itself (CMakeLists.txt: targets cvo_gpu_img_lib / cvo_gpu_lidar_lib exported as
+    UnifiedCvo::*, headers under include/UnifiedCvo-0.1): configure + build + install, then a 10-line consumer with
+    find_package(UnifiedCvo) links UnifiedCvo::cvo_gpu_img_lib.  hipcc cross-compiles gfx950 without a GPU."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not (shutil.which("cmake") and os.path.exists(hipcc)):
+        pytest.skip("cmake / hipcc not available")
+    build, prefix = tmp_path / "build", tmp_path / "prefix"
+    gen = ["-G", "Ninja"] if shutil.which("ninja") else []
+    subprocess.check_call(["cmake", "-S", cases.ROOT, "-B", str(build), f"-DCMAKE_CXX_COMPILER={hipcc}",
+                           f"-DCMAKE_INSTALL_PREFIX={prefix}"] + gen, stdout=subprocess.DEVNULL)
+    subprocess.check_call(["cmake", "--build", str(build), "-j", "8"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["cmake", "--install", str(build)], stdout=subprocess.DEVNULL)
+    assert (prefix / "include" / "UnifiedCvo-0.1" / "cvo" / "CvoGPU.hpp").exists()
+    assert (prefix / "include" / "UnifiedCvo-0.1" / "cvo_hip.h").exists()
+    cons = tmp_path / "consumer"
+    cons.mkdir()
+    (cons / "CMakeLists.txt").write_text(
+        "cmake_minimum_required(VERSION 3.18)\nproject(consumer LANGUAGES CXX)\nset(CMAKE_CXX_STANDARD 17)\n"
+        "find_package(UnifiedCvo REQUIRED)\nadd_executable(consumer main.cpp)\n"
+        "target_link_libraries(consumer PRIVATE UnifiedCvo::cvo_gpu_img_lib)\n")
+    (cons / "main.cpp").write_text(
+        '#include <cstdio>\n#include "cvo/CvoGPU.hpp"\n'
+        "int main(int argc, char** argv) {\n"
+        "  cvo::CvoParams p;\n  cvo_params_default(&p);\n"
+        '  std::printf("%d %d %d %zu\\n", p.nearest_neighbors_max, NUM_CLASSES, FEATURE_DIMENSIONS, sizeof(cvo::CvoPoint));\n'
+        "  if (argc > 1) { cvo::CvoGPU g(argv[1]); return g.get_params().MAX_ITER > 0 ? 0 : 1; }\n  return 0;\n}\n")
+    subprocess.check_call(["cmake", "-S", str(cons), "-B", str(cons / "b"), f"-DCMAKE_CXX_COMPILER={hipcc}",
+                           f"-DCMAKE_PREFIX_PATH={prefix}"] + gen, stdout=subprocess.DEVNULL)
+    subprocess.check_call(["cmake", "--build", str(cons / "b")], stdout=subprocess.DEVNULL)
+    out = subprocess.check_output([str(cons / "b" / "consumer")], text=True).split()
+    assert out == ["512", "19", "5", "192"]      # defaults of CvoParams() + the PUBLIC compile definitions of the target
+
+
 PCIO = os.path.join(HOST, "cvo_pointcloud_io")
 
 

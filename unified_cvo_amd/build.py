@@ -48,6 +48,17 @@ def headers():
     return hs
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources: keys measurements that belong to one version of the kernels
+    (profiles/kernel_traffic.json carries it; bench.py reports PMC traffic only while it matches)."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(sources() + [q for q in headers() if q.startswith(CSRC)]):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
