@@ -2,7 +2,7 @@
 //   * the pcl overloads (arrays of the 192-byte CvoPoint record) of align / inner_product_gpu / function_angle,
 //   * align(..., Association*) under is_exporting_association,
 //   * inner_product_cpu and function_angle(..., is_gpu = false).
-// usage: cvo_api_surface source.pcd target.pcd params.yaml max_iter ell
+// usage: cvo_api_surface source.pcd target.pcd params.yaml max_iter ell [ell_init]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +19,7 @@ int main(int argc, char* argv[]) {
   cvo::CvoParams& p = cvo_align.get_params();
   p.MAX_ITER = std::atoi(argv[4]);
   p.is_exporting_association = 1;
+  if (argc > 6) p.ell_init = std::strtof(argv[6], nullptr);
   cvo_align.write_params(&p);
   const float ell = std::strtof(argv[5], nullptr);
   const cvo::Mat4f init = cvo::Mat4f::Identity();

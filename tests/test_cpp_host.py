@@ -139,7 +139,7 @@ def test_api_surface_driver(tmp_path):
     yaml = os.path.join(cases.CONFIGS, "outdoor.yaml")
     max_iter, ell = 400, 0.9
     out = subprocess.check_output([surf, str(tmp_path / "source.pcd"), str(tmp_path / "target.pcd"), yaml, str(max_iter),
-                                   str(ell)], text=True)
+                                   str(ell), "2.5"], text=True)
     rows = {l.split()[0]: l.split()[1:] for l in out.strip().splitlines()}
     assert rows["ret"] == ["0", "0"] and rows["aos_equals_soa"] == ["1"]
 
@@ -148,6 +148,7 @@ def test_api_surface_driver(tmp_path):
         P = read_cvo_params_yaml(yaml)
     P.MAX_ITER = max_iter
     P.is_exporting_association = 1
+    P.ell_init = 2.5       # (the yaml's 0.2 leaves the two demo clouds, 5.8 m apart, without a single pair)
     src, tgt = CvoPointCloud.from_xyzrgb(sx, sr), CvoPointCloud.from_xyzrgb(tx, tr)
     gpu = CvoGPU(params=P)
     g = gpu.align(src, tgt, np.eye(4))
@@ -204,7 +205,7 @@ def test_sharded_cpp_host_matches_batch(tmp_path):
         args += [str(tmp_path / f"s{p}.pcd"), str(tmp_path / f"t{p}.pcd")]
         pairs.append((CvoPointCloud.from_xyz(src), CvoPointCloud.from_xyz(tgt)))
     out = subprocess.check_output([shard, yaml, "250", "1"] + args, text=True)
-    lines = [l.split() for l in out.strip().splitlines()]
+    lines = [l.split() for l in out.strip().splitlines() if l.startswith(("pair ", "devices "))]  # (RCCL prints a banner)
     assert lines[-1][:4] == ["devices", "1", "pairs", "5"]
     P = cases.load_params("geometric_gpu")
     P.MAX_ITER = 250
