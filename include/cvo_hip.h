@@ -270,6 +270,8 @@ int cvo_debug_scalar_math(cvo_ctx* ctx, int op, int n, const double* in, double*
 /* CVO_VERIFY_LISTS=1 (environment, read when a call starts): rows k_verify re-derived with the literal scan during the
  * last align call, summed over pairs and iterations (0 when the check was off). */
 int cvo_debug_verified_rows(cvo_ctx* ctx, unsigned long long* rows);
+/* Free / total bytes of the context's device (hipMemGetInfo), for leak checks without a second HIP runtime in the process. */
+int cvo_debug_device_memory(cvo_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 const char* cvo_version(void);
 
 #ifdef __cplusplus

@@ -495,8 +495,8 @@ def test_contexts_and_clouds_release_device_memory():
     an 8-pair workspace alone is ~100 MB
     per cycle: a leak would show at once; scripts/leak_check.py prints the curve)."""
     import gc
-    import torch
     P, src, tgt, init = cases.config2(n=4000)
+    probe = CvoGPU(params=P)   # (hipMemGetInfo through the C-ABI: no second HIP runtime - torch's - in this process)
 
     def cycle():
         gpu = CvoGPU(params=P)
@@ -512,13 +512,12 @@ def test_contexts_and_clouds_release_device_memory():
     first = cycle()
     for _ in range(4):  # (the HIP runtime grows its own pools in 64 MiB steps during the first cycles)
         cycle()
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
+    free0 = probe.debug_device_memory()[0]
     for _ in range(20):
         assert np.array_equal(cycle(), first)
-    torch.cuda.synchronize()
-    free1 = torch.cuda.mem_get_info()[0]
-    assert free0 - free1 < 200 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 20 cycles"
+    free1 = probe.debug_device_memory()[0]
+    # (one cycle allocates ~0.4 GB; the runtime's own pools move in steps of a few hundred MiB at most)
+    assert free0 - free1 < 1 << 30, f"device memory shrank by {(free0 - free1) >> 20} MiB over 20 cycles"
 
 
 def test_upload_many_matches_single_uploads():

@@ -131,7 +131,7 @@ EXPORTED = [
     "cvo_function_angle", "cvo_association", "cvo_association_non_isotropic", "cvo_cloud_transformed", "cvo_edge_kernel_matrix", "cvo_debug_last_ell", "cvo_debug_time_scan", "cvo_debug_time_kernels",
     "cvo_debug_kernel_clock",
     "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
-    "cvo_align_association", "cvo_debug_scalar_math", "cvo_debug_verified_rows",
+    "cvo_align_association", "cvo_debug_scalar_math", "cvo_debug_verified_rows", "cvo_debug_device_memory",
 ]
 
 _lib = None
@@ -190,6 +190,7 @@ def lib():
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cvo_debug_scalar_math.argtypes = [vp, ip, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.cvo_debug_verified_rows.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    L.cvo_debug_device_memory.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     for name in EXPORTED:
         getattr(L, name)  # AttributeError here = the library does not export what the header declares
     _lib = L

@@ -546,6 +546,12 @@ class CvoGPU:
         self._check(self.L.cvo_debug_scalar_math(self.ctx, op, n, a.ctypes.data_as(dp), out.ctypes.data_as(dp)))
         return out
 
+    def debug_device_memory(self):
+        """(free, total) bytes of this context's device."""
+        f, t = C.c_size_t(), C.c_size_t()
+        self._check(self.L.cvo_debug_device_memory(self.ctx, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     def debug_verified_rows(self):
         v = C.c_ulonglong()
         self._check(self.L.cvo_debug_verified_rows(self.ctx, C.byref(v)))

@@ -71,7 +71,8 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", os.path.join(ROOT, "include"), "-o", LIB] + sources()
+    extra = os.environ.get("CVO_EXTRA_HIPCC_FLAGS", "").split()  # (experiments: -DCVO_ASSOC_WAVES=6 ...)
+    cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-I", os.path.join(ROOT, "include"), "-o", LIB] + sources()
     if verbose:
         print("[unified_cvo_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

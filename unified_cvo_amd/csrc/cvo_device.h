@@ -118,16 +118,20 @@ struct PairState {
 // upload (xorder / yorder map sorted position -> original index).  k_scan works entirely in sorted
 // space so that 4-row groups and 64-target chunks are spatially compact and whole tiles can be
 // rejected by a bounding-box test; k_assoc maps candidates back and restores ascending original j.
+// One nonzero of the ELL kernel matrix, as k_assoc leaves it for k_coeff: the kernel value and the TRANSFORMED target
+// the pair was evaluated with (so that the coefficient pass neither gathers the target again nor repeats the
+// transform: one streaming 16-byte load per nonzero).  The column index j lives in a parallel array (ell_j) that only
+// the exports and the self-check read.
 struct EllEntry {
-  float a;
-  int j;
+  float a, yx, yy, yz;
 };
+static_assert(sizeof(EllEntry) == 16, "EllEntry");
 
 // The row arrays of the per-iteration kernels open every pair's workspace, at offsets that depend only on the
 // launch-wide padded row count: a block computes their addresses from kernel arguments (arena of the launch's
 // first pair, stride between pairs, padded rows) and requests its rows together with the descriptor and the
 // state, instead of one cold round trip later (every kernel starts with an invalidated L2 on this multi-die part).
-//   cand_cnt int[Np] | ip int[Np] | nnz_row u32[Np] | pad | xp4 float4[Np] | cand_j 128 B x Np | ell [K_max][N]
+//   cand_cnt int[Np] | ip int[Np] | nnz_row u32[Np] | pad | xp4 float4[Np] | cand_j 128 B x Np | ell [K_max][N] | ell_j
 constexpr int ROW_PAD = 256;
 __host__ __device__ inline size_t row_off_cand_cnt(int) { return 0; }
 __host__ __device__ inline size_t row_off_ip(int Np) { return (size_t)4 * Np; }
@@ -145,7 +149,8 @@ struct PairDesc {
   float4* xp4;     // [N] source xyz of the row at each position
   int* ip;         // [N] ORIGINAL index of the row at each position
   const float4* y4;   // target xyz (initial cloud), ORIGINAL index
-  EllEntry* ell;              // ELL kernel matrix [K_max][N] by POSITION: value + column (ORIGINAL j, ascending in a row)
+  EllEntry* ell;              // ELL kernel matrix [K_max][N] by POSITION: value + transformed target, ascending ORIGINAL j in a row
+  int* ell_j;                 // [K_max][N]: the column (ORIGINAL j) of every entry
   unsigned* nnz_row;          // nonzeros[N], by position
   double* flow_part;          // [nblk_assoc + DENSE_BLOCKS][8]: omega(3), v(3), sum a, pad (row blocks, then k_assoc_dense)
   unsigned long long* cnt_part;  // [nblk_assoc + DENSE_BLOCKS][4]: nnz, max, candidates, overflow rows
@@ -461,46 +466,42 @@ __device__ inline void cubic_roots_wave(const double coef[4], double re[3], doub
   if (fabs(b) > bound) bound = fabs(b);
   if (fabs(c) > bound) bound = fabs(c);
   bound = 1.0 + bound;
-  // task list in the order cubic_roots fills r[]: kind 1 = the value x0 itself, 2 = outward search from x0 in
-  // direction x1, 3 = bracket [x0, x1]
-  int kind0 = 0, kind1 = 0, kind2 = 0, nr = 0;
-  double p0 = 0, q0 = 0, p1 = 0, q1 = 0, p2 = 0, q2 = 0;
-  auto push = [&](int kind, double p, double q) {
-    if (nr == 0) {
-      kind0 = kind;
-      p0 = p;
-      q0 = q;
-    } else if (nr == 1) {
-      kind1 = kind;
-      p1 = p;
-      q1 = q;
-    } else {
-      kind2 = kind;
-      p2 = p;
-      q2 = q;
-    }
-    nr++;
-  };
+  // The (up to) three searches cubic_roots runs one after the other, each on its own lane: kind 1 = the value p
+  // itself, 2 = outward search from p in direction q, 3 = bracket [p, q], 0 = nothing.  Lane 0: the root left of the
+  // first critical point (or the single root of a monotone cubic), lane 1: the root between the critical points,
+  // lane 2: the root right of the second one; r[] lists the results that exist in that order, as cubic_roots does.
+  // (No run-time indexed task list: that would live in scratch memory.)
+  bool hasA = false, hasB = false, hasC = false;
+  int kindA = 0, kindC = 0;
+  double pA = 0, qA = 0, pB = 0, qB = 0, pC = 0, qC = 0;
   const double dq = a * a - 3.0 * b;
   if (!(dq > 0.0)) {
     const double xi = -a / 3.0;
     const double fi = f(xi);
-    if (fi == 0.0)
-      push(1, xi, 0.0);
-    else
-      push(2, xi, fi < 0.0 ? 1.0 : -1.0);
+    hasA = true;
+    kindA = fi == 0.0 ? 1 : 2;
+    pA = xi;
+    qA = fi < 0.0 ? 1.0 : -1.0;
   } else {
     const double s = sqrt(dq);
     const double t = (a >= 0.0) ? (-a - s) : (-a + s);
     const double xa = t / 3.0, xb = (t != 0.0) ? b / t : 0.0;
     const double x1 = xa < xb ? xa : xb, x2 = xa < xb ? xb : xa;
     const double f1 = f(x1), f2 = f(x2);
-    if (f1 >= 0.0) push(f1 == 0.0 ? 1 : 2, x1, -1.0);
-    if (f1 > 0.0 && f2 < 0.0) push(3, x1, x2);
-    if (f2 <= 0.0) push(f2 == 0.0 ? 1 : 2, x2, 1.0);
+    hasA = f1 >= 0.0;
+    kindA = f1 == 0.0 ? 1 : 2;
+    pA = x1;
+    qA = -1.0;
+    hasB = f1 > 0.0 && f2 < 0.0;
+    pB = x1;
+    qB = x2;
+    hasC = f2 <= 0.0;
+    kindC = f2 == 0.0 ? 1 : 2;
+    pC = x2;
+    qC = 1.0;
   }
-  const int kind = lane == 0 ? kind0 : (lane == 1 ? kind1 : (lane == 2 ? kind2 : 0));
-  const double p = lane == 0 ? p0 : (lane == 1 ? p1 : p2), q = lane == 0 ? q0 : (lane == 1 ? q1 : q2);
+  const int kind = lane == 0 ? (hasA ? kindA : 0) : (lane == 1 ? (hasB ? 3 : 0) : (lane == 2 ? (hasC ? kindC : 0) : 0));
+  const double p = lane == 0 ? pA : (lane == 1 ? pB : pC), q = lane == 0 ? qA : (lane == 1 ? qB : qC);
   double val = 0.0, lo = 0.0, hi = 0.0;
   bool refine = false;
   if (kind == 1) {
@@ -513,10 +514,12 @@ __device__ inline void cubic_roots_wave(const double coef[4], double re[3], doub
     refine = true;
   }
   if (refine) val = cubic_solve_bracket(a, b, c, lo, hi);
+  const double vA = __shfl(val, 0), vB = __shfl(val, 1), vC = __shfl(val, 2);
+  const int nr = (hasA ? 1 : 0) + (hasB ? 1 : 0) + (hasC ? 1 : 0);
   double r[3];
-  r[0] = __shfl(val, 0);
-  r[1] = __shfl(val, 1);
-  r[2] = __shfl(val, 2);
+  r[0] = hasA ? vA : (hasB ? vB : vC);
+  r[1] = hasA ? (hasB ? vB : vC) : vC;
+  r[2] = vC;
   if (nr == 3) {
     for (int i = 0; i < 3; i++) {
       re[i] = r[i];
@@ -630,16 +633,33 @@ __device__ inline double se3_log_norm(const double R[9], const double t[3]) {
     q[1] = (R[2] - R[6]) * s;
     q[2] = (R[3] - R[1]) * s;
   } else {
+    // Eigen's quaternion-from-matrix, branch tr <= 0: i = index of the largest diagonal entry, j = i + 1, k = j + 1
+    // (mod 3).  Spelled out per case: run-time indices into q / R would put both arrays into scratch memory.
     int i = 0;
     if (R[4] > R[0]) i = 1;
-    if (R[8] > R[4 * i]) i = 2;
-    int j = (i + 1) % 3, k = (j + 1) % 3;
-    double s = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-    q[i] = 0.5 * s;
-    s = 0.5 / s;
-    q[3] = (R[3 * k + j] - R[3 * j + k]) * s;
-    q[j] = (R[3 * j + i] + R[3 * i + j]) * s;
-    q[k] = (R[3 * k + i] + R[3 * i + k]) * s;
+    if (R[8] > (i == 0 ? R[0] : R[4])) i = 2;
+    if (i == 0) {
+      double s = sqrt(R[0] - R[4] - R[8] + 1.0);
+      q[0] = 0.5 * s;
+      s = 0.5 / s;
+      q[3] = (R[7] - R[5]) * s;
+      q[1] = (R[3] + R[1]) * s;
+      q[2] = (R[6] + R[2]) * s;
+    } else if (i == 1) {
+      double s = sqrt(R[4] - R[8] - R[0] + 1.0);
+      q[1] = 0.5 * s;
+      s = 0.5 / s;
+      q[3] = (R[2] - R[6]) * s;
+      q[2] = (R[7] + R[5]) * s;
+      q[0] = (R[1] + R[3]) * s;
+    } else {
+      double s = sqrt(R[8] - R[0] - R[4] + 1.0);
+      q[2] = 0.5 * s;
+      s = 0.5 / s;
+      q[3] = (R[3] - R[1]) * s;
+      q[0] = (R[2] + R[6]) * s;
+      q[1] = (R[5] + R[7]) * s;
+    }
   }
   double squared_n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
   double n = sqrt(squared_n);

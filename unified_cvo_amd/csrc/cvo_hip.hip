@@ -40,7 +40,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, gate, gate_flow, done, cand_cnt, rowperm, xp4, ip, cand_j, ell, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, gate, gate_flow, done, cand_cnt, rowperm, xp4, ip, cand_j, ell, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -135,7 +135,8 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.xp4 = row_off_xp4(Npad);
   L.cand_j = row_off_cand_j(Npad);  // ASSOC_CAP16 x u16 == ASSOC_CAP32 x i32 == 128 bytes per row
   L.ell = row_off_ell(Npad);
-  size_t off = align_up(L.ell + sizeof(EllEntry) * (size_t)Npad * Kmax, 256);
+  L.ell_j = align_up(L.ell + sizeof(EllEntry) * (size_t)Npad * Kmax, 256);
+  size_t off = align_up(L.ell_j + sizeof(int) * (size_t)Npad * Kmax, 256);
   auto take = [&](size_t bytes) {
     size_t o = off;
     off = align_up(off + bytes, 256);
@@ -514,7 +515,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
                "workspace of %d pair(s) of %d x %d points needs %.1f GiB (candidate bitmap N*M/8 = %.1f GiB per pair, ELL "
                "%.1f GiB per pair) but %.1f GiB of device memory are free: split the batch or the clouds",
                n_pairs, N, M, need / 1073741824.0, (double)N * S->d.Mpad / 8.0 / 1073741824.0,
-               (double)S->d.Npad * Kmax * 8.0 / 1073741824.0, (free_b + ctx->arena_bytes) / 1073741824.0);
+               (double)S->d.Npad * Kmax * 20.0 / 1073741824.0, (free_b + ctx->arena_bytes) / 1073741824.0);
       return fail(ctx, CVO_E_NOMEM, msg);
     }
   }
@@ -603,6 +604,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.ip = (int*)(base + S->L.ip);
     D.cand_j = (void*)(base + S->L.cand_j);
     D.ell = (EllEntry*)(base + S->L.ell);
+    D.ell_j = (int*)(base + S->L.ell_j);
     D.nnz_row = (unsigned*)(base + S->L.nnz_row);
     D.flow_part = (double*)(base + S->L.flow_part);
     D.cnt_part = (unsigned long long*)(base + S->L.cnt_part);
@@ -1318,10 +1320,8 @@ static int fetch_ell(cvo_ctx* ctx, int pair, std::vector<unsigned>& nz, std::vec
   if (mx) {
     std::vector<EllEntry> ep((size_t)mx * N);
     HIP_TRY(ctx, hipMemcpy(ep.data(), D.ell, sizeof(EllEntry) * (size_t)mx * N, hipMemcpyDeviceToHost));
-    for (size_t q = 0; q < ep.size(); q++) {
-      ap[q] = ep[q].a;
-      jp[q] = ep[q].j;
-    }
+    HIP_TRY(ctx, hipMemcpy(jp.data(), D.ell_j, sizeof(int) * (size_t)mx * N, hipMemcpyDeviceToHost));
+    for (size_t q = 0; q < ep.size(); q++) ap[q] = ep[q].a;
   }
   nz.assign(N, 0);
   a.assign((size_t)mx * N, 0.f);
@@ -1548,7 +1548,11 @@ int cvo_align_association(cvo_ctx* ctx, int pair, int* row_ptr, int* col, float*
   unsigned mx = 0;
   for (int q = 0; q < N; q++) mx = std::max(mx, nzp[q]);
   std::vector<EllEntry> ep((size_t)mx * N);
-  if (mx) HIP_TRY(ctx, hipMemcpy(ep.data(), D.ell, sizeof(EllEntry) * (size_t)mx * N, hipMemcpyDeviceToHost));
+  std::vector<int> ej((size_t)mx * N);
+  if (mx) {
+    HIP_TRY(ctx, hipMemcpy(ep.data(), D.ell, sizeof(EllEntry) * (size_t)mx * N, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(ej.data(), D.ell_j, sizeof(int) * (size_t)mx * N, hipMemcpyDeviceToHost));
+  }
   std::vector<int> pos_of(N, -1);  // original row -> position
   for (int q = 0; q < N; q++) {
     if (ip[q] < 0 || ip[q] >= N) return fail(ctx, CVO_E_HIP, "cvo_align_association: corrupt row index");
@@ -1564,9 +1568,8 @@ int cvo_align_association(cvo_ctx* ctx, int pair, int* row_ptr, int* col, float*
     }
     const int q = pos_of[r];
     if (sidx < nzp[q]) {
-      const EllEntry& e = ep[sidx * (size_t)N + q];
-      *j = e.j;
-      *a = e.a;
+      *j = ej[sidx * (size_t)N + q];
+      *a = ep[sidx * (size_t)N + q].a;
     } else {
       *j = -1;
       *a = 0.f;
@@ -1623,6 +1626,14 @@ int cvo_debug_scalar_math(cvo_ctx* ctx, int op, int n, const double* in, double*
   if (e != hipSuccess) rc = fail(ctx, CVO_E_HIP, std::string("cvo_debug_scalar_math: ") + hipGetErrorString(e));
   cleanup();
   return rc;
+}
+
+int cvo_debug_device_memory(cvo_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+  if (!ctx || !free_bytes || !total_bytes) return fail(ctx, CVO_E_INVALID, "cvo_debug_device_memory: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemGetInfo(free_bytes, total_bytes));
+  return CVO_OK;
 }
 
 int cvo_debug_verified_rows(cvo_ctx* ctx, unsigned long long* rows) {

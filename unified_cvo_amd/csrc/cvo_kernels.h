@@ -27,6 +27,14 @@
 #pragma once
 #include "cvo_device.h"
 
+// min. waves per SIMD the register allocator is asked to leave room for (__launch_bounds__ second argument)
+#ifndef CVO_COEFF_WAVES
+#define CVO_COEFF_WAVES 1
+#endif
+#ifndef CVO_ASSOC_WAVES
+#define CVO_ASSOC_WAVES 1
+#endif
+
 namespace cvo_dev {
 
 // Wave-wide reductions on the DPP cross-lane paths (no LDS traffic, unlike ds_bpermute shuffles): a butterfly
@@ -45,6 +53,15 @@ __device__ __forceinline__ double dpp_f64(double v) {
 }
 __device__ __forceinline__ double lane_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+  const unsigned lo = (unsigned)dpp_i32<CTRL>((int)(unsigned)v), hi = (unsigned)dpp_i32<CTRL>((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long lane_u64(unsigned long long v, int l) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l) << 32) |
+         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
 }
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_f64<DPP_XOR1>(v);
@@ -474,7 +491,8 @@ __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* _
   float4 yt;
   if (!eval_pair<GENERAL>(P, D, pose, i, r, j, y0, a, yt)) return;
   if (a > P.sp_thres) {
-    D->ell[(size_t)A.nnz * N + pos] = EllEntry{a, j};
+    D->ell[(size_t)A.nnz * N + pos] = EllEntry{a, yt.x, yt.y, yt.z};
+    D->ell_j[(size_t)A.nnz * N + pos] = j;
     A.nnz++;
     const V3 pye{yt.x, yt.y, yt.z};
     const V3 cr = cross_dev(pxe, pye);
@@ -749,8 +767,41 @@ struct AssocRowHead {
   int cnt, ip, j1;
   float4 x;
 };
+// Block reduction of NC doubles per thread through LDS: every thread deposits its values (column-major: conflict-free
+// 8-byte writes), then lane (c, g) of the first wave - eight lanes per component - adds the values of threads
+// g, g + 8, g + 16, ... in that order and the eight partial sums meet through a 3-step DPP butterfly; lanes with g == 0
+// return the total of component c = lane / 8 (valid for lane < 8 * NC).  ~20 wave-instructions per wave instead of ~27
+// per COMPONENT for a DPP / readlane reduction of doubles (the epilogues were a third of k_assoc's instructions).
+// The order of the additions is fixed.  Contains a __syncthreads().
+template <int NC>
+struct BlockRedShared {
+  double v[NC][ASSOC_THREADS + 8];  // (+ 8: components land on different banks)
+};
+template <int NC>
+__device__ __forceinline__ double block_reduce_lds(BlockRedShared<NC>& S, const double (&x)[NC]) {
+  static_assert(NC <= 8, "eight lanes per component in one wave");
+#pragma unroll
+  for (int c = 0; c < NC; c++) S.v[c][threadIdx.x] = x[c];
+  __syncthreads();
+  double t = 0;
+  if (threadIdx.x < 8 * NC) {
+    const int c = threadIdx.x >> 3, g = threadIdx.x & 7;
+    double p[ASSOC_THREADS / 8];
+#pragma unroll
+    for (int k = 0; k < ASSOC_THREADS / 8; k++) p[k] = S.v[c][8 * k + g];
+#pragma unroll
+    for (int k = 0; k < ASSOC_THREADS / 8; k++) t += p[k];
+  }
+  if (threadIdx.x < 64) {  // (whole wave: the DPP steps need their partner lanes active)
+    t += dpp_f64<DPP_XOR1>(t);
+    t += dpp_f64<DPP_XOR2>(t);
+    t += dpp_f64<DPP_HALF_MIRROR>(t);
+  }
+  return t;
+}
+
 struct AssocShared {
-  double red[ASSOC_THREADS / 64][8];
+  BlockRedShared<7> red;
   unsigned long long cnt[ASSOC_THREADS / 64][4];
 };
 
@@ -800,32 +851,24 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
     g_phase_ticks[0][blockIdx.x & 8191][2] = tt2;
   }
   // per-row (omega_i / c, v_i / d) cast to double, then reduced in double (CvoGPU.cu:784-787, 824-825)
-  double red[7] = {(double)(A.o0 / P.c), (double)(A.o1 / P.c), (double)(A.o2 / P.c), (double)(A.v0 / P.d),
-                   (double)(A.v1 / P.d), (double)(A.v2 / P.d), A.asum};
+  const double red[7] = {(double)(A.o0 / P.c), (double)(A.o1 / P.c), (double)(A.o2 / P.c), (double)(A.v0 / P.d),
+                         (double)(A.v1 / P.d), (double)(A.v2 / P.d), A.asum};
   constexpr int NW = ASSOC_THREADS / 64;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int c = 0; c < 7; c++) red[c] = wave_sum(red[c]);
   const unsigned long long nn = wave_sum_u32(A.nnz);  // 64 rows x K_max
   const unsigned mx = wave_max_u32(A.nnz);
   const unsigned long long nc = wave_sum_u32((unsigned)min(ncand, 0x3ffffffull));
   const unsigned long long nov = (unsigned long long)__builtin_popcountll(__ballot(overflowed != 0));
   if (lane == 0) {
-#pragma unroll
-    for (int c = 0; c < 7; c++) S.red[wave][c] = red[c];
     S.cnt[wave][0] = nn;
     S.cnt[wave][1] = mx;
     S.cnt[wave][2] = nc;
     S.cnt[wave][3] = nov;
   }
-  __syncthreads();
-  if (threadIdx.x < 7) {
-    const int c = threadIdx.x;
-    double t = S.red[0][c];
-#pragma unroll
-    for (int w = 1; w < NW; w++) t += S.red[w][c];
-    st_x<true>(D->flow_part + (size_t)bx * 8 + c, t);  // read by another block of this launch (flow_gate)
-  } else if (threadIdx.x == 8) {
+  const double tot = block_reduce_lds<7>(S.red, red);  // (its barrier also covers S.cnt)
+  if (threadIdx.x < 56 && (threadIdx.x & 7) == 0) {
+    st_x<true>(D->flow_part + (size_t)bx * 8 + (threadIdx.x >> 3), tot);  // read by another block of this launch (flow_gate)
+  } else if (threadIdx.x == 57) {
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
     for (int w = 0; w < NW; w++) {
@@ -845,7 +888,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
 // INSTR = true is the instrumented instantiation (CVO_KERNEL_CLOCK / CVO_PHASE_TICKS); the production one carries no
 // time stamps at all.
 template <typename IdxT, int ASSOC_CAP, bool GENERAL, bool INSTR>
-__global__ __launch_bounds__(ASSOC_THREADS) void k_assoc(const PairDesc* __restrict__ descs,
+__global__ __launch_bounds__(ASSOC_THREADS, CVO_ASSOC_WAVES) void k_assoc(const PairDesc* __restrict__ descs,
                                                           const DevParams* __restrict__ Pp,
                                                           const PairState* __restrict__ states,
                                                           const char* __restrict__ arena, int lean_nblk_pairs,
@@ -963,7 +1006,8 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
           const unsigned rank = nnz + below;
           const bool keep = ok[h] && rank < (unsigned)K;  // `if (num_inds == num_neighbors) break;`
           if (keep) {
-            D->ell[(size_t)rank * N + r_sorted] = EllEntry{a[h], j0 + 64 * h + lane};
+            D->ell[(size_t)rank * N + r_sorted] = EllEntry{a[h], yt[h].x, yt[h].y, yt[h].z};
+            D->ell_j[(size_t)rank * N + r_sorted] = j0 + 64 * h + lane;
             // flow terms of this lane's pair (CvoGPU.cu:767-769)
             const V3 pye{yt[h].x, yt[h].y, yt[h].z};
             const V3 cr = cross_dev(pxe, pye);
@@ -1056,7 +1100,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
 // thread per row position, blocks of ASSOC_THREADS rows.
 // ------------------------------------------------------------------------------------------
 struct CoeffShared {
-  double red[ASSOC_THREADS / 64][4];
+  BlockRedShared<4> red;
 };
 
 // one nonzero (i, j): compute_step_size_xi for target j (CvoGPU.cu:974-986) + compute_step_size_poly_coeff
@@ -1098,9 +1142,7 @@ __device__ __forceinline__ void coeff_entry(const XiMats& M, const float4 x, flo
 struct CoeffRowHead {
   unsigned nnz;
   float4 x;
-  int idx_n;
-  float a_n;
-  float4 y_n;
+  EllEntry e_n;  // the row's first entry of this block's slice
 };
 // COH: the block partial is read by another block of the same launch.
 template <bool COH>
@@ -1122,38 +1164,17 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
       temp_ell = compute_range_ell(temp_ell, d2_sqrt);
     }
     const float temp_coef = (float)(1 / (2.0 * temp_ell * temp_ell));
-    const Pose pose = load_pose(st);
-    int idx_n = h.idx_n;
-    float a_n = h.a_n;
-    float4 y_n = h.y_n;
+    EllEntry e_n = h.e_n;
     for (unsigned s = (unsigned)q; s < nnz; s += (unsigned)nsplit) {
-      const float A_ij = a_n;
-      const float4 y0 = y_n;
-      if (s + nsplit < nnz) {
-        const EllEntry e = D->ell[(size_t)(s + nsplit) * N + i];
-        idx_n = e.j;
-        a_n = e.a;
-        y_n = D->y4[idx_n];
-      }
-      const V3 yy = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
-      coeff_entry(Mu, x, temp_coef, yy, A_ij, Bi, Ci, Di, Ei);
+      const EllEntry e = e_n;
+      if (s + nsplit < nnz) e_n = D->ell[(size_t)(s + nsplit) * N + i];  // next entry in flight
+      // (the transformed target k_assoc evaluated the pair with: transform_point of the same operands, stored)
+      coeff_entry(Mu, x, temp_coef, V3{e.yx, e.yy, e.yz}, e.a, Bi, Ci, Di, Ei);
     }
   }
-  double red[4] = {Bi, Ci, Di, Ei};
-  constexpr int NW = ASSOC_THREADS / 64;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int c = 0; c < 4; c++) red[c] = wave_sum(red[c]);
-  if (lane == 0)
-    for (int c = 0; c < 4; c++) S.red[wave][c] = red[c];
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    const int c = threadIdx.x;
-    double t = S.red[0][c];
-#pragma unroll
-    for (int w = 1; w < NW; w++) t += S.red[w][c];
-    st_x<COH>(D->coef_part + ((size_t)bx * nsplit + q) * 4 + c, t);
-  }
+  const double red[4] = {Bi, Ci, Di, Ei};
+  const double tot = block_reduce_lds<4>(S.red, red);
+  if (threadIdx.x < 32 && (threadIdx.x & 7) == 0) st_x<COH>(D->coef_part + ((size_t)bx * nsplit + q) * 4 + (threadIdx.x >> 3), tot);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1234,12 +1255,14 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     // The four thrust::reduce of compute_step_size (CvoGPU.cu:1118-1121) and the nonzero / max counts
     // (SparseKernelMat.cu:37-46, CvoGPU.cu:1518): lane l owns component (l & 3) of blocks l>>2, l>>2 + 16, ...
     // so all loads are in flight at once; a fixed xor-shuffle tree finishes (deterministic order).
+    // Row c of 16 lanes owns component c; lane l of the row takes blocks l, l + 16, ... (eight loads in flight), the
+    // row meets through a DPP butterfly (no LDS) and every lane reads the four results with v_readlane.
     const int nba = n_flow_parts, nbc = D.nblk_coeff;
-    const int c = tid & 3;
+    const int c = tid >> 4, bl = tid & 15;
     double s = 0;
     if (P.mode == 0) {
       // eight (coherent) loads in flight per lane, summed in block order
-      for (int b0 = tid >> 2; b0 < nbc; b0 += 128) {
+      for (int b0 = bl; b0 < nbc; b0 += 128) {
         double v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -1250,10 +1273,10 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         for (int u = 0; u < 8; u++) s += v[u];
       }
     } else if (c == 0) {
-      for (int b = tid >> 2; b < nba; b += 16) s += D.flow_part[(size_t)b * 8 + 6];
+      for (int b = bl; b < nba; b += 16) s += D.flow_part[(size_t)b * 8 + 6];
     }
     unsigned long long q = 0;  // (written by the association kernel(s), i.e. before this launch: plain loads)
-    for (int b0 = tid >> 2; b0 < nba; b0 += 128) {
+    for (int b0 = bl; b0 < nba; b0 += 128) {
       unsigned long long v[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
@@ -1263,15 +1286,25 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
 #pragma unroll
       for (int u = 0; u < 8; u++) q = (c == 1) ? max(q, v[u]) : q + v[u];
     }
-#pragma unroll
-    for (int o = 4; o < 64; o <<= 1) {
-      s += __shfl_xor(s, o);
-      const unsigned long long v = __shfl_xor(q, o);
-      q = (c == 1) ? max(q, v) : q + v;
+    s += dpp_f64<DPP_XOR1>(s);
+    s += dpp_f64<DPP_XOR2>(s);
+    s += dpp_f64<DPP_HALF_MIRROR>(s);
+    s += dpp_f64<DPP_MIRROR>(s);
+    {
+      auto meet = [&](unsigned long long o) { q = (c == 1) ? max(q, o) : q + o; };
+      meet(dpp_u64<DPP_XOR1>(q));
+      meet(dpp_u64<DPP_XOR2>(q));
+      meet(dpp_u64<DPP_HALF_MIRROR>(q));
+      meet(dpp_u64<DPP_MIRROR>(q));
     }
-    if (tid < 4) {
-      s_c[tid] = s;
-      s_n[tid] = q;
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) {
+      const double sv = lane_f64(s, 16 * cc);
+      const unsigned long long qv = lane_u64(q, 16 * cc);
+      if (tid == 0) {
+        s_c[cc] = sv;
+        s_n[cc] = qv;
+      }
     }
   }
   __syncthreads();
@@ -1348,7 +1381,20 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
           }
           for (int q = 0; q < 9; q++) st->R[q] = R[q] = Rn[q];
           for (int q = 0; q < 3; q++) st->T[q] = T[q] = Tn[q];
-          dist = se3_log_norm(dR, dT);  // CvoGPU.cu:1473-1476
+          // dist = || log SE3(dR, dT) || (CvoGPU.cu:1473-1476) decides one thing: dist < eps_2.  dR / dT are the float
+          // Exp_SEK3 of a unit twist times `step`, so in exact arithmetic dist = step * |xi|_6 = step; the float
+          // rounding of dtrans (6e-8 per entry, entries <= 1) and of the normalisation move it by < 1e-6 + 1e-4 step.
+          // When step clears eps_2 by that margin the comparison is decided and the ~300 dependent double-precision
+          // instructions of the log (quaternion, atan, sin / cos) stay off the serial tail: exact shortcut, like the
+          // min_step clamp of select_step.  Not taken when the value itself is recorded (trace) and in Exp_SEK3's
+          // theta < 1e-6 branch (translation v instead of step * v: dist ~ 1 there).
+          const bool want_trace = !dry && D.trace && st->n_trace < P.trace_capacity &&
+                                  (k < P.trace_dense || (P.trace_every > 0 && k % P.trace_every == 0));
+          const float theta_f = sqrtf(om[0] * om[0] + (om[1] * om[1] + om[2] * om[2]));
+          if (!want_trace && theta_f >= 1e-6f && step * 0.9999f - 1e-6f > P.eps_2 && step <= 1.f)
+            dist = (double)step;
+          else
+            dist = se3_log_norm(dR, dT);
           const float ip_curr = (float)((double)nnz / sqrt((double)D.N * (double)D.M));  // 1486
           const bool need_decay_ell = dry ? false : indicator_update(st, sq, eq, ip_curr, P.window, P.stable_thr, e_front, s_front);
           if (dist < (double)P.eps_2) {  // CvoGPU.cu:1505-1508
@@ -1481,12 +1527,14 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     }
     for (int q = 0; q < 9; q++) st->Rinv[q] = Ri[q];
     for (int q = 0; q < 3; q++) st->Tinv[q] = Ti[q];
-    for (int i = 0; i < 3; i++) {
-      for (int j = 0; j < 3; j++) st->out_T[4 * j + i] = Ri[3 * i + j];
-      st->out_T[12 + i] = Ti[i];
+    if (done || INIT || P.mode != 0) {  // the returned matrix (final update_tf, CvoGPU.cu:1562): only read once the pair is done
+      for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) st->out_T[4 * j + i] = Ri[3 * i + j];
+        st->out_T[12 + i] = Ti[i];
+      }
+      st->out_T[3] = st->out_T[7] = st->out_T[11] = 0;
+      st->out_T[15] = 1;
     }
-    st->out_T[3] = st->out_T[7] = st->out_T[11] = 0;
-    st->out_T[15] = 1;
     if (clk0 && !dry) {  // CVO_KERNEL_CLOCK (k_coeff): this launch's interval and the association's, see PairState
       if (st->clk_last_assoc) {
         st->clk_sum[0] += st->clk_last_assoc;
@@ -1528,7 +1576,7 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
 // flags: bit 0 = lean graph, the rest see update_body.
 // ------------------------------------------------------------------------------------------
 template <bool INSTR>
-__global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restrict__ descs,
+__global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const PairDesc* __restrict__ descs,
                                                          const DevParams* __restrict__ Pp, PairState* states,
                                                          const char* __restrict__ arena, int flags, int nblk_split_pairs,
                                                          unsigned stride256, int Npad) {
@@ -1549,11 +1597,8 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     const int pos = pb.bx * ASSOC_THREADS + threadIdx.x;  // < Npad; values of rows >= N are never used
     head.nnz = reinterpret_cast<const unsigned*>(wb + row_off_nnz(Npad))[pos];
     head.x = reinterpret_cast<const float4*>(wb + row_off_xp4(Npad))[pos];
-    EllEntry e{0.f, 0};
-    if (cq == 0) e = reinterpret_cast<const EllEntry*>(wb + row_off_ell(Npad))[pos];
-    head.idx_n = e.j;
-    head.a_n = e.a;
-    head.y_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    head.e_n = EllEntry{0.f, 0.f, 0.f, 0.f};
+    if (cq == 0) head.e_n = reinterpret_cast<const EllEntry*>(wb + row_off_ell(Npad))[pos];
   }
   const int csplit = D->csplit;
   if (cq >= csplit) return;
@@ -1570,9 +1615,8 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
     const float4* a2 = D->xp4;
     const EllEntry* a3 = D->ell;
     const int a4 = D->M;
-    const float4* a5 = D->y4;
-    const float e = st_in->ell, r0 = st_in->Rinv[0], t0 = st_in->Tinv[0];
-    asm volatile("" ::"s"(n), "s"(nb), "s"(ep), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(e), "s"(r0), "s"(t0));
+    const float e = st_in->ell;
+    asm volatile("" ::"s"(n), "s"(nb), "s"(ep), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e));
   }
   const bool replay = (flags & 8) != 0;  // cvo_debug_time_kernels: same work, nothing written back
   if (!replay && status_v != 0) return;
@@ -1599,11 +1643,7 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
   __shared__ int s_last;
   const int N_ = D->N, pos_ = pb.bx * ASSOC_THREADS + threadIdx.x;
   if (pos_ >= N_) head.nnz = 0;
-  if (cq > 0 && (unsigned)cq < head.nnz) {  // (small clouds only: the slices of a row beyond the first)
-    const EllEntry e = D->ell[(size_t)cq * N_ + pos_];
-    head.idx_n = e.j;
-    head.a_n = e.a;
-  }
+  if (cq > 0 && (unsigned)cq < head.nnz) head.e_n = D->ell[(size_t)cq * N_ + pos_];  // (small clouds only: later slices)
   // the twist and its matrices (twist_finalize): wave-uniform scalar loads
   XiMats Mu;
   {
@@ -1611,7 +1651,6 @@ __global__ __launch_bounds__(ASSOC_THREADS) void k_coeff(const PairDesc* __restr
 #pragma unroll
     for (int q = 0; q < (int)(sizeof(XiMats) / sizeof(float)); q++) mu[q] = st_in->xi[q];
   }
-  if ((unsigned)cq < head.nnz) head.y_n = D->y4[head.idx_n];
   float twist[6];
   for (int c = 0; c < 3; c++) {
     twist[c] = Mu.omega[c];
@@ -1691,9 +1730,10 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
       const bool keep = ok && rank < (unsigned)K;
       if (keep) {
         const EllEntry e = D->ell[(size_t)rank * N + pos];
-        if (e.j != j)
+        if (D->ell_j[(size_t)rank * N + pos] != j)
           err = 2;
-        else if (__float_as_uint(e.a) != __float_as_uint(a))
+        else if (__float_as_uint(e.a) != __float_as_uint(a) || __float_as_uint(e.yx) != __float_as_uint(yt.x) ||
+                 __float_as_uint(e.yy) != __float_as_uint(yt.y) || __float_as_uint(e.yz) != __float_as_uint(yt.z))
           err = 3;
       }
       nnz += (unsigned)__builtin_popcountll(__ballot(keep));
