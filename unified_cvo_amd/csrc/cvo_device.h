@@ -46,6 +46,7 @@ struct DevParams {
   float rebuild_shrink;  // rebuild when ell < rebuild_shrink * ell_build (the lists would be (1/shrink)^3 too long)
   int lean_U;            // iterations between two rebuild opportunities in the lean graph
   float skin_min, skin_max;  // clamp of the skin (fractions of the cut-off radius) before skin_frac
+  float skin_blend;          // share of the pooled motion budget both the rotation and the translation allowance get on top of their own
   int dense_regime;      // 0: never switch a pair to the all-rows-dense regime (CVO_NO_DENSE_REGIME)
   float lean_skin;       // skin of the lean graph in units of (lean_U x the motion of one iteration)
   int kernel_clock;  // CVO_KERNEL_CLOCK: accumulate per-pair kernel durations in PairState::clk_*
@@ -83,7 +84,12 @@ struct PairState {
   float out_T[16];  // column-major [R^T | -R^T T]
   // candidate-list reuse: pose / ell the current bitmap was built with and its skin
   float Rb[9], Tb[3];
-  float ell_build, skin;
+  float ell_build;
+  // Skin of the current lists, per row: skin_i = skin_rot * rho_i + skin_tr, rho_i >= |y0| of every target that can
+  // come within the row's cut-off while the lists live (k_prep).  The lists stay supersets of the exact test while
+  // |Rinv - Rb|_F <= skin_rot and |Tinv - Tb| <= skin_tr: rows near the sensor, whose targets a rotation moves little,
+  // get a thin skin; only the farthest rows pay for the whole motion bound.
+  float skin_rot, skin_tr;
   int n_builds;
   int want_full, n_stalls;  // host hint: this pair needs the graph with per-iteration rebuild / dense kernels
   int all_dense;

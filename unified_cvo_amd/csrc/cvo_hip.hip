@@ -273,6 +273,8 @@ DevParams make_dev_params(const cvo_params_t& p) {
   d.skin_frac = 2.0f;
   d.lean_skin = 1.3f;
   d.dense_regime = getenv("CVO_NO_DENSE_REGIME") ? 0 : 1;
+  d.skin_blend = 0.25f;
+  if (const char* e = getenv("CVO_SKIN_BLEND")) d.skin_blend = std::min(1.f, std::max(0.f, (float)atof(e)));
   d.skin_min = 0.05f;
   d.skin_max = 0.25f;
   if (const char* e = getenv("CVO_SKIN_MIN")) d.skin_min = std::max(0.f, (float)atof(e));
@@ -631,12 +633,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
       st.K = opts->K0;
     }
     st.K_last = st.K;
-    // the slice bits start clean (k_prep clears a row's bits again before every rebuild)
-    HIP_TRY(ctx, hipMemsetAsync(D.rowbits, 0, sizeof(unsigned) * (size_t)(S->N + 4) * S->d.rbw_max, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(D.tile_count, 0, sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(D.gate, 0, sizeof(int), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(D.gate_flow, 0, sizeof(int), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(D.done, 0, sizeof(int), ctx->stream));
+    // (the pair's counters - gate, gate_flow, done, tile_count - are zeroed by k_update<INIT>; the slice bits of a row
+    // are cleared by k_prep before every build, the first one included: five memsets per pair used to cost 10 us each call)
   }
   // the blocks of k_assoc beyond a smaller pair's N still write their (zero) partials, but the
   // partial arrays of pairs whose N is smaller than the batch maximum are fully covered by nblk.

@@ -935,6 +935,11 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_ASSOC_WAVES) void k_assoc(const 
   pair_clock_begin(INSTR && P.kernel_clock && lean == 1 && pb.bx == 0, const_cast<PairState*>(st), 0);
   __shared__ AssocShared S;
   assoc_phase<IdxT, ASSOC_CAP, GENERAL, INSTR>(P, D, st, S, pb.bx, head);
+  // Everything from here on - the block's partial is on its way, the last-block counter, possibly the twist - is the
+  // first wave's business.  The other waves retire now instead of sitting on their registers through a store
+  // acknowledgement and an atomic round trip (~2 us of a ~7 us wave life; with thousands of waves queued behind them
+  // that wait was throughput, not just latency).  A barrier only counts the waves that are still alive.
+  if (threadIdx.x >= 64) return;
   // lean graph: nothing else adds to the flow, the twist of the iteration can be finished here
   if ((lean & 3) && P.mode == 0) {  // (bit 1: the timing replay includes it)
     const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && lean == 1, st, 0);
@@ -1444,10 +1449,11 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     float Ri[9], Ti[3];
     update_tf(st->R, st->T, Ri, Ti);
     {
-      // Candidate-list reuse.  A target moves by at most |Ri - Rb|_F * max|y0| + |Ti - Tb| between the pose
-      // the bitmap was built with and the one applied next; as long as that stays below the skin the scan
-      // added to every cut-off radius (and ell, hence every radius, has not grown) the bitmap still
-      // contains every pair the exact test of k_assoc can accept.
+      // Candidate-list reuse.  Target j moves by at most |Ri - Rb|_F * |y0_j| + |Ti - Tb| between the pose the
+      // bitmap was built with and the one applied next.  The scan added skin_rot * rho_i + skin_tr to the cut-off
+      // radius of row i, rho_i >= |y0_j| for every target that can come within the row's radius (k_prep); so as long
+      // as |Ri - Rb|_F <= skin_rot and |Ti - Tb| <= skin_tr (and ell, hence every radius, has not grown) the bitmap
+      // still contains every pair the exact test of k_assoc can accept.
       const float ell_next = st->ell;
       const float radius = ell_next * sqrtf(fmaxf(-2.f * P.log_geo, 0.f));  // cut-off radius for l = ell
       float dr = 0, dt = 0, dr1 = 0, dt1 = 0, tn = 0;
@@ -1463,15 +1469,21 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         tn += Ti[q] * Ti[q];
       }
       const float ymax = D.ymax;
-      const float slack = 1e-5f * (ymax + sqrtf(tn) + 1.f);  // rounding of the two transform evaluations
-      float moved = (sqrtf(dr) * ymax + sqrtf(dt)) * 1.001f + slack;
-      float step_move = sqrtf(dr1) * ymax + sqrtf(dt1);  // bound on what this iteration alone moved
-      if (P.debug_no_motion_bound) moved = step_move = 0.f;  // (tests: a deliberately broken bound, see DevParams)
+      (void)tn;
+      float rot_b = sqrtf(dr) * 1.001f, tr_b = sqrtf(dt) * 1.001f;   // since the build (the rounding slack of the two
+                                                                      // transform evaluations is part of every row's skin)
+      float rot_1 = sqrtf(dr1), tr_1 = sqrtf(dt1);                    // this iteration alone
+      float step_move = rot_1 * ymax + tr_1;                          // what this iteration moved the farthest target
+      if (P.debug_no_motion_bound) rot_b = tr_b = rot_1 = tr_1 = step_move = 0.f;  // (tests: a deliberately broken bound)
+      // share of the allowances used up / used per iteration (inf when an allowance is zero and something moved)
+      auto share = [](float used, float allowance) { return used <= 0.f ? 0.f : (allowance > 0.f ? used / allowance : __builtin_inff()); };
+      const float used = fmaxf(share(rot_b, st->skin_rot), share(tr_b, st->skin_tr));
+      const float rate = fmaxf(share(rot_1, st->skin_rot), share(tr_1, st->skin_tr));
       // the list is unusable for the coming iteration ...
-      bool rebuild = INIT || P.mode != 0 || !(moved <= st->skin) || ell_next > st->ell_build ||
+      bool rebuild = INIT || P.mode != 0 || !(used <= 1.f) || ell_next > st->ell_build ||
                      ell_next < P.rebuild_shrink * st->ell_build;
       // ... or would expire before the next rebuild opportunity of the lean graph
-      if (trio_follows && horizon > 0 && !(moved + 1.25f * (float)horizon * step_move <= st->skin)) rebuild = true;
+      if (trio_follows && horizon > 0 && !(used + 1.25f * (float)horizon * rate <= 1.f)) rebuild = true;
       // Dense regime (rows sitting on K_max, e.g. the first iterations of an outdoor pair at a large ell): when most
       // rows overflow their lists anyway, lists are pointless - every row goes to k_assoc_dense (the reference's
       // literal ordered scan), nothing is rebuilt while that lasts, and the pair returns to lists once the rows have
@@ -1514,13 +1526,21 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
           }
         }
         if (!(s == s)) s = 0.f;
-        st->skin = s * radius;
+        // s * radius is what the FARTHEST target may move; split into a rotation and a translation allowance in the
+        // proportion of the current motion (plus a blend of the pooled budget for either, so that a change of
+        // direction does not expire the lists at once): every row's skin follows from its own distance (k_prep)
+        {
+          const float life = step_move > 0.f ? s * radius / step_move : 0.f;  // iterations at the current speed
+          const float bl = P.skin_blend;
+          st->skin_rot = life * ((1.f - bl) * rot_1 + bl * step_move / fmaxf(ymax, 1e-20f));
+          st->skin_tr = life * ((1.f - bl) * tr_1 + bl * step_move);
+          if (!(st->skin_rot == st->skin_rot) || !(st->skin_tr == st->skin_tr)) st->skin_rot = st->skin_tr = 0.f;
+        }
         st->want_full = want_full;
         if (!dry) *D.want_out = want_full;
         st->n_builds = INIT ? 1 : st->n_builds + 1;
         st->rebuild = 1;  // cleared by k_list once bitmap and lists are current
-      } else if (st->want_full && st->n_ovf == 0 &&
-                 moved + fminf(P.lean_skin, 1.3f) * (float)P.lean_U * step_move <= st->skin) {
+      } else if (st->want_full && st->n_ovf == 0 && used + fminf(P.lean_skin, 1.3f) * (float)P.lean_U * rate <= 1.f) {
         st->want_full = 0;  // the motion has slowed down enough for the lean graph
         if (!dry) *D.want_out = 0;
       }
@@ -1563,6 +1583,12 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
   if (!INIT && status[blockIdx.x] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.x;
   if (!INIT && (flags & 1) && (D->st->rebuild || D->st->n_ovf > 0)) return;  // lean graph: the pair is waiting (k_assoc)
+  if (INIT && threadIdx.x == 0) {  // the pair's cross-block counters start at zero
+    *D->gate = 0;
+    *D->gate_flow = 0;
+    *D->done = 0;
+    *D->tile_count = 0ull;
+  }
   const DevParams P = *Pp;
   __shared__ UpdateShared U;
   update_body<INIT, false>(load_upd_desc(D), P, flags, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, U, nullptr,
@@ -1659,6 +1685,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   const unsigned long long tt1 = INSTR ? __builtin_readcyclecounter() : 0ull;
   coeff_rows<true>(P, D, st_in, S.c, Mu, head, pb.bx, cq, csplit);
   const unsigned long long tt2 = INSTR ? __builtin_readcyclecounter() : 0ull;
+  if (threadIdx.x >= 64) return;  // the counter and (in one block of the pair) the update are the first wave's, see k_assoc
   // the scalar state, for whichever block turns out to be the last one: in flight while the counter round trip runs
   unsigned hot_regs[2] = {0u, 0u};
   if (threadIdx.x < 64) {
@@ -1927,7 +1954,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
   if (rs >= D->NGpad * ROWS_PER_GROUP) return;  // whole waves drop out together (NGpad*4 is a multiple of 256)
   const float ell = st->ell;  // == st->ell_build: a rebuild always uses the current lengthscale
   if (rs == 0) D->st->n_ovf = 0;  // k_list refills the overflow list of k_assoc_dense
-  const float skin = st->skin;
+  // per-row skin = skin_rot * rho_i + skin_tr (+ rounding slack), see PairState / update_body
+  const float skin_rot = st->skin_rot, skin_tr = st->skin_tr;
+  const float tb_norm = sqrtf(__builtin_fmaf(st->Tinv[2], st->Tinv[2], __builtin_fmaf(st->Tinv[1], st->Tinv[1], st->Tinv[0] * st->Tinv[0])));
   float ux = 0, uy = 0, uz = 0, cw = -INF, rad = 0;
   float lox = INF, loy = INF, loz = INF, hix = -INF, hiy = -INF, hiz = -INF;
   if (rs < N) {
@@ -1935,7 +1964,13 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
     const RowData r = make_row(P, x, ell);
     // cut-off of the scan: (sqrt(thr) + skin)^2, rounded up, so that the bitmap stays a superset of the
     // exact test while the targets move by less than `skin` (and ell does not grow)
-    const float rs_ = __builtin_fmaf(sqrtf(fmaxf(r.d2_thres, 0.f)), 1.000001f, skin);
+    // rho_i bounds |y0| of every target that can enter the row's ball while the lists live: such a target sits at
+    // y_t = Rinv y0 + Tinv with |y_t - x_i| < r_i and |Tinv - Tb| <= skin_tr, Rinv a (float) rotation
+    const float r_i = sqrtf(fmaxf(r.d2_thres, 0.f));
+    const float a_to_sensor = sqrtf(__builtin_fmaf(x.z, x.z, __builtin_fmaf(x.y, x.y, x.x * x.x)));
+    const float rho = 1.001f * (a_to_sensor + r_i + tb_norm + skin_tr);
+    const float skin = __builtin_fmaf(skin_rot, rho, skin_tr) + 2e-5f * (rho + 1.f);
+    const float rs_ = __builtin_fmaf(r_i, 1.000001f, (skin_rot > 0.f || skin_tr > 0.f) ? skin : 0.f);
     const float thr = rs_ * rs_ * 1.000001f;
     ux = x.x - cx;
     uy = x.y - cy;
