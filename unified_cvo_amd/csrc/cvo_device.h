@@ -52,6 +52,8 @@ struct DevParams {
   int kernel_clock;  // CVO_KERNEL_CLOCK: accumulate per-pair kernel durations in PairState::clk_*
   int phase_ticks;  // CVO_PHASE_TICKS: leave per-block phase timestamps (g_phase_ticks) for cvo_debug_time_kernels
   int verify_lists;  // CVO_VERIFY_LISTS: k_verify re-derives every row with the literal scan after each association
+  int keep_columns;  // write ell_j (the column of every ELL entry): exports, traces, the self-check and the single
+                     // evaluations need it, the optimiser loop itself never reads it (4 of 20 bytes per nonzero)
   int debug_no_motion_bound;  // CVO_DEBUG_NO_MOTION_BOUND (tests only): the update pretends no target ever moves, so
                               // lists outlive their validity - what CVO_VERIFY_LISTS exists to catch
 };

@@ -548,6 +548,9 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   if (const char* e = getenv("CVO_LEAN_U")) dp.lean_U = std::max(1, atoi(e));
   if (opts && opts->max_iterations > 0) dp.max_iter = std::min(dp.max_iter, opts->max_iterations);
   dp.trace_capacity = trace_cap;
+  // the columns of the ELL entries (ell_j) are only written when somebody can ask for them afterwards
+  dp.keep_columns = (mode != 0 || trace_cap > 0 || dp.verify_lists || params->is_exporting_association ||
+                     getenv("CVO_KEEP_COLUMNS")) ? 1 : 0;
   dp.trace_dense = opts ? opts->trace_dense : 0;
   dp.trace_every = opts ? opts->trace_every : 0;
   *dp_out = dp;
@@ -1503,6 +1506,9 @@ int cvo_edge_kernel_matrix(cvo_ctx* ctx, const cvo_params_t* params, const cvo_c
 
 int cvo_debug_last_ell(cvo_ctx* ctx, int K, float* mat, int* ind, unsigned int* nonzeros) {
   if (!ctx || ctx->last_pairs < 1 || K <= 0) return fail(ctx, CVO_E_INVALID, "cvo_debug_last_ell: bad argument");
+  if (!ctx->last_params.keep_columns)
+    return fail(ctx, CVO_E_INVALID, "cvo_debug_last_ell: the last call kept no column indices (request a trace, "
+                                    "is_exporting_association or CVO_KEEP_COLUMNS=1)");
   std::vector<unsigned> nz;
   std::vector<float> a;
   std::vector<int> jj;
@@ -1527,6 +1533,9 @@ int cvo_align_association(cvo_ctx* ctx, int pair, int* row_ptr, int* col, float*
                           int* stride_written, int* stride_read) {
   if (!ctx || !row_ptr || pair < 0 || pair >= ctx->last_pairs || ctx->last_params.mode != 0)
     return fail(ctx, CVO_E_INVALID, "cvo_align_association: no align call to export from");
+  if (!ctx->last_params.keep_columns)
+    return fail(ctx, CVO_E_INVALID, "cvo_align_association: the last align ran without params.is_exporting_association (the "
+                                    "column indices of the kernel matrix were not kept)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const PairDesc& D = ctx->h_descs[pair];
   const PairState& st = ctx->h_states[pair];

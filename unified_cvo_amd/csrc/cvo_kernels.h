@@ -492,7 +492,7 @@ __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* _
   if (!eval_pair<GENERAL>(P, D, pose, i, r, j, y0, a, yt)) return;
   if (a > P.sp_thres) {
     D->ell[(size_t)A.nnz * N + pos] = EllEntry{a, yt.x, yt.y, yt.z};
-    D->ell_j[(size_t)A.nnz * N + pos] = j;
+    if (P.keep_columns) D->ell_j[(size_t)A.nnz * N + pos] = j;
     A.nnz++;
     const V3 pye{yt.x, yt.y, yt.z};
     const V3 cr = cross_dev(pxe, pye);
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
           const bool keep = ok[h] && rank < (unsigned)K;  // `if (num_inds == num_neighbors) break;`
           if (keep) {
             D->ell[(size_t)rank * N + r_sorted] = EllEntry{a[h], yt[h].x, yt[h].y, yt[h].z};
-            D->ell_j[(size_t)rank * N + r_sorted] = j0 + 64 * h + lane;
+            if (P.keep_columns) D->ell_j[(size_t)rank * N + r_sorted] = j0 + 64 * h + lane;
             // flow terms of this lane's pair (CvoGPU.cu:767-769)
             const V3 pye{yt[h].x, yt[h].y, yt[h].z};
             const V3 cr = cross_dev(pxe, pye);
