@@ -300,11 +300,42 @@ def main():
                 log(f"[bench] single pair, {name}: {best.iterations} iterations, {best.seconds*1e3:.2f} ms "
                     f"({best.seconds*1e6/max(best.iterations,1):.2f} us/iteration)")
         upload_ms_per_cloud = t_h2d * 1e3 / max(2 * len(host_clouds), 1)
-        pcie_inclusive = {"value": aligns / (elapsed + args.steps * t_h2d), "unit": "align/s",
-                          "upload_ms_per_cloud": round(upload_ms_per_cloud, 4), "upload_threads": available_cpus(),
-                          "note": "every step re-uploads its 2 x pairs_per_gpu clouds (spatial ordering + one H2D copy "
-                                  "per cloud) before solving; `value` above has them resident, as registration_seconds "
-                                  "of the reference excludes its H2D copies"}
+        # PCIe-inclusive, as a frame pipeline runs it: while the GPU solves batch k the host threads order and upload
+        # batch k + 1 (cvo_cloud_upload_many on its own streams); every step pays for fresh inputs, the timed region
+        # is the steady state of that pipeline.  `sequential_value` is upload-then-solve without any overlap.
+        pcie_inclusive = {"sequential_value": aligns / (elapsed + args.steps * t_h2d), "unit": "align/s",
+                          "upload_ms_per_cloud": round(upload_ms_per_cloud, 4), "upload_threads": available_cpus()}
+        if world == 1 and args.max_iterations <= 0:
+            import threading
+            all_host = [a for a, _ in host_clouds] + [b_ for _, b_ in host_clouds]
+            nxt = {}
+
+            def prefetch():
+                nxt["clouds"] = gpu.upload_many(all_host, threads=max(1, available_cpus() - 1))
+
+            cur = gpu.upload_many(all_host, threads=available_cpus())
+            n_pipe = max(args.steps, 3)
+            torch.cuda.synchronize()
+            tp0 = time.perf_counter()
+            for _ in range(n_pipe):
+                th = threading.Thread(target=prefetch)
+                th.start()
+                gpu.align_batch(cur[:B], cur[B:], inits)
+                th.join()
+                for h in cur:
+                    h.free()
+                cur = nxt["clouds"]
+            torch.cuda.synchronize()
+            t_pipe = time.perf_counter() - tp0
+            for h in cur:
+                h.free()
+            pcie_inclusive.update({"value": B * n_pipe / t_pipe, "ms_per_step": round(t_pipe / n_pipe * 1e3, 3), "steps": n_pipe,
+                                   "fraction_of_resident_rate": round(B * n_pipe / t_pipe / value, 4)})
+            log(f"[bench] PCIe-inclusive pipeline: {B * n_pipe / t_pipe:.1f} align/s ({t_pipe / n_pipe * 1e3:.1f} ms per step, "
+                f"{100.0 * B * n_pipe / t_pipe / value:.0f}% of the resident rate)")
+        pcie_inclusive["note"] = ("every step uploads its 2 x pairs_per_gpu clouds afresh (spatial ordering + one H2D copy "
+                                  "per cloud); `value` of the bench line has them resident, as registration_seconds of the "
+                                  "reference excludes its H2D copies")
         out = {
             "metric": "frame-pair align()/sec, 10k x 10k geometric clouds", "value": value, "unit": "align/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

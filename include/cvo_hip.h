@@ -153,13 +153,21 @@ int cvo_ctx_synchronize(cvo_ctx* ctx);
 
 /* ---- clouds: replaces CvoPointCloud_to_gpu (CvoGPU_impl.cu:206-285) ------------------
  * xyz: n x 3.  feat: n x 5 row-major or NULL.  label: n x 19 row-major or NULL.
- * geotype: n x 2 or NULL.  Missing arrays are stored as zeros, as the reference leaves the
- * default-constructed CvoPoint fields (PointSegmentedDistribution.hpp:40-56). */
+ * geotype: n x 2 or NULL.  Missing arrays read as zeros, as the reference leaves the
+ * default-constructed CvoPoint fields (PointSegmentedDistribution.hpp:40-56); they are neither uploaded nor allocated
+ * until a call needs them.  Thread-safe: clouds may be uploaded from several host threads of one context at once
+ * (each call orders its points on the calling thread and copies on a stream of its own). */
 int cvo_cloud_upload(cvo_ctx* ctx, int n, const float* xyz, const float* feat, const float* label,
                      const float* geotype, cvo_cloud** out);
 /* Replaces pcl_PointCloud_to_gpu (CvoGPU_impl.cu:287-362): n records of the 192-byte AoS
  * CvoPoint = pcl::PointSegmentedDistribution<5,19> (PointSegmentedDistribution.hpp:17-99). */
 int cvo_cloud_upload_aos192(cvo_ctx* ctx, int n, const void* cvo_points, cvo_cloud** out);
+/* n_clouds clouds at once from a pool of `threads` host threads (0 = default): the per-cloud work of cvo_cloud_upload -
+ * spatial ordering, one allocation, one copy on the thread's own stream - runs in parallel.  n / xyz: per-cloud sizes and
+ * pointers; feat / label / geotype: arrays of per-cloud pointers, the arrays or single entries may be NULL.
+ * out: n_clouds handles (all NULL on error). */
+int cvo_cloud_upload_many(cvo_ctx* ctx, int n_clouds, const int* n, const float* const* xyz, const float* const* feat,
+                          const float* const* label, const float* const* geotype, int threads, cvo_cloud** out);
 int cvo_cloud_size(const cvo_cloud* c);
 void cvo_cloud_free(cvo_cloud* c);
 

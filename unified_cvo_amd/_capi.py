@@ -131,7 +131,7 @@ EXPORTED = [
     "cvo_function_angle", "cvo_association", "cvo_association_non_isotropic", "cvo_cloud_transformed", "cvo_edge_kernel_matrix", "cvo_debug_last_ell", "cvo_debug_time_scan", "cvo_debug_time_kernels",
     "cvo_debug_kernel_clock",
     "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
-    "cvo_align_association", "cvo_debug_scalar_math", "cvo_debug_verified_rows", "cvo_debug_device_memory",
+    "cvo_align_association", "cvo_debug_scalar_math", "cvo_debug_verified_rows", "cvo_debug_device_memory", "cvo_cloud_upload_many",
 ]
 
 _lib = None
@@ -161,6 +161,8 @@ def lib():
     L.cvo_ctx_synchronize.argtypes = [vp]
     L.cvo_cloud_upload.argtypes = [vp, ip, fp, fp, fp, fp, C.POINTER(vp)]
     L.cvo_cloud_upload_aos192.argtypes = [vp, ip, vp, C.POINTER(vp)]
+    L.cvo_cloud_upload_many.argtypes = [vp, ip, C.POINTER(C.c_int), C.POINTER(fp), C.POINTER(fp), C.POINTER(fp),
+                                        C.POINTER(fp), ip, C.POINTER(vp)]
     L.cvo_cloud_size.argtypes = [vp]
     L.cvo_cloud_free.argtypes = [vp]
     L.cvo_cloud_free.restype = None

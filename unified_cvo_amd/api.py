@@ -301,20 +301,36 @@ class CvoGPU:
         return DeviceCloud(self, pc)
 
     def upload_many(self, clouds, threads=None):
-        """Uploads a list of clouds from a thread pool: cvo_cloud_upload is self-contained (host-side k-d ordering, one
-        allocation, one copy) and releases the GIL, so the ordering of different clouds runs on different cores."""
-        from concurrent.futures import ThreadPoolExecutor
+        """Uploads a list of clouds with cvo_cloud_upload_many: a pool of host threads inside the library, each cloud
+        ordered / allocated / copied by one of them on its own stream (one ctypes call, the GIL is released for all of it)."""
         clouds = list(clouds)
+        k = len(clouds)
+        if k == 0:
+            return []
         if threads is None:
             try:
                 threads = len(os.sched_getaffinity(0))
             except AttributeError:
                 threads = os.cpu_count() or 1
-        threads = max(1, min(int(threads), len(clouds), 32))
-        if threads == 1:
-            return [self.upload(c) for c in clouds]
-        with ThreadPoolExecutor(max_workers=threads) as ex:
-            return list(ex.map(self.upload, clouds))
+        threads = max(1, min(int(threads), k, 32))
+        arrs = [pc.device_arrays() for pc in clouds]
+        fpp = C.POINTER(C.c_float)
+        n = (C.c_int * k)(*[a[0].shape[0] for a in arrs])
+
+        def col(i):
+            if all(a[i] is None for a in arrs):
+                return None
+            return (fpp * k)(*[_fptr(a[i]) if a[i] is not None else C.cast(None, fpp) for a in arrs])
+
+        xyz = (fpp * k)(*[_fptr(a[0]) for a in arrs])
+        out = (C.c_void_p * k)()
+        self._check(self.L.cvo_cloud_upload_many(self.ctx, k, n, xyz, col(1), col(2), col(3), threads, out))
+        res = []
+        for i in range(k):
+            d = DeviceCloud.__new__(DeviceCloud)
+            d.gpu, d.n, d._keep, d.handle = self, int(n[i]), None, C.c_void_p(out[i])
+            res.append(d)
+        return res
 
     def upload_aos192(self, records):
         """pcl_PointCloud_to_gpu: uploads an array of 192-byte CvoPoint records (dtype CVO_POINT_DTYPE)."""

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -12,6 +13,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cvo_kernels.h"
@@ -31,6 +33,10 @@ struct cvo_cloud {
   float4* feat = nullptr;   // 2 float4 per point
   float4* label = nullptr;  // 5 float4 per point
   float2* geo = nullptr;
+  // Attributes the caller did not supply are zeros (what the reference leaves in the default-constructed CvoPoint).
+  // They are not uploaded: a zeroed slab is allocated the first time a call needs them (colour / semantic /
+  // geometric-type kernels on a cloud without those arrays), see ensure_attributes.
+  mutable char* zero_slab = nullptr;
   int* order = nullptr;        // spatial (k-d) order: sorted position -> original index
   std::vector<int> h_order;  // host copy (the ELL is stored by sorted row; exports map it back)
   float cx = 0, cy = 0, cz = 0;  // centroid (used only as the cull centre)
@@ -63,6 +69,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct cvo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t upload_stream = nullptr;  // cvo_cloud_upload copies here (never waits for, nor delays, the solver's streams)
   std::string err;
   // workspace
   char* arena = nullptr;
@@ -113,6 +120,25 @@ int fail(cvo_ctx* ctx, int code, const std::string& msg) {
     if (e__ != hipSuccess)                                                                       \
       return fail(ctx, CVO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));           \
   } while (0)
+
+// A cloud that lacks an attribute array the kernels of a call dereference gets a zeroed one (once).
+int ensure_attributes(cvo_ctx* ctx, const cvo_cloud* c, bool need_feat, bool need_label, bool need_geo) {
+  if ((!need_feat || c->feat) && (!need_label || c->label) && (!need_geo || c->geo)) return CVO_OK;
+  cvo_cloud* m = const_cast<cvo_cloud*>(c);
+  const size_t nn = (size_t)std::max(c->n, 1);
+  const size_t o_feat = 0, o_label = align_up(sizeof(float4) * 2 * nn, 256), o_geo = o_label + align_up(sizeof(float4) * 5 * nn, 256);
+  const size_t bytes = o_geo + align_up(sizeof(float2) * nn, 256);
+  if (!m->zero_slab) {
+    HIP_TRY(ctx, hipSetDevice(c->device));
+    hipError_t e = hipMalloc(&m->zero_slab, bytes);
+    if (e != hipSuccess) return fail(ctx, CVO_E_NOMEM, std::string("cloud hipMalloc: ") + hipGetErrorString(e));
+    HIP_TRY(ctx, hipMemsetAsync(m->zero_slab, 0, bytes, ctx->stream));
+  }
+  if (!m->feat) m->feat = (float4*)(m->zero_slab + o_feat);
+  if (!m->label) m->label = (float4*)(m->zero_slab + o_label);
+  if (!m->geo) m->geo = (float2*)(m->zero_slab + o_geo);
+  return CVO_OK;
+}
 
 struct Dims {
   int Mpad, nchunks, rbw_max, nblk_assoc, nblk_coeff, NG, NGpad, Npad;
@@ -500,6 +526,16 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be attributed to this one
+  {  // attribute arrays the kernels of this call read but a cloud was uploaded without: zeros, as upstream has them
+    const bool nf = params->is_using_intensity != 0, nl = params->is_using_semantics != 0,
+               ng = params->is_using_geometric_type != 0 && mode != 2;
+    if (nf || nl || ng)
+      for (int p = 0; p < n_pairs; p++) {
+        int rc0 = ensure_attributes(ctx, sources[p], nf, nl, ng);
+        if (rc0 == CVO_OK) rc0 = ensure_attributes(ctx, targets[p], nf, nl, ng);
+        if (rc0 != CVO_OK) return rc0;
+      }
+  }
   const int trace_cap = (opts && opts->trace) ? opts->trace_capacity : 0;
   const int Kmax = params->nearest_neighbors_max;
   S->N = N;
@@ -783,6 +819,9 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
     ok = ok && hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 2; i++) ok = ok && hipEventCreateWithFlags(&c->ev_chk[i][g], hipEventDisableTiming) == hipSuccess;
   }
+  // (after the sub-batch streams: HIP deals streams to hardware queues in creation order, and the four sub-batch
+  // streams of a batch must land on four different compute pipes - a stream created in between cost 2.4x)
+  ok = ok && hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
   if (!ok) {
     cvo_ctx_destroy(c);
     return CVO_E_HIP;
@@ -809,6 +848,7 @@ void cvo_ctx_destroy(cvo_ctx* c) {
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
   delete c;
 }
 
@@ -853,7 +893,7 @@ static void kd_split(KdPoint* pts, int lo, int hi) {
   kd_split(pts, lo + left, hi);
 }
 
-static void spatial_order(const std::vector<float>& x4, int n, std::vector<int>& order) {
+static void spatial_order(const float* x4, int n, std::vector<int>& order) {
   order.resize(n);
   for (int i = 0; i < n; i++) order[i] = i;
   if (n < 8 || getenv("CVO_NO_SORT")) return;
@@ -870,16 +910,44 @@ static void spatial_order(const std::vector<float>& x4, int n, std::vector<int>&
   for (int r = 0; r < n; r++) order[r] = pts[r].i;
 }
 
-static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, const std::vector<float>& feat,
-                         const std::vector<float>& label, const std::vector<float>& geo, cvo_cloud** out) {
+// One cloud: spatial order on the calling thread, ONE device allocation and ONE host-to-device copy (a hipMalloc / a
+// synchronous copy cost ~100 us each) of exactly the arrays the caller supplied.  xyz: n x 3 (stride3) or n x 4
+// records of `stride` bytes; feat / label / geo may be NULL.  Self-contained and thread-safe: it touches the context
+// only to read its device ordinal, and copies on the stream it is given.
+struct HostCloud {
+  int n;
+  const char* xyz;   size_t xyz_stride;    // 3 floats at xyz + i * xyz_stride
+  const char* feat;  size_t feat_stride;   // FD floats, or NULL
+  const char* label; size_t label_stride;  // NC floats, or NULL
+  const char* geo;   size_t geo_stride;    // 2 floats, or NULL
+};
+
+static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t stream, cvo_cloud** out) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int n = h.n;
   cvo_cloud* c = new cvo_cloud();
   c->ctx = ctx;
   c->device = ctx->device;
   c->n = n;
+  const size_t nn = (size_t)std::max(n, 1);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  const size_t o_x4 = take(sizeof(float4) * nn), o_xs4 = take(sizeof(float4) * nn), o_order = take(sizeof(int) * nn);
+  const size_t o_feat = h.feat ? take(sizeof(float4) * 2 * nn) : 0, o_label = h.label ? take(sizeof(float4) * 5 * nn) : 0,
+               o_geo = h.geo ? take(sizeof(float2) * nn) : 0;
+  std::vector<char> stage(off, 0);  // (pageable: the copy below is synchronous with respect to this thread only)
+  float* x4 = reinterpret_cast<float*>(&stage[o_x4]);
   double sx = 0, sy = 0, sz = 0, r2max = 0;
   for (int i = 0; i < n; i++) {
-    const double px = x4[4 * (size_t)i], py = x4[4 * (size_t)i + 1], pz = x4[4 * (size_t)i + 2];
+    const float* p = reinterpret_cast<const float*>(h.xyz + (size_t)i * h.xyz_stride);
+    x4[4 * (size_t)i] = p[0];
+    x4[4 * (size_t)i + 1] = p[1];
+    x4[4 * (size_t)i + 2] = p[2];
+    const double px = p[0], py = p[1], pz = p[2];
     sx += px;
     sy += py;
     sz += pz;
@@ -893,17 +961,24 @@ static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, cons
     c->cz = (float)(sz / n);
   }
   if (!std::isfinite(c->cx) || !std::isfinite(c->cy) || !std::isfinite(c->cz)) c->cx = c->cy = c->cz = 0.f;
-  // one device allocation and one host-to-device copy per cloud (a hipMalloc / a synchronous copy cost ~100 us
-  // each: six of both took longer than the spatial ordering itself)
-  const size_t nn = (size_t)std::max(n, 1);
-  size_t off = 0;
-  auto take = [&](size_t bytes) {
-    const size_t o = off;
-    off = align_up(off + bytes, 256);
-    return o;
-  };
-  const size_t o_x4 = take(sizeof(float4) * nn), o_xs4 = take(sizeof(float4) * nn), o_feat = take(sizeof(float4) * 2 * nn),
-               o_label = take(sizeof(float4) * 5 * nn), o_geo = take(sizeof(float2) * nn), o_order = take(sizeof(int) * nn);
+  if (h.feat) {
+    float* f8 = reinterpret_cast<float*>(&stage[o_feat]);
+    for (int i = 0; i < n; i++) std::memcpy(&f8[FD_PAD * (size_t)i], h.feat + (size_t)i * h.feat_stride, sizeof(float) * FD);
+  }
+  if (h.label) {
+    float* l20 = reinterpret_cast<float*>(&stage[o_label]);
+    for (int i = 0; i < n; i++) std::memcpy(&l20[NC_PAD * (size_t)i], h.label + (size_t)i * h.label_stride, sizeof(float) * NC);
+  }
+  if (h.geo) {
+    float* g2 = reinterpret_cast<float*>(&stage[o_geo]);
+    for (int i = 0; i < n; i++) std::memcpy(&g2[2 * (size_t)i], h.geo + (size_t)i * h.geo_stride, sizeof(float) * 2);
+  }
+  std::vector<int> order;
+  spatial_order(x4, n, order);
+  float* xs = reinterpret_cast<float*>(&stage[o_xs4]);
+  for (int r = 0; r < n; r++) std::memcpy(&xs[4 * (size_t)r], &x4[4 * (size_t)order[r]], 16);
+  if (n > 0) std::memcpy(&stage[o_order], order.data(), sizeof(int) * (size_t)n);
+  c->h_order = std::move(order);
   hipError_t e = hipMalloc(&c->slab, off);
   c->slab_bytes = off;
   if (e != hipSuccess) {
@@ -912,23 +987,17 @@ static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, cons
   }
   c->x4 = (float4*)(c->slab + o_x4);
   c->xs4 = (float4*)(c->slab + o_xs4);
-  c->feat = (float4*)(c->slab + o_feat);
-  c->label = (float4*)(c->slab + o_label);
-  c->geo = (float2*)(c->slab + o_geo);
   c->order = (int*)(c->slab + o_order);
+  c->feat = h.feat ? (float4*)(c->slab + o_feat) : nullptr;
+  c->label = h.label ? (float4*)(c->slab + o_label) : nullptr;
+  c->geo = h.geo ? (float2*)(c->slab + o_geo) : nullptr;
   if (n > 0) {
-    std::vector<char> stage(off, 0);
-    std::memcpy(&stage[o_x4], x4.data(), sizeof(float) * 4 * (size_t)n);
-    std::memcpy(&stage[o_feat], feat.data(), sizeof(float) * FD_PAD * (size_t)n);
-    std::memcpy(&stage[o_label], label.data(), sizeof(float) * NC_PAD * (size_t)n);
-    std::memcpy(&stage[o_geo], geo.data(), sizeof(float) * 2 * (size_t)n);
-    std::vector<int> order;
-    spatial_order(x4, n, order);
-    float* xs = reinterpret_cast<float*>(&stage[o_xs4]);
-    for (int r = 0; r < n; r++) std::memcpy(&xs[4 * (size_t)r], &x4[4 * (size_t)order[r]], 16);
-    std::memcpy(&stage[o_order], order.data(), sizeof(int) * (size_t)n);
-    c->h_order = std::move(order);
-    HIP_TRY(ctx, hipMemcpy(c->slab, stage.data(), off, hipMemcpyHostToDevice));
+    e = hipMemcpyAsync(c->slab, stage.data(), off, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+      cvo_cloud_free(c);
+      return fail(ctx, CVO_E_HIP, std::string("cloud upload: ") + hipGetErrorString(e));
+    }
   }
   *out = c;
   return CVO_OK;
@@ -937,35 +1006,76 @@ static int upload_packed(cvo_ctx* ctx, int n, const std::vector<float>& x4, cons
 int cvo_cloud_upload(cvo_ctx* ctx, int n, const float* xyz, const float* feat, const float* label,
                      const float* geotype, cvo_cloud** out) {
   if (!ctx || !out || n < 0 || (n > 0 && !xyz)) return fail(ctx, CVO_E_INVALID, "cvo_cloud_upload: bad argument");
-  std::vector<float> x4(4 * (size_t)n, 0.f), f8(FD_PAD * (size_t)n, 0.f), l20(NC_PAD * (size_t)n, 0.f),
-      g2(2 * (size_t)n, 0.f);
-  for (int i = 0; i < n; i++) {
-    for (int c = 0; c < 3; c++) x4[4 * (size_t)i + c] = xyz[3 * (size_t)i + c];
-    if (feat)
-      for (int c = 0; c < FD; c++) f8[FD_PAD * (size_t)i + c] = feat[FD * (size_t)i + c];
-    if (label)
-      for (int c = 0; c < NC; c++) l20[NC_PAD * (size_t)i + c] = label[NC * (size_t)i + c];
-    if (geotype)
-      for (int c = 0; c < 2; c++) g2[2 * (size_t)i + c] = geotype[2 * (size_t)i + c];
+  const HostCloud h{n, (const char*)xyz, 12, (const char*)feat, sizeof(float) * FD, (const char*)label, sizeof(float) * NC,
+                    (const char*)geotype, 8};
+  return upload_host_cloud(ctx, h, ctx->upload_stream, out);
+}
+
+// n_clouds clouds from a pool of host threads (each cloud: spatial ordering on its thread, one allocation, one copy on
+// that thread's own stream).  Arrays of per-cloud pointers; feat / label / geotype (the arrays or single entries) may be
+// NULL.  On error every cloud of the call is released.
+int cvo_cloud_upload_many(cvo_ctx* ctx, int n_clouds, const int* n, const float* const* xyz, const float* const* feat,
+                          const float* const* label, const float* const* geotype, int threads, cvo_cloud** out) {
+  if (!ctx || !out || n_clouds < 0 || (n_clouds > 0 && (!n || !xyz)))
+    return fail(ctx, CVO_E_INVALID, "cvo_cloud_upload_many: bad argument");
+  for (int q = 0; q < n_clouds; q++) {
+    out[q] = nullptr;
+    if (n[q] < 0 || (n[q] > 0 && !xyz[q])) return fail(ctx, CVO_E_INVALID, "cvo_cloud_upload_many: bad cloud");
   }
-  return upload_packed(ctx, n, x4, f8, l20, g2, out);
+  if (n_clouds == 0) return CVO_OK;
+  const int T = std::max(1, std::min(std::min(threads > 0 ? threads : 8, n_clouds), 64));
+  std::vector<int> rcs(T, CVO_OK);
+  std::vector<std::string> errs(T);
+  std::atomic<int> next(0);
+  auto work = [&](int t) {
+    hipStream_t s = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+      rcs[t] = CVO_E_HIP;
+      errs[t] = "cvo_cloud_upload_many: stream creation failed";
+      return;
+    }
+    cvo_ctx local;  // error text of this thread (the shared context's string is not thread-safe)
+    local.device = ctx->device;
+    for (;;) {
+      const int q = next.fetch_add(1);
+      if (q >= n_clouds || rcs[t] != CVO_OK) break;
+      const HostCloud h{n[q], (const char*)xyz[q], 12, (const char*)(feat ? feat[q] : nullptr), sizeof(float) * FD,
+                        (const char*)(label ? label[q] : nullptr), sizeof(float) * NC,
+                        (const char*)(geotype ? geotype[q] : nullptr), 8};
+      cvo_cloud* c = nullptr;
+      const int rc = upload_host_cloud(&local, h, s, &c);
+      if (rc != CVO_OK) {
+        rcs[t] = rc;
+        errs[t] = local.err;
+        break;
+      }
+      c->ctx = ctx;
+      out[q] = c;
+    }
+    (void)hipStreamDestroy(s);
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < T; t++) pool.emplace_back(work, t);
+  work(0);
+  for (auto& th : pool) th.join();
+  for (int t = 0; t < T; t++)
+    if (rcs[t] != CVO_OK) {
+      for (int q = 0; q < n_clouds; q++) {
+        if (out[q]) cvo_cloud_free(out[q]);
+        out[q] = nullptr;
+      }
+      return fail(ctx, rcs[t], errs[t]);
+    }
+  return CVO_OK;
 }
 
 int cvo_cloud_upload_aos192(cvo_ctx* ctx, int n, const void* pts, cvo_cloud** out) {
   if (!ctx || !out || n < 0 || (n > 0 && !pts)) return fail(ctx, CVO_E_INVALID, "cvo_cloud_upload_aos192: bad argument");
   // PointSegmentedDistribution<5,19> byte offsets: xyz@0, features@20,
-  // label_distribution@44, geometric_type@120, sizeof = 192.
-  std::vector<float> x4(4 * (size_t)n, 0.f), f8(FD_PAD * (size_t)n, 0.f), l20(NC_PAD * (size_t)n, 0.f),
-      g2(2 * (size_t)n, 0.f);
+  // label_distribution@44, geometric_type@120, sizeof = 192: read in place, record by record.
   const char* b = (const char*)pts;
-  for (int i = 0; i < n; i++) {
-    const char* r = b + 192 * (size_t)i;
-    std::memcpy(&x4[4 * (size_t)i], r + 0, 12);
-    std::memcpy(&f8[FD_PAD * (size_t)i], r + 20, 4 * FD);
-    std::memcpy(&l20[NC_PAD * (size_t)i], r + 44, 4 * NC);
-    std::memcpy(&g2[2 * (size_t)i], r + 120, 8);
-  }
-  return upload_packed(ctx, n, x4, f8, l20, g2, out);
+  const HostCloud h{n, b, 192, b + 20, 192, b + 44, 192, b + 120, 192};
+  return upload_host_cloud(ctx, h, ctx->upload_stream, out);
 }
 
 // ---- multi-frame edge kernel ---------------------------------------------------------
@@ -985,7 +1095,11 @@ int cvo_cloud_transformed(cvo_ctx* ctx, const cvo_cloud* in, const float pose12[
     return fail(ctx, CVO_E_NOMEM, std::string("cloud hipMalloc: ") + hipGetErrorString(e));
   }
   // same slab layout: features, labels, geometric types and the spatial order are copied, coordinates rewritten
-  auto rebase = [&](const void* p) { return c->slab + ((const char*)p - in->slab); };
+  // (attributes the input was uploaded without - NULL or pointing into its zero slab - stay absent in the copy)
+  auto rebase = [&](const void* p) -> char* {
+    const char* q = (const char*)p;
+    return (q && q >= in->slab && q < in->slab + in->slab_bytes) ? c->slab + (q - in->slab) : nullptr;
+  };
   c->x4 = (float4*)rebase(in->x4);
   c->xs4 = (float4*)rebase(in->xs4);
   c->feat = (float4*)rebase(in->feat);
@@ -1021,6 +1135,7 @@ void cvo_cloud_free(cvo_cloud* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->slab) (void)hipFree(c->slab);
+  if (c->zero_slab) (void)hipFree(c->zero_slab);
   delete c;
 }
 
