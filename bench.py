@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=400)
     ap.add_argument("--no-single-pair", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the PCIe-inclusive pipeline leg")
     args = ap.parse_args()
 
     import torch
@@ -305,7 +306,7 @@ def main():
         # is the steady state of that pipeline.  `sequential_value` is upload-then-solve without any overlap.
         pcie_inclusive = {"sequential_value": aligns / (elapsed + args.steps * t_h2d), "unit": "align/s",
                           "upload_ms_per_cloud": round(upload_ms_per_cloud, 4), "upload_threads": available_cpus()}
-        if world == 1 and args.max_iterations <= 0:
+        if world == 1 and args.max_iterations <= 0 and not args.no_pipeline:
             import threading
             all_host = [a for a, _ in host_clouds] + [b_ for _, b_ in host_clouds]
             nxt = {}

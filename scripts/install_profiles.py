@@ -15,10 +15,10 @@ for f in ("bench_n1.json", "bench_under_rocprof.json"):
     json.dump(json.loads(line), open(dst + f, "w"), indent=1)
 raw = json.load(open(src + "pmc_summary_raw.json"))
 raw.pop("cvo_dev::k_hold", None)
-cmd = ("rocprofv3 --pmc <counters> --output-format csv -- python bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline (one pass "
-       "per counter group, no trace domains; every launch covers one sub-batch of 16 pairs x 10k x 10k; averages over all launches "
-       "of the run, including the early-exit launches of k_prep / k_scan / k_list / k_assoc_dense in iterations that do not rebuild; "
-       "summarised on the GPU box by scripts/summarize_pmc.py)")
+cmd = ("rocprofv3 --pmc <counters> --output-format csv -- python one_batch.py (scripts/profile_round.sh: one cvo_align_batch of the "
+       "headline workload, 64 x 10k x 10k, 2000 iterations; one pass per counter group, no trace domains; every launch covers one "
+       "sub-batch of 16 pairs; averages over all launches of the run, including the early-exit launches of k_prep / k_scan / k_list / "
+       "k_assoc_dense in iterations that do not rebuild; summarised on the GPU box by scripts/summarize_pmc.py)")
 json.dump({"command": cmd, "kernels": raw}, open(dst + "pmc_summary.json", "w"), indent=0)
 def hbm(prefix):
     k = max((q for q in raw if q.startswith(prefix)), key=lambda q: raw[q]["FETCH_SIZE"]["launches"])  # (template arguments vary)

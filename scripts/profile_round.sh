@@ -1,16 +1,34 @@
+# The round's profile set, run on the GPU box (gpurun): bench line, rocprofv3 kernel trace of the same command, PMC
+# passes (one counter group per pass, no trace domains), every BASELINE config next to the oracle.
+#   ROUND=r2 bash scripts/profile_round.sh      -> gpurun_out/r2_prof/ ; then scripts/install_profiles.py r2 (here)
 set -x
-R=/root/repo
+R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${ROUND:-r2}_prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 900 python $R/bench.py --gpus 1 --steps 2 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.log
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-single-pair > $O/bench_under_rocprof.json 2> $O/rocprof.log
+timeout 600 python $R/bench.py --gpus 1 --steps 2 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-single-pair --no-pipeline > $O/bench_under_rocprof.json 2> $O/rocprof.log
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+# PMC: the headline batch itself (one cvo_align_batch of 64 x 10k x 10k, 2000 iterations; launches of 16 pairs), not
+# the whole bench harness - counter collection serialises every dispatch
+cat > /tmp/one_batch.py <<PY
+import os, sys
+sys.path.insert(0, "$R"); sys.path.insert(0, "$R/tests")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import cases
+from unified_cvo_amd import CvoGPU
+P = cases.load_params("geometric_gpu")
+pairs = [cases.config2(n=10000, pair_id=p) for p in range(64)]
+gpu = CvoGPU(params=P)
+both = gpu.upload_many([a[1] for a in pairs] + [a[2] for a in pairs])
+r = gpu.align_batch(both[:64], both[64:], [a[3] for a in pairs])
+print(r[0].iterations, r[0].seconds)
+PY
 i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
   i=$((i+1))
-  timeout 900 rocprofv3 --pmc $grp --output-format csv -d /tmp/pmc$i -o p -- python $R/bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline --no-single-pair > /tmp/pmc$i.json 2> /tmp/pmc$i.log
+  timeout 180 rocprofv3 --pmc $grp --output-format csv -d /tmp/pmc$i -o p -- python /tmp/one_batch.py > /tmp/pmc$i.json 2> /tmp/pmc$i.log || tail -3 /tmp/pmc$i.log
 done
-python $R/scripts/summarize_pmc.py $O/pmc_summary_raw.json /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 /tmp/pmc4
-cd $R && timeout 900 python scripts/run_configs.py $O/configs.json > $O/configs.log 2>&1
+python $R/scripts/summarize_pmc.py $O/pmc_summary_raw.json /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 /tmp/pmc4 /tmp/pmc5 > $O/pmc_summary.txt
+cd $R && timeout 600 python scripts/run_configs.py $O/configs.json > $O/configs.log 2>&1
 tail -3 $O/bench_n1.log

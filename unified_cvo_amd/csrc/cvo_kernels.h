@@ -1530,7 +1530,8 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         // proportion of the current motion (plus a blend of the pooled budget for either, so that a change of
         // direction does not expire the lists at once): every row's skin follows from its own distance (k_prep)
         {
-          const float life = step_move > 0.f ? s * radius / step_move : 0.f;  // iterations at the current speed
+          // (normalised so that the farthest row gets exactly s * radius)
+          const float life = step_move > 0.f ? s * radius / (step_move * (1.f + P.skin_blend)) : 0.f;  // iterations at the current speed
           const float bl = P.skin_blend;
           st->skin_rot = life * ((1.f - bl) * rot_1 + bl * step_move / fmaxf(ymax, 1e-20f));
           st->skin_tr = life * ((1.f - bl) * tr_1 + bl * step_move);
