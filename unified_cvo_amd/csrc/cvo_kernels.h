@@ -569,7 +569,11 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
     const int* yorder = D->yorder;
     D->cand_cnt[pos] = cnt_all;
     D->rowperm[pos] = rr;
-    D->xp4[pos] = D->xs4[rr];
+    {  // the row's head for the per-iteration kernels: coordinates + its candidate count in one 16-byte record
+      float4 xh = D->xs4[rr];
+      xh.w = __int_as_float(cnt_all);
+      D->xp4[pos] = xh;
+    }
     D->ip[pos] = D->xorder[rr];
     if (cnt_all > ASSOC_CAP) {
       // more candidates than a list holds (dense regime, e.g. rows sitting on K_max): k_assoc_dense
@@ -904,10 +908,10 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_ASSOC_WAVES) void k_assoc(const 
   {
     const char* wb = arena + (size_t)pb.pair * ((size_t)stride256 << 8);
     const int pos = pb.bx * ASSOC_THREADS + threadIdx.x;  // < Npad; values of rows >= N are never used
-    head.cnt = reinterpret_cast<const int*>(wb + row_off_cand_cnt(Npad))[pos];
-    head.ip = reinterpret_cast<const int*>(wb + row_off_ip(Npad))[pos];
+    head.ip = GENERAL ? reinterpret_cast<const int*>(wb + row_off_ip(Npad))[pos] : 0;  // (only the feature lookups need it)
     head.j1 = (int)reinterpret_cast<const IdxT*>(wb + row_off_cand_j(Npad))[pos];
     head.x = reinterpret_cast<const float4*>(wb + row_off_xp4(Npad))[pos];
+    head.cnt = __float_as_int(head.x.w);  // (k_list packs the row's candidate count next to its coordinates)
   }
   // everything the prologue branches on, requested in one burst of scalar loads (a chain of dependent ~0.5 us
   // round trips in front of every block is what this latency-bound kernel can least afford)
