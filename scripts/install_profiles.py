@@ -1,12 +1,44 @@
-"""Copies the outputs of scripts/profile_round.sh (gpurun_out/<round>_prof) into profiles/<round> and refreshes
-profiles/kernel_traffic.json from the PMC passes (keyed on the hash of the kernel sources they were measured on).
-Usage: install_profiles.py [round, default r2]"""
-import csv, json, os, shutil, sys
+"""Installs the outputs of scripts/profile_round.sh.
+
+  on the GPU box (called by profile_round.sh):   install_profiles.py <round> --traffic
+      writes profiles/kernel_traffic.json from the PMC passes (keyed on the hash of the kernel sources they were
+      measured on) so that the bench run that follows reports roofline.traffic, and a copy next to the other outputs;
+  here, afterwards:                               install_profiles.py <round>
+      copies gpurun_out/<round>_prof/* into profiles/<round>/ and profiles/kernel_traffic.json.
+"""
+import csv
+import json
+import os
+import shutil
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r2"
+rnd = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r2"
 src = os.path.join(ROOT, "gpurun_out", rnd + "_prof") + "/"
 dst = os.path.join(ROOT, "profiles", rnd) + "/"
+KT = os.path.join(ROOT, "profiles", "kernel_traffic.json")
+
+if "--traffic" in sys.argv:
+    from unified_cvo_amd import build as hipbuild
+    raw = json.load(open(src + "pmc_summary_raw.json"))
+
+    def hbm(prefix):
+        k = max((q for q in raw if q.startswith(prefix)), key=lambda q: raw[q]["FETCH_SIZE"]["launches"])  # (template arguments vary)
+        return int((2 * raw[k]["FETCH_SIZE"]["avg_per_launch"] + raw[k]["WRITE_SIZE"]["avg_per_launch"]) * 1024)
+
+    kt = {"points": 10000, "pairs": 16,
+          "hbm_bytes_per_launch": {"k_coeff": hbm("cvo_dev::k_coeff"), "k_assoc": hbm("cvo_dev::k_assoc<"), "k_scan": hbm("cvo_dev::k_scan<")},
+          "correction": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE counts 64 B per "
+                        "128-B request; WRITE_SIZE uncalibrated)",
+          "source": f"profiles/{rnd}/pmc_summary.json (separate --pmc passes for FETCH_SIZE and WRITE_SIZE over one cvo_align_batch of the "
+                    "headline workload; average per launch of one 16-pair sub-batch)",
+          "source_sha": hipbuild.source_hash()}
+    json.dump(kt, open(KT, "w"), indent=1)
+    shutil.copy(KT, src + "kernel_traffic.json")
+    print(json.dumps(kt["hbm_bytes_per_launch"]))
+    sys.exit(0)
+
 os.makedirs(dst, exist_ok=True)
 for f in ("bench_kernel_stats.csv", "configs.json"):
     shutil.copy(src + f, dst + f)
@@ -20,17 +52,8 @@ cmd = ("rocprofv3 --pmc <counters> --output-format csv -- python one_batch.py (s
        "sub-batch of 16 pairs; averages over all launches of the run, including the early-exit launches of k_prep / k_scan / k_list / "
        "k_assoc_dense in iterations that do not rebuild; summarised on the GPU box by scripts/summarize_pmc.py)")
 json.dump({"command": cmd, "kernels": raw}, open(dst + "pmc_summary.json", "w"), indent=0)
-def hbm(prefix):
-    k = max((q for q in raw if q.startswith(prefix)), key=lambda q: raw[q]["FETCH_SIZE"]["launches"])  # (template arguments vary)
-    return int((2 * raw[k]["FETCH_SIZE"]["avg_per_launch"] + raw[k]["WRITE_SIZE"]["avg_per_launch"]) * 1024)
-kt = json.load(open(os.path.join(ROOT, "profiles", "kernel_traffic.json")))
-from unified_cvo_amd import build as hipbuild
-kt["source_sha"] = hipbuild.source_hash()
-kt["source"] = f"profiles/{rnd}/pmc_summary.json (separate --pmc passes for FETCH_SIZE and WRITE_SIZE; average per launch of one 16-pair sub-batch)"
-kt["hbm_bytes_per_launch"] = {"k_coeff": hbm("cvo_dev::k_coeff"), "k_assoc": hbm("cvo_dev::k_assoc<"),
-                              "k_scan": hbm("cvo_dev::k_scan<")}
-json.dump(kt, open(os.path.join(ROOT, "profiles", "kernel_traffic.json"), "w"), indent=1)
+shutil.copy(src + "kernel_traffic.json", KT)
 d = json.load(open(dst + "bench_n1.json"))
-print("value", d["value"], "ms/step", d["ms_per_step"], "k_coeff", d["roofline"]["avg_launch_ms"], "k_assoc", d["roofline"]["other_kernels"][0]["avg_launch_ms"])
+print("value", d["value"], "ms/step", d["ms_per_step"], "k_coeff", d["roofline"]["avg_launch_ms"], "traffic", d["roofline"]["traffic"])
 for row in list(csv.DictReader(open(dst + "bench_kernel_stats.csv")))[:5]:
     print(row["Name"][:50], row["Calls"], row["AverageNs"])

@@ -6,9 +6,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${ROUND:-r2}_prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 600 python $R/bench.py --gpus 1 --steps 2 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.log
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-single-pair --no-pipeline > $O/bench_under_rocprof.json 2> $O/rocprof.log
-cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 # PMC: the headline batch itself (one cvo_align_batch of 64 x 10k x 10k, 2000 iterations; launches of 16 pairs), not
 # the whole bench harness - counter collection serialises every dispatch
 cat > /tmp/one_batch.py <<PY
@@ -30,5 +27,10 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_IN
   timeout 180 rocprofv3 --pmc $grp --output-format csv -d /tmp/pmc$i -o p -- python /tmp/one_batch.py > /tmp/pmc$i.json 2> /tmp/pmc$i.log || tail -3 /tmp/pmc$i.log
 done
 python $R/scripts/summarize_pmc.py $O/pmc_summary_raw.json /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 /tmp/pmc4 /tmp/pmc5 > $O/pmc_summary.txt
+# the PMC traffic of THIS build goes into profiles/kernel_traffic.json before the bench run, which reports it
+python $R/scripts/install_profiles.py ${ROUND:-r2} --traffic
+timeout 600 python $R/bench.py --gpus 1 --steps 2 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-single-pair --no-pipeline > $O/bench_under_rocprof.json 2> $O/rocprof.log
+cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 cd $R && timeout 600 python scripts/run_configs.py $O/configs.json > $O/configs.log 2>&1
 tail -3 $O/bench_n1.log
