@@ -45,6 +45,7 @@ struct DevParams {
   float skin_frac;
   float rebuild_shrink;  // rebuild when ell < rebuild_shrink * ell_build (the lists would be (1/shrink)^3 too long)
   int lean_U;            // iterations between two rebuild opportunities in the lean graph
+  int lean_U2;           // ... and in the short lean graph (motion too fast for lean_U, slow enough for a list to last lean_U2)
   float skin_min, skin_max;  // clamp of the skin (fractions of the cut-off radius) before skin_frac
   float skin_blend;          // share of the pooled motion budget both the rotation and the translation allowance get on top of their own
   int dense_regime;      // 0: never switch a pair to the all-rows-dense regime (CVO_NO_DENSE_REGIME)
@@ -93,7 +94,8 @@ struct PairState {
   // get a thin skin; only the farthest rows pay for the whole motion bound.
   float skin_rot, skin_tr;
   int n_builds;
-  int want_full, n_stalls;  // host hint: this pair needs the graph with per-iteration rebuild / dense kernels
+  int want_full, n_stalls;  // host hint: 2 = this pair needs the graph with per-iteration rebuild / dense kernels,
+                            // 1 = the short lean graph (a rebuild opportunity every lean_U2 iterations), 0 = the lean graph
   int all_dense;
   float skin_scale;  // backs the skin off while rows overflow their lists (see update_body)
   // all_dense = dense regime: every row is served by k_assoc_dense, no lists (see update_body)

@@ -91,8 +91,8 @@ struct cvo_ctx {
   hipEvent_t ev_chk[2][MAX_GROUPS] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
   // graph cache (one per group)
-  hipGraphExec_t graph_exec[MAX_GROUPS][2] = {};  // [group][0 = full chunk, 1 = lean chunk]
-  GraphKey graph_key[MAX_GROUPS][2] = {};
+  hipGraphExec_t graph_exec[MAX_GROUPS][3] = {};  // [group][0 = full chunk, 1 = lean chunk, 2 = short lean chunk]
+  GraphKey graph_key[MAX_GROUPS][3] = {};
   int last_chunks = 0, last_lean_launches = 0, last_full_launches = 0;
   // last call (debug hooks)
   int last_pairs = 0;
@@ -216,7 +216,7 @@ void free_workspace(cvo_ctx* c) {
 
 void drop_graphs(cvo_ctx* c) {
   for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++)
-    for (int v = 0; v < 2; v++)
+    for (int v = 0; v < 3; v++)
       if (c->graph_exec[g][v]) {
         (void)hipGraphExecDestroy(c->graph_exec[g][v]);
         c->graph_exec[g][v] = nullptr;
@@ -582,6 +582,9 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   dp.groups_per_block = S->gpb;
   dp.lean_U = 8;
   if (const char* e = getenv("CVO_LEAN_U")) dp.lean_U = std::max(1, atoi(e));
+  dp.lean_U2 = 2;
+  if (const char* e = getenv("CVO_LEAN_U2")) dp.lean_U2 = std::max(0, atoi(e));  // 0 = no short lean graph
+  if (dp.lean_U2 >= dp.lean_U) dp.lean_U2 = 0;
   if (opts && opts->max_iterations > 0) dp.max_iter = std::min(dp.max_iter, opts->max_iterations);
   dp.trace_capacity = trace_cap;
   // the columns of the ELL entries (ell_j) are only written when somebody can ask for them afterwards
@@ -1179,6 +1182,8 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
 
   if (max_iter > 0) {
     const int lean_U = std::max(1, std::min(dp.lean_U, U));
+    const int lean_U2 = std::max(0, std::min(dp.lean_U2, U));
+    auto lean_period = [&](int v) { return v == 2 ? lean_U2 : lean_U; };
     auto get_graph = [&](int g, int v) -> int {
       GraphKey key;
       key.n_pairs = geom[g].n_pairs;
@@ -1191,7 +1196,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       key.npb = S.geom.npb;
       key.idx16 = S.geom.idx16 ? 1 : 0;
       key.general = S.geom.general ? 1 : 0;
-      key.U = U * 256 + lean_U;
+      key.U = U * 256 + lean_period(v);
       key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0);
       key.arena = geom[g].arena.base;
       key.stride256 = geom[g].arena.stride256;
@@ -1203,7 +1208,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       }
       hipGraph_t gr = nullptr;
       HIP_TRY(ctx, hipStreamBeginCapture(geom[g].stream, hipStreamCaptureModeThreadLocal));
-      launch_chunk(ctx, geom[g], U, v == 1, lean_U);
+      launch_chunk(ctx, geom[g], U, v != 0, lean_period(v));
       // (the capture is always ended, whatever the launches reported: a stream left in capture mode would poison
       // every later call on this context)
       const hipError_t e_launch = hipGetLastError();
@@ -1224,8 +1229,8 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     const int n_chunks = (max_iter + U - 1) / U;
     const int chunk_cap = 4 * n_chunks + 16;
     const bool allow_lean = getenv("CVO_NO_LEAN") == nullptr;
-    bool lean_next[cvo_ctx::MAX_GROUPS];
-    for (int g = 0; g < G; g++) lean_next[g] = false;  // the first iterations move fast: full graph
+    int graph_next[cvo_ctx::MAX_GROUPS];  // 0 = full, 1 = lean, 2 = short lean
+    for (int g = 0; g < G; g++) graph_next[g] = 0;  // the first iterations move fast: full graph
     bool all_done = false;
     int ch = 0;
     int n_lean_launch = 0, n_full_launch = 0;
@@ -1235,7 +1240,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     for (; ch < chunk_cap && !all_done; ch++) {
       const int slot = ch & 1;
       for (int g = 0; g < G; g++) {
-        const int v = lean_next[g] ? 1 : 0;
+        const int v = graph_next[g];
         (v ? n_lean_launch : n_full_launch)++;
         if (use_graph) {
           rc = get_graph(g, v);
@@ -1244,7 +1249,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
           HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g][v], geom[g].stream));
           t_launch += ms_since(tl);
         } else {
-          launch_chunk(ctx, geom[g], U, v == 1, lean_U);
+          launch_chunk(ctx, geom[g], U, v != 0, lean_period(v));
           HIP_TRY(ctx, hipGetLastError());
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status[slot] + geom[g].p0, ctx->d_status + geom[g].p0,
@@ -1263,10 +1268,11 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
         all_done = true;
         for (int p = 0; p < n_pairs; p++) all_done = all_done && ctx->h_status[ws][p] != 0;
         for (int g = 0; g < G; g++) {
-          bool want_full = false;
+          int want = 0;  // the most demanding unfinished pair of the group decides: 2 = full, 1 = short lean, 0 = lean
           for (int p = geom[g].p0; p < geom[g].p0 + geom[g].n_pairs; p++)
-            want_full = want_full || (ctx->h_status[ws][p] == 0 && ctx->h_status[ws][ctx->cap_pairs + p] != 0);
-          lean_next[g] = allow_lean && !want_full;
+            if (ctx->h_status[ws][p] == 0) want = std::max(want, ctx->h_status[ws][ctx->cap_pairs + p]);
+          if (want == 1 && lean_U2 <= 0) want = 2;
+          graph_next[g] = !allow_lean ? 0 : (want >= 2 ? 0 : (want == 1 ? 2 : 1));
           if (getenv("CVO_VERBOSE") && atoi(getenv("CVO_VERBOSE")) >= 2 && ch < 12) {
             int nw = 0;
             for (int p = geom[g].p0; p < geom[g].p0 + geom[g].n_pairs; p++) nw += ctx->h_status[ws][ctx->cap_pairs + p] != 0;

@@ -1510,7 +1510,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         // rebuilds; s ~ 1.5 sqrt(step / radius) balances the two for this kernel set.  The lean graph only has a
         // rebuild opportunity every lean_U iterations, so it needs s >= ~1.3 lean_U step / radius; when that is
         // too much (fast motion) or rows overflow their lists, ask the host for the full graph.
-        int want_full = 1;
+        int want_full = 2;
         float s = 0.f;
         // rows that overflow their lists fall back to the literal scan over all targets (k_assoc_dense): fine for a few
         // rows or a small cloud, ruinous if a generous skin pushes many rows of a large one over the edge - the skin
@@ -1522,9 +1522,13 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
           const float rel = step_move / radius;
           s = st->skin_scale * P.skin_frac * fminf(fmaxf(1.5f * sqrtf(rel), P.skin_min), P.skin_max);
           const float s_lean = fmaxf(s, P.lean_skin * (float)P.lean_U * rel);
+          const float s_lean2 = fmaxf(s, P.lean_skin * (float)P.lean_U2 * rel);
           if (s_lean <= 0.5f && st->n_ovf == 0) {
             s = s_lean;
             want_full = 0;
+          } else if (P.lean_U2 > 0 && s_lean2 <= 0.5f && st->n_ovf == 0) {
+            s = s_lean2;  // too fast for lean_U iterations between rebuilds, slow enough for lean_U2
+            want_full = 1;
           } else if (!(s >= 2.f * rel)) {
             s = 0.f;  // would not survive two iterations: plain scan every iteration
           }
@@ -1545,9 +1549,17 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         if (!dry) *D.want_out = want_full;
         st->n_builds = INIT ? 1 : st->n_builds + 1;
         st->rebuild = 1;  // cleared by k_list once bitmap and lists are current
-      } else if (st->want_full && st->n_ovf == 0 && used + fminf(P.lean_skin, 1.3f) * (float)P.lean_U * rate <= 1.f) {
-        st->want_full = 0;  // the motion has slowed down enough for the lean graph
-        if (!dry) *D.want_out = 0;
+      } else if (st->want_full && st->n_ovf == 0) {  // has the motion slowed down enough for a leaner graph?
+        const float c = fminf(P.lean_skin, 1.3f);
+        int want = st->want_full;
+        if (used + c * (float)P.lean_U * rate <= 1.f)
+          want = 0;
+        else if (P.lean_U2 > 0 && used + c * (float)P.lean_U2 * rate <= 1.f)
+          want = min(want, 1);
+        if (want != st->want_full) {
+          st->want_full = want;
+          if (!dry) *D.want_out = want;
+        }
       }
     }
     for (int q = 0; q < 9; q++) st->Rinv[q] = Ri[q];
@@ -1656,8 +1668,8 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
       if (pb.bx == 0 && cq == 0 && threadIdx.x == 0) {
         st->n_stalls++;
         if (ovf > 0) {
-          st->want_full = 1;
-          *D->want_out = 1;
+          st->want_full = 2;
+          *D->want_out = 2;
         }
       }
       return;
