@@ -1112,11 +1112,17 @@ int cvo_cloud_transformed(cvo_ctx* ctx, const cvo_cloud* in, const float pose12[
   Pose12 P;
   for (int q = 0; q < 12; q++) P.T[q] = pose12[q];
   if (in->n > 0) {
-    HIP_TRY(ctx, hipMemcpyAsync(c->slab, in->slab, in->slab_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_transform_pose, dim3((in->n + 255) / 256), dim3(256), 0, ctx->stream, in->n, P, in->x4, in->xs4,
-                       c->x4, c->xs4);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    e = hipMemcpyAsync(c->slab, in->slab, in->slab_bytes, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_transform_pose, dim3((in->n + 255) / 256), dim3(256), 0, ctx->stream, in->n, P, in->x4, in->xs4,
+                         c->x4, c->xs4);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      cvo_cloud_free(c);
+      return fail(ctx, CVO_E_HIP, std::string("cvo_cloud_transformed: ") + hipGetErrorString(e));
+    }
   }
   // cull centre and motion bound of the moved cloud (neither influences a result)
   const float* T = pose12;
