@@ -1269,6 +1269,14 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     const int nba = n_flow_parts, nbc = D.nblk_coeff;
     const int c = tid >> 4, bl = tid & 15;
     double s = 0;
+    // the counts were written by the association kernel(s), i.e. before this launch: plain loads, requested ahead of
+    // the coherent ones so that the two round trips overlap
+    unsigned long long vq[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int b = bl + 16 * u;
+      vq[u] = b < nba ? D.cnt_part[(size_t)b * 4 + c] : 0ull;
+    }
     if (P.mode == 0) {
       // eight (coherent) loads in flight per lane, summed in block order
       for (int b0 = bl; b0 < nbc; b0 += 128) {
@@ -1284,8 +1292,10 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     } else if (c == 0) {
       for (int b = bl; b < nba; b += 16) s += D.flow_part[(size_t)b * 8 + 6];
     }
-    unsigned long long q = 0;  // (written by the association kernel(s), i.e. before this launch: plain loads)
-    for (int b0 = bl; b0 < nba; b0 += 128) {
+    unsigned long long q = 0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) q = (c == 1) ? max(q, vq[u]) : q + vq[u];
+    for (int b0 = bl + 128; b0 < nba; b0 += 128) {
       unsigned long long v[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
@@ -1363,11 +1373,18 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         const float* om = st->omega;
         const float* vv = st->v;
         double dist = 0;
-        auto norm3d = [](const float* a) {
+        auto sqnorm3d = [](const float* a) {
           const double x = a[0], y = a[1], z = a[2];
-          return sqrt(x * x + (y * y + z * z));
+          return x * x + (y * y + z * z);
         };
-        if (norm3d(om) < (double)P.eps && norm3d(vv) < (double)P.eps) {  // CvoGPU.cu:1454-1458
+        // `omega.norm() < eps && v.norm() < eps` (double sqrt of the float-derived sums).  The twist is normalised, so
+        // one of the two is ~1: sqrt is monotonic and correctly rounded, x > eps^2 (1 + 1e-12) decides sqrt(x) >= eps
+        // without the ~60 dependent instructions of a double square root on the serial tail (exact shortcut).
+        const double n2o = sqnorm3d(om), n2v = sqnorm3d(vv);
+        const double eps2_hi = (double)P.eps * (double)P.eps * (1.0 + 1e-12);
+        bool vanished = false;
+        if (!(n2o > eps2_hi || n2v > eps2_hi)) vanished = sqrt(n2o) < (double)P.eps && sqrt(n2v) < (double)P.eps;
+        if (vanished) {  // CvoGPU.cu:1454-1458
           auto norm3f = [](const float* a) { return sqrtf(a[0] * a[0] + (a[1] * a[1] + a[2] * a[2])); };
           if ((double)norm3f(om) < 1e-8 && (double)norm3f(vv) < 1e-8) st->ret = -1;
           done = 1;
@@ -1458,9 +1475,14 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
       // radius of row i, rho_i >= |y0_j| for every target that can come within the row's radius (k_prep); so as long
       // as |Ri - Rb|_F <= skin_rot and |Ti - Tb| <= skin_tr (and ell, hence every radius, has not grown) the bitmap
       // still contains every pair the exact test of k_assoc can accept.
+      // (None of this reaches a result: the allowances only have to be what k_prep adds to the radii, and the motion
+      // bounds carry a 0.1 % margin - hardware square roots and reciprocals, 1 ulp, instead of ~12 dependent
+      // instructions per IEEE sqrtf / division on the serial tail.)
+      auto fsqrt = [](float x) { return __builtin_amdgcn_sqrtf(x); };
+      auto frcp = [](float x) { return __builtin_amdgcn_rcpf(x); };
       const float ell_next = st->ell;
-      const float radius = ell_next * sqrtf(fmaxf(-2.f * P.log_geo, 0.f));  // cut-off radius for l = ell
-      float dr = 0, dt = 0, dr1 = 0, dt1 = 0, tn = 0;
+      const float radius = ell_next * fsqrt(fmaxf(-2.f * P.log_geo, 0.f));  // cut-off radius for l = ell
+      float dr = 0, dt = 0, dr1 = 0, dt1 = 0;
       for (int q = 0; q < 9; q++) {
         const float a = Ri[q] - st->Rb[q], b = Ri[q] - st->Rinv[q];
         dr += a * a;
@@ -1470,17 +1492,15 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         const float a = Ti[q] - st->Tb[q], b = Ti[q] - st->Tinv[q];
         dt += a * a;
         dt1 += b * b;
-        tn += Ti[q] * Ti[q];
       }
       const float ymax = D.ymax;
-      (void)tn;
-      float rot_b = sqrtf(dr) * 1.001f, tr_b = sqrtf(dt) * 1.001f;   // since the build (the rounding slack of the two
+      float rot_b = fsqrt(dr) * 1.001f, tr_b = fsqrt(dt) * 1.001f;   // since the build (the rounding slack of the two
                                                                       // transform evaluations is part of every row's skin)
-      float rot_1 = sqrtf(dr1), tr_1 = sqrtf(dt1);                    // this iteration alone
+      float rot_1 = fsqrt(dr1), tr_1 = fsqrt(dt1);                    // this iteration alone
       float step_move = rot_1 * ymax + tr_1;                          // what this iteration moved the farthest target
       if (P.debug_no_motion_bound) rot_b = tr_b = rot_1 = tr_1 = step_move = 0.f;  // (tests: a deliberately broken bound)
       // share of the allowances used up / used per iteration (inf when an allowance is zero and something moved)
-      auto share = [](float used, float allowance) { return used <= 0.f ? 0.f : (allowance > 0.f ? used / allowance : __builtin_inff()); };
+      auto share = [&](float used, float allowance) { return used <= 0.f ? 0.f : (allowance > 0.f ? used * frcp(allowance) : __builtin_inff()); };
       const float used = fmaxf(share(rot_b, st->skin_rot), share(tr_b, st->skin_tr));
       const float rate = fmaxf(share(rot_1, st->skin_rot), share(tr_1, st->skin_tr));
       // the list is unusable for the coming iteration ...
@@ -1519,8 +1539,8 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         else if (st->n_ovf > 0 && !st->all_dense) st->skin_scale = fmaxf(0.5f * st->skin_scale, 1.f / 64.f);
         else st->skin_scale = fminf(1.f, 1.1f * st->skin_scale);
         if (!INIT && P.mode == 0 && P.use_geo && radius > 0.f && P.skin_frac > 0.f && !st->all_dense) {
-          const float rel = step_move / radius;
-          s = st->skin_scale * P.skin_frac * fminf(fmaxf(1.5f * sqrtf(rel), P.skin_min), P.skin_max);
+          const float rel = step_move * frcp(radius);
+          s = st->skin_scale * P.skin_frac * fminf(fmaxf(1.5f * fsqrt(rel), P.skin_min), P.skin_max);
           const float s_lean = fmaxf(s, P.lean_skin * (float)P.lean_U * rel);
           const float s_lean2 = fmaxf(s, P.lean_skin * (float)P.lean_U2 * rel);
           if (s_lean <= 0.5f && st->n_ovf == 0) {
@@ -1539,9 +1559,9 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         // direction does not expire the lists at once): every row's skin follows from its own distance (k_prep)
         {
           // (normalised so that the farthest row gets exactly s * radius)
-          const float life = step_move > 0.f ? s * radius / (step_move * (1.f + P.skin_blend)) : 0.f;  // iterations at the current speed
+          const float life = step_move > 0.f ? s * radius * frcp(step_move * (1.f + P.skin_blend)) : 0.f;  // iterations at the current speed
           const float bl = P.skin_blend;
-          st->skin_rot = life * ((1.f - bl) * rot_1 + bl * step_move / fmaxf(ymax, 1e-20f));
+          st->skin_rot = life * ((1.f - bl) * rot_1 + bl * step_move * frcp(fmaxf(ymax, 1e-20f)));
           st->skin_tr = life * ((1.f - bl) * tr_1 + bl * step_move);
           if (!(st->skin_rot == st->skin_rot) || !(st->skin_tr == st->skin_tr)) st->skin_rot = st->skin_tr = 0.f;
         }
