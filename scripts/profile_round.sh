@@ -29,7 +29,7 @@ done
 python $R/scripts/summarize_pmc.py $O/pmc_summary_raw.json /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 /tmp/pmc4 /tmp/pmc5 > $O/pmc_summary.txt
 # the PMC traffic of THIS build goes into profiles/kernel_traffic.json before the bench run, which reports it
 python $R/scripts/install_profiles.py ${ROUND:-r2} --traffic
-timeout 600 python $R/bench.py --gpus 1 --steps 2 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.log
+timeout 600 python $R/bench.py --gpus 1 --steps 10 --warmup 3 > $O/bench_n1.json 2> $O/bench_n1.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-single-pair --no-pipeline > $O/bench_under_rocprof.json 2> $O/rocprof.log
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 cd $R && timeout 600 python scripts/run_configs.py $O/configs.json > $O/configs.log 2>&1

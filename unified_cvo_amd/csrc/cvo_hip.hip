@@ -91,8 +91,11 @@ struct cvo_ctx {
   hipEvent_t ev_chk[2][MAX_GROUPS] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
   // graph cache (one per group)
-  hipGraphExec_t graph_exec[MAX_GROUPS][3] = {};  // [group][0 = full chunk, 1 = lean chunk, 2 = short lean chunk]
-  GraphKey graph_key[MAX_GROUPS][3] = {};
+  // [group][0 = full chunk, 1 = lean chunk, 2 = short lean chunk; + 3 for the instrumented kernels (CVO_KERNEL_CLOCK /
+  // CVO_PHASE_TICKS), cached side by side so that a caller can time single steps of a loop without re-capturing]
+  static constexpr int GRAPH_VARIANTS = 6;
+  hipGraphExec_t graph_exec[MAX_GROUPS][GRAPH_VARIANTS] = {};
+  GraphKey graph_key[MAX_GROUPS][GRAPH_VARIANTS] = {};
   int last_chunks = 0, last_lean_launches = 0, last_full_launches = 0;
   // last call (debug hooks)
   int last_pairs = 0;
@@ -216,7 +219,7 @@ void free_workspace(cvo_ctx* c) {
 
 void drop_graphs(cvo_ctx* c) {
   for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++)
-    for (int v = 0; v < 3; v++)
+    for (int v = 0; v < cvo_ctx::GRAPH_VARIANTS; v++)
       if (c->graph_exec[g][v]) {
         (void)hipGraphExecDestroy(c->graph_exec[g][v]);
         c->graph_exec[g][v] = nullptr;
@@ -1190,7 +1193,9 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     const int lean_U = std::max(1, std::min(dp.lean_U, U));
     const int lean_U2 = std::max(0, std::min(dp.lean_U2, U));
     auto lean_period = [&](int v) { return v == 2 ? lean_U2 : lean_U; };
+    const int v_instr = S.geom.instr ? 3 : 0;  // the instrumented kernels have their own cached graphs
     auto get_graph = [&](int g, int v) -> int {
+      const int vi = v + v_instr;
       GraphKey key;
       key.n_pairs = geom[g].n_pairs;
       key.p0 = geom[g].p0;
@@ -1207,10 +1212,10 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       key.arena = geom[g].arena.base;
       key.stride256 = geom[g].arena.stride256;
       key.Npad = geom[g].arena.Npad;
-      if (ctx->graph_exec[g][v] && ctx->graph_key[g][v] == key) return CVO_OK;
-      if (ctx->graph_exec[g][v]) {
-        (void)hipGraphExecDestroy(ctx->graph_exec[g][v]);
-        ctx->graph_exec[g][v] = nullptr;
+      if (ctx->graph_exec[g][vi] && ctx->graph_key[g][vi] == key) return CVO_OK;
+      if (ctx->graph_exec[g][vi]) {
+        (void)hipGraphExecDestroy(ctx->graph_exec[g][vi]);
+        ctx->graph_exec[g][vi] = nullptr;
       }
       hipGraph_t gr = nullptr;
       HIP_TRY(ctx, hipStreamBeginCapture(geom[g].stream, hipStreamCaptureModeThreadLocal));
@@ -1220,14 +1225,14 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       const hipError_t e_launch = hipGetLastError();
       hipError_t e = hipStreamEndCapture(geom[g].stream, &gr);
       if (e == hipSuccess && e_launch != hipSuccess) e = e_launch;
-      if (e == hipSuccess) e = hipGraphInstantiate(&ctx->graph_exec[g][v], gr, nullptr, nullptr, 0);
+      if (e == hipSuccess) e = hipGraphInstantiate(&ctx->graph_exec[g][vi], gr, nullptr, nullptr, 0);
       if (gr) (void)hipGraphDestroy(gr);
       if (e != hipSuccess) {
-        ctx->graph_exec[g][v] = nullptr;
+        ctx->graph_exec[g][vi] = nullptr;
         for (int q = 0; q < G; q++) (void)hipStreamSynchronize(geom[q].stream);  // other groups may be in flight
         return fail(ctx, CVO_E_HIP, std::string("graph capture / instantiate: ") + hipGetErrorString(e));
       }
-      ctx->graph_key[g][v] = key;
+      ctx->graph_key[g][vi] = key;
       return CVO_OK;
     };
     // Chunks are enqueued until every pair has finished.  A pair advances one iteration per slot unless it is
@@ -1252,7 +1257,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
           rc = get_graph(g, v);
           if (rc != CVO_OK) return rc;
           const auto tl = now();
-          HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g][v], geom[g].stream));
+          HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g][v + v_instr], geom[g].stream));
           t_launch += ms_since(tl);
         } else {
           launch_chunk(ctx, geom[g], U, v != 0, lean_period(v));
