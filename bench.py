@@ -61,6 +61,11 @@ def log(*a):
 
 
 def main():
+    # ONE line on stdout: libraries print there too (RCCL's five-line version banner at communicator creation), so file
+    # descriptor 1 is pointed at stderr for the run and the JSON line goes to a private copy of the original stdout.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -376,7 +381,7 @@ def main():
             f"({assoc_alone_ms*1e3:.1f} alone on the GPU), k_coeff {coeff_ms*1e3:.1f} us ({coeff_alone_ms*1e3:.1f} alone), k_scan {scan_ms*1e3:.1f} us (runs in {100.0*builds/max(iters_total,1):.1f}% of the "
             f"iterations); {pair_rate/1e12:.1f} T algorithmic pair-tests/s, {100*executed_frac:.3f}% of them executed")
         assert int(stat.abs().sum().item()) == 0, "some align() returned -1"
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
