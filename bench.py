@@ -26,10 +26,10 @@ import numpy as np
 # 0.25 s per step under torchrun).  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # Per-pair kernel durations inside the timed loop (roofline.avg_launch_ms) come from the instrumented instantiation of the
-# per-iteration kernels (CVO_KERNEL_CLOCK); it costs ~3 % of a step, so only the LAST timed step runs it - the other
-# steps run the production kernels.  CVO_KERNEL_CLOCK=0 in the environment switches the instrumented step off.
-CLOCK_LAST_STEP = os.environ.get("CVO_KERNEL_CLOCK", "1") != "0"
-os.environ["CVO_KERNEL_CLOCK"] = "0"
+# per-iteration kernels (cvo_align_opts_t.kernel_clock); it costs ~3 % of a step, so only the LAST timed step runs it -
+# the other steps run the production kernels.  CVO_KERNEL_CLOCK=0 in the environment switches the instrumented step off
+# (the variable itself is cleared: set, it would instrument every call).
+CLOCK_LAST_STEP = os.environ.pop("CVO_KERNEL_CLOCK", "1") != "0"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -121,12 +121,8 @@ def main():
     kw = dict(max_iterations=args.max_iterations) if args.max_iterations > 0 else {}
 
     def step(clocked=False):
-        if clocked:  # (the library reads the switch at every call and keeps both sets of graphs)
-            os.environ["CVO_KERNEL_CLOCK"] = "1"
-        try:
-            res = gpu.align_batch(src, tgt, inits, **kw)
-        finally:
-            os.environ["CVO_KERNEL_CLOCK"] = "0"
+        # (cvo_align_opts_t.kernel_clock: the library keeps the graphs of both kernel instantiations)
+        res = gpu.align_batch(src, tgt, inits, kernel_clock=clocked, **kw)
         gpu.poses_to_device(pose_buf.data_ptr(), hi - lo)
         status = torch.tensor([r.ret for r in res], dtype=torch.int32, device=dev)
         poses, stat = sharding.gather_poses(pose_buf, status, total_pairs, world, rank)

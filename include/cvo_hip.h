@@ -141,6 +141,9 @@ typedef struct cvo_align_opts_t {
   int* n_trace;          /* out: rows written (per pair) */
   int iters_per_launch;  /* iterations enqueued per host check (0 = default) */
   int use_graph;         /* 0 = default (on), 1 = force plain launches, 2 = force graph */
+  int kernel_clock;      /* 1: this call runs the instrumented instantiation of the per-iteration kernels, which time
+                            every launch on the device clock (read back with cvo_debug_kernel_clock; ~3 % slower);
+                            0 = follow the CVO_KERNEL_CLOCK environment switch */
 } cvo_align_opts_t;
 
 /* ---- context ------------------------------------------------------------------------ */

@@ -475,6 +475,25 @@ def test_kernel_clock_and_phase_stamps_do_not_change_results(monkeypatch):
         gpu2.debug_kernel_clock()
 
 
+def test_kernel_clock_per_call_option_alternates_with_production_kernels():
+    """cvo_align_opts_t.kernel_clock times single calls of a loop (bench.py: the last timed step): instrumented and
+    production calls alternate on one context without disturbing each other (both sets of graphs stay cached) and
+    return the same bits."""
+    P, src, tgt, init = cases.config2(n=3000)
+    gpu = CvoGPU(params=P)
+    s, t = gpu.upload_many([src, tgt])
+    ref = gpu.align(s, t, init, max_iterations=200)
+    for clocked in (True, False, True, False):
+        a = gpu.align(s, t, init, max_iterations=200, kernel_clock=clocked)
+        assert a.iterations == ref.iterations and np.array_equal(a.transform, ref.transform)
+        if clocked:
+            t_assoc, t_coeff, n = gpu.debug_kernel_clock()
+            assert 150 <= n <= 200 and 5e-4 < t_assoc < 1.0 and 5e-4 < t_coeff < 1.0
+        else:
+            with pytest.raises(Exception):
+                gpu.debug_kernel_clock()
+
+
 @pytest.mark.parametrize("env", [{}, {"CVO_NO_DENSE_REGIME": "1"}, {"CVO_NO_LEAN": "1"}])
 def test_config1_is_reproducible_run_to_run(monkeypatch, env):
     """The demo pair stops on an accidentally small step: one flipped bit anywhere changes its iteration

@@ -120,6 +120,7 @@ class cvo_align_opts_t(C.Structure):
         ("n_trace", C.POINTER(C.c_int)),
         ("iters_per_launch", C.c_int),
         ("use_graph", C.c_int),
+        ("kernel_clock", C.c_int),
     ]
 
 

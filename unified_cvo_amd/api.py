@@ -340,7 +340,7 @@ class CvoGPU:
         return pc if isinstance(pc, DeviceCloud) else DeviceCloud(self, pc)
 
     def _opts(self, max_iterations=0, ell0=None, K0=None, trace_capacity=0, trace_dense=0, trace_every=0,
-              n_pairs=1, iters_per_launch=0, use_graph=0):
+              n_pairs=1, iters_per_launch=0, use_graph=0, kernel_clock=False):
         o = _capi.cvo_align_opts_t()
         o.max_iterations = max_iterations
         keep = []
@@ -359,6 +359,7 @@ class CvoGPU:
             keep = [tr, nt]
         o.iters_per_launch = iters_per_launch
         o.use_graph = use_graph
+        o.kernel_clock = 1 if kernel_clock else 0
         return o, keep
 
     def align(self, source, target, T_target_frame_to_source_frame, **kw):

@@ -589,6 +589,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   if (const char* e = getenv("CVO_LEAN_U2")) dp.lean_U2 = std::max(0, atoi(e));  // 0 = no short lean graph
   if (dp.lean_U2 >= dp.lean_U) dp.lean_U2 = 0;
   if (opts && opts->max_iterations > 0) dp.max_iter = std::min(dp.max_iter, opts->max_iterations);
+  if (opts && opts->kernel_clock) dp.kernel_clock = 1;
   dp.trace_capacity = trace_cap;
   // the columns of the ELL entries (ell_j) are only written when somebody can ask for them afterwards
   dp.keep_columns = (mode != 0 || trace_cap > 0 || dp.verify_lists || params->is_exporting_association ||
