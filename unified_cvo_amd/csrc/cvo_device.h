@@ -155,7 +155,10 @@ struct PairDesc {
   int N, M, nblk_assoc, nblk_coeff;  // nblk_coeff = nblk_assoc * csplit partials of the coefficient phase
   // k_list orders the rows of every 256-row window by candidate count; POSITION = index in that order
   int* cand_cnt;   // [N] candidates of the row at each position
-  void* cand_j;    // [ASSOC_CAP][N] cached candidate lists by position (original target index, ascending), u16 or i32
+  void* cand_j;    // [ASSOC_CAP][N] cached candidate lists by position, in ascending ORIGINAL target index, u16 or i32.
+                   // An entry is the original index (colour / semantic kernels: the feature arrays are in original
+                   // order) or the target's SORTED position (geometry-only kernels: they gather from ys4, where the
+                   // candidates of neighbouring rows share cache lines)
   float4* xp4;     // [N] source xyz of the row at each position
   int* ip;         // [N] ORIGINAL index of the row at each position
   const float4* y4;   // target xyz (initial cloud), ORIGINAL index
@@ -184,6 +187,7 @@ struct PairDesc {
   const int* xorder;
   const float4* ys4;  // target xyz (initial cloud), SORTED order
   const int* yorder;
+  const int* yinv;    // original target index -> sorted position (inverse of yorder)
   float4* ycull;  // SORTED: {y~x, y~y, y~z, |y~|^2}, y~ = yt - centre; pads are {0,0,0,+inf}
   float4* xcull;  // SORTED: {-2x~x, -2x~y, -2x~z, thres_i + margin_i - |x~|^2}
   int* rowperm;    // [N] position -> sorted row

@@ -38,6 +38,7 @@ struct cvo_cloud {
   // geometric-type kernels on a cloud without those arrays), see ensure_attributes.
   mutable char* zero_slab = nullptr;
   int* order = nullptr;        // spatial (k-d) order: sorted position -> original index
+  int* inv = nullptr;          // its inverse: original index -> sorted position
   std::vector<int> h_order;  // host copy (the ELL is stored by sorted row; exports map it back)
   float cx = 0, cy = 0, cz = 0;  // centroid (used only as the cull centre)
   float rmax = 0;                // largest |p| (bounds the motion of any point under a pose change)
@@ -361,14 +362,22 @@ void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const D
 // 1-D grid of the XCD-aware row-block kernels (see pair_block)
 inline dim3 row_grid(int nblk, int n_pairs) { return dim3((unsigned)(nblk * ((n_pairs + 7) / 8 * 8))); }
 
-void launch_list(hipStream_t s, bool idx16, int N, int n_pairs, const PairDesc* descs, const DevParams* dp,
+// bypos: list entries are sorted target positions (the geometry-only association kernels), else original indices
+void launch_list(hipStream_t s, bool idx16, bool bypos, int N, int n_pairs, const PairDesc* descs, const DevParams* dp,
                  const int* st) {
   const int nblk = (N + LIST_THREADS - 1) / LIST_THREADS;
   const dim3 blk(LIST_THREADS), grid = row_grid(nblk, n_pairs);
-  if (idx16)
-    hipLaunchKernelGGL((k_list<unsigned short, ASSOC_CAP16>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
-  else
-    hipLaunchKernelGGL((k_list<int, ASSOC_CAP32>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
+  if (idx16) {
+    if (bypos)
+      hipLaunchKernelGGL((k_list<unsigned short, ASSOC_CAP16, true>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
+    else
+      hipLaunchKernelGGL((k_list<unsigned short, ASSOC_CAP16, false>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
+  } else {
+    if (bypos)
+      hipLaunchKernelGGL((k_list<int, ASSOC_CAP32, true>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
+    else
+      hipLaunchKernelGGL((k_list<int, ASSOC_CAP32, false>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
+  }
 }
 
 // Where the workspaces of a launch's pairs are (kernel arguments of the row-block kernels, see row_off_*)
@@ -461,7 +470,7 @@ void launch_rebuild(cvo_ctx* c, const LaunchGeom& g) {
   const int* st = c->d_status + g.p0;
   hipLaunchKernelGGL(k_prep, dim3(g.npb, g.n_pairs), dim3(PREP_THREADS), 0, g.stream, descs, c->d_params, st);
   launch_scan(g.stream, g.T, dim3(g.gx, g.gy, g.n_pairs), descs, c->d_params, st, 0);
-  launch_list(g.stream, g.idx16, g.N, g.n_pairs, descs, c->d_params, st);
+  launch_list(g.stream, g.idx16, !g.general, g.N, g.n_pairs, descs, c->d_params, st);
 }
 
 // One optimiser iteration over the current lists: association, [overflow rows], coefficients + update (the last
@@ -636,6 +645,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.ylabel = Y->label;
     D.ygeo = Y->geo;
     D.yorder = Y->order;
+    D.yinv = Y->inv;
     D.ycull = (float4*)(base + S->L.ycull);
     D.xcull = (float4*)(base + S->L.xcull);
     D.gbox = (float4*)(base + S->L.gbox);
@@ -943,7 +953,8 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
     off = align_up(off + bytes, 256);
     return o;
   };
-  const size_t o_x4 = take(sizeof(float4) * nn), o_xs4 = take(sizeof(float4) * nn), o_order = take(sizeof(int) * nn);
+  const size_t o_x4 = take(sizeof(float4) * nn), o_xs4 = take(sizeof(float4) * nn), o_order = take(sizeof(int) * nn),
+               o_inv = take(sizeof(int) * nn);
   const size_t o_feat = h.feat ? take(sizeof(float4) * 2 * nn) : 0, o_label = h.label ? take(sizeof(float4) * 5 * nn) : 0,
                o_geo = h.geo ? take(sizeof(float2) * nn) : 0;
   std::vector<char> stage(off, 0);  // (pageable: the copy below is synchronous with respect to this thread only)
@@ -985,6 +996,10 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
   float* xs = reinterpret_cast<float*>(&stage[o_xs4]);
   for (int r = 0; r < n; r++) std::memcpy(&xs[4 * (size_t)r], &x4[4 * (size_t)order[r]], 16);
   if (n > 0) std::memcpy(&stage[o_order], order.data(), sizeof(int) * (size_t)n);
+  {
+    int* inv = reinterpret_cast<int*>(&stage[o_inv]);
+    for (int r = 0; r < n; r++) inv[order[r]] = r;
+  }
   c->h_order = std::move(order);
   hipError_t e = hipMalloc(&c->slab, off);
   c->slab_bytes = off;
@@ -995,6 +1010,7 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
   c->x4 = (float4*)(c->slab + o_x4);
   c->xs4 = (float4*)(c->slab + o_xs4);
   c->order = (int*)(c->slab + o_order);
+  c->inv = (int*)(c->slab + o_inv);
   c->feat = h.feat ? (float4*)(c->slab + o_feat) : nullptr;
   c->label = h.label ? (float4*)(c->slab + o_label) : nullptr;
   c->geo = h.geo ? (float2*)(c->slab + o_geo) : nullptr;
@@ -1113,6 +1129,7 @@ int cvo_cloud_transformed(cvo_ctx* ctx, const cvo_cloud* in, const float pose12[
   c->label = (float4*)rebase(in->label);
   c->geo = (float2*)rebase(in->geo);
   c->order = (int*)rebase(in->order);
+  c->inv = (int*)rebase(in->inv);
   Pose12 P;
   for (int q = 0; q < 12; q++) P.T[q] = pose12[q];
   if (in->n > 0) {

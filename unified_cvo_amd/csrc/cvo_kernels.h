@@ -492,7 +492,7 @@ __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* _
   if (!eval_pair<GENERAL>(P, D, pose, i, r, j, y0, a, yt)) return;
   if (a > P.sp_thres) {
     D->ell[(size_t)A.nnz * N + pos] = EllEntry{a, yt.x, yt.y, yt.z};
-    if (P.keep_columns) D->ell_j[(size_t)A.nnz * N + pos] = j;
+    if (P.keep_columns) D->ell_j[(size_t)A.nnz * N + pos] = GENERAL ? j : D->yorder[j];  // (geometry-only lists: j is a sorted position)
     A.nnz++;
     const V3 pye{yt.x, yt.y, yt.z};
     const V3 cr = cross_dev(pxe, pye);
@@ -520,7 +520,7 @@ __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* _
 // ------------------------------------------------------------------------------------------
 constexpr int LIST_THREADS = 256;
 
-template <typename IdxT, int ASSOC_CAP>
+template <typename IdxT, int ASSOC_CAP, bool BYPOS>
 __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restrict__ descs,
                                                         const DevParams* __restrict__ Pp,
                                                         const int* __restrict__ status, int nblk, int n_pairs) {
@@ -619,13 +619,17 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
       // ascending original j (the order of the reference's first-K truncation and float accumulation): every entry
       // is written straight to its rank (the indices of a row are distinct); cnt^2 independent LDS reads instead of
       // an insertion sort's chain of dependent shifts
+      // BYPOS: the list entry is the target's sorted position (gathered while the rank is counted), the ORDER stays
+      // that of the original indices
       IdxT* out = reinterpret_cast<IdxT*>(D->cand_j);
+      const int* yinv = D->yinv;
       for (int k = 0; k < cnt; k++) {
         const int j = (int)list[k];
+        const int entry = BYPOS ? yinv[j] : j;
         int rank = 0;
 #pragma unroll 4
         for (int m2 = 0; m2 < cnt; m2++) rank += ((int)list[m2] < j) ? 1 : 0;
-        out[(size_t)rank * N + pos] = (IdxT)j;
+        out[(size_t)rank * N + pos] = (IdxT)entry;
       }
     }
   }
@@ -832,17 +836,20 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
       const V3 pxe{x.x, x.y, x.z};
       const Pose pose = load_pose(st);
       const IdxT* cj = reinterpret_cast<const IdxT*>(D->cand_j) + pos;
+      // geometry-only: list entries are sorted positions, the coordinates come from the spatially ordered copy of the
+      // target cloud - the candidates of the 64 neighbouring rows of a wave fall into a few cache lines instead of 64
+      const float4* __restrict__ ysrc = GENERAL ? D->y4 : D->ys4;
       // exact evaluation in ascending original j; index and coordinates of the next candidates are in
       // flight while the current one is evaluated
       int j1 = cnt > 0 ? j1s : 0;
       int j2 = cnt > 1 ? j2s : 0;
       if (INSTR) tt1 = __builtin_readcyclecounter();
-      float4 y1 = D->y4[j1];
+      float4 y1 = ysrc[j1];
       for (int k = 0; k < cnt && A.nnz < (unsigned)K; k++) {
         const int j = j1;
         const float4 ycur = y1;
         j1 = j2;
-        if (k + 1 < cnt) y1 = D->y4[j1];
+        if (k + 1 < cnt) y1 = ysrc[j1];
         if (k + 2 < cnt) j2 = (int)cj[(size_t)(k + 2) * N];
         visit_pair<GENERAL>(P, D, pose, i, pos, N, r, pxe, j, ycur, A);
       }
@@ -924,7 +931,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_ASSOC_WAVES) void k_assoc(const 
     const int* a0 = D->cand_cnt;
     const void* a1 = D->cand_j;
     const float4* a2 = D->xp4;
-    const float4* a3 = D->y4;
+    const float4* a3 = GENERAL ? D->y4 : D->ys4;
     const EllEntry* a4 = D->ell;
     const float e = st->ell, r0 = st->Rinv[0], t0 = st->Tinv[0];
     asm volatile("" ::"s"(n), "s"(k), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e), "s"(r0), "s"(t0), "s"(P.sp_thres),
