@@ -155,12 +155,11 @@ struct PairDesc {
   int N, M, nblk_assoc, nblk_coeff;  // nblk_coeff = nblk_assoc * csplit partials of the coefficient phase
   // k_list orders the rows of every 256-row window by candidate count; POSITION = index in that order
   int* cand_cnt;   // [N] candidates of the row at each position
-  void* cand_j;    // [ASSOC_CAP][N] cached candidate lists by position, in ascending ORIGINAL target index, u16 or i32.
-                   // An entry is the original index (colour / semantic kernels: the feature arrays are in original
-                   // order) or the target's SORTED position (geometry-only kernels: they gather from ys4, where the
-                   // candidates of neighbouring rows share cache lines)
+  void* cand_j;    // [ASSOC_CAP][N] cached candidate lists by position, u16 or i32: the targets' SORTED positions, in
+                   // ascending ORIGINAL target index (coordinates and features are gathered from the spatially ordered
+                   // arrays, where the candidates of neighbouring rows share cache lines)
   float4* xp4;     // [N] source xyz of the row at each position
-  int* ip;         // [N] ORIGINAL index of the row at each position
+  int* ip;         // [N] sorted row at each position = the row's index into the (spatially ordered) feature arrays
   const float4* y4;   // target xyz (initial cloud), ORIGINAL index
   EllEntry* ell;              // ELL kernel matrix [K_max][N] by POSITION: value + transformed target, ascending ORIGINAL j in a row
   int* ell_j;                 // [K_max][N]: the column (ORIGINAL j) of every entry
@@ -191,6 +190,7 @@ struct PairDesc {
   float4* ycull;  // SORTED: {y~x, y~y, y~z, |y~|^2}, y~ = yt - centre; pads are {0,0,0,+inf}
   float4* xcull;  // SORTED: {-2x~x, -2x~y, -2x~z, thres_i + margin_i - |x~|^2}
   int* rowperm;    // [N] position -> sorted row
+  int* iorig;      // [N] position -> ORIGINAL row index (the exports; stays valid after the clouds are gone)
   float4* gbox;   // [NGpad][2]: AABB of each sorted row group, grown by the group's cut-off radius
   float4* cellbox;  // [NGpad/16][2]: AABB of each cell of 16 row groups (level 1 of the scan)
   float4* sbox;   // [nslices][2]: AABB of each scan slice (T chunks)

@@ -30,9 +30,9 @@ struct cvo_cloud {
   size_t slab_bytes = 0;
   float4* x4 = nullptr;
   float4* xs4 = nullptr;    // x4 permuted into the spatial order
-  float4* feat = nullptr;   // 2 float4 per point
-  float4* label = nullptr;  // 5 float4 per point
-  float2* geo = nullptr;
+  float4* feat = nullptr;   // 2 float4 per point      } in SPATIAL order (position r = point order[r]): the kernels
+  float4* label = nullptr;  // 5 float4 per point      } index them by sorted position, like the coordinates they
+  float2* geo = nullptr;    //                         } gather per candidate
   // Attributes the caller did not supply are zeros (what the reference leaves in the default-constructed CvoPoint).
   // They are not uploaded: a zeroed slab is allocated the first time a call needs them (colour / semantic /
   // geometric-type kernels on a cloud without those arrays), see ensure_attributes.
@@ -47,7 +47,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, gate, gate_flow, done, cand_cnt, rowperm, xp4, ip, cand_j, ell, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, gate, gate_flow, done, cand_cnt, rowperm, iorig, xp4, ip, cand_j, ell, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -186,6 +186,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.gate_flow = take(sizeof(int));
   L.done = take(sizeof(int));
   L.rowperm = take(sizeof(int) * (size_t)N);
+  L.iorig = take(sizeof(int) * (size_t)N);
   L.flow_part = take(sizeof(double) * 8 * (size_t)(nba + DENSE_BLOCKS));
   L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)(nba + DENSE_BLOCKS));
   L.coef_part = take(sizeof(double) * 4 * (size_t)nbc * COEFF_SPLIT_MAX);
@@ -362,22 +363,14 @@ void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const D
 // 1-D grid of the XCD-aware row-block kernels (see pair_block)
 inline dim3 row_grid(int nblk, int n_pairs) { return dim3((unsigned)(nblk * ((n_pairs + 7) / 8 * 8))); }
 
-// bypos: list entries are sorted target positions (the geometry-only association kernels), else original indices
-void launch_list(hipStream_t s, bool idx16, bool bypos, int N, int n_pairs, const PairDesc* descs, const DevParams* dp,
+void launch_list(hipStream_t s, bool idx16, int N, int n_pairs, const PairDesc* descs, const DevParams* dp,
                  const int* st) {
   const int nblk = (N + LIST_THREADS - 1) / LIST_THREADS;
   const dim3 blk(LIST_THREADS), grid = row_grid(nblk, n_pairs);
-  if (idx16) {
-    if (bypos)
-      hipLaunchKernelGGL((k_list<unsigned short, ASSOC_CAP16, true>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
-    else
-      hipLaunchKernelGGL((k_list<unsigned short, ASSOC_CAP16, false>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
-  } else {
-    if (bypos)
-      hipLaunchKernelGGL((k_list<int, ASSOC_CAP32, true>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
-    else
-      hipLaunchKernelGGL((k_list<int, ASSOC_CAP32, false>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
-  }
+  if (idx16)
+    hipLaunchKernelGGL((k_list<unsigned short, ASSOC_CAP16>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
+  else
+    hipLaunchKernelGGL((k_list<int, ASSOC_CAP32>), grid, blk, 0, s, descs, dp, st, nblk, n_pairs);
 }
 
 // Where the workspaces of a launch's pairs are (kernel arguments of the row-block kernels, see row_off_*)
@@ -470,7 +463,7 @@ void launch_rebuild(cvo_ctx* c, const LaunchGeom& g) {
   const int* st = c->d_status + g.p0;
   hipLaunchKernelGGL(k_prep, dim3(g.npb, g.n_pairs), dim3(PREP_THREADS), 0, g.stream, descs, c->d_params, st);
   launch_scan(g.stream, g.T, dim3(g.gx, g.gy, g.n_pairs), descs, c->d_params, st, 0);
-  launch_list(g.stream, g.idx16, !g.general, g.N, g.n_pairs, descs, c->d_params, st);
+  launch_list(g.stream, g.idx16, g.N, g.n_pairs, descs, c->d_params, st);
 }
 
 // One optimiser iteration over the current lists: association, [overflow rows], coefficients + update (the last
@@ -660,6 +653,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.rowperm = (int*)(base + S->L.rowperm);
     D.xp4 = (float4*)(base + S->L.xp4);
     D.ip = (int*)(base + S->L.ip);
+    D.iorig = (int*)(base + S->L.iorig);
     D.cand_j = (void*)(base + S->L.cand_j);
     D.ell = (EllEntry*)(base + S->L.ell);
     D.ell_j = (int*)(base + S->L.ell_j);
@@ -979,20 +973,22 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
     c->cz = (float)(sz / n);
   }
   if (!std::isfinite(c->cx) || !std::isfinite(c->cy) || !std::isfinite(c->cz)) c->cx = c->cy = c->cz = 0.f;
+  std::vector<int> order;
+  spatial_order(x4, n, order);
+  // colour, class distributions and geometric types are kept in SPATIAL order only (position r holds the attributes of
+  // point order[r]): the kernels index them by sorted position, like the coordinates they gather per candidate
   if (h.feat) {
     float* f8 = reinterpret_cast<float*>(&stage[o_feat]);
-    for (int i = 0; i < n; i++) std::memcpy(&f8[FD_PAD * (size_t)i], h.feat + (size_t)i * h.feat_stride, sizeof(float) * FD);
+    for (int r = 0; r < n; r++) std::memcpy(&f8[FD_PAD * (size_t)r], h.feat + (size_t)order[r] * h.feat_stride, sizeof(float) * FD);
   }
   if (h.label) {
     float* l20 = reinterpret_cast<float*>(&stage[o_label]);
-    for (int i = 0; i < n; i++) std::memcpy(&l20[NC_PAD * (size_t)i], h.label + (size_t)i * h.label_stride, sizeof(float) * NC);
+    for (int r = 0; r < n; r++) std::memcpy(&l20[NC_PAD * (size_t)r], h.label + (size_t)order[r] * h.label_stride, sizeof(float) * NC);
   }
   if (h.geo) {
     float* g2 = reinterpret_cast<float*>(&stage[o_geo]);
-    for (int i = 0; i < n; i++) std::memcpy(&g2[2 * (size_t)i], h.geo + (size_t)i * h.geo_stride, sizeof(float) * 2);
+    for (int r = 0; r < n; r++) std::memcpy(&g2[2 * (size_t)r], h.geo + (size_t)order[r] * h.geo_stride, sizeof(float) * 2);
   }
-  std::vector<int> order;
-  spatial_order(x4, n, order);
   float* xs = reinterpret_cast<float*>(&stage[o_xs4]);
   for (int r = 0; r < n; r++) std::memcpy(&xs[4 * (size_t)r], &x4[4 * (size_t)order[r]], 16);
   if (n > 0) std::memcpy(&stage[o_order], order.data(), sizeof(int) * (size_t)n);
@@ -1701,7 +1697,7 @@ int cvo_align_association(cvo_ctx* ctx, int pair, int* row_ptr, int* col, float*
   std::vector<unsigned> nzp(N);
   std::vector<int> ip(N);
   HIP_TRY(ctx, hipMemcpy(nzp.data(), D.nnz_row, sizeof(unsigned) * (size_t)N, hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(ip.data(), D.ip, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(ip.data(), D.iorig, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
   unsigned mx = 0;
   for (int q = 0; q < N; q++) mx = std::max(mx, nzp[q]);
   std::vector<EllEntry> ep((size_t)mx * N);

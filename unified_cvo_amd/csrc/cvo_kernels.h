@@ -398,6 +398,8 @@ __device__ __forceinline__ Pose load_pose(const PairState* st) {
 
 // GENERAL = false is the geometry-only specialisation (no colour / semantic / geometric-type code at all:
 // 1/3 fewer VGPRs, one more wave per SIMD for the latency-bound association kernel).
+// i / j index the FEATURE arrays (colour, class distributions, geometric types), which clouds keep in spatial order:
+// i = the row's sorted position, j = the target's sorted position.
 template <bool GENERAL>
 __device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __restrict__ D, const Pose& pose, int i,
                                           const RowData& r, int j, const float4 y0, float& a_out, float4& yt_out) {
@@ -492,7 +494,7 @@ __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* _
   if (!eval_pair<GENERAL>(P, D, pose, i, r, j, y0, a, yt)) return;
   if (a > P.sp_thres) {
     D->ell[(size_t)A.nnz * N + pos] = EllEntry{a, yt.x, yt.y, yt.z};
-    if (P.keep_columns) D->ell_j[(size_t)A.nnz * N + pos] = GENERAL ? j : D->yorder[j];  // (geometry-only lists: j is a sorted position)
+    if (P.keep_columns) D->ell_j[(size_t)A.nnz * N + pos] = D->yorder[j];  // (list entries are sorted positions)
     A.nnz++;
     const V3 pye{yt.x, yt.y, yt.z};
     const V3 cr = cross_dev(pxe, pye);
@@ -520,7 +522,7 @@ __device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* _
 // ------------------------------------------------------------------------------------------
 constexpr int LIST_THREADS = 256;
 
-template <typename IdxT, int ASSOC_CAP, bool BYPOS>
+template <typename IdxT, int ASSOC_CAP>
 __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restrict__ descs,
                                                         const DevParams* __restrict__ Pp,
                                                         const int* __restrict__ status, int nblk, int n_pairs) {
@@ -574,7 +576,8 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
       xh.w = __int_as_float(cnt_all);
       D->xp4[pos] = xh;
     }
-    D->ip[pos] = D->xorder[rr];
+    D->ip[pos] = rr;  // the row's index into the (spatially ordered) feature arrays
+    D->iorig[pos] = D->xorder[rr];
     if (cnt_all > ASSOC_CAP) {
       // more candidates than a list holds (dense regime, e.g. rows sitting on K_max): k_assoc_dense
       // evaluates these rows against all targets, 64 at a time.  Only counted here: the list itself is written in
@@ -619,13 +622,13 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
       // ascending original j (the order of the reference's first-K truncation and float accumulation): every entry
       // is written straight to its rank (the indices of a row are distinct); cnt^2 independent LDS reads instead of
       // an insertion sort's chain of dependent shifts
-      // BYPOS: the list entry is the target's sorted position (gathered while the rank is counted), the ORDER stays
-      // that of the original indices
+      // the list entry is the target's sorted position (gathered while the rank is counted), the ORDER is that of the
+      // original indices
       IdxT* out = reinterpret_cast<IdxT*>(D->cand_j);
       const int* yinv = D->yinv;
       for (int k = 0; k < cnt; k++) {
         const int j = (int)list[k];
-        const int entry = BYPOS ? yinv[j] : j;
+        const int entry = yinv[j];
         int rank = 0;
 #pragma unroll 4
         for (int m2 = 0; m2 < cnt; m2++) rank += ((int)list[m2] < j) ? 1 : 0;
@@ -836,9 +839,9 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
       const V3 pxe{x.x, x.y, x.z};
       const Pose pose = load_pose(st);
       const IdxT* cj = reinterpret_cast<const IdxT*>(D->cand_j) + pos;
-      // geometry-only: list entries are sorted positions, the coordinates come from the spatially ordered copy of the
+      // list entries are sorted positions: coordinates (and features) come from the spatially ordered arrays of the
       // target cloud - the candidates of the 64 neighbouring rows of a wave fall into a few cache lines instead of 64
-      const float4* __restrict__ ysrc = GENERAL ? D->y4 : D->ys4;
+      const float4* __restrict__ ysrc = D->ys4;
       // exact evaluation in ascending original j; index and coordinates of the next candidates are in
       // flight while the current one is evaluated
       int j1 = cnt > 0 ? j1s : 0;
@@ -931,7 +934,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_ASSOC_WAVES) void k_assoc(const 
     const int* a0 = D->cand_cnt;
     const void* a1 = D->cand_j;
     const float4* a2 = D->xp4;
-    const float4* a3 = GENERAL ? D->y4 : D->ys4;
+    const float4* a3 = D->ys4;
     const EllEntry* a4 = D->ell;
     const float e = st->ell, r0 = st->Rinv[0], t0 = st->Tinv[0];
     asm volatile("" ::"s"(n), "s"(k), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e), "s"(r0), "s"(t0), "s"(P.sp_thres),
@@ -1011,7 +1014,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
           const int j = j0 + 64 * h + lane;
           if (j < M) {
             const float4 y0 = D->y4[j];
-            ok[h] = eval_pair<GENERAL>(P, D, pose, i, r, j, y0, a[h], yt[h]) && (a[h] > P.sp_thres);
+            ok[h] = eval_pair<GENERAL>(P, D, pose, i, r, GENERAL ? D->yinv[j] : 0, y0, a[h], yt[h]) && (a[h] > P.sp_thres);
           }
         }
         int nstaged = 0;
@@ -1795,7 +1798,7 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
       float a = 0.f;
       float4 yt;
       bool ok = false;
-      if (j < M) ok = eval_pair<GENERAL>(P, D, pose, i, r, j, D->y4[j], a, yt) && (a > P.sp_thres);
+      if (j < M) ok = eval_pair<GENERAL>(P, D, pose, i, r, GENERAL ? D->yinv[j] : 0, D->y4[j], a, yt) && (a > P.sp_thres);
       const unsigned long long m = __ballot(ok);
       const unsigned rank = nnz + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
       const bool keep = ok && rank < (unsigned)K;
