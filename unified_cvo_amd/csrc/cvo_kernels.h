@@ -706,16 +706,20 @@ __device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, i
   acc += dpp_f64<0x128>(acc);  // row_ror:8 : groups g and g ^ 1
   acc += __shfl_xor(acc, 16);
   acc += __shfl_xor(acc, 32);
+  // every lane now holds the total of component (lane & 7): lane q converts / divides ITS component, so the six
+  // IEEE divisions of the normalisation are one (this wave is the serial tail of the pair's iteration)
+  float own = (float)acc;
   float ov[6];
 #pragma unroll
-  for (int q = 0; q < 6; q++) ov[q] = (float)lane_f64(acc, q);
+  for (int q = 0; q < 6; q++) ov[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, own), q));
   float z = 0;  // Eigen normalize(): z = squaredNorm(); if (z > 0) *this /= sqrt(z)
 #pragma unroll
   for (int q = 0; q < 6; q++) z = z + ov[q] * ov[q];
   if (z > 0) {
     const float sq = sqrtf(z);
+    own = own / sq;
 #pragma unroll
-    for (int q = 0; q < 6; q++) ov[q] = ov[q] / sq;
+    for (int q = 0; q < 6; q++) ov[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, own), q));
   }
   XiMats M;
   xi_mats(ov, ov + 3, M);
@@ -1674,14 +1678,23 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     if (cq == 0) head.e_n = reinterpret_cast<const EllEntry*>(wb + row_off_ell(Npad))[pos];
   }
   const int csplit = D->csplit;
-  if (cq >= csplit) return;
   PairState* const st = states + pb.pair;  // == D->st, without the dependent pointer load
   // The state as this launch found it, through a read-only view so that the loads are scalar (only the block that
   // finishes last writes the state, after every block has read it); one burst together with what the row loop
   // needs first, see k_assoc.
   const PairState* __restrict__ st_in = states + pb.pair;
   const int status_v = st_in->status, rebuild_v = st_in->rebuild, ovf = st_in->n_ovf;
+  const DevParams P = *Pp;
+  // the twist and its matrices (twist_finalize): wave-uniform scalar loads
+  XiMats Mu;
   {
+    float* mu = reinterpret_cast<float*>(&Mu);
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(XiMats) / sizeof(float)); q++) mu[q] = st_in->xi[q];
+  }
+  {
+    // (everything the kernel will branch on or start its row loop with - the slice count, the parameters and the twist
+    // matrices included - requested before the first wait: each dependent round of scalar loads is ~0.3-0.5 us here)
     const int n = D->N, nb = D->nblk_assoc, ep = st_in->epoch;
     const double* a0 = D->flow_part;
     const unsigned* a1 = D->nnz_row;
@@ -1689,8 +1702,10 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     const EllEntry* a3 = D->ell;
     const int a4 = D->M;
     const float e = st_in->ell;
-    asm volatile("" ::"s"(n), "s"(nb), "s"(ep), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e));
+    asm volatile("" ::"s"(n), "s"(nb), "s"(ep), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e), "s"(csplit), "s"(P.mode),
+                 "s"(P.sp_thres), "s"(Mu.omega[0]), "s"(Mu.m2.m[0][0]), "s"(Mu.m4.m[2][2]), "s"(Mu.v[2]));
   }
+  if (cq >= csplit) return;
   const bool replay = (flags & 8) != 0;  // cvo_debug_time_kernels: same work, nothing written back
   if (!replay && status_v != 0) return;
   if (flags & 1) {
@@ -1705,7 +1720,6 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
       return;
     }
   }
-  const DevParams P = *Pp;
   if (P.mode != 0) return;
   pair_clock_begin(INSTR && P.kernel_clock && !replay && pb.bx == 0 && cq == 0, st, 1);
   const int epoch = st_in->epoch;  // launches of this kernel the pair has completed (bumped by the updating block)
@@ -1717,13 +1731,6 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   const int N_ = D->N, pos_ = pb.bx * ASSOC_THREADS + threadIdx.x;
   if (pos_ >= N_) head.nnz = 0;
   if (cq > 0 && (unsigned)cq < head.nnz) head.e_n = D->ell[(size_t)cq * N_ + pos_];  // (small clouds only: later slices)
-  // the twist and its matrices (twist_finalize): wave-uniform scalar loads
-  XiMats Mu;
-  {
-    float* mu = reinterpret_cast<float*>(&Mu);
-#pragma unroll
-    for (int q = 0; q < (int)(sizeof(XiMats) / sizeof(float)); q++) mu[q] = st_in->xi[q];
-  }
   float twist[6];
   for (int c = 0; c < 3; c++) {
     twist[c] = Mu.omega[c];
