@@ -548,6 +548,9 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   // k_list packs a row's candidate count next to an 8-bit row number; the candidate bitmap of a pair takes
   // N * M / 8 bytes (DESIGN.md "Data layout"), every pair of a batch sized by the batch maxima
   if (M >= (1 << 23)) return fail(ctx, CVO_E_INVALID, "target clouds are limited to 8388607 points");
+  // (the update reduces an iteration's nonzero count in 32 bits: rows x nearest_neighbors_max must fit)
+  if ((unsigned long long)N * (unsigned long long)std::max(params->nearest_neighbors_max, 1) >= (1ull << 32))
+    return fail(ctx, CVO_E_INVALID, "source rows x nearest_neighbors_max must stay below 2^32");
   S->L = make_layout(N, M, Kmax, trace_cap, &S->d);
   {
     size_t free_b = 0, total_b = 0;

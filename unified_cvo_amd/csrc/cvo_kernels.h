@@ -51,6 +51,20 @@ __device__ __forceinline__ double dpp_f64(double v) {
   const int lo = dpp_i32<CTRL>(__double2loint(v)), hi = dpp_i32<CTRL>(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+// own + partner across rows of 16 lanes (lane ^ 16, lane ^ 32) on gfx950's v_permlane16_swap / v_permlane32_swap:
+// with both operands = v the two results are {own, partner} in an order that depends on the lane's half - the sum
+// does not (IEEE addition commutes), so this is bit for bit `v + __shfl_xor(v, 16 / 32)` without the two
+// ds_bpermute round trips through the LDS (scripts/ubench/permlane_swap.hip prints what the instructions return).
+__device__ __forceinline__ double xor16_sum(double v) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double xor32_sum(double v) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
 __device__ __forceinline__ double lane_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
@@ -704,8 +718,8 @@ __device__ __forceinline__ double coeff_twist_load(const PairDesc* __restrict__ 
 __device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, int nparts) {
   double acc = coeff_twist_load<true>(D, nparts);
   acc += dpp_f64<0x128>(acc);  // row_ror:8 : groups g and g ^ 1
-  acc += __shfl_xor(acc, 16);
-  acc += __shfl_xor(acc, 32);
+  acc = xor16_sum(acc);
+  acc = xor32_sum(acc);
   // every lane now holds the total of component (lane & 7): lane q converts / divides ITS component, so the six
   // IEEE divisions of the normalisation are one (this wave is the serial tail of the pair's iteration)
   float own = (float)acc;
@@ -1285,11 +1299,14 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     double s = 0;
     // the counts were written by the association kernel(s), i.e. before this launch: plain loads, requested ahead of
     // the coherent ones so that the two round trips overlap
-    unsigned long long vq[8];
+    // (every count of one iteration fits 32 bits - at most rows x K_max nonzeros, rows x targets candidates, checked
+    // at set-up - and the block partials are read as such: the 64-bit DPP steps cost four times the instructions)
+    const unsigned* cnt32 = reinterpret_cast<const unsigned*>(D.cnt_part);
+    unsigned vq[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int b = bl + 16 * u;
-      vq[u] = b < nba ? D.cnt_part[(size_t)b * 4 + c] : 0ull;
+      vq[u] = b < nba ? cnt32[((size_t)b * 4 + c) * 2] : 0u;
     }
     if (P.mode == 0) {
       // eight (coherent) loads in flight per lane, summed in block order
@@ -1306,15 +1323,15 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     } else if (c == 0) {
       for (int b = bl; b < nba; b += 16) s += D.flow_part[(size_t)b * 8 + 6];
     }
-    unsigned long long q = 0;
+    unsigned q = 0;
 #pragma unroll
     for (int u = 0; u < 8; u++) q = (c == 1) ? max(q, vq[u]) : q + vq[u];
     for (int b0 = bl + 128; b0 < nba; b0 += 128) {
-      unsigned long long v[8];
+      unsigned v[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int b = b0 + 16 * u;
-        v[u] = b < nba ? D.cnt_part[(size_t)b * 4 + c] : 0ull;
+        v[u] = b < nba ? cnt32[((size_t)b * 4 + c) * 2] : 0u;
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) q = (c == 1) ? max(q, v[u]) : q + v[u];
@@ -1324,16 +1341,16 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     s += dpp_f64<DPP_HALF_MIRROR>(s);
     s += dpp_f64<DPP_MIRROR>(s);
     {
-      auto meet = [&](unsigned long long o) { q = (c == 1) ? max(q, o) : q + o; };
-      meet(dpp_u64<DPP_XOR1>(q));
-      meet(dpp_u64<DPP_XOR2>(q));
-      meet(dpp_u64<DPP_HALF_MIRROR>(q));
-      meet(dpp_u64<DPP_MIRROR>(q));
+      auto meet = [&](unsigned o) { q = (c == 1) ? max(q, o) : q + o; };
+      meet((unsigned)dpp_i32<DPP_XOR1>((int)q));
+      meet((unsigned)dpp_i32<DPP_XOR2>((int)q));
+      meet((unsigned)dpp_i32<DPP_HALF_MIRROR>((int)q));
+      meet((unsigned)dpp_i32<DPP_MIRROR>((int)q));
     }
 #pragma unroll
     for (int cc = 0; cc < 4; cc++) {
       const double sv = lane_f64(s, 16 * cc);
-      const unsigned long long qv = lane_u64(q, 16 * cc);
+      const unsigned long long qv = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)q, 16 * cc);
       if (tid == 0) {
         s_c[cc] = sv;
         s_n[cc] = qv;
@@ -1499,13 +1516,13 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
       float dr = 0, dt = 0, dr1 = 0, dt1 = 0;
       for (int q = 0; q < 9; q++) {
         const float a = Ri[q] - st->Rb[q], b = Ri[q] - st->Rinv[q];
-        dr += a * a;
-        dr1 += b * b;
+        dr = __builtin_fmaf(a, a, dr);
+        dr1 = __builtin_fmaf(b, b, dr1);
       }
       for (int q = 0; q < 3; q++) {
         const float a = Ti[q] - st->Tb[q], b = Ti[q] - st->Tinv[q];
-        dt += a * a;
-        dt1 += b * b;
+        dt = __builtin_fmaf(a, a, dt);
+        dt1 = __builtin_fmaf(b, b, dt1);
       }
       const float ymax = D.ymax;
       float rot_b = fsqrt(dr) * 1.001f, tr_b = fsqrt(dt) * 1.001f;   // since the build (the rounding slack of the two
