@@ -94,7 +94,7 @@ struct cvo_ctx {
   // graph cache (one per group)
   // [group][0 = full chunk, 1 = lean chunk, 2 = short lean chunk; + 3 for the instrumented kernels (CVO_KERNEL_CLOCK /
   // CVO_PHASE_TICKS), cached side by side so that a caller can time single steps of a loop without re-capturing]
-  static constexpr int GRAPH_VARIANTS = 6;
+  static constexpr int GRAPH_VARIANTS = 12;  // ... x 2 chunk lengths (the early chunks of a call are shorter)
   hipGraphExec_t graph_exec[MAX_GROUPS][GRAPH_VARIANTS] = {};
   GraphKey graph_key[MAX_GROUPS][GRAPH_VARIANTS] = {};
   int last_chunks = 0, last_lean_launches = 0, last_full_launches = 0;
@@ -1181,8 +1181,14 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   const auto t_host1 = std::chrono::steady_clock::now();
 
   const int max_iter = dp.max_iter;
+  // Iterations per chunk (= per host check).  A chunk boundary costs a stream ~15 us (graph launch, the two status
+  // copies, the event), a longer chunk lets a finished or re-planned sub-batch run on for nothing: 16 iterations for
+  // the first 256 (short warm-started solves end there, and the early requests change quickly), 32 afterwards.
   int U = (opts && opts->iters_per_launch > 0) ? opts->iters_per_launch : 16;
   U = std::max(1, std::min(U, std::max(1, max_iter)));
+  const bool adaptive_chunks = !(opts && opts->iters_per_launch > 0) && !getenv("CVO_FIXED_CHUNKS") && max_iter >= 512;
+  const int U_late = adaptive_chunks ? 2 * U : U;
+  const int n_early_chunks = adaptive_chunks ? 256 / U : 0;
   const int graph_mode = opts ? opts->use_graph : 0;
   const bool use_graph = graph_mode != 1;
 
@@ -1211,8 +1217,8 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     const int lean_U2 = std::max(0, std::min(dp.lean_U2, U));
     auto lean_period = [&](int v) { return v == 2 ? lean_U2 : lean_U; };
     const int v_instr = S.geom.instr ? 3 : 0;  // the instrumented kernels have their own cached graphs
-    auto get_graph = [&](int g, int v) -> int {
-      const int vi = v + v_instr;
+    auto get_graph = [&](int g, int v, int Uc) -> int {
+      const int vi = v + v_instr + (Uc != U ? 6 : 0);
       GraphKey key;
       key.n_pairs = geom[g].n_pairs;
       key.p0 = geom[g].p0;
@@ -1224,7 +1230,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       key.npb = S.geom.npb;
       key.idx16 = S.geom.idx16 ? 1 : 0;
       key.general = S.geom.general ? 1 : 0;
-      key.U = U * 256 + lean_period(v);
+      key.U = Uc * 256 + lean_period(v);
       key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0);
       key.arena = geom[g].arena.base;
       key.stride256 = geom[g].arena.stride256;
@@ -1236,7 +1242,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       }
       hipGraph_t gr = nullptr;
       HIP_TRY(ctx, hipStreamBeginCapture(geom[g].stream, hipStreamCaptureModeThreadLocal));
-      launch_chunk(ctx, geom[g], U, v != 0, lean_period(v));
+      launch_chunk(ctx, geom[g], Uc, v != 0, lean_period(v));
       // (the capture is always ended, whatever the launches reported: a stream left in capture mode would poison
       // every later call on this context)
       const hipError_t e_launch = hipGetLastError();
@@ -1267,17 +1273,18 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     for (; ch < chunk_cap && !all_done; ch++) {
       const int slot = ch & 1;
+      const int Uc = ch < n_early_chunks ? U : U_late;
       for (int g = 0; g < G; g++) {
         const int v = graph_next[g];
         (v ? n_lean_launch : n_full_launch)++;
         if (use_graph) {
-          rc = get_graph(g, v);
+          rc = get_graph(g, v, Uc);
           if (rc != CVO_OK) return rc;
           const auto tl = now();
-          HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g][v + v_instr], geom[g].stream));
+          HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g][v + v_instr + (Uc != U ? 6 : 0)], geom[g].stream));
           t_launch += ms_since(tl);
         } else {
-          launch_chunk(ctx, geom[g], U, v != 0, lean_period(v));
+          launch_chunk(ctx, geom[g], Uc, v != 0, lean_period(v));
           HIP_TRY(ctx, hipGetLastError());
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status[slot] + geom[g].p0, ctx->d_status + geom[g].p0,
