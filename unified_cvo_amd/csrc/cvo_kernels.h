@@ -486,7 +486,13 @@ __device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __
 // ------------------------------------------------------------------------------------------
 // k_assoc: ordered association + flow, one thread per (sorted) source row.
 // ------------------------------------------------------------------------------------------
-constexpr int ASSOC_THREADS = 128;
+// Rows per block of the two per-iteration kernels.  256 (four waves) against 128: half as many arrivals queue up on a
+// pair's last-block counters and half as many partials are re-read by the serial tails (-1.9 % of the step); 512
+// loses 10 % (the block reduction and its registers grow, a block waits for the slowest of eight waves).
+#ifndef CVO_ASSOC_THREADS
+#define CVO_ASSOC_THREADS 256
+#endif
+constexpr int ASSOC_THREADS = CVO_ASSOC_THREADS;
 // candidates per row the sorted per-thread LDS list holds: 64 with 16-bit indices (M < 65536, 16.6 KB
 // per block so ~9 blocks share a CU), 32 with 32-bit indices
 constexpr int ASSOC_CAP16 = 64;
