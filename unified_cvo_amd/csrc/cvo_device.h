@@ -46,6 +46,8 @@ struct DevParams {
   float rebuild_shrink;  // rebuild when ell < rebuild_shrink * ell_build (the lists would be (1/shrink)^3 too long)
   int lean_U;            // iterations between two rebuild opportunities in the lean graph
   int lean_U2;           // ... and in the short lean graph (motion too fast for lean_U, slow enough for a list to last lean_U2)
+  int shrink_align;      // optional (ell-shrink) rebuilds wait for an iteration count with (k & shrink_align) == 0:
+                         // 63 when several pairs share a sub-batch (their rebuilds then share a pass), 0 otherwise
   float skin_min, skin_max;  // clamp of the skin (fractions of the cut-off radius) before skin_frac
   float skin_blend;          // share of the pooled motion budget both the rotation and the translation allowance get on top of their own
   int dense_regime;      // 0: never switch a pair to the all-rows-dense regime (CVO_NO_DENSE_REGIME)

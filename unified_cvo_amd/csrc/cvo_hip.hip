@@ -593,6 +593,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   dp.lean_U2 = 2;
   if (const char* e = getenv("CVO_LEAN_U2")) dp.lean_U2 = std::max(0, atoi(e));  // 0 = no short lean graph
   if (dp.lean_U2 >= dp.lean_U) dp.lean_U2 = 0;
+  dp.shrink_align = n_pairs >= 8 ? 63 : 0;
+  if (const char* e = getenv("CVO_SHRINK_ALIGN")) dp.shrink_align = std::max(0, atoi(e));
   if (opts && opts->max_iterations > 0) dp.max_iter = std::min(dp.max_iter, opts->max_iterations);
   if (opts && opts->kernel_clock) dp.kernel_clock = 1;
   dp.trace_capacity = trace_cap;

@@ -1541,8 +1541,15 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
       const float used = fmaxf(share(rot_b, st->skin_rot), share(tr_b, st->skin_tr));
       const float rate = fmaxf(share(rot_1, st->skin_rot), share(tr_1, st->skin_tr));
       // the list is unusable for the coming iteration ...
-      bool rebuild = INIT || P.mode != 0 || !(used <= 1.f) || ell_next > st->ell_build ||
-                     ell_next < P.rebuild_shrink * st->ell_build;
+      // (A list built for a larger ell stays a superset: rebuilding it after ell has shrunk only sheds candidates.  That
+      // rebuild is optional, so it waits for a rebuild opportunity - flagged in the middle of a lean period it would
+      // stall the pair until the next one - and, in a batch, for an iteration count that is a multiple of 64: the pairs
+      // of a sub-batch decay in step, their shrink rebuilds then share one pass of the rebuild kernels instead of
+      // putting real work into a different one each.)
+      const bool shrink_due = ell_next < P.rebuild_shrink * st->ell_build;
+      const bool shrink_now = shrink_due && trio_follows &&
+                              ((st->k & P.shrink_align) == 0 || ell_next < 0.85f * P.rebuild_shrink * st->ell_build);
+      bool rebuild = INIT || P.mode != 0 || !(used <= 1.f) || ell_next > st->ell_build || shrink_now;
       // ... or would expire before the next rebuild opportunity of the lean graph
       if (trio_follows && horizon > 0 && !(used + 1.25f * (float)horizon * rate <= 1.f)) rebuild = true;
       // Dense regime (rows sitting on K_max, e.g. the first iterations of an outdoor pair at a large ell): when most
