@@ -426,6 +426,27 @@ def test_result_does_not_depend_on_list_reuse(monkeypatch):
     assert np.array_equal(a.transform, c.transform)
 
 
+def test_batch_scheduling_switches_do_not_change_results(monkeypatch):
+    """In a batch the optional (ell-shrink) rebuilds wait for common iteration counts, lists that would not reach the
+    next of them are renewed early, and chunks grow from 16 to 32 iterations after the first 256: scheduling only -
+    the poses are bit-identical with all of it switched off."""
+    cs = [cases.config2(n=2000, pair_id=p) for p in range(8)]
+    P = cs[0][0]
+    runs = []
+    for env in ({}, {"CVO_SHRINK_ALIGN": "0"}, {"CVO_FIXED_CHUNKS": "1", "CVO_SHRINK_ALIGN": "15"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        gpu = CvoGPU(params=P)
+        res = gpu.align_batch([c[1] for c in cs], [c[2] for c in cs], [c[3] for c in cs], max_iterations=700)
+        runs.append((res, gpu.debug_list_builds()[0]))
+        for k in env:
+            monkeypatch.delenv(k)
+    for res, _ in runs[1:]:
+        for a, b in zip(runs[0][0], res):
+            assert a.iterations == b.iterations == 700 and np.array_equal(a.transform, b.transform)
+    assert len({b for _, b in runs}) > 1          # the schedules really differed (list builds)
+
+
 def test_lean_graph_waits_do_not_change_results(monkeypatch):
     """A rebuild opportunity only every 16 iterations makes pairs wait for their next list; the trajectory is the
     same as with an opportunity in every iteration."""
