@@ -978,8 +978,9 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_ASSOC_WAVES) void k_assoc(const 
   // acknowledgement and an atomic round trip (~2 us of a ~7 us wave life; with thousands of waves queued behind them
   // that wait was throughput, not just latency).  A barrier only counts the waves that are still alive.
   if (threadIdx.x >= 64) return;
-  // lean graph: nothing else adds to the flow, the twist of the iteration can be finished here
-  if ((lean & 3) && P.mode == 0) {  // (bit 1: the timing replay includes it)
+  // lean graph, or a pair without overflow rows in the full one (k_assoc_dense then has nothing to add and leaves at
+  // once): nothing else adds to the flow, the twist of the iteration can be finished here
+  if (((lean & 3) || n_ovf_v == 0) && P.mode == 0) {  // (bit 1: the timing replay includes it)
     const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && lean == 1, st, 0);
     const bool last = flow_gate(D, nblk, nblk);
     if (last && threadIdx.x == 0 && clk0) D->st->clk_last_assoc = pair_clock_ticks(clk0);  // added up by the update
@@ -1008,6 +1009,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
   const int K = st->K;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n_ovf = st->n_ovf;
+  if (n_ovf == 0 && P.mode == 0) return;  // nothing to add: k_assoc has finished the twist, the update skips these slots
   const bool all_dense = st->all_dense != 0;
   __shared__ float2 s_hits[DENSE_WAVES][128][6];  // per wave: the hits of one step, compacted ({flow term, value} per component)
   double red[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -1784,7 +1786,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   }
   const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && !replay, st, 1);
   const UpdDesc upd = load_upd_desc(D);
-  const int n_flow_upd = (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS;
+  const int n_flow_upd = ((flags & 1) || ovf == 0) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS;  // (see k_assoc_dense)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partial stores before the counter, see flow_gate
   __syncthreads();
   if (threadIdx.x == 0) {
