@@ -203,6 +203,8 @@ struct PairDesc {
   int* row_cnt;               // [N sorted rows]: candidates of the row in the bitmap (k_prep zeroes, k_scan adds)
   unsigned long long* tile_count;  // [1]: fine tiles executed so far this call (statistics)
   int* ovf_rows;   // [N]: positions of rows with more candidates than a list holds (handled by k_assoc_dense)
+  unsigned long long* ovf_bits;  // [ceil(N / 64)]: bit p % 64 of word p / 64 <=> position p overflows (k_list's blocks ->
+                                 // its last block, coherent stores / loads)
   PairState* st;
   cvo_trace_t* trace;
   int* status_out;  // mirror of st->status for cheap host polling

@@ -47,7 +47,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, gate, gate_flow, done, cand_cnt, rowperm, iorig, xp4, ip, cand_j, ell, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, done, cand_cnt, rowperm, iorig, xp4, ip, cand_j, ell, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -182,6 +182,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.row_cnt = take(sizeof(int) * (size_t)N);
   L.tile_count = take(sizeof(unsigned long long));
   L.ovf_rows = take(sizeof(int) * (size_t)N);
+  L.ovf_bits = take(sizeof(unsigned long long) * (((size_t)N + 63) / 64 + 4));
   L.gate = take(sizeof(int));
   L.gate_flow = take(sizeof(int));
   L.done = take(sizeof(int));
@@ -654,6 +655,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.row_cnt = (int*)(base + S->L.row_cnt);
     D.tile_count = (unsigned long long*)(base + S->L.tile_count);
     D.ovf_rows = (int*)(base + S->L.ovf_rows);
+    D.ovf_bits = (unsigned long long*)(base + S->L.ovf_bits);
     D.cand_cnt = (int*)(base + S->L.cand_cnt);
     D.rowperm = (int*)(base + S->L.rowperm);
     D.xp4 = (float4*)(base + S->L.xp4);

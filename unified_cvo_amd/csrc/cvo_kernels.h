@@ -600,10 +600,9 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
     D->iorig[pos] = D->xorder[rr];
     if (cnt_all > ASSOC_CAP) {
       // more candidates than a list holds (dense regime, e.g. rows sitting on K_max): k_assoc_dense
-      // evaluates these rows against all targets, 64 at a time.  Only counted here: the list itself is written in
-      // ascending position order by the block that finishes last (below), so that the order in which
-      // k_assoc_dense's waves accumulate their rows never depends on the arrival order of atomics.
-      atomicAdd(&D->st->n_ovf, 1);
+      // evaluates these rows against all targets, 64 at a time.  Only flagged here (below, one bit per position): the
+      // list itself is written in ascending position order by the block that finishes last, so that the order in
+      // which k_assoc_dense's waves accumulate their rows never depends on the arrival order of atomics.
     } else {
       const unsigned* rb = D->rowbits + (size_t)rr * rbw;
       int cnt = 0;  // sorted-space positions of the candidates (the mask words come from L1/L2 this time)
@@ -658,35 +657,58 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
   }
   // The block that finishes last validates the list: every block has read `rebuild` by then, and the
   // kernels of the iteration (stream order) see rebuild == 0 <=> bitmap, lists and overflow list are current.
+  // Which positions overflow: one 64-bit word per wave, the only thing of this block another block of the launch
+  // reads (the last one, below) - a coherent (sc1) store the wave waits for, then the gate.  (An agent-scope fence in
+  // front of the gate - write back the XCD's L2 with a block's freshly written lists in it - cost 4 ms of the 74 ms
+  // step: 3.5 us and more per block, four blocks per CU.)
+  {
+    const bool ov = rr < N && cnt_all > ASSOC_CAP;
+    const unsigned long long m = __ballot(ov);
+    if ((tid & 63) == 0) {
+      st_x<true>(D->ovf_bits + (pos >> 6), m);
+      if (m) atomicAdd(&D->st->n_ovf, __builtin_popcountll(m));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every wave drains its own stores, see flow_gate)
   __shared__ int s_last_block;
   __syncthreads();
   if (tid == 0) {
-    __threadfence();
     const int done = atomicAdd(D->gate, 1);
     s_last_block = (done == nblk - 1) ? 1 : 0;
   }
   __syncthreads();
   if (!s_last_block) return;
   // Overflow list in ascending position order (dense regime: every row overflows, the list is the identity and
-  // k_assoc_dense does not read it).  The counts of the other blocks are read coherently: they were written inside
-  // this launch, possibly on another XCD (each writer fenced before its gate increment).
+  // k_assoc_dense does not read it), from the waves' bit words: thread t takes word t of a 256-word chunk.
   const int n_ovf = __hip_atomic_load(&D->st->n_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (n_ovf > 0 && !D->st->all_dense) {
     __shared__ int s_wave_cnt[LIST_THREADS / 64];
+    const int nwords = (N + 63) >> 6;
     int base = 0;
-    for (int p0 = 0; p0 < N; p0 += LIST_THREADS) {
-      const int p = p0 + tid;
-      const bool ov = p < N && __hip_atomic_load(D->cand_cnt + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > ASSOC_CAP;
-      const unsigned long long m = __ballot(ov);
-      if ((tid & 63) == 0) s_wave_cnt[tid >> 6] = __builtin_popcountll(m);
+    for (int w0 = 0; w0 < nwords; w0 += LIST_THREADS) {
+      const int wi = w0 + tid;
+      unsigned long long bits = wi < nwords ? ld_x<true>(D->ovf_bits + wi) : 0ull;
+      const int mine = __builtin_popcountll(bits);
+      // exclusive prefix of the popcounts over the chunk: inside the wave by a DPP-free shuffle scan, across waves via LDS
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += v;
+      }
+      if ((tid & 63) == 63) s_wave_cnt[tid >> 6] = incl;
       __syncthreads();
-      int off = base, tot = 0;
+      int off = base + incl - mine, tot = 0;
 #pragma unroll
       for (int w = 0; w < LIST_THREADS / 64; w++) {
         off += (w < (tid >> 6)) ? s_wave_cnt[w] : 0;
         tot += s_wave_cnt[w];
       }
-      if (ov) D->ovf_rows[off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = p;
+      while (bits) {
+        const int b = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        D->ovf_rows[off++] = (wi << 6) + b;
+      }
       base += tot;
       __syncthreads();
     }
