@@ -556,7 +556,6 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
   const int T = Pp->T;
   const int rbw = D->rbw;
   __shared__ IdxT s_list[LIST_THREADS * ASSOC_STRIDE];
-  __shared__ __attribute__((aligned(16))) int s_key[LIST_THREADS];
   __shared__ int s_row[LIST_THREADS];
   const int tid = threadIdx.x;
   const int w0row = pb.bx * LIST_THREADS;
@@ -566,19 +565,54 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
     const int rc = D->row_cnt[w0row + tid];
     ncand = D->st->all_dense ? ASSOC_CAP + 1 : rc;
   }
-  // ---- stable rank by min(count, CAP + 1): every thread counts the keys that sort before its own
-  s_key[tid] = (w0row + tid < N) ? min(ncand, ASSOC_CAP + 1) : ASSOC_CAP + 2;  // overflow rows last, pad rows behind them
+  // ---- stable rank by key = min(count, CAP + 1) (overflow rows last, pad rows behind them): a counting sort.  Every
+  // wave finds, key by key among the keys it holds, how many of its lanes have that key and where a lane stands among
+  // them (ballots); the per-wave counts meet in LDS, one wave turns them into the first position of every key.
+  // (~200 wave instructions; counting the 256 keys that sort before one's own took ~1 100.)
+  constexpr int NKEY = ASSOC_CAP + 3;
+  constexpr int NWV = LIST_THREADS / 64;
+  __shared__ int s_hist[NWV][NKEY];
+  __shared__ int s_first[NKEY];
+  const int key = (w0row + tid < N) ? min(ncand, ASSOC_CAP + 1) : ASSOC_CAP + 2;
+  for (int q = tid; q < NWV * NKEY; q += LIST_THREADS) (&s_hist[0][0])[q] = 0;
+  __syncthreads();
+  int eq_lower = 0;
+  {
+    const int wv = tid >> 6;
+    const unsigned lo = __builtin_amdgcn_mbcnt_lo(~0u, 0u);
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, lo);
+    unsigned long long todo = __ballot(true);
+    while (todo) {
+      const int leader = __builtin_ctzll(todo);
+      const int k0 = __builtin_amdgcn_readlane(key, leader);
+      const unsigned long long m = __ballot(key == k0);
+      if (key == k0) eq_lower = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if ((int)lane == leader) s_hist[wv][k0] = __builtin_popcountll(m);
+      todo &= ~m;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {  // first position of every key: exclusive prefix of the keys' totals (NKEY <= 128: two per lane)
+    int t0 = 0, t1 = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; w++) {
+      t0 += (2 * tid < NKEY) ? s_hist[w][2 * tid] : 0;
+      t1 += (2 * tid + 1 < NKEY) ? s_hist[w][2 * tid + 1] : 0;
+    }
+    int incl = t0 + t1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (tid >= o) incl += v;
+    }
+    const int excl = incl - (t0 + t1);
+    if (2 * tid < NKEY) s_first[2 * tid] = excl;
+    if (2 * tid + 1 < NKEY) s_first[2 * tid + 1] = excl + t0;
+  }
   __syncthreads();
   {
-    const int mine = s_key[tid];
-    int rank = 0;
-    for (int t = 0; t < LIST_THREADS; t += 4) {  // wave-uniform 16-byte LDS reads (broadcast)
-      const int4 o = *reinterpret_cast<const int4*>(&s_key[t]);
-      rank += (o.x < mine || (o.x == mine && t < tid)) ? 1 : 0;
-      rank += (o.y < mine || (o.y == mine && t + 1 < tid)) ? 1 : 0;
-      rank += (o.z < mine || (o.z == mine && t + 2 < tid)) ? 1 : 0;
-      rank += (o.w < mine || (o.w == mine && t + 3 < tid)) ? 1 : 0;
-    }
+    int rank = s_first[key] + eq_lower;
+    for (int w = 0; w < (tid >> 6); w++) rank += s_hist[w][key];
     s_row[rank] = tid | (ncand << 8);  // position `rank` of the window holds row tid (ncand <= ~M < 2^23)
   }
   __syncthreads();
