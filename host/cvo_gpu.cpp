@@ -147,6 +147,7 @@ void CvoGPU::write_params(const CvoParams* p_cpu) {
 
 int CvoGPU::align(const CvoPointCloud& source_points, const CvoPointCloud& target_points, const Mat4f& init,
                   Mat4f& transform, Association* association, double* registration_seconds) const {
+  std::lock_guard<std::mutex> lk(call_mutex);  // (see CvoGPU.hpp: the const entry points share one context)
   if (source_points.num_points() == 0 || target_points.num_points() == 0) return 0;
   DeviceCloud s, t;
   upload(ctx, source_points, s);
@@ -164,6 +165,7 @@ int CvoGPU::align(const CvoPointCloud& source_points, const CvoPointCloud& targe
 
 int CvoGPU::align(const CvoPoint* src_pts, int n_source, const CvoPoint* tgt_pts, int n_target, const Mat4f& init,
                   Mat4f& transform, Association* association, double* registration_seconds) const {
+  std::lock_guard<std::mutex> lk(call_mutex);  // (see CvoGPU.hpp: the const entry points share one context)
   if (n_source == 0 || n_target == 0) return 0;
   DeviceCloud s, t;
   check(ctx, cvo_cloud_upload_aos192(ctx, n_source, src_pts, &s.h), "cvo_cloud_upload_aos192");
@@ -180,6 +182,7 @@ int CvoGPU::align(const CvoPoint* src_pts, int n_source, const CvoPoint* tgt_pts
 
 float CvoGPU::inner_product_gpu(const CvoPoint* src_pts, int n_source, const CvoPoint* tgt_pts, int n_target, const Mat4f& T,
                                 float ell) const {
+  std::lock_guard<std::mutex> lk(call_mutex);  // (see CvoGPU.hpp: the const entry points share one context)
   if (n_source == 0 || n_target == 0) return 0.f;
   DeviceCloud s, t;
   check(ctx, cvo_cloud_upload_aos192(ctx, n_source, src_pts, &s.h), "cvo_cloud_upload_aos192");
@@ -191,6 +194,7 @@ float CvoGPU::inner_product_gpu(const CvoPoint* src_pts, int n_source, const Cvo
 
 float CvoGPU::function_angle(const CvoPoint* src_pts, int n_source, const CvoPoint* tgt_pts, int n_target, const Mat4f& T,
                              float ell, bool is_approximate) const {
+  std::lock_guard<std::mutex> lk(call_mutex);  // (see CvoGPU.hpp: the const entry points share one context)
   if (n_source == 0 || n_target == 0) return 0.f;  // upstream CvoGPU.cu:1855-1857
   DeviceCloud s, t;
   check(ctx, cvo_cloud_upload_aos192(ctx, n_source, src_pts, &s.h), "cvo_cloud_upload_aos192");
@@ -204,6 +208,7 @@ std::vector<int> CvoGPU::align_batch(const std::vector<const CvoPointCloud*>& so
                                      const std::vector<const CvoPointCloud*>& targets,
                                      const std::vector<Mat4f>& inits, std::vector<Mat4f>& transforms,
                                      double* seconds) const {
+  std::lock_guard<std::mutex> lk(call_mutex);  // (see CvoGPU.hpp: the const entry points share one context)
   const int n = (int)sources.size();
   if ((int)targets.size() != n || (int)inits.size() != n) throw std::runtime_error("align_batch: size mismatch");
   std::vector<DeviceCloud> s(n), t(n);
@@ -230,6 +235,7 @@ std::vector<int> CvoGPU::align_batch(const std::vector<const CvoPointCloud*>& so
 }
 
 float CvoGPU::inner_product_gpu(const CvoPointCloud& a, const CvoPointCloud& b, const Mat4f& T, float ell) const {
+  std::lock_guard<std::mutex> lk(call_mutex);  // (see CvoGPU.hpp: the const entry points share one context)
   if (a.num_points() == 0 || b.num_points() == 0) return 0.f;
   DeviceCloud s, t;
   upload(ctx, a, s);
@@ -241,6 +247,7 @@ float CvoGPU::inner_product_gpu(const CvoPointCloud& a, const CvoPointCloud& b, 
 
 float CvoGPU::function_angle(const CvoPointCloud& a, const CvoPointCloud& b, const Mat4f& T, float ell,
                              bool is_approximate, bool is_gpu) const {
+  std::lock_guard<std::mutex> lk(call_mutex);  // (see CvoGPU.hpp: the const entry points share one context)
   if (a.num_points() == 0 || b.num_points() == 0) return 0.f;
   if (!is_gpu) {  // upstream CvoGPU.cu:1827-1843: the host inner product in all three places
     const float fxfz = inner_product_cpu(a, b, T, ell);
@@ -266,6 +273,7 @@ float CvoGPU::function_angle(const CvoPointCloud& a, const CvoPointCloud& b, con
 
 void CvoGPU::compute_association_gpu(const CvoPointCloud& a, const CvoPointCloud& b, const Mat4f& T, float ell,
                                      Association& association) const {
+  std::lock_guard<std::mutex> lk(call_mutex);  // (see CvoGPU.hpp: the const entry points share one context)
   if (a.num_points() == 0 || b.num_points() == 0) return;
   DeviceCloud s, t;
   upload(ctx, a, s);
@@ -275,6 +283,7 @@ void CvoGPU::compute_association_gpu(const CvoPointCloud& a, const CvoPointCloud
 
 void CvoGPU::compute_association_gpu(const CvoPointCloud& a, const CvoPointCloud& b, const Mat4f& T, const Mat3f& kernel,
                                      Association& association) const {
+  std::lock_guard<std::mutex> lk(call_mutex);  // (see CvoGPU.hpp: the const entry points share one context)
   if (a.num_points() == 0 || b.num_points() == 0) return;
   DeviceCloud s, t;
   upload(ctx, a, s);

@@ -4,6 +4,7 @@
 // an array of the 192-byte CvoPoint record instead of pcl::PointCloud<CvoPoint> (UnifiedCvo/pcl_interop.hpp forwards
 // pcl clouds where PCL exists).  The multi-frame overloads (Ceres IRLS) are out of scope.
 #pragma once
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,12 @@ class CvoGPU {
   CvoGPU& operator=(const CvoGPU&) = delete;
 
   CvoParams& get_params() { return params; }
+  // Upstream returns the DEVICE copy of the parameter struct (CvoGPU.hpp:52; its only users are the multi-frame IRLS
+  // drivers, which hand it to CvoFrameGPU / BinaryStateGPU).  This backend passes the parameters to its kernels by
+  // value at every launch, so there is no resident device copy to point at: the block the backend reads - the host
+  // struct - is returned.  Valid as an opaque handle for this library's own classes; not dereferenceable in user
+  // device code.
+  const CvoParams* get_params_gpu() const { return &params; }
   // Upstream re-uploads *p_cpu to the device copy only (CvoGPU.cu:73-77); here the backend reads the
   // host struct at every call, so this stores *p_cpu as the parameters the next calls use.
   void write_params(const CvoParams* p_cpu);
@@ -68,6 +75,11 @@ class CvoGPU {
  private:
   CvoParams params;
   cvo_ctx* ctx = nullptr;
+  // Upstream's align() const is re-entrant (all state is per call, CvoGPU.cu:1605-1632); here the const entry points
+  // share one context (streams, cached workspace, graphs), which is not thread-safe: they serialise on this mutex, so
+  // concurrent callers of ONE object get upstream's behaviour (upstream serialises them on the default stream as
+  // well).  For concurrency use one CvoGPU per host thread, or align_batch.
+  mutable std::mutex call_mutex;
 };
 
 }  // namespace cvo

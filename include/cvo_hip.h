@@ -150,6 +150,11 @@ typedef struct cvo_align_opts_t {
 int cvo_ctx_create(int device, cvo_ctx** out);
 void cvo_ctx_destroy(cvo_ctx* ctx);
 const char* cvo_last_error(const cvo_ctx* ctx);
+/* Tuning / diagnostic switches of a context (none changes a result; the list is in unified_cvo_amd/csrc/cvo_hip.hip,
+ * kOptionNames, and DESIGN.md).  A context reads CVO_<NAME> from the environment ONCE, in cvo_ctx_create; afterwards
+ * only this call changes them (value NULL = unset), so no library call depends on the process environment while it
+ * runs.  `name` with or without the CVO_ prefix.  Unknown names: CVO_E_INVALID. */
+int cvo_ctx_set_option(cvo_ctx* ctx, const char* name, const char* value);
 /* HIP stream of the context as an opaque pointer (hipStream_t). */
 void* cvo_ctx_stream(cvo_ctx* ctx);
 int cvo_ctx_synchronize(cvo_ctx* ctx);
@@ -158,8 +163,10 @@ int cvo_ctx_synchronize(cvo_ctx* ctx);
  * xyz: n x 3.  feat: n x 5 row-major or NULL.  label: n x 19 row-major or NULL.
  * geotype: n x 2 or NULL.  Missing arrays read as zeros, as the reference leaves the
  * default-constructed CvoPoint fields (PointSegmentedDistribution.hpp:40-56); they are neither uploaded nor allocated
- * until a call needs them.  Thread-safe: clouds may be uploaded from several host threads of one context at once
- * (each call orders its points on the calling thread and copies on a stream of its own). */
+ * until a call needs them.  Uploads of one context serialise on its upload stream (cvo_cloud_upload_many is the
+ * parallel form); they never wait for, nor delay, a solve in flight.  A cloud handed to an align / inner-product
+ * call may get a zeroed attribute slab attached by that call (see above): do not share ONE cvo_cloud between
+ * concurrent calls of different contexts' threads. */
 int cvo_cloud_upload(cvo_ctx* ctx, int n, const float* xyz, const float* feat, const float* label,
                      const float* geotype, cvo_cloud** out);
 /* Replaces pcl_PointCloud_to_gpu (CvoGPU_impl.cu:287-362): n records of the 192-byte AoS
@@ -242,47 +249,6 @@ int cvo_edge_kernel_matrix(cvo_ctx* ctx, const cvo_params_t* params, const cvo_c
                            const cvo_cloud* frame2_transformed, float ell, int num_neighbors, float* mat, int* ind,
                            unsigned int* nonzeros, unsigned int* nonzero_sum);
 
-/* ---- test / profiling hooks ---------------------------------------------------------- */
-/* Dumps the ELL kernel matrix of the LAST iteration executed by cvo_align_ex (row stride K):
- * mat/ind sized n_source*K, nonzeros sized n_source; K = the num_neighbors of that iteration. */
-int cvo_debug_last_ell(cvo_ctx* ctx, int K, float* mat, int* ind, unsigned int* nonzeros);
-/* A batch is enqueued as n_groups sub-batches (one stream each) of pairs_per_group pairs: these are the
- * launches a profiler sees. */
-int cvo_debug_last_geometry(cvo_ctx* ctx, int* n_groups, int* pairs_per_group);
-/* Re-issues the k_scan launches of one optimiser iteration (one per sub-batch) `reps` times on the final
- * state of the last call, timed with HIP events on the context's stream (bench.py's roofline leg).
- * *ms = average milliseconds per k_scan launch (of pairs_per_group pairs). */
-int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms);
-/* Tile-culling statistics of the last align call (all pairs, all iterations): number of fine tiles
- * the scan executed and the tile shape; executed pair tests = tiles * rows_per_tile * targets_per_tile. */
-int cvo_debug_scan_stats(cvo_ctx* ctx, unsigned long long* tiles, int* rows_per_tile, int* targets_per_tile);
-/* Re-issues the two per-iteration kernels (k_assoc; k_coeff including its update tail) one launch per sub-batch,
- * `reps` times, on the state the last call left behind and without writing anything back; timed with HIP events on
- * the context's stream.  *ms_* = average milliseconds per launch (of pairs_per_group pairs). */
-int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_coeff);
-/* Kernel durations inside the optimiser loop itself.  With CVO_KERNEL_CLOCK set in the environment when the context is
- * created, the first block of a pair in k_assoc (lean graph) / k_coeff stamps its entry on the device's constant-rate counter
- * (s_memrealtime) and the block that finishes the pair's work in the launch (twist reduction / update) closes the
- * interval; the per-pair sums are part of the state.  Returns the averages of the last align call in ms - first
- * block in to last block out per pair and launch, the quantity rocprofv3 --kernel-trace --stats averages per launch -
- * and the number of k_coeff intervals behind them.  The counter's rate is calibrated against HIP events. */
-int cvo_debug_kernel_clock(cvo_ctx* ctx, float* ms_assoc, float* ms_coeff, unsigned long long* launches);
-/* Candidate-list reuse of the last align call, summed over the pairs: how many times the candidate bitmap was
- * (re)built by k_scan, the optimiser iterations run, and the candidate pairs k_assoc evaluated exactly. */
-int cvo_debug_list_builds(cvo_ctx* ctx, unsigned long long* builds, unsigned long long* iterations,
-                          unsigned long long* candidate_evaluations);
-/* Number of candidate pairs in the bitmap the last iteration used (superset of nnz). */
-int cvo_debug_last_candidates(cvo_ctx* ctx, unsigned long long* out);
-/* Runs the device's scalar restatements of the reference's host-side maths (cubic roots of poly_solver_order3,
- * the step selection of compute_step_size, Exp_SEK3, ||SE3 log||, update_tf, the indicator windows) on caller-supplied
- * inputs, so that the device code itself can be pinned against numpy / scipy.  ops and layouts: k_scalar_math in
- * unified_cvo_amd/csrc/cvo_kernels.h.  in / out: host arrays of 16 doubles per item (op 7: one item of 2 + n / n). */
-int cvo_debug_scalar_math(cvo_ctx* ctx, int op, int n, const double* in, double* out);
-/* CVO_VERIFY_LISTS=1 (environment, read when a call starts): rows k_verify re-derived with the literal scan during the
- * last align call, summed over pairs and iterations (0 when the check was off). */
-int cvo_debug_verified_rows(cvo_ctx* ctx, unsigned long long* rows);
-/* Free / total bytes of the context's device (hipMemGetInfo), for leak checks without a second HIP runtime in the process. */
-int cvo_debug_device_memory(cvo_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 const char* cvo_version(void);
 
 #ifdef __cplusplus

@@ -1138,7 +1138,9 @@ static int align_core(const OracleParams* p, const OracleCloud* x, const OracleC
   // row-major buffers are read with a stride they were not written with (whatever that yields is what upstream
   // returns; entries beyond rows * K_used are leftovers of earlier iterations).  source_inliers / target_inliers /
   // the pairs of a row are reported in row order (upstream fills them from an OpenMP loop, order unspecified).
-  if (assoc && k > 0) {
+  // (after ANY loop whose body ran once: a `break` in iteration 0 - flow vanished, or dist < eps_2 with a
+  // warm start at the optimum and min_step < eps_2 - leaves k == 0 and still exports iteration 0's matrix)
+  if (assoc && max_iter > 0) {
     assoc->K_used = K_used;
     assoc->K_final = num_neighbors;
     const int rows = X.n, cols = num_neighbors;

@@ -1,4 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/cvo_hip.h declares (no compute calls here)."""
+"""The C-ABI library loads and exports every symbol include/cvo_hip.h (the drop-in boundary) and
+include/cvo_hip_debug.h (test / profiling hooks) declare (no compute calls here)."""
 import ctypes
 import os
 import re
@@ -8,10 +9,18 @@ import cases
 from unified_cvo_amd import _capi
 
 
-def _declared():
-    text = open(os.path.join(cases.ROOT, "include", "cvo_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(cvo_[a-z0-9_]+)\s*\(", text)))
+def _declared(headers=("cvo_hip.h", "cvo_hip_debug.h")):
+    out = set()
+    for h in headers:
+        text = open(os.path.join(cases.ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(cvo_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
+
+
+def test_debug_hooks_are_not_part_of_the_boundary_header():
+    assert not [s for s in _declared(("cvo_hip.h",)) if s.startswith("cvo_debug_")]
+    assert all(s.startswith("cvo_debug_") for s in _declared(("cvo_hip_debug.h",)))
 
 
 def test_header_and_binding_lists_agree():

@@ -1,0 +1,155 @@
+"""BASELINE.json's own shapes and the kernel-level micro-fixtures inside the driver-run GPU suite:
+
+  * config 5's per-GPU shape: a batch of 64 independent 10k x 10k geometric pairs (seeds 1000+p / 2000+p, four
+    sub-batch streams) - per-iteration traces of one pair per sub-batch against the oracle, all 64 poses bit-identical
+    to 64 solo align() calls, and one whole 2000-iteration pair against the oracle's final pose;
+  * config 2 at its literal 5000 x 5000: per-iteration prefix + final pose against the oracle;
+  * 256 x 256 full-ELL fixtures (tests/golden/micro_ell.npz; geo / geo+colour /
+    geo+colour+semantic / K-cap) - the semantics of /root/reference/src/cvo/CvoGPU.cu:477-593;
+  * every entry of tests/golden/oracle_traces.json (config 1 demo and config 3 included) without any oracle call.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from test_gpu_parity import _cmp_trace, _ocloud, TOL_TWIST, TOL_POSE, TOL_POSE_CLAMPED, TOL_IP_REL
+from unified_cvo_amd import CvoGPU, CvoPointCloud
+
+pytestmark = pytest.mark.gpu
+
+MICRO = os.path.join(cases.GOLDEN, "micro_ell.npz")
+MICRO_CASES = ["geo", "geo_colour", "geo_col_sem", "kcap"]
+MICRO_PARAMS = {"geo": "geometric_gpu", "geo_colour": "intensity_gpu", "geo_col_sem": "semantic_img_gpu0",
+                "kcap": "geometric_gpu"}
+
+
+def micro_case(name):
+    """(params, source, target, pose, ell, K, mat, ind, nonzeros) of one fixture; shared with the CPU-side test."""
+    z = np.load(MICRO)
+    get = lambda k: z[f"{name}/{k}"] if f"{name}/{k}" in z.files else None
+    P = cases.load_params(MICRO_PARAMS[name])
+    src = CvoPointCloud.from_arrays(get("xs"), get("fs"), get("ls"), get("gs"))
+    tgt = CvoPointCloud.from_arrays(get("xt"), get("ft"), get("lt"), get("gt"))
+    ell, K = float(get("ell_K")[0]), int(get("ell_K")[1])
+    return P, src, tgt, get("T"), ell, K, get("mat"), get("ind"), get("nonzeros")
+
+
+@pytest.mark.parametrize("name", MICRO_CASES)
+def test_micro_fixture_full_ell(name):
+    """One association pass on the committed 256 x 256 inputs: `ind_row2col` and `nonzeros` bit-exact (ordered first-K
+    truncation included), `mat` to 2e-7 relative (1 float ulp: exp() of ocml vs the glibc the fixture was made with)."""
+    P, src, tgt, T, ell, K, mat, ind, nz = micro_case(name)
+    gpu = CvoGPU(params=P)
+    gpu.align(src, tgt, T, max_iterations=1, ell0=ell, K0=K)
+    gmat, gind, gnz = gpu.debug_last_ell(src.num_points(), K)
+    assert np.array_equal(gnz, nz)
+    assert np.array_equal(gind, ind)
+    assert np.allclose(gmat, mat, rtol=2e-7, atol=0)
+    if name == "kcap":
+        assert (gnz == K).sum() > 128 and np.all(np.diff(gind[gnz == K], axis=1) > 0)   # first K in ascending j
+
+
+def test_every_committed_golden_trace():
+    """HIP path vs all four entries of tests/golden/oracle_traces.json (no oracle call at all): the demo pair on the
+    neighbour cap for 1000 iterations, configs 2 / 3 / 4 at n = 2000 to their own ends."""
+    with open(os.path.join(cases.GOLDEN, "oracle_traces.json")) as f:
+        gold = {c["name"]: c for c in json.load(f)["cases"]}
+    builders = {"config1_demo_geometric_k1000": cases.config1, "config2_n2000": cases.config2,
+                "config3_n2000": cases.config3, "config4_n2000": cases.config4}
+    assert set(gold) == set(builders)
+    for name, builder in builders.items():
+        gc = gold[name]
+        P, src, tgt, init = builder(**gc["kwargs"])
+        gpu = CvoGPU(params=P)
+        g = gpu.align(src, tgt, init, trace_capacity=400, trace_dense=50, trace_every=100,
+                      max_iterations=gc["max_iterations"])
+        assert (g.iterations, g.ret) == (gc["iterations"], gc["ret"]) or name == "config4_n2000"
+        got = {t.k: t for t in g.trace}
+        strict = 100 if name.startswith("config1") else 50   # (config 1: DESIGN.md section 4, claim made at k = 100)
+        for t in gc["trace"]:
+            if t["k"] >= strict:
+                continue  # beyond the dense prefix trajectories may differ in the last bits
+            a = got[t["k"]]
+            assert (a.K, a.nnz, a.max_nnz) == (t["K"], t["nnz"], t["max_nnz"]), (name, t["k"])
+            assert a.ell == pytest.approx(t["ell"], rel=1e-7)
+            assert np.allclose(list(a.omega) + list(a.v), t["omega"] + t["v"], atol=TOL_TWIST)
+        if name == "config4_n2000":
+            assert abs(g.iterations - gc["iterations"]) <= 2
+        # final pose: 1e-4 where the end is well conditioned (config 4's eps_2 stop), 2e-4 for the runs that end
+        # clamped at min_step (configs 2 / 3); config 1 at k = 1000 agrees bit for bit with the default-convention
+        # oracle in practice, the bound asserted is the north_star's
+        tol = TOL_POSE if name in ("config4_n2000", "config1_demo_geometric_k1000") else TOL_POSE_CLAMPED
+        assert cases.max_abs_diff(g.transform, gc["transform"]) <= tol, name
+        ell = P.ell_init
+        assert gpu.inner_product_gpu(src, tgt, init, ell) == pytest.approx(gc["inner_product_init"], rel=TOL_IP_REL)
+        assert gpu.function_angle(src, tgt, init, ell, True) == pytest.approx(gc["function_angle_init"], rel=TOL_IP_REL)
+        final = np.linalg.inv(np.array(gc["transform"], np.float64)).astype(np.float32)
+        assert gpu.inner_product_gpu(src, tgt, final, ell) == pytest.approx(gc["inner_product_final"], rel=TOL_IP_REL)
+        assert gpu.function_angle(src, tgt, final, ell, False) == pytest.approx(gc["function_angle_final_exact"],
+                                                                                rel=TOL_IP_REL)
+
+
+def test_config2_literal_5k(oracle):
+    """BASELINE.json configs[1] at its literal size: 5000 x 5000 xyz, cvo_geometric_params_gpu.yaml, identity init.
+    Every iteration of a 300-iteration prefix follows the oracle; the whole run (all MAX_ITER = 2000 iterations, the
+    loop ends clamped at min_step) ends within 2e-4 = 2 * min_step of the oracle's pose."""
+    P, src, tgt, init = cases.config2(n=5000)
+    gpu = CvoGPU(params=P)
+    op, ox, oy = oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt)
+    n_it = 300
+    g = gpu.align(src, tgt, init, max_iterations=n_it, trace_capacity=n_it, trace_dense=n_it)
+    o = oracle.align(op, ox, oy, init, trace_capacity=n_it, trace_dense=n_it, max_iterations=n_it)
+    assert g.iterations == o["iterations"] == n_it and len(g.trace) == len(o["trace"]) == n_it
+    for a, b in zip(g.trace, o["trace"]):
+        _cmp_trace(a, b)
+    assert cases.max_abs_diff(g.transform, o["transform"]) <= 1e-6
+    g = gpu.align(src, tgt, init)
+    o = oracle.align(op, ox, oy, init)
+    assert g.iterations == o["iterations"] == P.MAX_ITER == 2000 and g.ret == o["ret"] == 0
+    assert cases.max_abs_diff(g.transform, o["transform"]) <= TOL_POSE_CLAMPED
+    for T in (init, np.linalg.inv(g.transform.astype(np.float64)).astype(np.float32)):
+        assert gpu.inner_product_gpu(src, tgt, T, P.ell_init) == pytest.approx(
+            oracle.inner_product(op, ox, oy, T, P.ell_init), rel=TOL_IP_REL)
+
+
+def test_config5_per_gpu_shape_64_pairs_of_10k(oracle):
+    """BASELINE.json configs[4] as one GPU sees it: 64 independent 10k x 10k geometric pairs (pair p: seeds 1000+p /
+    2000+p) solved as ONE batch on four sub-batch streams.
+      * 320 iterations with full traces: one pair of every sub-batch is compared with the oracle iteration by iteration
+        (integer decisions exact, twist / coefficients / pose to the tolerances of _cmp_trace);
+      * all 64 poses, iteration counts, final ell and K are bit-identical to 64 solo align() calls;
+      * pair 0 run to the end (2000 iterations): final pose within 2e-4 of the oracle's."""
+    n_pairs, n, n_it = 64, 10000, 320
+    cs = [cases.config2(n=n, pair_id=p) for p in range(n_pairs)]
+    P = cs[0][0]
+    gpu = CvoGPU(params=P)
+    clouds = gpu.upload_many([c[1] for c in cs] + [c[2] for c in cs])
+    srcs, tgts, inits = clouds[:n_pairs], clouds[n_pairs:], [c[3] for c in cs]
+    res = gpu.align_batch(srcs, tgts, inits, max_iterations=n_it, trace_capacity=n_it, trace_dense=n_it)
+    n_groups, per_group = gpu.debug_last_geometry()
+    assert n_groups == 4 and per_group == 16
+    assert all(r.iterations == n_it and r.ret == 0 for r in res)
+    op = oracle.params_from(P)
+    for p in (0, 16, 32, 48):
+        o = oracle.align(op, _ocloud(oracle, cs[p][1]), _ocloud(oracle, cs[p][2]), inits[p], trace_capacity=n_it,
+                         trace_dense=n_it, max_iterations=n_it)
+        assert len(res[p].trace) == len(o["trace"]) == n_it
+        for a, b in zip(res[p].trace, o["trace"]):
+            _cmp_trace(a, b)
+        assert cases.max_abs_diff(res[p].transform, o["transform"]) <= 1e-6
+    solo = CvoGPU(params=P)
+    for p in range(n_pairs):
+        s, t = solo.upload_many([cs[p][1], cs[p][2]])
+        one = solo.align(s, t, inits[p], max_iterations=n_it)
+        assert (one.iterations, one.ret, one.final_ell, one.final_num_neighbors) == (
+            res[p].iterations, res[p].ret, res[p].final_ell, res[p].final_num_neighbors), p
+        assert np.array_equal(one.transform, res[p].transform), p
+        s.free()
+        t.free()
+    full = gpu.align(srcs[0], tgts[0], inits[0])
+    o = oracle.align(op, _ocloud(oracle, cs[0][1]), _ocloud(oracle, cs[0][2]), inits[0])
+    assert full.iterations == o["iterations"] == 2000 and full.ret == o["ret"] == 0
+    assert cases.max_abs_diff(full.transform, o["transform"]) <= TOL_POSE_CLAMPED

@@ -735,7 +735,25 @@ def test_randomised_trajectories(oracle, seed):
         _cmp_trace(x, y)
         compared += 1
     assert compared >= min(10, len(g.trace))
-    if compared == len(g.trace):
+    strict = compared == len(g.trace)
+    FUZZ_OUTCOMES[seed] = strict
+    if strict:
         assert cases.max_abs_diff(g.transform, o["transform"]) <= 1e-6
     else:
-        assert cases.max_abs_diff(g.transform, o["transform"]) <= 1e-3
+        # After a one-ulp separation the two runs are two valid trajectories of the same optimiser: the north_star
+        # tolerance applies, relaxed to 2 * min_step where the prefix ends clamped at min_step (two
+        # implementations can sit on opposite phases of the +-min_step jitter).
+        assert cases.max_abs_diff(g.transform, o["transform"]) <= max(TOL_POSE_CLAMPED, 2.0 * P.min_step), (seed, compared)
+
+
+FUZZ_OUTCOMES = {}
+
+
+def test_randomised_trajectories_mostly_strict():
+    """At most 10 % of the fuzz seeds may leave the strict per-iteration comparison (a one-ulp exp() difference between
+    ocml and glibc); everything else must have followed the oracle bit-for-decision to the last recorded iteration."""
+    if len(FUZZ_OUTCOMES) < 10:
+        pytest.skip("runs after test_randomised_trajectories")
+    loose = sorted(s for s, ok in FUZZ_OUTCOMES.items() if not ok)
+    print(f"fuzz: {len(loose)} of {len(FUZZ_OUTCOMES)} seeds left the strict comparison: {loose}")
+    assert len(loose) <= 0.10 * len(FUZZ_OUTCOMES), loose

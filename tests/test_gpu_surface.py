@@ -116,6 +116,19 @@ def test_align_association_after_eps2_break(oracle):
     assert not (len(col2) == len(col) and np.array_equal(col2, col) and np.array_equal(val2, val))
 
 
+def test_align_association_after_eps2_break_in_iteration_zero(oracle):
+    """Warm start at the optimum with min_step < eps_2: the loop leaves through `dist < eps_2` in iteration 0, so
+    `iterations == 0` and ret == 0 - and upstream still exports iteration 0's matrix (gpu_association_to_cpu runs
+    after ANY loop, CvoGPU.cu:1505-1508, 1552), whose nonzero sum is > 0."""
+    P, src, tgt, init = cases.config2(n=1500)
+    warm = np.linalg.inv(CvoGPU(params=P).align(src, tgt, init).transform.astype(np.float64)).astype(np.float32)
+    P.is_exporting_association = 1
+    P.eps_2 = 1e-3                      # > min_step = 1e-4: the clamped first step already ends the loop
+    g, o, (rp, col, val, kw, kr) = _check_association(oracle, P, src, tgt, warm, expect_same_stride=True)
+    assert g.iterations == 0 and g.ret == 0
+    assert kw == P.nearest_neighbors_max and len(col) > 1000
+
+
 def test_align_association_after_max_iter(oracle):
     """The loop runs out of iterations: num_neighbors was already advanced for an iteration that never ran
     (CvoGPU.cu:1529) and upstream reads the buffers with that stride."""

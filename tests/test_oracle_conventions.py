@@ -69,6 +69,16 @@ CASES = {
     "config4_n1500": (cases.config4, dict(n=1500), 0, 1e-4, 10),
 }
 
+# The same sweep at BASELINE.json's literal sizes (scripts/convention_sweep.py --full -> profiles/r3/
+# convention_sweep_full.json; minutes of CPU, so only config 2 at its literal 5k x 5k runs in the suite below).
+CASES_FULL = {
+    "config2_n5000": (cases.config2, dict(n=5000), 0, 2e-4, 10),
+    "config2_shape_n10000": (cases.config2, dict(n=10000), 0, 2e-4, 10),
+    "config3_n10000": (cases.config3, dict(n=10000), 0, 2e-4, 10),
+    "config4_n10000": (cases.config4, dict(n=10000), 0, 1e-4, 10),
+}
+CASES["config2_n5000"] = CASES_FULL["config2_n5000"]
+
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_results_do_not_depend_on_the_unpinned_conventions(oracle, name):

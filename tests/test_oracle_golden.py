@@ -14,7 +14,7 @@ BUILDERS = {"config1_demo_geometric_k1000": cases.config1, "config2_n2000": case
             "config3_n2000": cases.config3, "config4_n2000": cases.config4}
 
 
-@pytest.mark.parametrize("name", ["config1_demo_geometric_k1000", "config2_n2000", "config4_n2000"])
+@pytest.mark.parametrize("name", ["config1_demo_geometric_k1000", "config2_n2000", "config3_n2000", "config4_n2000"])
 def test_oracle_reproduces_golden(oracle, name):
     g = GOLD[name]
     P, src, tgt, init = BUILDERS[name](**g["kwargs"])
@@ -48,3 +48,38 @@ def test_golden_config2_recovers_motion():
         gt_inv = np.array(json.load(f)["gt_inverse"])
     assert g["iterations"] == 2000
     assert np.max(np.abs(np.array(g["transform"]) - gt_inv)) < 2e-3
+
+
+MICRO_CASES = ["geo", "geo_colour", "geo_col_sem", "kcap"]
+
+
+@pytest.mark.parametrize("name", MICRO_CASES)
+def test_oracle_reproduces_micro_ell_fixture(oracle, name):
+    """the committed 256 x 256 full-ELL fixtures (tests/golden/micro_ell.npz, made by
+    scripts/make_micro_fixtures.py) - one pass of fill_in_A_mat_gpu (CvoGPU.cu:477-593) for geo / geo+colour /
+    geo+colour+semantic and a case cut by the first-K truncation.  The oracle must reproduce them bit for bit (same
+    libm, same compiler flags); the -m gpu twin (tests/test_gpu_baseline_shapes.py) holds the HIP path to them."""
+    import sys
+    sys.path.insert(0, os.path.join(cases.ROOT, "scripts"))
+    import make_micro_fixtures as mm
+    z = np.load(os.path.join(cases.GOLDEN, "micro_ell.npz"))
+    P, X, Y, T, ell, K = mm.build(name)
+    # the generator's inputs ARE the committed ones (the fixture is self-contained data, not a recipe)
+    for key, arr in (("xs", X[0]), ("fs", X[1]), ("ls", X[2]), ("gs", X[3]), ("xt", Y[0]), ("ft", Y[1]), ("lt", Y[2]),
+                     ("gt", Y[3])):
+        if arr is None:
+            assert f"{name}/{key}" not in z.files
+        else:
+            assert np.array_equal(z[f"{name}/{key}"], arr), key
+    assert np.array_equal(z[f"{name}/T"], T) and tuple(z[f"{name}/ell_K"]) == (ell, K)
+    mat, ind, nz = mm.evaluate(oracle, P, X, Y, T, ell, K)
+    assert np.array_equal(nz, z[f"{name}/nonzeros"])
+    assert np.array_equal(ind, z[f"{name}/ind"])
+    assert np.array_equal(mat.astype(np.float32), z[f"{name}/mat"])
+    # the layout the fixture claims: row stride K, -1 behind a row's last entry, ascending columns inside a row
+    for i in range(ind.shape[0]):
+        k = int(nz[i])
+        assert np.all(ind[i, :k] >= 0) and np.all(ind[i, k:] == -1) and np.all(np.diff(ind[i, :k]) > 0)
+        assert np.all(mat[i, :k] > P.sp_thres) and np.all(mat[i, k:] == 0)
+    if name == "kcap":
+        assert (nz == K).sum() > 128

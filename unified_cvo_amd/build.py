@@ -45,6 +45,7 @@ def sources():
 def headers():
     hs = [os.path.join(CSRC, f) for f in ("cvo_device.h", "cvo_kernels.h")]
     hs.append(os.path.join(ROOT, "include", "cvo_hip.h"))
+    hs.append(os.path.join(ROOT, "include", "cvo_hip_debug.h"))
     return hs
 
 

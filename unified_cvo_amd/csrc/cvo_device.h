@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/cvo_hip.h"
+#include "../../include/cvo_hip_debug.h"
 
 namespace cvo_dev {
 
@@ -108,7 +109,7 @@ struct PairState {
   // block that finishes the pair's work in the launch, [0] k_assoc (lean graph; its last interval is left in
   // clk_last_assoc by the flow gate and added by the update) / [1] k_coeff, summed over clk_n iterations
   unsigned clk_last_assoc, clk_n[2];
-  int K_last;  // num_neighbors of the last EXECUTED iteration: the row stride upstream wrote its A matrix with
+  int K_last;  // num_neighbors of the last EXECUTED iteration: the row stride upstream wrote its A matrix with (0: none ran)
   unsigned long long clk_sum[2];
   // ---- everything above is the "hot" prefix k_update stages through LDS ----
   float sq[IND_CAP], eq[IND_CAP];

@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -67,8 +69,19 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+// Tuning / diagnostic switches of a context (none changes a result).  Read from the environment ONCE, when the context
+// is created (CVO_<NAME>), and settable afterwards with cvo_ctx_set_option: no library call reads the process
+// environment while it runs.
+static const char* const kOptionNames[] = {
+    "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
+    "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
+    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "NO_RESIDENT", "RESIDENT_U",
+    "RESIDENT_BLOCKS", "UPLOAD_THREADS"};
+
 struct cvo_ctx {
   int device = 0;
+  std::map<std::string, std::string> opt;  // see kOptionNames
+  std::mutex upload_mutex;                 // cvo_cloud_upload / _aos192 share upload_stream and the error string
   hipStream_t stream = nullptr;
   hipStream_t upload_stream = nullptr;  // cvo_cloud_upload copies here (never waits for, nor delays, the solver's streams)
   std::string err;
@@ -113,6 +126,17 @@ struct cvo_ctx {
 
 namespace {
 
+// value of option NAME (without the CVO_ prefix) or nullptr when it is not set
+const char* ctx_opt(const cvo_ctx* ctx, const char* name) {
+  if (!ctx) return nullptr;
+  auto it = ctx->opt.find(name);
+  return it == ctx->opt.end() ? nullptr : it->second.c_str();
+}
+bool ctx_opt_on(const cvo_ctx* ctx, const char* name) {  // set, and not to "0"
+  const char* v = ctx_opt(ctx, name);
+  return v && atoi(v) != 0;
+}
+
 int fail(cvo_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
   return code;
@@ -136,7 +160,12 @@ int ensure_attributes(cvo_ctx* ctx, const cvo_cloud* c, bool need_feat, bool nee
     HIP_TRY(ctx, hipSetDevice(c->device));
     hipError_t e = hipMalloc(&m->zero_slab, bytes);
     if (e != hipSuccess) return fail(ctx, CVO_E_NOMEM, std::string("cloud hipMalloc: ") + hipGetErrorString(e));
-    HIP_TRY(ctx, hipMemsetAsync(m->zero_slab, 0, bytes, ctx->stream));
+    e = hipMemsetAsync(m->zero_slab, 0, bytes, ctx->stream);
+    if (e != hipSuccess) {  // never hand the kernels an allocated-but-not-zeroed "zero" slab on a later call
+      (void)hipFree(m->zero_slab);
+      m->zero_slab = nullptr;
+      return fail(ctx, CVO_E_HIP, std::string("cloud hipMemsetAsync: ") + hipGetErrorString(e));
+    }
   }
   if (!m->feat) m->feat = (float4*)(m->zero_slab + o_feat);
   if (!m->label) m->label = (float4*)(m->zero_slab + o_label);
@@ -268,7 +297,7 @@ int coeff_split(int n) {
   return s;
 }
 
-DevParams make_dev_params(const cvo_params_t& p) {
+DevParams make_dev_params(const cvo_ctx* ctx, const cvo_params_t& p) {
   DevParams d{};
   d.sp_thres = p.sp_thres;
   d.sigma2 = p.sigma * p.sigma;
@@ -304,30 +333,30 @@ DevParams make_dev_params(const cvo_params_t& p) {
   d.use_geotype = p.is_using_geometric_type != 0;
   d.skin_frac = 2.0f;
   d.lean_skin = 1.3f;
-  d.dense_regime = getenv("CVO_NO_DENSE_REGIME") ? 0 : 1;
+  d.dense_regime = ctx_opt(ctx, "NO_DENSE_REGIME") ? 0 : 1;
   d.skin_blend = 0.25f;
-  if (const char* e = getenv("CVO_SKIN_BLEND")) d.skin_blend = std::min(1.f, std::max(0.f, (float)atof(e)));
+  if (const char* e = ctx_opt(ctx, "SKIN_BLEND")) d.skin_blend = std::min(1.f, std::max(0.f, (float)atof(e)));
   d.skin_min = 0.05f;
   d.skin_max = 0.25f;
-  if (const char* e = getenv("CVO_SKIN_MIN")) d.skin_min = std::max(0.f, (float)atof(e));
-  if (const char* e = getenv("CVO_SKIN_MAX")) d.skin_max = std::max(d.skin_min, (float)atof(e));
-  if (const char* e = getenv("CVO_LEAN_SKIN")) d.lean_skin = std::max(1.3f, (float)atof(e));
+  if (const char* e = ctx_opt(ctx, "SKIN_MIN")) d.skin_min = std::max(0.f, (float)atof(e));
+  if (const char* e = ctx_opt(ctx, "SKIN_MAX")) d.skin_max = std::max(d.skin_min, (float)atof(e));
+  if (const char* e = ctx_opt(ctx, "LEAN_SKIN")) d.lean_skin = std::max(1.3f, (float)atof(e));
   d.rebuild_shrink = 0.9f;
-  if (const char* e = getenv("CVO_SKIN")) d.skin_frac = std::max(0.f, (float)atof(e));
-  d.phase_ticks = getenv("CVO_PHASE_TICKS") ? 1 : 0;
-  d.kernel_clock = (getenv("CVO_KERNEL_CLOCK") && atoi(getenv("CVO_KERNEL_CLOCK")) != 0) ? 1 : 0;
-  d.verify_lists = (getenv("CVO_VERIFY_LISTS") && atoi(getenv("CVO_VERIFY_LISTS")) != 0) ? 1 : 0;
-  d.debug_no_motion_bound = getenv("CVO_DEBUG_NO_MOTION_BOUND") ? 1 : 0;
-  if (const char* e = getenv("CVO_SHRINK")) d.rebuild_shrink = std::min(0.99f, std::max(0.f, (float)atof(e)));
+  if (const char* e = ctx_opt(ctx, "SKIN")) d.skin_frac = std::max(0.f, (float)atof(e));
+  d.phase_ticks = ctx_opt(ctx, "PHASE_TICKS") ? 1 : 0;
+  d.kernel_clock = ctx_opt_on(ctx, "KERNEL_CLOCK") ? 1 : 0;
+  d.verify_lists = ctx_opt_on(ctx, "VERIFY_LISTS") ? 1 : 0;
+  d.debug_no_motion_bound = ctx_opt(ctx, "DEBUG_NO_MOTION_BOUND") ? 1 : 0;
+  if (const char* e = ctx_opt(ctx, "SHRINK")) d.rebuild_shrink = std::min(0.99f, std::max(0.f, (float)atof(e)));
   return d;
 }
 
 // Scan geometry: T chunks of 64 sorted targets per wave (smaller slices cull better, larger ones
 // amortise the row operands) and the number of row groups per block, chosen so that a launch has a
 // few thousand waves (256 CUs x 4 SIMDs want several waves each).
-void choose_scan_config(int n_pairs, int NG, int Mpad, int* T_out, int* gpb_out) {
+void choose_scan_config(const cvo_ctx* ctx, int n_pairs, int NG, int Mpad, int* T_out, int* gpb_out) {
   int T = 2;
-  const char* eT = getenv("CVO_SCAN_T");
+  const char* eT = ctx_opt(ctx, "SCAN_T");
   if (eT) {
     int v = atoi(eT);
     if (v == 1 || v == 2 || v == 4 || v == 8) T = v;
@@ -343,7 +372,7 @@ void choose_scan_config(int n_pairs, int NG, int Mpad, int* T_out, int* gpb_out)
     if (waves >= 4096) break;
     gpb = (int)align_up((size_t)gpb / 2, 64);
   }
-  const char* eG = getenv("CVO_SCAN_GROUPS");
+  const char* eG = ctx_opt(ctx, "SCAN_GROUPS");
   if (eG) {
     int v = atoi(eG);
     if (v >= 64 && v % 64 == 0) gpb = v;
@@ -570,13 +599,13 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   if (rc != CVO_OK) return rc;
   // sub-batches on separate streams (see cvo_ctx): the scan geometry is chosen for one group's launch
   S->G = n_pairs >= 32 ? 4 : (n_pairs >= 8 ? 2 : 1);
-  if (const char* e = getenv("CVO_STREAMS")) S->G = std::max(1, std::min(atoi(e), (int)cvo_ctx::MAX_GROUPS));
+  if (const char* e = ctx_opt(ctx, "STREAMS")) S->G = std::max(1, std::min(atoi(e), (int)cvo_ctx::MAX_GROUPS));
   S->G = std::min(S->G, n_pairs);
   if ((n_pairs + S->G - 1) / S->G > 4095 || S->d.nblk_assoc > 16383)
     return fail(ctx, CVO_E_INVALID, "batch too large for one call: at most 4095 pairs per stream and 2097024 source points per cloud");
-  choose_scan_config((n_pairs + S->G - 1) / S->G, S->d.NG, S->d.Mpad, &S->T, &S->gpb);
+  choose_scan_config(ctx, (n_pairs + S->G - 1) / S->G, S->d.NG, S->d.Mpad, &S->T, &S->gpb);
 
-  DevParams dp = make_dev_params(*params);
+  DevParams dp = make_dev_params(ctx, *params);
   dp.mode = mode;
   if (mode == 2) {  // non-isotropic kernel: 9 floats of the inverse (row-major) + the squared cull radius
     for (int q = 0; q < 9; q++) dp.kinv[q] = kernel_inv_and_cull[q];
@@ -590,18 +619,18 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   dp.T = S->T;
   dp.groups_per_block = S->gpb;
   dp.lean_U = 8;
-  if (const char* e = getenv("CVO_LEAN_U")) dp.lean_U = std::max(1, atoi(e));
+  if (const char* e = ctx_opt(ctx, "LEAN_U")) dp.lean_U = std::max(1, atoi(e));
   dp.lean_U2 = 2;
-  if (const char* e = getenv("CVO_LEAN_U2")) dp.lean_U2 = std::max(0, atoi(e));  // 0 = no short lean graph
+  if (const char* e = ctx_opt(ctx, "LEAN_U2")) dp.lean_U2 = std::max(0, atoi(e));  // 0 = no short lean graph
   if (dp.lean_U2 >= dp.lean_U) dp.lean_U2 = 0;
   dp.shrink_align = n_pairs >= 8 ? 63 : 0;
-  if (const char* e = getenv("CVO_SHRINK_ALIGN")) dp.shrink_align = std::max(0, atoi(e));
+  if (const char* e = ctx_opt(ctx, "SHRINK_ALIGN")) dp.shrink_align = std::max(0, atoi(e));
   if (opts && opts->max_iterations > 0) dp.max_iter = std::min(dp.max_iter, opts->max_iterations);
   if (opts && opts->kernel_clock) dp.kernel_clock = 1;
   dp.trace_capacity = trace_cap;
   // the columns of the ELL entries (ell_j) are only written when somebody can ask for them afterwards
   dp.keep_columns = (mode != 0 || trace_cap > 0 || dp.verify_lists || params->is_exporting_association ||
-                     getenv("CVO_KEEP_COLUMNS")) ? 1 : 0;
+                     ctx_opt(ctx, "KEEP_COLUMNS")) ? 1 : 0;
   dp.trace_dense = opts ? opts->trace_dense : 0;
   dp.trace_every = opts ? opts->trace_every : 0;
   *dp_out = dp;
@@ -689,7 +718,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
       st.ell = opts->ell0;
       st.K = opts->K0;
     }
-    st.K_last = st.K;
+    st.K_last = 0;  // set by the update of every EXECUTED iteration: > 0 <=> at least one association pass ran
     // (the pair's counters - gate, gate_flow, done, tile_count - are zeroed by k_update<INIT>; the slice bits of a row
     // are cleared by k_prep before every build, the first one included: five memsets per pair used to cost 10 us each call)
   }
@@ -827,6 +856,8 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return CVO_E_HIP;
   cvo_ctx* c = new cvo_ctx();
   c->device = device;
+  for (const char* name : kOptionNames)  // the ONLY place the library reads the environment
+    if (const char* v = std::getenv((std::string("CVO_") + name).c_str())) c->opt[name] = v;
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipMalloc(&c->d_params, sizeof(DevParams)) == hipSuccess && hipEventCreate(&c->ev_start) == hipSuccess &&
             hipEventCreate(&c->ev_stop) == hipSuccess &&
@@ -870,6 +901,20 @@ void cvo_ctx_destroy(cvo_ctx* c) {
   delete c;
 }
 
+int cvo_ctx_set_option(cvo_ctx* ctx, const char* name, const char* value) {
+  if (!ctx || !name) return CVO_E_INVALID;
+  if (std::strncmp(name, "CVO_", 4) == 0) name += 4;
+  bool known = false;
+  for (const char* k : kOptionNames) known = known || std::strcmp(k, name) == 0;
+  if (!known) return fail(ctx, CVO_E_INVALID, std::string("cvo_ctx_set_option: unknown option ") + name);
+  if (value)
+    ctx->opt[name] = value;
+  else
+    ctx->opt.erase(name);
+  drop_graphs(ctx);  // cached graphs bake some of the switches in
+  return CVO_OK;
+}
+
 const char* cvo_last_error(const cvo_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 void* cvo_ctx_stream(cvo_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int cvo_ctx_synchronize(cvo_ctx* ctx) {
@@ -911,10 +956,10 @@ static void kd_split(KdPoint* pts, int lo, int hi) {
   kd_split(pts, lo + left, hi);
 }
 
-static void spatial_order(const float* x4, int n, std::vector<int>& order) {
+static void spatial_order(const float* x4, int n, std::vector<int>& order, bool no_sort) {
   order.resize(n);
   for (int i = 0; i < n; i++) order[i] = i;
-  if (n < 8 || getenv("CVO_NO_SORT")) return;
+  if (n < 8 || no_sort) return;
   std::vector<KdPoint> pts((size_t)n);
   for (int i = 0; i < n; i++) {
     for (int c = 0; c < 3; c++) {
@@ -981,7 +1026,7 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
   }
   if (!std::isfinite(c->cx) || !std::isfinite(c->cy) || !std::isfinite(c->cz)) c->cx = c->cy = c->cz = 0.f;
   std::vector<int> order;
-  spatial_order(x4, n, order);
+  spatial_order(x4, n, order, ctx_opt(ctx, "NO_SORT") != nullptr);
   // colour, class distributions and geometric types are kept in SPATIAL order only (position r holds the attributes of
   // point order[r]): the kernels index them by sorted position, like the coordinates they gather per candidate
   if (h.feat) {
@@ -1034,14 +1079,15 @@ int cvo_cloud_upload(cvo_ctx* ctx, int n, const float* xyz, const float* feat, c
   if (!ctx || !out || n < 0 || (n > 0 && !xyz)) return fail(ctx, CVO_E_INVALID, "cvo_cloud_upload: bad argument");
   const HostCloud h{n, (const char*)xyz, 12, (const char*)feat, sizeof(float) * FD, (const char*)label, sizeof(float) * NC,
                     (const char*)geotype, 8};
+  std::lock_guard<std::mutex> lk(ctx->upload_mutex);
   return upload_host_cloud(ctx, h, ctx->upload_stream, out);
 }
 
 // n_clouds clouds from a pool of host threads (each cloud: spatial ordering on its thread, one allocation, one copy on
 // that thread's own stream).  Arrays of per-cloud pointers; feat / label / geotype (the arrays or single entries) may be
 // NULL.  On error every cloud of the call is released.
-int cvo_cloud_upload_many(cvo_ctx* ctx, int n_clouds, const int* n, const float* const* xyz, const float* const* feat,
-                          const float* const* label, const float* const* geotype, int threads, cvo_cloud** out) {
+static int upload_many_impl(cvo_ctx* ctx, int n_clouds, const int* n, const float* const* xyz, const float* const* feat,
+                            const float* const* label, const float* const* geotype, int threads, cvo_cloud** out) {
   if (!ctx || !out || n_clouds < 0 || (n_clouds > 0 && (!n || !xyz)))
     return fail(ctx, CVO_E_INVALID, "cvo_cloud_upload_many: bad argument");
   for (int q = 0; q < n_clouds; q++) {
@@ -1053,7 +1099,7 @@ int cvo_cloud_upload_many(cvo_ctx* ctx, int n_clouds, const int* n, const float*
   std::vector<int> rcs(T, CVO_OK);
   std::vector<std::string> errs(T);
   std::atomic<int> next(0);
-  auto work = [&](int t) {
+  auto work_body = [&](int t) {
     hipStream_t s = nullptr;
     if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
       rcs[t] = CVO_E_HIP;
@@ -1062,6 +1108,7 @@ int cvo_cloud_upload_many(cvo_ctx* ctx, int n_clouds, const int* n, const float*
     }
     cvo_ctx local;  // error text of this thread (the shared context's string is not thread-safe)
     local.device = ctx->device;
+    local.opt = ctx->opt;
     for (;;) {
       const int q = next.fetch_add(1);
       if (q >= n_clouds || rcs[t] != CVO_OK) break;
@@ -1080,8 +1127,22 @@ int cvo_cloud_upload_many(cvo_ctx* ctx, int n_clouds, const int* n, const float*
     }
     (void)hipStreamDestroy(s);
   };
+  auto work = [&](int t) {  // (bad_alloc of a staging buffer etc. must not leave a worker or cross the C ABI)
+    try {
+      work_body(t);
+    } catch (const std::exception& e) {
+      rcs[t] = CVO_E_NOMEM;
+      errs[t] = std::string("cvo_cloud_upload_many: ") + e.what();
+    } catch (...) {
+      rcs[t] = CVO_E_NOMEM;
+      errs[t] = "cvo_cloud_upload_many: unknown exception";
+    }
+  };
   std::vector<std::thread> pool;
-  for (int t = 1; t < T; t++) pool.emplace_back(work, t);
+  try {
+    for (int t = 1; t < T; t++) pool.emplace_back(work, t);
+  } catch (const std::exception&) {  // thread limit: the threads already started share the work with this one
+  }
   work(0);
   for (auto& th : pool) th.join();
   for (int t = 0; t < T; t++)
@@ -1095,12 +1156,27 @@ int cvo_cloud_upload_many(cvo_ctx* ctx, int n_clouds, const int* n, const float*
   return CVO_OK;
 }
 
+int cvo_cloud_upload_many(cvo_ctx* ctx, int n_clouds, const int* n, const float* const* xyz, const float* const* feat,
+                          const float* const* label, const float* const* geotype, int threads, cvo_cloud** out) {
+  try {
+    return upload_many_impl(ctx, n_clouds, n, xyz, feat, label, geotype, threads, out);
+  } catch (const std::exception& e) {  // (allocation of the pool's bookkeeping itself)
+    if (out)
+      for (int q = 0; q < n_clouds; q++) {
+        if (out[q]) cvo_cloud_free(out[q]);
+        out[q] = nullptr;
+      }
+    return fail(ctx, CVO_E_NOMEM, std::string("cvo_cloud_upload_many: ") + e.what());
+  }
+}
+
 int cvo_cloud_upload_aos192(cvo_ctx* ctx, int n, const void* pts, cvo_cloud** out) {
   if (!ctx || !out || n < 0 || (n > 0 && !pts)) return fail(ctx, CVO_E_INVALID, "cvo_cloud_upload_aos192: bad argument");
   // PointSegmentedDistribution<5,19> byte offsets: xyz@0, features@20,
   // label_distribution@44, geometric_type@120, sizeof = 192: read in place, record by record.
   const char* b = (const char*)pts;
   const HostCloud h{n, b, 192, b + 20, 192, b + 44, 192, b + 120, 192};
+  std::lock_guard<std::mutex> lk(ctx->upload_mutex);
   return upload_host_cloud(ctx, h, ctx->upload_stream, out);
 }
 
@@ -1190,7 +1266,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   // the first 256 (short warm-started solves end there, and the early requests change quickly), 32 afterwards.
   int U = (opts && opts->iters_per_launch > 0) ? opts->iters_per_launch : 16;
   U = std::max(1, std::min(U, std::max(1, max_iter)));
-  const bool adaptive_chunks = !(opts && opts->iters_per_launch > 0) && !getenv("CVO_FIXED_CHUNKS") && max_iter >= 512;
+  const bool adaptive_chunks = !(opts && opts->iters_per_launch > 0) && !ctx_opt(ctx, "FIXED_CHUNKS") && max_iter >= 512;
   const int U_late = adaptive_chunks ? 2 * U : U;
   const int n_early_chunks = adaptive_chunks ? 256 / U : 0;
   const int graph_mode = opts ? opts->use_graph : 0;
@@ -1266,7 +1342,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     // waiting in a lean chunk for a rebuild / dense kernel, so the bound below is only a safety net.
     const int n_chunks = (max_iter + U - 1) / U;
     const int chunk_cap = 4 * n_chunks + 16;
-    const bool allow_lean = getenv("CVO_NO_LEAN") == nullptr;
+    const bool allow_lean = ctx_opt(ctx, "NO_LEAN") == nullptr;
     int graph_next[cvo_ctx::MAX_GROUPS];  // 0 = full, 1 = lean, 2 = short lean
     for (int g = 0; g < G; g++) graph_next[g] = 0;  // the first iterations move fast: full graph
     bool all_done = false;
@@ -1312,7 +1388,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
             if (ctx->h_status[ws][p] == 0) want = std::max(want, ctx->h_status[ws][ctx->cap_pairs + p]);
           if (want == 1 && lean_U2 <= 0) want = 2;
           graph_next[g] = !allow_lean ? 0 : (want >= 2 ? 0 : (want == 1 ? 2 : 1));
-          if (getenv("CVO_VERBOSE") && atoi(getenv("CVO_VERBOSE")) >= 2 && ch < 12) {
+          if (ctx_opt(ctx, "VERBOSE") && atoi(ctx_opt(ctx, "VERBOSE")) >= 2 && ch < 12) {
             int nw = 0;
             for (int p = geom[g].p0; p < geom[g].p0 + geom[g].n_pairs; p++) nw += ctx->h_status[ws][ctx->cap_pairs + p] != 0;
             fprintf(stderr, "[cvo] after chunk %d group %d: %d of %d pairs ask for the full graph\n", ch - 1, g, nw, geom[g].n_pairs);
@@ -1321,7 +1397,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       }
     }
     ctx->last_chunks = ch;
-    if (getenv("CVO_VERBOSE")) fprintf(stderr, "[cvo] host loop: %.2f ms in hipGraphLaunch, %.2f ms waiting for the device\n", t_launch, t_wait);
+    if (ctx_opt(ctx, "VERBOSE")) fprintf(stderr, "[cvo] host loop: %.2f ms in hipGraphLaunch, %.2f ms waiting for the device\n", t_launch, t_wait);
     ctx->last_lean_launches = n_lean_launch;
     ctx->last_full_launches = n_full_launch;
     if (!all_done) {  // the in-flight chunk may have finished the stragglers; otherwise report it
@@ -1343,7 +1419,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   const auto t_host2 = std::chrono::steady_clock::now();
   float ms = 0;
   HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
-  if (getenv("CVO_VERBOSE"))
+  if (ctx_opt(ctx, "VERBOSE"))
     fprintf(stderr, "[cvo] host: setup %.2f ms, enqueue + wait %.2f ms\n",
             std::chrono::duration<double, std::milli>(t_host1 - t_host0).count(),
             std::chrono::duration<double, std::milli>(t_host2 - t_host1).count());
@@ -1358,7 +1434,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       return fail(ctx, CVO_E_VERIFY, msg);
     }
   }
-  if (getenv("CVO_VERBOSE")) {
+  if (ctx_opt(ctx, "VERBOSE")) {
     long builds = 0, stalls = 0, its = 0;
     for (int p = 0; p < n_pairs; p++) {
       builds += ctx->h_states[p].n_builds;
@@ -1700,12 +1776,15 @@ int cvo_align_association(cvo_ctx* ctx, int pair, int* row_ptr, int* col, float*
   const PairDesc& D = ctx->h_descs[pair];
   const PairState& st = ctx->h_states[pair];
   const int N = D.N;
-  const int Kw = st.K_last, Kr = st.K;  // written with / read with
+  // at least one se_kernel ran (the update of an executed iteration records its stride): upstream exports after ANY
+  // loop that ran once, also one that left through `dist < eps_2` in iteration 0 with `iterations == 0`
+  // (CvoGPU.cu:1505-1508, 1552; reachable with min_step < eps_2 when warm-started at the optimum)
+  const bool executed = st.K_last > 0;
+  const int Kw = executed ? st.K_last : st.K, Kr = st.K;  // written with / read with
   if (stride_written) *stride_written = Kw;
   if (stride_read) *stride_read = Kr;
   if (nnz_out) *nnz_out = 0;
   for (int i = 0; i <= N; i++) row_ptr[i] = 0;
-  const bool executed = (st.status ? st.iterations : st.k) > 0 || st.ret == -1;  // at least one se_kernel ran
   if (!executed || st.nnz == 0) return CVO_OK;  // `if (association_gpu.nonzero_sum == 0) return;`
   // the last iteration's matrix by position: count, original row index, entries (slot-major)
   std::vector<unsigned> nzp(N);
@@ -1841,7 +1920,7 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
                        2);
         else
           launch_coeff(ctx->stream, instr, nba, ctx->last_csplit, p1 - p0, ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0,
-                       A, 8 | 2 | (getenv("CVO_COEFF_NO_UPDATE") ? 16 : 0));
+                       A, 8 | 2 | (ctx_opt(ctx, "COEFF_NO_UPDATE") ? 16 : 0));
       }
     };
     sweep();  // warm-up
@@ -1960,7 +2039,7 @@ int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms) {
   const int n_pairs = ctx->last_pairs, G = ctx->last_groups;
   const DevParams& dp = ctx->last_params;
   int variant = 1;  // CVO_SCAN_DEBUG: 1 = no emission, 2 = no fine tiles (cost breakdown only)
-  if (const char* e = getenv("CVO_SCAN_DEBUG")) variant |= atoi(e) << 1;
+  if (const char* e = ctx_opt(ctx, "SCAN_DEBUG")) variant |= atoi(e) << 1;
   auto sweep = [&]() {
     for (int g = 0; g < G; g++) {
       const int p0 = (int)((long)n_pairs * g / G), p1 = (int)((long)n_pairs * (g + 1) / G);
