@@ -96,11 +96,25 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # torchrun with one rank also exercises RCCL
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+    # The step ends with an RCCL all-gather of the poses whatever the world size is: a plain `python bench.py --gpus 1`
+    # forms a one-rank process group too, so that the timed region contains what `config.parallelism` says it does.
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    use_dist = True
+    try:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    except Exception as e:  # noqa: BLE001
+        if world > 1:
+            raise
+        use_dist = False
+        log(f"[bench] one-rank RCCL process group failed to initialise ({e}): the step runs without the all-gather")
+    # host threads this rank may use (uploads, CPU baseline): the box's usable CPUs are shared by the local ranks
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    n_threads = max(1, available_cpus() // local_world)
 
     n = args.points
     B = args.pairs_per_gpu
@@ -113,7 +127,7 @@ def main():
     host_clouds = [(q[1], q[2]) for q in pairs]
     t_gen = time.time() - t_up
     t_up = time.time()
-    both = gpu.upload_many([a for a, _ in host_clouds] + [b for _, b in host_clouds], threads=available_cpus())
+    both = gpu.upload_many([a for a, _ in host_clouds] + [b for _, b in host_clouds], threads=n_threads)
     src, tgt = both[:len(host_clouds)], both[len(host_clouds):]
     t_h2d = time.time() - t_up
     inits = [q[3] for q in pairs]
@@ -221,7 +235,16 @@ def main():
                 e["alone_on_gpu_launch_ms"] = round(alone_ms, 5)
             return e
 
-        dom = kernel_entry("cvo_dev::k_coeff", coeff_ms, 1.0, coeff_alone_ms)
+        # the dominant kernel is whichever of the two per-iteration kernels measures longer inside the loop
+        ent_coeff = kernel_entry("cvo_dev::k_coeff", coeff_ms, 1.0, coeff_alone_ms)
+        ent_assoc = kernel_entry("cvo_dev::k_assoc", assoc_ms, 1.0, assoc_alone_ms)
+        dom, other = (ent_coeff, ent_assoc) if coeff_ms >= assoc_ms else (ent_assoc, ent_coeff)
+        # memory-side traffic of a whole step from the PMC bytes per launch: every iteration of every sub-batch launches
+        # both kernels once (rebuild kernels: 2 % of the iterations, not counted)
+        step_traffic_gbs = None
+        if ent_coeff["traffic"] and ent_assoc["traffic"]:
+            launches = n_groups * mean_iters
+            step_traffic_gbs = round((ent_coeff["traffic"] + ent_assoc["traffic"]) * launches / (elapsed / args.steps) / 1e9, 1)
         roofline = {
             "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_note,
@@ -231,8 +254,8 @@ def main():
                                   "kernels, ~3 % slower; the other timed steps run the production kernels)" if clocked
                                   else "HIP events around replayed launches, alone on the GPU"),
             "pairs_per_launch": ppl, "sub_batches": n_groups, "timed_at_iteration": mid_iters,
-            "other_kernels": [kernel_entry("cvo_dev::k_assoc", assoc_ms, 1.0, assoc_alone_ms),
-                              kernel_entry("cvo_dev::k_scan", scan_ms, round(builds / max(iters_total, 1), 5))],
+            "step_traffic_gbs": step_traffic_gbs,
+            "other_kernels": [other, kernel_entry("cvo_dev::k_scan", scan_ms, round(builds / max(iters_total, 1), 5))],
             # The path is an all-pairs accumulation with O(N+M) compulsory bytes: HBM is not the binding roof
             # (SURVEY.md 8(d)).  The VALU view: algorithmic pair tests per second of the whole job against the FP32
             # vector roof for the 8-flop cull test.  Bounding-box culling and candidate-list reuse skip almost all of
@@ -246,7 +269,7 @@ def main():
         cpu_baseline = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import pyoracle as po
-            threads = available_cpus()
+            threads = n_threads
             po.set_num_threads(threads)
             op = po.params_from(P)
             ox, oy = po.Cloud.from_pointcloud(host_clouds[0][0]), po.Cloud.from_pointcloud(host_clouds[0][1])
@@ -325,16 +348,16 @@ def main():
         # batch k + 1 (cvo_cloud_upload_many on its own streams); every step pays for fresh inputs, the timed region
         # is the steady state of that pipeline.  `sequential_value` is upload-then-solve without any overlap.
         pcie_inclusive = {"sequential_value": aligns / (elapsed + args.steps * t_h2d), "unit": "align/s",
-                          "upload_ms_per_cloud": round(upload_ms_per_cloud, 4), "upload_threads": available_cpus()}
+                          "upload_ms_per_cloud": round(upload_ms_per_cloud, 4), "upload_threads": n_threads}
         if world == 1 and args.max_iterations <= 0 and not args.no_pipeline:
             import threading
             all_host = [a for a, _ in host_clouds] + [b_ for _, b_ in host_clouds]
             nxt = {}
 
             def prefetch():
-                nxt["clouds"] = gpu.upload_many(all_host, threads=max(1, available_cpus() - 1))
+                nxt["clouds"] = gpu.upload_many(all_host, threads=max(1, n_threads - 1))
 
-            cur = gpu.upload_many(all_host, threads=available_cpus())
+            cur = gpu.upload_many(all_host, threads=n_threads)
             n_pipe = max(args.steps, 3)
             torch.cuda.synchronize()
             tp0 = time.perf_counter()
@@ -366,12 +389,18 @@ def main():
                                    f"(seeds 1000+p / 2000+p), cvo_geometric_params_gpu.yaml, identity init, "
                                    f"{mean_iters:.0f} optimiser iterations per align()",
                        "pairs_per_gpu": B, "points": n, "iterations_per_align": mean_iters,
-                       "parallelism": f"pairs sharded {B}/GPU over {world} GPU(s); one RCCL all-gather of poses per step"},
+                       "parallelism": (f"pairs sharded {B}/GPU over {world} GPU(s); one RCCL all-gather of poses per step "
+                                       f"(process group of {world} rank(s))" if use_dist else
+                                       f"{B} pairs on 1 GPU; NO collective ran (the one-rank process group failed to initialise)"),
+                       "timed_steps": (f"{args.steps} steps; the LAST one runs the instrumented instantiation of the per-iteration "
+                                       "kernels (device clock per launch, ~3 % slower), the others the production kernels"
+                                       if CLOCK_LAST_STEP else f"{args.steps} steps, production kernels"),
+                       "host_threads_per_rank": n_threads},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "single_pair": single_pair,
             "pcie_inclusive": pcie_inclusive,
         }
         h2d_rate = (2 * n * 16 * 1.0) * B / max(t_h2d, 1e-9) / 1e9
-        log(f"[bench] inputs: generated in {t_gen:.2f}s, uploaded in {t_h2d:.3f}s ({h2d_rate:.2f} GB/s incl. host-side k-d ordering on {available_cpus()} threads); "
+        log(f"[bench] inputs: generated in {t_gen:.2f}s, uploaded in {t_h2d:.3f}s ({h2d_rate:.2f} GB/s incl. host-side k-d ordering on {n_threads} threads); "
             f"PCIe-inclusive rate = {aligns / (elapsed + args.steps * t_h2d):.2f} align/s")
         log(f"[bench] loop {loop_s:.4f}s/step on rank 0; per launch of {ppl} pairs: k_assoc {assoc_ms*1e3:.1f} us "
             f"({assoc_alone_ms*1e3:.1f} alone on the GPU), k_coeff {coeff_ms*1e3:.1f} us ({coeff_alone_ms*1e3:.1f} alone), k_scan {scan_ms*1e3:.1f} us (runs in {100.0*builds/max(iters_total,1):.1f}% of the "

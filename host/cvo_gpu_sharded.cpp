@@ -1,5 +1,6 @@
 // cvo::CvoGPUSharded over the C-ABI + RCCL (see include/UnifiedCvo/cvo/CvoGPUSharded.hpp).
 #include "cvo/CvoGPUSharded.hpp"
+#include "cvo/ShardPlan.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -92,11 +93,7 @@ CvoParams& CvoGPUSharded::get_params() { return impl->gpus[0]->get_params(); }
 void CvoGPUSharded::write_params(const CvoParams* p) {
   for (auto& g : impl->gpus) g->write_params(p);
 }
-int CvoGPUSharded::device_of(int p, int n) const {
-  const int D = (int)impl->devices.size();
-  const int per = (n + D - 1) / D;
-  return per > 0 ? p / per : 0;
-}
+int CvoGPUSharded::device_of(int p, int n) const { return ShardPlan(n, (int)impl->devices.size()).device_of(p); }
 
 std::vector<int> CvoGPUSharded::align_batch(const std::vector<const CvoPointCloud*>& sources,
                                             const std::vector<const CvoPointCloud*>& targets,
@@ -109,7 +106,8 @@ std::vector<int> CvoGPUSharded::align_batch(const std::vector<const CvoPointClou
   transforms.assign(n, Mat4f::Identity());
   std::vector<int> rets(n, 0);
   if (n == 0) return rets;
-  const int per = (n + D - 1) / D;  // contiguous blocks; the last device may hold fewer (padded with identity poses)
+  const ShardPlan plan(n, D);  // contiguous blocks; the last devices may hold fewer (padded with identity poses)
+  const int per = plan.per;
   impl->reserve(per);
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<std::exception_ptr> errs(D);
@@ -118,7 +116,7 @@ std::vector<int> CvoGPUSharded::align_batch(const std::vector<const CvoPointClou
     th.emplace_back([&, d] {
       try {
         hip_ok(hipSetDevice(impl->devices[d]), "hipSetDevice");
-        const int lo = std::min(n, d * per), hi = std::min(n, lo + per);
+        const int lo = plan.lo(d), hi = plan.hi(d);
         std::vector<float> poses(16 * (size_t)per, 0.f);
         std::vector<int> rr(per, 0);
         for (int q = 0; q < per; q++) std::memcpy(&poses[16 * (size_t)q], Mat4f::Identity().data(), sizeof(float) * 16);
@@ -160,9 +158,10 @@ std::vector<int> CvoGPUSharded::align_batch(const std::vector<const CvoPointClou
   std::vector<int> all_r((size_t)per * D);
   hip_ok(hipMemcpy(all.data(), impl->recv[read_from], sizeof(float) * all.size(), hipMemcpyDeviceToHost), "hipMemcpy");
   hip_ok(hipMemcpy(all_r.data(), impl->recv_ret[read_from], sizeof(int) * all_r.size(), hipMemcpyDeviceToHost), "hipMemcpy");
-  for (int p = 0; p < n; p++) {  // rank-major blocks of `per` slots: pair p sits at slot p
-    std::memcpy(transforms[p].data(), &all[16 * (size_t)p], sizeof(float) * 16);
-    rets[p] = all_r[p];
+  for (int p = 0; p < n; p++) {  // rank-major blocks of `per` slots
+    const size_t slot = (size_t)plan.slot_of(p);
+    std::memcpy(transforms[p].data(), &all[16 * slot], sizeof(float) * 16);
+    rets[p] = all_r[slot];
   }
   if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return rets;

@@ -336,3 +336,24 @@ def test_pointcloud_raw_image_format(tmp_path):
     assert (int(kv["points"]), int(kv["features"]), int(kv["classes"])) == (n, F, C)
     assert float(kv["sum_xyz"]) == pytest.approx(rows[:, 3 + F:3 + F + 3].sum(), rel=1e-5)
     assert float(kv["sum_features"]) == pytest.approx(rows[:, 3:3 + F].sum(), rel=1e-5)
+
+
+def test_shard_plan_partition_and_gather_arithmetic():
+    """cvo::CvoGPUSharded's partition / gather index maths (include/UnifiedCvo/cvo/ShardPlan.hpp) driven WITHOUT devices
+    for D = 8 and n in {512, 100, 5} (BASELINE.json configs[4]: 512 pairs -> 64 per GPU; a ragged tail; fewer pairs than
+    GPUs), plus D = 1 / 3: contiguous blocks, every pair on exactly one device, read back from its own gather slot."""
+    exe = os.path.join(HOST, "cvo_shard_plan_check")
+    assert os.path.exists(exe), "build the host tools first (make -C host)"
+    out = subprocess.check_output([exe, "8", "512", "100", "5", "0", "8", "9"], text=True).splitlines()
+    assert out[0] == "D=8 n=512 per=64 counts=64,64,64,64,64,64,64,64"
+    assert out[1] == "D=8 n=100 per=13 counts=13,13,13,13,13,13,13,9"
+    assert out[2] == "D=8 n=5 per=1 counts=1,1,1,1,1,0,0,0"
+    assert out[3] == "D=8 n=0 per=0 counts=0,0,0,0,0,0,0,0"
+    for D in ("1", "3"):
+        subprocess.check_call([exe, D, "1", "7", "64", "100"], stdout=subprocess.DEVNULL)
+    # the Python host shards the same way (unified_cvo_amd/sharding.py)
+    from unified_cvo_amd import sharding
+    for n in (512, 100, 5):
+        counts = [hi - lo for lo, hi in (sharding.shard_range(n, 8, r) for r in range(8))]
+        line = [l for l in out if l.startswith(f"D=8 n={n} ")][0]
+        assert line.endswith("counts=" + ",".join(map(str, counts)))
