@@ -52,6 +52,10 @@ int cvo_debug_scalar_math(cvo_ctx* ctx, int op, int n, const double* in, double*
 /* CVO_VERIFY_LISTS=1 (environment, read when a call starts): rows k_verify re-derived with the literal scan during the
  * last align call, summed over pairs and iterations (0 when the check was off). */
 int cvo_debug_verified_rows(cvo_ctx* ctx, unsigned long long* rows);
+/* XCD-resident iteration: per-phase tick sums of k_resident (100 MHz device counter) collected while CVO_PHASE_TICKS is
+ * set, since the last call of this function (layout: g_res_ticks in unified_cvo_amd/csrc/cvo_kernels.h), and the
+ * blocks per pair of the last call's resident launches (0 = the call used the two-kernel iteration). */
+int cvo_debug_resident_ticks(cvo_ctx* ctx, unsigned long long out[16], int* blocks_per_pair);
 /* Free / total bytes of the context's device (hipMemGetInfo), for leak checks without a second HIP runtime in the process. */
 int cvo_debug_device_memory(cvo_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 #ifdef __cplusplus

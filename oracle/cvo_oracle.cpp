@@ -332,13 +332,16 @@ static bool build_grid(const CloudView& Y, double cell, TargetGrid& G) {
   return true;
 }
 
+// xq: the row's point in the frame the grid was built in; slack: absolute allowance on top of the cut-off radius for
+// whatever separates that frame from the one the exact test runs in.
 inline unsigned se_row_grid(const OracleParams& P, const CloudView& X, int i, const CloudView& Y, const TargetGrid& G,
-                            int K, float ell, float* mat_row, int* ind_row, std::vector<int>& cand) {
+                            int K, float ell, float* mat_row, int* ind_row, std::vector<int>& cand, const double xq[3],
+                            double slack) {
   RowConsts rc = row_consts(P, X.p(i), ell);
   // every j with (float) d2 < d2_thres lies within this radius of x_i (1e-5 relative + absolute slack for the float
   // evaluation of d2)
-  const double r = std::sqrt(std::max((double)rc.d2_thres, 0.0)) * (1.0 + 1e-5) + 1e-6;
-  const float* x = X.p(i);
+  const double r = std::sqrt(std::max((double)rc.d2_thres, 0.0)) * (1.0 + 1e-5) + 1e-6 + slack;
+  const double* x = xq;
   const int x0 = G.cell_of(x[0] - r, G.ox, G.nx), x1 = G.cell_of(x[0] + r, G.ox, G.nx);
   const int y0 = G.cell_of(x[1] - r, G.oy, G.ny), y1 = G.cell_of(x[1] + r, G.oy, G.ny);
   const int z0 = G.cell_of(x[2] - r, G.oz, G.nz), z1 = G.cell_of(x[2] + r, G.oz, G.nz);
@@ -365,15 +368,43 @@ inline unsigned se_row_grid(const OracleParams& P, const CloudView& X, int i, co
 
 // se_kernel (CvoGPU.cu:648-683) + reset_state_at_new_iter (CvoState.cu:143-157): rows are
 // written from slot 0; slot nnz holds ind = -1, mat = 0 when nnz < K (what memset leaves).
+// A grid that outlives the iteration (the align loop's): built over the INITIAL targets y0, queried with the row's point
+// mapped into that frame, x' = R x + T (y_t = R^T (y0 - T) is an isometry of y0, so |y0 - x'| = |y_t - x| up to the
+// float rounding of the transform: a few 1e-6 of |y|, covered by `slack`).  Candidates still go through pair_value()
+// against the TRANSFORMED targets in ascending j: identical results, no O(M) rebuild per iteration.
+struct PersistentGrid {
+  TargetGrid G;
+  double cell = 0;
+  bool valid = false;
+};
 void se_kernel_impl(const OracleParams& P, const CloudView& X, const CloudView& Y, int K, float ell,
-                    float* mat, int* ind, unsigned* nonzeros, bool literal) {
+                    float* mat, int* ind, unsigned* nonzeros, bool literal, PersistentGrid* pg = nullptr,
+                    const CloudView* Y0 = nullptr, const float* Rpose = nullptr, const float* Tpose = nullptr) {
   const int n = X.n, m = Y.n;
   if (g_use_grid && !literal && P.is_using_geometry && n > 0 && m > 0) {
     // cell = the largest cut-off radius of any row: at most 3 x 3 x 3 cells per query
     double rmax = 0;
     for (int i = 0; i < n; i++) rmax = std::max(rmax, (double)row_consts(P, X.p(i), ell).d2_thres);
-    TargetGrid G;
-    if (rmax > 0 && build_grid(Y, std::sqrt(rmax), G)) {
+    const double rad = std::sqrt(std::max(rmax, 0.0));
+    TargetGrid local;
+    const TargetGrid* G = nullptr;
+    double slack = 0, ymax = 0;
+    if (pg && Y0 && Rpose && Tpose && rad > 0) {
+      // (re)build when the cut-off outgrew the cells or shrank to well below them (ell decays during a solve)
+      if (!pg->valid || rad > pg->cell || rad < 0.4 * pg->cell) {
+        pg->valid = build_grid(*Y0, rad, pg->G);
+        pg->cell = rad;
+      }
+      if (pg->valid) {
+        G = &pg->G;
+        for (int j = 0; j < m; j++)
+          for (int c = 0; c < 3; c++) ymax = std::max(ymax, (double)std::fabs(Y0->p(j)[c]));
+        slack = 1e-5 * (ymax + 1.0) + 1e-5;  // float transform of the targets + the float (R, T) <-> (R^T, -R^T T) pair
+      }
+    } else if (rad > 0 && build_grid(Y, rad, local)) {
+      G = &local;
+    }
+    if (G) {
 #pragma omp parallel
       {
         std::vector<int> cand;
@@ -381,7 +412,12 @@ void se_kernel_impl(const OracleParams& P, const CloudView& X, const CloudView& 
         for (int i = 0; i < n; i++) {
           float* mr = mat + (size_t)i * K;
           int* ir = ind + (size_t)i * K;
-          unsigned nn = se_row_grid(P, X, i, Y, G, K, ell, mr, ir, cand);
+          const float* x = X.p(i);
+          double xq[3] = {x[0], x[1], x[2]};
+          if (pg && G == &pg->G)
+            for (int c = 0; c < 3; c++)
+              xq[c] = (double)Rpose[3 * c] * x[0] + (double)Rpose[3 * c + 1] * x[1] + (double)Rpose[3 * c + 2] * x[2] + (double)Tpose[c];
+          unsigned nn = se_row_grid(P, X, i, Y, *G, K, ell, mr, ir, cand, xq, slack);
           if ((int)nn < K) {
             ir[nn] = -1;
             mr[nn] = 0;
@@ -906,6 +942,7 @@ struct Workspace {
   // export of align() can tell the difference (it may read them with another stride, see export_align_association).
   bool literal_buffers = false;
   int K_alloc = 0;
+  PersistentGrid grid;  // "best-effort CPU" variant: a grid over the initial targets, kept across iterations
 };
 
 // One pass of the loop body of align_impl, CvoGPU.cu:1387-1531, up to (not including) the
@@ -934,7 +971,7 @@ IterResult iterate(const OracleParams& P, const CloudView& X, const CloudView& Y
   ws.nonzeros.resize(n);
   {
     const auto ts = std::chrono::steady_clock::now();
-    se_kernel_impl(P, X, Y, K, ell, ws.mat.data(), ws.ind.data(), ws.nonzeros.data(), false);  // 1419
+    se_kernel_impl(P, X, Y, K, ell, ws.mat.data(), ws.ind.data(), ws.nonzeros.data(), false, &ws.grid, &Y0, R, T);  // 1419
     g_scan_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
   }
   unsigned nnz = 0, mx = 0;  // compute_nonzeros SparseKernelMat.cu:37-46; max_element CvoGPU.cu:1518

@@ -133,7 +133,7 @@ EXPORTED = [
     "cvo_debug_kernel_clock",
     "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
     "cvo_align_association", "cvo_debug_scalar_math", "cvo_debug_verified_rows", "cvo_debug_device_memory", "cvo_cloud_upload_many",
-    "cvo_ctx_set_option",
+    "cvo_ctx_set_option", "cvo_debug_resident_ticks",
 ]
 
 _lib = None

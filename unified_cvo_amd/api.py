@@ -293,6 +293,12 @@ class CvoGPU:
     def get_params(self):
         return self.params
 
+    def set_option(self, name, value):
+        """cvo_ctx_set_option: a tuning / diagnostic switch of this context (the CVO_<NAME> environment variables are read
+        once, when the context is created); value None clears it."""
+        v = None if value is None else str(value).encode()
+        self._check(self.L.cvo_ctx_set_option(self.ctx, name.encode(), v))
+
     def write_params(self, p):
         """CvoGPU::write_params (CvoGPU.cu:73-77): the device copy is refreshed per call here."""
         self.params = p
@@ -528,6 +534,13 @@ class CvoGPU:
         a, c, n = C.c_float(), C.c_float(), C.c_ulonglong()
         self._check(self.L.cvo_debug_kernel_clock(self.ctx, C.byref(a), C.byref(c), C.byref(n)))
         return a.value, c.value, n.value
+
+    def debug_resident_ticks(self):
+        """(per-phase tick sums of k_resident under CVO_PHASE_TICKS, blocks per pair of the last call's resident launches)."""
+        out = (C.c_ulonglong * 16)()
+        nb = C.c_int()
+        self._check(self.L.cvo_debug_resident_ticks(self.ctx, out, C.byref(nb)))
+        return [int(x) for x in out], nb.value
 
     def debug_last_geometry(self):
         """(sub-batches of the last call, pairs per sub-batch): the k_scan launches a profiler sees."""

@@ -49,7 +49,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, done, cand_cnt, rowperm, iorig, xp4, ip, cand_j, ell, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, done, rsync, cand_cnt, rowperm, iorig, xp4, ip, cand_j, ell, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -75,7 +75,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static const char* const kOptionNames[] = {
     "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
     "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
-    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "NO_RESIDENT", "RESIDENT_U",
+    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "RESIDENT", "RESIDENT_U",
     "RESIDENT_BLOCKS", "UPLOAD_THREADS"};
 
 struct cvo_ctx {
@@ -92,6 +92,9 @@ struct cvo_ctx {
   PairState* d_states = nullptr;
   int* d_status = nullptr;
   DevParams* d_params = nullptr;
+  ResidentTeams* d_teams = nullptr;  // [MAX_GROUPS]: self-placement counters of the resident launches, one per sub-batch stream
+  bool resident_off = false;         // a resident launch timed out on this context: two-kernel graphs from then on
+  int last_resident_nb = 0;          // blocks per pair of the last call's resident launches (0 = not used)
   int cap_pairs = 0;
   std::vector<PairDesc> h_descs;
   std::vector<PairState> h_states;
@@ -215,6 +218,7 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.gate = take(sizeof(int));
   L.gate_flow = take(sizeof(int));
   L.done = take(sizeof(int));
+  L.rsync = take(sizeof(ResidentSync));
   L.rowperm = take(sizeof(int) * (size_t)N);
   L.iorig = take(sizeof(int) * (size_t)N);
   L.flow_part = take(sizeof(double) * 8 * (size_t)(nba + DENSE_BLOCKS));
@@ -477,6 +481,8 @@ void launch_dense(hipStream_t s, bool general, int N, int n_pairs, const PairDes
 
 struct LaunchGeom {
   int n_pairs, p0, T, gx, gy, nba, nbc, npb, N, csplit;
+  int group = 0;        // sub-batch index (its stream, its ResidentTeams)
+  int res_nb = 0;       // k_resident: blocks per pair (0 = the lean graphs use the two-kernel iteration)
   bool idx16, general, instr, verify;
   hipStream_t stream;
   ArenaArg arena;  // of pair p0
@@ -508,6 +514,33 @@ void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags) {
   launch_coeff(g.stream, g.instr, g.nba, g.csplit, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0));
 }
 
+// U lean iterations of every pair of the sub-batch in one launch (k_resident).  Grid: 8 XCDs x ceil(n_pairs / 8) pairs x
+// res_nb blocks; the blocks place themselves (see the kernel), so only the total matters.
+void launch_resident(cvo_ctx* c, const LaunchGeom& g, int U) {
+  const int ppx = (g.n_pairs + 7) / 8;
+  const dim3 grid((unsigned)(8 * ppx * (g.res_nb + 1))), blk(ASSOC_THREADS);  // res_nb row blocks + the tail block per pair
+  const int packed = (U & 0xff) | (g.res_nb << 8) | (int)((unsigned)g.n_pairs << 20);
+  const int nblk_split = g.nba | (g.csplit << 14) | ((g.p0 & 7) << 20);
+  const PairDesc* descs = c->d_descs + g.p0;
+  PairState* st = c->d_states + g.p0;
+  ResidentTeams* teams = c->d_teams + g.group;
+#define CVO_LAUNCH_RESIDENT(IDX, CAP, GEN)                                                                              \
+  hipLaunchKernelGGL((k_resident<IDX, CAP, GEN>), grid, blk, 0, g.stream, descs, c->d_params, st, g.arena.base, teams, packed, \
+                     nblk_split, g.arena.stride256, g.arena.Npad)
+  if (g.idx16) {
+    if (g.general)
+      CVO_LAUNCH_RESIDENT(unsigned short, ASSOC_CAP16, true);
+    else
+      CVO_LAUNCH_RESIDENT(unsigned short, ASSOC_CAP16, false);
+  } else {
+    if (g.general)
+      CVO_LAUNCH_RESIDENT(int, ASSOC_CAP32, true);
+    else
+      CVO_LAUNCH_RESIDENT(int, ASSOC_CAP32, false);
+  }
+#undef CVO_LAUNCH_RESIDENT
+}
+
 // A chunk of U iterations.  Full: every iteration can rebuild its candidate list and serve overflow rows.
 // Lean: rebuild opportunities only every lean_U iterations; pairs that need more wait for a full chunk.
 void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U) {
@@ -515,6 +548,13 @@ void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U)
     for (int u = 0; u < U; u++) {
       launch_rebuild(c, g);
       launch_core(c, g, false, 2);
+    }
+    return;
+  }
+  if (g.res_nb > 0) {  // the lean iterations between two rebuild opportunities in ONE launch
+    for (int u = 0; u < U; u += lean_U) {
+      launch_rebuild(c, g);
+      launch_resident(c, g, std::min(lean_U, U - u));
     }
     return;
   }
@@ -658,6 +698,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.NG = (X->n + ROWS_PER_GROUP - 1) / ROWS_PER_GROUP;
     D.NGpad = S->d.NGpad;
     D.ymax = Y->rmax;
+    D.sqrt_nm = std::sqrt((double)X->n * (double)Y->n);
     D.cx = X->cx;
     D.cy = X->cy;
     D.cz = X->cz;
@@ -704,6 +745,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.gate = (int*)(base + S->L.gate);
     D.gate_flow = (int*)(base + S->L.gate_flow);
     D.done = (int*)(base + S->L.done);
+    D.rsync = (ResidentSync*)(base + S->L.rsync);
 
     PairState& st = ctx->h_states[p];
     std::memset(&st, 0, sizeof(st));
@@ -751,6 +793,30 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.general = dp.use_col || dp.use_sem || dp.use_geotype;
   S->geom.instr = dp.kernel_clock || dp.phase_ticks;
   S->geom.verify = dp.verify_lists != 0;
+  // XCD-resident lean iterations (k_resident): calls with FEW pairs in flight (an iteration is a chain of latencies
+  // there; large batches are throughput-bound and keep the two-kernel iteration, whose launches fill the chip at a
+  // higher occupancy than blocks that wait for each other can).  The align loop only, not under the kernel clock or the
+  // list self-check (they hook into the two-kernel iteration), every pair with one coefficient slice per row block
+  // (clouds above 4096 points).  All blocks of a launch must be co-resident and the launches of the G sub-batch streams
+  // run side by side: row blocks per pair = what keeps the total at or below 1.5 blocks of 256 threads per CU (the
+  // kernel is built for 2).
+  S->geom.res_nb = 0;
+  // OFF by default (option RESIDENT=1): measured on MI355X it does not beat the two launches it replaces - DESIGN.md
+  // section 3, ROUND_LOG.md round 3 have the numbers (an L2-local hop is 260 ns, a reduce + broadcast among the blocks of
+  // a pair 1.5 - 2 us: what a launch boundary plus its cold prologue cost).  Kept because it is bit-identical, bounded
+  // and the harness for any further in-launch experiment; tests/test_gpu_parity.py runs it.
+  if (mode == 0 && ctx_opt_on(ctx, "RESIDENT") && !ctx->resident_off && !dp.kernel_clock && !S->geom.verify && S->geom.csplit == 1 &&
+      (n_pairs <= 16 || ctx_opt(ctx, "RESIDENT_BLOCKS"))) {
+    const int per_group = (n_pairs + S->G - 1) / S->G, ppx = (per_group + 7) / 8;
+    int nb = std::max(1, 48 / (S->G * ppx) - 1);
+    if (const char* e = ctx_opt(ctx, "RESIDENT_BLOCKS")) nb = std::max(1, atoi(e));
+    nb = std::min(std::min(nb, S->d.nblk_assoc), 4094);
+    // (never more than the chip holds at 2 blocks per CU, whatever the option says: a launch that is not fully resident
+    // would wait for its own queued blocks until the time-out)
+    while (nb > 1 && (long)S->G * ppx * (nb + 1) > 64) nb--;
+    if ((long)S->G * ppx * (nb + 1) <= 64) S->geom.res_nb = nb;
+  }
+  ctx->last_resident_nb = S->geom.res_nb;
   ctx->last_xorder = sources[0]->h_order;
   ctx->last_groups = S->G;
   ctx->last_pairs = n_pairs;
@@ -859,7 +925,12 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
   for (const char* name : kOptionNames)  // the ONLY place the library reads the environment
     if (const char* v = std::getenv((std::string("CVO_") + name).c_str())) c->opt[name] = v;
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-            hipMalloc(&c->d_params, sizeof(DevParams)) == hipSuccess && hipEventCreate(&c->ev_start) == hipSuccess &&
+            hipMalloc(&c->d_params, sizeof(DevParams)) == hipSuccess &&
+            hipMalloc(&c->d_teams, sizeof(ResidentTeams) * cvo_ctx::MAX_GROUPS) == hipSuccess &&
+            // (cleared on the context's own stream: a synchronous hipMemset would run on the NULL stream, whose hardware
+            // queue is then the first one this process creates - see the note on the sub-batch streams below)
+            hipMemsetAsync(c->d_teams, 0, sizeof(ResidentTeams) * cvo_ctx::MAX_GROUPS, c->stream) == hipSuccess &&
+            hipEventCreate(&c->ev_start) == hipSuccess &&
             hipEventCreate(&c->ev_stop) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
   c->gstream[0] = c->stream;
@@ -868,8 +939,16 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
     ok = ok && hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 2; i++) ok = ok && hipEventCreateWithFlags(&c->ev_chk[i][g], hipEventDisableTiming) == hipSuccess;
   }
-  // (after the sub-batch streams: HIP deals streams to hardware queues in creation order, and the four sub-batch
-  // streams of a batch must land on four different compute pipes - a stream created in between cost 2.4x)
+  // HIP binds a stream to a hardware queue when the stream is first USED, in the order of first use, and the four
+  // sub-batch streams of a batch must sit on four different compute pipes (two of them on one pipe take turns kernel by
+  // kernel: 205 ms instead of 69 ms per step for the headline batch, measured when a process's first context uploaded
+  // its clouds - a pool of temporary streams - before its first solve).  So the sub-batch streams are touched here, in
+  // order, before any other stream of this context exists.
+  for (int g = 0; ok && g < 4; g++) {
+    hipLaunchKernelGGL(k_hold, dim3(1), dim3(64), 0, c->gstream[g], 0ull);
+    ok = ok && hipGetLastError() == hipSuccess;
+  }
+  for (int g = 0; ok && g < 4; g++) ok = ok && hipStreamSynchronize(c->gstream[g]) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
   if (!ok) {
     cvo_ctx_destroy(c);
@@ -887,6 +966,7 @@ void cvo_ctx_destroy(cvo_ctx* c) {
   drop_graphs(c);
   free_workspace(c);
   if (c->d_params) (void)hipFree(c->d_params);
+  if (c->d_teams) (void)hipFree(c->d_teams);
   for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++) {
     for (int i = 0; i < 2; i++)
       if (c->ev_chk[i][g]) (void)hipEventDestroy(c->ev_chk[i][g]);
@@ -1278,6 +1358,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   for (int g = 0; g < G; g++) {
     const int p0 = (int)((long)n_pairs * g / G), p1 = (int)((long)n_pairs * (g + 1) / G);
     geom[g] = S.geom;
+    geom[g].group = g;
     geom[g].p0 = p0;
     geom[g].n_pairs = p1 - p0;
     geom[g].arena.base = S.geom.arena.base + S.L.total * (size_t)p0;
@@ -1294,6 +1375,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
 
   if (max_iter > 0) {
     const int lean_U = std::max(1, std::min(dp.lean_U, U));
+    bool resident_broken = false;
     const int lean_U2 = std::max(0, std::min(dp.lean_U2, U));
     auto lean_period = [&](int v) { return v == 2 ? lean_U2 : lean_U; };
     const int v_instr = S.geom.instr ? 3 : 0;  // the instrumented kernels have their own cached graphs
@@ -1311,7 +1393,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       key.idx16 = S.geom.idx16 ? 1 : 0;
       key.general = S.geom.general ? 1 : 0;
       key.U = Uc * 256 + lean_period(v);
-      key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0);
+      key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0) | (geom[g].res_nb << 2);
       key.arena = geom[g].arena.base;
       key.stride256 = geom[g].arena.stride256;
       key.Npad = geom[g].arena.Npad;
@@ -1386,6 +1468,14 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
           int want = 0;  // the most demanding unfinished pair of the group decides: 2 = full, 1 = short lean, 0 = lean
           for (int p = geom[g].p0; p < geom[g].p0 + geom[g].n_pairs; p++)
             if (ctx->h_status[ws][p] == 0) want = std::max(want, ctx->h_status[ws][ctx->cap_pairs + p]);
+          if (want >= 3) {  // a resident launch timed out: its pairs are served by the two-kernel graphs from now on
+            want = 2;
+            if (!resident_broken)
+              fprintf(stderr, "[cvo] warning: a resident launch timed out (blocks of a pair not co-resident); this context "
+                              "continues with the two-kernel iteration\n");
+            resident_broken = true;
+            for (int q = 0; q < G; q++) geom[q].res_nb = 0;  // (graphs are keyed on it: the next ones are captured anew)
+          }
           if (want == 1 && lean_U2 <= 0) want = 2;
           graph_next[g] = !allow_lean ? 0 : (want >= 2 ? 0 : (want == 1 ? 2 : 1));
           if (ctx_opt(ctx, "VERBOSE") && atoi(ctx_opt(ctx, "VERBOSE")) >= 2 && ch < 12) {
@@ -1397,6 +1487,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       }
     }
     ctx->last_chunks = ch;
+    if (resident_broken) ctx->resident_off = true;
     if (ctx_opt(ctx, "VERBOSE")) fprintf(stderr, "[cvo] host loop: %.2f ms in hipGraphLaunch, %.2f ms waiting for the device\n", t_launch, t_wait);
     ctx->last_lean_launches = n_lean_launch;
     ctx->last_full_launches = n_full_launch;
@@ -1872,6 +1963,19 @@ int cvo_debug_scalar_math(cvo_ctx* ctx, int op, int n, const double* in, double*
   if (e != hipSuccess) rc = fail(ctx, CVO_E_HIP, std::string("cvo_debug_scalar_math: ") + hipGetErrorString(e));
   cleanup();
   return rc;
+}
+
+// CVO_PHASE_TICKS=1: the resident kernel's per-phase tick sums (g_res_ticks, 100 MHz) since the last call of this
+// function; out[16].  Also reports how many blocks per pair the last call's resident launches used (*blocks_per_pair).
+int cvo_debug_resident_ticks(cvo_ctx* ctx, unsigned long long* out, int* blocks_per_pair) {
+  if (!ctx || !out) return CVO_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_res_ticks), sizeof(unsigned long long) * 16));
+  unsigned long long zero[16] = {};
+  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_res_ticks), zero, sizeof zero));
+  if (blocks_per_pair) *blocks_per_pair = ctx->last_resident_nb;
+  return CVO_OK;
 }
 
 int cvo_debug_device_memory(cvo_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {

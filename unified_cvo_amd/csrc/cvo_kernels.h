@@ -401,6 +401,14 @@ __device__ __forceinline__ RowData make_row(const DevParams& P, const float4 x, 
 struct Pose {  // the transform applied to the target cloud this iteration (update_tf, CvoGPU.cu:94-112)
   float Ri[9], Ti[3];
 };
+// What the row loops of one iteration need from the pair's state, by value: the two-kernel path fills it with scalar
+// loads of the state an EARLIER launch wrote, the resident kernel with L1-bypassing loads of the state another block of
+// the SAME launch wrote (a cached or compiler-hoisted copy would be stale there).
+struct IterView {
+  int K;
+  float ell;
+  Pose pose;
+};
 __device__ __forceinline__ Pose load_pose(const PairState* st) {
   Pose p;
 #pragma unroll
@@ -409,14 +417,22 @@ __device__ __forceinline__ Pose load_pose(const PairState* st) {
   for (int q = 0; q < 3; q++) p.Ti[q] = st->Tinv[q];
   return p;
 }
+__device__ __forceinline__ IterView load_iter_view(const PairState* st) {
+  IterView v;
+  v.K = st->K;
+  v.ell = st->ell;
+  v.pose = load_pose(st);
+  return v;
+}
 
 // GENERAL = false is the geometry-only specialisation (no colour / semantic / geometric-type code at all:
 // 1/3 fewer VGPRs, one more wave per SIMD for the latency-bound association kernel).
 // i / j index the FEATURE arrays (colour, class distributions, geometric types), which clouds keep in spatial order:
 // i = the row's sorted position, j = the target's sorted position.
+// The pair arithmetic for an already transformed target yt (everything of CvoGPU.cu:528-573 but the transform).
 template <bool GENERAL>
-__device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __restrict__ D, const Pose& pose, int i,
-                                          const RowData& r, int j, const float4 y0, float& a_out, float4& yt_out) {
+__device__ __forceinline__ bool eval_pair_yt(const DevParams& P, const PairDesc* __restrict__ D, int i, const RowData& r, int j,
+                                             const float4 yt, float& a_out) {
   float sk = 1, ck = 1, k = 1, geo_sim = 1;
   if (GENERAL && P.use_geotype) {  // compute_geometric_type_ip, CvoGPU.cu:203-215
     const float2 ga = D->xgeo[i], gb = D->ygeo[j];
@@ -426,10 +442,6 @@ __device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __
     geo_sim = dab * dab / (n2a * n2b);
     if ((double)geo_sim < 0.01) return false;
   }
-  // transform_point_R_T (CvoGPU_impl.cu:31-82) of the INITIAL target y0 = y4[j], recomputed where it is needed
-  const V3 ytv = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
-  const float4 yt = make_float4(ytv.x, ytv.y, ytv.z, 0.f);
-  yt_out = yt;
   if (P.use_geo && P.mode == 2) {
     // mahananobis_distance (CvoGPU.cu:152-171): dist = a - b, (dist^T * kernel_inv) * dist; no cut-off (236-238, 279-284)
     const float d0 = r.x - yt.x, d1 = r.y - yt.y, d2v = r.z - yt.z;
@@ -482,7 +494,17 @@ __device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __
   a_out = ck * k * sk * geo_sim;
   return true;
 }
-
+// transform_point_R_T (CvoGPU_impl.cu:31-82) of the INITIAL target y0 = y4[j], recomputed where it is needed, then the
+// pair arithmetic.  (The gates of a pair - geometric type, distance, colour, semantics - only ever reject: the order in
+// which they are tested does not reach a result.)
+template <bool GENERAL>
+__device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __restrict__ D, const Pose& pose, int i,
+                                          const RowData& r, int j, const float4 y0, float& a_out, float4& yt_out) {
+  const V3 ytv = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
+  const float4 yt = make_float4(ytv.x, ytv.y, ytv.z, 0.f);
+  yt_out = yt;
+  return eval_pair_yt<GENERAL>(P, D, i, r, j, yt, a_out);
+}
 // ------------------------------------------------------------------------------------------
 // k_assoc: ordered association + flow, one thread per (sorted) source row.
 // ------------------------------------------------------------------------------------------
@@ -504,14 +526,13 @@ struct RowAcc {
   unsigned nnz = 0;
 };
 
-// One accepted/rejected pair (i, j): CvoGPU.cu:528-589 + the flow terms of 758-782.
+// One pair (i, j) that passed the geometric cut-off, with its transformed target: the rest of CvoGPU.cu:528-589 (kernel
+// values, a > sp_thres, ELL store) + the flow terms of 758-782.
 template <bool GENERAL>
-__device__ __forceinline__ void visit_pair(const DevParams& P, const PairDesc* __restrict__ D, const Pose& pose, int i,
-                                           int pos, int N, const RowData& r, const V3& pxe, int j, const float4 y0,
-                                           RowAcc& A) {
+__device__ __forceinline__ void visit_pair_yt(const DevParams& P, const PairDesc* __restrict__ D, int i, int pos, int N,
+                                              const RowData& r, const V3& pxe, int j, const float4 yt, RowAcc& A) {
   float a;
-  float4 yt;
-  if (!eval_pair<GENERAL>(P, D, pose, i, r, j, y0, a, yt)) return;
+  if (!eval_pair_yt<GENERAL>(P, D, i, r, j, yt, a)) return;
   if (a > P.sp_thres) {
     D->ell[(size_t)A.nnz * N + pos] = EllEntry{a, yt.x, yt.y, yt.z};
     if (P.keep_columns) D->ell_j[(size_t)A.nnz * N + pos] = D->yorder[j];  // (list entries are sorted positions)
@@ -777,7 +798,10 @@ __device__ __forceinline__ double coeff_twist_load(const PairDesc* __restrict__ 
   }
   return acc;
 }
-__device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, int nparts) {
+// GRAN: resident kernel - the 42 floats leave as data-tagged granules (ResidentSync::xi) instead of PairState::xi.
+template <bool GRAN = false>
+__device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, int nparts, unsigned long long* gran = nullptr,
+                                               unsigned tag = 0u, float* twist_out = nullptr) {
   double acc = coeff_twist_load<true>(D, nparts);
   acc += dpp_f64<0x128>(acc);  // row_ror:8 : groups g and g ^ 1
   acc = xor16_sum(acc);
@@ -799,11 +823,21 @@ __device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, i
   }
   XiMats M;
   xi_mats(ov, ov + 3, M);
+  if (twist_out) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) twist_out[q] = ov[q];
+  }
   if ((threadIdx.x & 63) == 0) {
     const float* mv = reinterpret_cast<const float*>(&M);
-    float* dst = D->st->xi;
+    if (GRAN) {
 #pragma unroll
-    for (int q = 0; q < (int)(sizeof(XiMats) / sizeof(float)); q++) dst[q] = mv[q];
+      for (int q = 0; q < (int)(sizeof(XiMats) / sizeof(float)); q++)
+        gran[q] = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(mv[q]);
+    } else {
+      float* dst = D->st->xi;
+#pragma unroll
+      for (int q = 0; q < (int)(sizeof(XiMats) / sizeof(float)); q++) dst[q] = mv[q];
+    }
   }
 }
 // The flow partial of this block is stored; the block that finds it was the last one of its pair reduces them.
@@ -896,12 +930,14 @@ struct AssocShared {
   unsigned long long cnt[ASSOC_THREADS / 64][4];
 };
 
-template <typename IdxT, int ASSOC_CAP, bool GENERAL, bool INSTR>
-__device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* __restrict__ D, const PairState* st,
+// LOCAL: the block partials are read by a block of the SAME XCD (resident kernel): plain stores keep the line in that
+// XCD's L2, where the reader's L1-bypassing loads find it; otherwise coherent (sc1, write-through) stores.
+template <typename IdxT, int ASSOC_CAP, bool GENERAL, bool INSTR, bool LOCAL = false>
+__device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* __restrict__ D, const IterView& iv,
                                             AssocShared& S, const int bx, const AssocRowHead& head) {
   const int N = D->N;
   const int pos = bx * ASSOC_THREADS + threadIdx.x;  // position in k_list's count-ordered row windows
-  const int K = st->K;
+  const int K = iv.K;
   RowAcc A;
   unsigned long long ncand = 0;
   unsigned overflowed = 0;
@@ -915,9 +951,9 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
     if (!overflowed) {
       const int i = head.ip;
       const float4 x = head.x;
-      const RowData r = make_row(P, x, st->ell);
+      const RowData r = make_row(P, x, iv.ell);
       const V3 pxe{x.x, x.y, x.z};
-      const Pose pose = load_pose(st);
+      const Pose& pose = iv.pose;
       const IdxT* cj = reinterpret_cast<const IdxT*>(D->cand_j) + pos;
       // list entries are sorted positions: coordinates (and features) come from the spatially ordered arrays of the
       // target cloud - the candidates of the 64 neighbouring rows of a wave fall into a few cache lines instead of 64
@@ -934,7 +970,12 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
         j1 = j2;
         if (k + 1 < cnt) y1 = ysrc[j1];
         if (k + 2 < cnt) j2 = (int)cj[(size_t)(k + 2) * N];
-        visit_pair<GENERAL>(P, D, pose, i, pos, N, r, pxe, j, ycur, A);
+        // (Tried in round 3: a first pass that only transforms and tests the distance, parking what passes in LDS, and
+        // the kernel values in a second pass over the parked entries - bit-identical, -8 % for a lone pair's resident
+        // iteration, +5 % for the 64-pair batch: most waves hold rows of one to three candidates, where the exp already
+        // runs once or twice per wave either way, and the second loop and its LDS traffic are pure overhead.)
+        const V3 ytv = transform_point(pose.Ri, pose.Ti, ycur.x, ycur.y, ycur.z);
+        visit_pair_yt<GENERAL>(P, D, i, pos, N, r, pxe, j, make_float4(ytv.x, ytv.y, ytv.z, 0.f), A);
       }
       D->nnz_row[pos] = A.nnz;
       if (INSTR) tt2 = __builtin_readcyclecounter();
@@ -961,7 +1002,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
   }
   const double tot = block_reduce_lds<7>(S.red, red);  // (its barrier also covers S.cnt)
   if (threadIdx.x < 56 && (threadIdx.x & 7) == 0) {
-    st_x<true>(D->flow_part + (size_t)bx * 8 + (threadIdx.x >> 3), tot);  // read by another block of this launch (flow_gate)
+    st_x<!LOCAL>(D->flow_part + (size_t)bx * 8 + (threadIdx.x >> 3), tot);  // read by another block of this launch (flow_gate)
   } else if (threadIdx.x == 57) {
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
@@ -1028,7 +1069,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_ASSOC_WAVES) void k_assoc(const 
   if ((lean & 1) && (rebuild_v || n_ovf_v > 0)) return;
   pair_clock_begin(INSTR && P.kernel_clock && lean == 1 && pb.bx == 0, const_cast<PairState*>(st), 0);
   __shared__ AssocShared S;
-  assoc_phase<IdxT, ASSOC_CAP, GENERAL, INSTR>(P, D, st, S, pb.bx, head);
+  assoc_phase<IdxT, ASSOC_CAP, GENERAL, INSTR>(P, D, load_iter_view(st), S, pb.bx, head);
   // Everything from here on - the block's partial is on its way, the last-block counter, possibly the twist - is the
   // first wave's business.  The other waves retire now instead of sitting on their registers through a store
   // acknowledgement and an atomic round trip (~2 us of a ~7 us wave life; with thousands of waves queued behind them
@@ -1247,7 +1288,7 @@ struct CoeffRowHead {
 };
 // COH: the block partial is read by another block of the same launch.
 template <bool COH>
-__device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* __restrict__ D, const PairState* st,
+__device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* __restrict__ D, const float ell,
                                            CoeffShared& S, const XiMats& Mu, const CoeffRowHead& h, const int bx,
                                            const int q, const int nsplit) {
   const int N = D->N;
@@ -1259,7 +1300,7 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
   const unsigned nnz = h.nnz;
   if ((unsigned)q < nnz) {
     const float4 x = h.x;
-    float temp_ell = st->ell;
+    float temp_ell = ell;
     if (P.use_range_ell) {
       const float d2_sqrt = sqrtf(dot3_dev(x.x, x.y, x.z, x.x, x.y, x.z));
       temp_ell = compute_range_ell(temp_ell, d2_sqrt);
@@ -1302,6 +1343,7 @@ struct UpdDesc {
   int* want_out;
   int nblk_coeff, N, M;
   float ymax;
+  double sqrt_nm;
 };
 __device__ __forceinline__ UpdDesc load_upd_desc(const PairDesc* __restrict__ D) {
   UpdDesc u;
@@ -1316,6 +1358,7 @@ __device__ __forceinline__ UpdDesc load_upd_desc(const PairDesc* __restrict__ D)
   u.N = D->N;
   u.M = D->M;
   u.ymax = D->ymax;
+  u.sqrt_nm = D->sqrt_nm;
   asm volatile("" ::"s"(u.st), "s"(u.coef_part), "s"(u.flow_part), "s"(u.cnt_part), "s"(u.trace), "s"(u.status_out),
                "s"(u.want_out), "s"(u.nblk_coeff), "s"(u.N), "s"(u.M), "s"(u.ymax));
   return u;
@@ -1326,10 +1369,20 @@ __device__ __forceinline__ UpdDesc load_upd_desc(const PairDesc* __restrict__ D)
 // timing (nothing is written back), bits 8.. = how many
 // iterations the list has to survive without another rebuild opportunity (0 in the full graph).  n_flow_parts: association partials to
 // sum (the lean graph has no k_assoc_dense, so its slots are not read).
-template <bool INIT, bool COH>
+// RES: called from the resident kernel - counts, state and indicator FIFOs were (or may have been) written by OTHER
+// blocks of the SAME launch, so they are read with L1-bypassing loads as well.
+struct NoEarlyPublish {
+  __device__ __forceinline__ void operator()(int, int, float, const float*, const float*) const {}
+};
+// Early: called by thread 0 as soon as everything the NEXT iteration's row blocks need is known - stop word (1 done,
+// 2 list expired, 3 overflow rows, 0 go on), K, ell, Rinv, Tinv - i.e. in front of the list bookkeeping, the skin
+// arithmetic and the write-back of the state (the resident kernel publishes them there: the next association runs while
+// this wave finishes its tail).
+template <bool INIT, bool COH, bool RES = false, typename Early = NoEarlyPublish>
 __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P, int flags,
                                             int n_flow_parts, UpdateShared& U, const float* twist,
-                                            const unsigned* preloaded_hot, unsigned long long clk0 = 0ull) {
+                                            const unsigned* preloaded_hot, unsigned long long clk0 = 0ull,
+                                            Early early = Early()) {
   PairState* const gst = D.st;
   const bool trio_follows = INIT || (flags & 2) != 0;
   const bool dry = (flags & 8) != 0;  // timing replay: compute everything, write nothing back
@@ -1370,7 +1423,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int b = bl + 16 * u;
-      vq[u] = b < nba ? cnt32[((size_t)b * 4 + c) * 2] : 0u;
+      vq[u] = b < nba ? ld_x<RES>(cnt32 + ((size_t)b * 4 + c) * 2) : 0u;
     }
     if (P.mode == 0) {
       // eight (coherent) loads in flight per lane, summed in block order
@@ -1387,25 +1440,28 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     } else if (c == 0) {
       for (int b = bl; b < nba; b += 16) s += D.flow_part[(size_t)b * 8 + 6];
     }
+    // (component 2, the candidate statistic, can exceed 32 bits for very large clouds before the dense regime engages:
+    // it saturates instead of wrapping; nnz / overflow rows are bounded by the set-up check)
+    auto addsat = [](unsigned a, unsigned b) { const unsigned r = a + b; return r < a ? 0xffffffffu : r; };
     unsigned q = 0;
 #pragma unroll
-    for (int u = 0; u < 8; u++) q = (c == 1) ? max(q, vq[u]) : q + vq[u];
+    for (int u = 0; u < 8; u++) q = (c == 1) ? max(q, vq[u]) : addsat(q, vq[u]);
     for (int b0 = bl + 128; b0 < nba; b0 += 128) {
       unsigned v[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int b = b0 + 16 * u;
-        v[u] = b < nba ? cnt32[((size_t)b * 4 + c) * 2] : 0u;
+        v[u] = b < nba ? ld_x<RES>(cnt32 + ((size_t)b * 4 + c) * 2) : 0u;
       }
 #pragma unroll
-      for (int u = 0; u < 8; u++) q = (c == 1) ? max(q, v[u]) : q + v[u];
+      for (int u = 0; u < 8; u++) q = (c == 1) ? max(q, v[u]) : addsat(q, v[u]);
     }
     s += dpp_f64<DPP_XOR1>(s);
     s += dpp_f64<DPP_XOR2>(s);
     s += dpp_f64<DPP_HALF_MIRROR>(s);
     s += dpp_f64<DPP_MIRROR>(s);
     {
-      auto meet = [&](unsigned o) { q = (c == 1) ? max(q, o) : q + o; };
+      auto meet = [&](unsigned o) { q = (c == 1) ? max(q, o) : addsat(q, o); };
       meet((unsigned)dpp_i32<DPP_XOR1>((int)q));
       meet((unsigned)dpp_i32<DPP_XOR2>((int)q));
       meet((unsigned)dpp_i32<DPP_HALF_MIRROR>((int)q));
@@ -1425,8 +1481,8 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
   // fronts of the indicator FIFOs (HBM), on their way while the step is computed
   float e_front = 0.f, s_front = 0.f;
   if (!INIT && tid == 0) {
-    e_front = eq[st->e_head];
-    s_front = sq[st->s_head];
+    e_front = ld_x<RES>(eq + st->e_head);
+    s_front = ld_x<RES>(sq + st->s_head);
   }
   // the step of this iteration: the cubic's real roots are searched on three lanes side by side
   float step_w = 0.f;
@@ -1516,7 +1572,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
             dist = (double)step;
           else
             dist = se3_log_norm(dR, dT);
-          const float ip_curr = (float)((double)nnz / sqrt((double)D.N * (double)D.M));  // 1486
+          const float ip_curr = (float)((double)nnz / D.sqrt_nm);  // 1486 (sqrt(N * M): IEEE, evaluated on the host)
           const bool need_decay_ell = dry ? false : indicator_update(st, sq, eq, ip_curr, P.window, P.stable_thr, e_front, s_front);
           if (dist < (double)P.eps_2) {  // CvoGPU.cu:1505-1508
             done = 1;
@@ -1630,6 +1686,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
           rebuild = false;
         }
       }
+      early(done ? 1 : (rebuild ? 2 : (st->n_ovf > 0 ? 3 : 0)), st->K, st->ell, Ri, Ti);
       if (rebuild) {
         for (int q = 0; q < 9; q++) st->Rb[q] = Ri[q];
         for (int q = 0; q < 3; q++) st->Tb[q] = Ti[q];
@@ -1734,6 +1791,8 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
     *D->done = 0;
     *D->tile_count = 0ull;
   }
+  if (INIT)  // the resident kernel's arrival counters and granules (tags of an earlier call must not match)
+    for (int q = threadIdx.x; q < (int)(sizeof(ResidentSync) / 8); q += 64) reinterpret_cast<unsigned long long*>(D->rsync)[q] = 0ull;
   const DevParams P = *Pp;
   __shared__ UpdateShared U;
   update_body<INIT, false>(load_upd_desc(D), P, flags, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, U, nullptr,
@@ -1831,7 +1890,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     twist[3 + c] = Mu.v[c];
   }
   const unsigned long long tt1 = INSTR ? __builtin_readcyclecounter() : 0ull;
-  coeff_rows<true>(P, D, st_in, S.c, Mu, head, pb.bx, cq, csplit);
+  coeff_rows<true>(P, D, st_in->ell, S.c, Mu, head, pb.bx, cq, csplit);
   const unsigned long long tt2 = INSTR ? __builtin_readcyclecounter() : 0ull;
   if (threadIdx.x >= 64) return;  // the counter and (in one block of the pair) the update are the first wave's, see k_assoc
   // the scalar state, for whichever block turns out to be the last one: in flight while the counter round trip runs
@@ -1864,6 +1923,345 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     g_phase_ticks[1][4096 + pb.pair][0] = tt0;
     g_phase_ticks[1][4096 + pb.pair][1] = tt3;
     g_phase_ticks[1][4096 + pb.pair][2] = __builtin_readcyclecounter();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_resident: up to U optimiser iterations of every pair of a (small) sub-batch in ONE launch - the lean iterations
+// between two rebuild opportunities, which the two-kernel path runs as U x [k_assoc, k_coeff].  For calls with few
+// pairs in flight (one frame pair at a time is the reference's own use: frame-to-frame tracking), where an iteration
+// is a chain of latencies - two launch gaps, two cold prologues, two last-block elections - and not throughput.
+//
+// The two earlier in-launch attempts (ROUND_LOG.md: k_persist, round 2's k_resident) exchanged partials, twist and state
+// with sc1 accesses - placement-independent, hence served behind the L2 - and lost to the two launches they replaced.
+// Here co-location is CREATED instead of hoped for: a block reads the XCD it actually runs on (HW_REG_XCC_ID), draws its
+// index among the blocks of that XCD from a per-XCD counter and takes the role (pair, block-of-pair) that index stands
+// for; pairs are bound to XCDs (pair p <-> XCD p % 8), so all blocks of a pair share one L2 BY CONSTRUCTION and the
+// exchange goes through it: plain stores (the line stays in that L2), relaxed atomics for arrival, L1-bypassing (sc1)
+// loads.  scripts/ubench/xcd_exchange.hip: one hop 260 ns (342 with sc1 stores), reduce + broadcast among 32 blocks of
+// an XCD 2.0 us against 3.7 us, and such a value is NEVER seen from another XCD.  No kernel boundary separates the
+// iterations, so the L2 stays valid: row heads, candidate lists, targets and the ELL entries are L2 / L1 hits.
+//
+// Roles of a pair's NB + 1 blocks:
+//   row blocks 0 .. NB-1  serve the row blocks role, role + NB, ... of BOTH passes (an ELL entry is read back by the thread
+//                         that wrote it); partials land in the same per-row-block slots as in the two-kernel path.
+//   tail block NB         waits for the row blocks' arrivals, reduces the partials with the same code in the same order
+//                         as the two-kernel path (results are bit-identical to it) and runs the reference's host-side
+//                         scalar code: twist_finalize after pass 1, update_body after pass 2.  It has no rows, so what
+//                         the next iteration needs (stop word, K, ell, Rinv, Tinv) is PUBLISHED AS SOON AS IT IS KNOWN
+//                         and the list bookkeeping, skins and the write-back of the state run while the row blocks are
+//                         already in the next association.
+// Broadcasts (head, twist matrices) are data-tagged 8-byte granules: one hop, no flag, no store drain.  Pairs advance
+// independently; a pair whose list expires (or that finishes) leaves the launch.  Every wait is bounded: a timeout
+// marks the pair (ResidentSync::abort, want = 3) and the host falls back to the two-kernel graphs.
+//
+// Residency: all blocks of a launch must be co-resident (they wait for each other): the host keeps the launches of all
+// sub-batch streams together at or below 1.5 blocks of 256 threads per CU; __launch_bounds__(256, 2) guarantees 2 (the
+// whole register file for two blocks: rows, twist and update code share one allocation without spilling).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 7u;
+}
+
+// CVO_PHASE_TICKS=1: where an iteration of the resident kernel goes, in ticks of the 100 MHz s_memrealtime counter, summed
+// over the iterations of every pair's row block 0 (thread 0): [0] wait for the head, [1] pass-1 rows, [2] arrive A,
+// [3] wait for the twist, [4] pass-2 rows, [5] arrive B, [8] iterations counted; by the tail blocks: [9] wait for
+// arrivals A, [10] twist_finalize, [11] wait for arrivals B, [12] update until the head is published, [13] rest of the
+// update, [14] iterations.  Read by cvo_debug_resident_ticks.
+__device__ unsigned long long g_res_ticks[16];
+
+struct ResidentShared {
+  union {
+    AssocShared a;
+    CoeffShared c;
+    UpdateShared u;
+  };
+  unsigned view[64];  // granule values / state dwords as the block's first wave received them
+  int slot, go;
+  unsigned xcc;
+};
+
+struct ResidentHead {
+  int stop;  // 0 go on, 1 finished, 2 list expired, 3 overflow rows
+  IterView iv;
+};
+
+// The tail block's early publication of the next iteration's head (see update_body).
+struct ResidentPublish {
+  unsigned long long* head;
+  unsigned tag;
+  unsigned long long* t_pub;  // CVO_PHASE_TICKS: when the head left
+  __device__ __forceinline__ void put(int q, unsigned bits) const { head[q] = ((unsigned long long)tag << 32) | (unsigned long long)bits; }
+  __device__ __forceinline__ void operator()(int stop, int K, float ell, const float* Ri, const float* Ti) const {
+    put(RES_HEAD_STOP, (unsigned)stop);
+    put(RES_HEAD_K, (unsigned)K);
+    put(RES_HEAD_ELL, __float_as_uint(ell));
+#pragma unroll
+    for (int q = 0; q < 9; q++) put(RES_HEAD_RINV + q, __float_as_uint(Ri[q]));
+#pragma unroll
+    for (int q = 0; q < 3; q++) put(RES_HEAD_TINV + q, __float_as_uint(Ti[q]));
+    if (t_pub) *t_pub = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+  }
+};
+
+template <typename IdxT, int ASSOC_CAP, bool GENERAL>
+__global__ __launch_bounds__(ASSOC_THREADS, 2) void k_resident(const PairDesc* __restrict__ descs,
+                                                               const DevParams* __restrict__ Pp, PairState* states,
+                                                               const char* __restrict__ arena, ResidentTeams* teams,
+                                                               int U_NB_pairs, int nblk_split, unsigned stride256, int Npad) {
+  static_assert(ASSOC_THREADS == 256, "roles are blocks of four waves");
+  __shared__ ResidentShared S;
+  const int U = U_NB_pairs & 0xff, NB = (U_NB_pairs >> 8) & 0xfff, n_pairs = (int)((unsigned)U_NB_pairs >> 20);
+  const int nblk = nblk_split & 0x3fff;  // (bits 14..19: the launch's coefficient split, 1 here)
+  const int xoff = (nblk_split >> 20) & 7;  // pair q of this launch lives on XCD (q + xoff) % 8: sub-batches spread over the chip
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // ---- self-placement
+  if (tid == 0) {
+    const unsigned x = xcc_id();
+    S.xcc = x;
+    S.slot = (int)__hip_atomic_fetch_add(&teams->joined[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const int xcc = (int)S.xcc, slot = S.slot;
+  const int pair = (slot / (NB + 1)) * 8 + ((xcc - xoff) & 7), role = slot % (NB + 1);
+  const bool is_tail = role == NB;
+  if (pair < n_pairs) {
+    // (descriptor and parameters through the kernel's __restrict__ arguments, the parameters by value: a laundered or
+    // local pointer makes every field a may-alias of the ELL stores and puts scalar re-loads into the row loops)
+    const PairDesc* __restrict__ D = descs + pair;
+    const PairDesc* D0 = D;
+    const DevParams P = *Pp;
+    PairState* const st = states + pair;
+    ResidentSync* const sy = D0->rsync;
+    const char* wb = arena + (size_t)pair * ((size_t)stride256 << 8);
+    bool aborted = false;
+    const bool ticks = P.phase_ticks != 0 && tid == 0 && (role == 0 || is_tail);
+    auto now = [] { return (unsigned long long)__builtin_amdgcn_s_memrealtime(); };
+    auto tick = [&](int slot_, unsigned long long& t) {
+      if (ticks) {
+        const unsigned long long t1 = now();
+        atomicAdd(&g_res_ticks[slot_], t1 - t);
+        t = t1;
+      }
+    };
+    // Waits until the first `n` granules of `g` carry `tag`, then leaves their values in S.view (every thread calls it;
+    // false = the launch is aborted).  One 8-byte load per lane and poll; granules need no ordering among themselves.
+    auto wait_granules = [&](const unsigned long long* g, int n, unsigned tag) {
+      if (wave == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int ok = 1;
+        for (;;) {
+          const unsigned long long v = lane < n ? ld_x<true>(g + lane) : ((unsigned long long)tag << 32);
+          if (__ballot((unsigned)(v >> 32) != tag) == 0ull) {
+            if (lane < n) S.view[lane] = (unsigned)v;
+            break;
+          }
+          if (ld_x<true>(&sy->abort) != 0u) {
+            ok = 0;
+            break;
+          }
+          if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)RESIDENT_TIMEOUT_TICKS) {
+            if (lane == 0) __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = 0;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) S.go = ok;
+      }
+      __syncthreads();
+      const bool ok = S.go != 0;
+      return ok;
+    };
+    // row blocks: this block's partials are stored (only the first wave stores partials; every wave's ELL entries are read
+    // back by the thread that wrote them)
+    auto arrive = [&](unsigned* ctr) {
+      if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // (also: the reduction's LDS is free again)
+      if (tid == 0) (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nobody waits for the result
+    };
+    // tail block: all NB row blocks have arrived (the counter is reset for the next iteration)
+    auto wait_arrivals = [&](unsigned* ctr) {
+      if (tid == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int ok = 1;
+        while (ld_x<true>(ctr) != (unsigned)NB) {
+          if (ld_x<true>(&sy->abort) != 0u) {
+            ok = 0;
+            break;
+          }
+          if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)RESIDENT_TIMEOUT_TICKS) {
+            __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = 0;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (ok) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        S.go = ok;
+      }
+      __syncthreads();
+      const bool ok = S.go != 0;
+      __syncthreads();
+      return ok;
+    };
+    if (ld_x<true>(&sy->abort) != 0u) aborted = true;  // (sticky: an aborted pair is left to the two-kernel path)
+    // ---- the state as the previous launch left it: head of iteration k0
+    int k0 = 0;
+    ResidentHead h;
+    {
+      if (wave == 0) S.view[lane] = ld_x<true>(reinterpret_cast<const unsigned*>(st) + lane);
+      __syncthreads();
+      const unsigned* v = S.view;
+      auto ui = [&](int q) { return __builtin_amdgcn_readfirstlane((int)v[q]); };
+      auto uf = [&](int q) { return __int_as_float(__builtin_amdgcn_readfirstlane((int)v[q])); };
+      static_assert(offsetof(PairState, status) == 0 && offsetof(PairState, rebuild) == 4 && offsetof(PairState, n_ovf) == 8 &&
+                        offsetof(PairState, K) == 12 && offsetof(PairState, ell) == 16 && offsetof(PairState, k) == 24 &&
+                        offsetof(PairState, Rinv) == 32 && offsetof(PairState, Tinv) == 68,
+                    "head of PairState");
+      h.stop = ui(0) != 0 ? 1 : (ui(1) != 0 ? 2 : (ui(2) > 0 ? 3 : 0));
+      h.iv.K = ui(3);
+      h.iv.ell = uf(4);
+      k0 = ui(6);
+#pragma unroll
+      for (int q = 0; q < 9; q++) h.iv.pose.Ri[q] = uf(8 + q);
+#pragma unroll
+      for (int q = 0; q < 3; q++) h.iv.pose.Ti[q] = uf(17 + q);
+      __syncthreads();
+    }
+    for (int u = 0; u < U && !aborted; u++) {
+      unsigned long long tk = ticks ? now() : 0ull;
+      const unsigned tag_head = 2u * (unsigned)(k0 + u), tag_xi = tag_head + 1u;
+      if (u > 0) {  // the head the tail block published in the middle of its update
+        if (!wait_granules(sy->head, RES_HEAD_WORDS, tag_head)) {
+          aborted = true;
+          break;
+        }
+        const unsigned* v = S.view;
+        auto ui = [&](int q) { return __builtin_amdgcn_readfirstlane((int)v[q]); };
+        auto uf = [&](int q) { return __int_as_float(__builtin_amdgcn_readfirstlane((int)v[q])); };
+        h.stop = ui(RES_HEAD_STOP);
+        h.iv.K = ui(RES_HEAD_K);
+        h.iv.ell = uf(RES_HEAD_ELL);
+#pragma unroll
+        for (int q = 0; q < 9; q++) h.iv.pose.Ri[q] = uf(RES_HEAD_RINV + q);
+#pragma unroll
+        for (int q = 0; q < 3; q++) h.iv.pose.Ti[q] = uf(RES_HEAD_TINV + q);
+        __syncthreads();  // (S.view is reused)
+      }
+      if (!is_tail) tick(0, tk);
+      if (h.stop == 1) break;
+      if (h.stop != 0) {  // waits for a rebuild opportunity / the full graph: tell the host (as lean k_coeff does)
+        if (is_tail && tid == 0) {
+          // (the update of the previous iteration, if it ran in this launch, is this block's own: program order)
+          st->n_stalls += U - u;
+          if (h.stop == 3) {
+            st->want_full = 2;
+            *D->want_out = 2;
+          }
+        }
+        break;
+      }
+      if (!is_tail) {
+        // ---- pass 1: association + flow over this block's row blocks
+        for (int rb = role; rb < nblk; rb += NB) {
+          AssocRowHead head;
+          const int pos = rb * ASSOC_THREADS + tid;  // < Npad
+          head.ip = GENERAL ? reinterpret_cast<const int*>(wb + row_off_ip(Npad))[pos] : 0;
+          head.j1 = (int)reinterpret_cast<const IdxT*>(wb + row_off_cand_j(Npad))[pos];
+          head.x = reinterpret_cast<const float4*>(wb + row_off_xp4(Npad))[pos];
+          head.cnt = __float_as_int(head.x.w);
+          if (rb != role) __syncthreads();  // the reduction's LDS is reused
+          assoc_phase<IdxT, ASSOC_CAP, GENERAL, false, true>(P, D, h.iv, S.a, rb, head);
+        }
+        tick(1, tk);
+        arrive(&sy->arrive_a);
+        tick(2, tk);
+        // ---- the twist and its matrices, from the tail block
+        if (!wait_granules(sy->xi, (int)(sizeof(XiMats) / sizeof(float)), tag_xi)) {
+          aborted = true;
+          break;
+        }
+        XiMats Mu;
+        {
+          float* mu = reinterpret_cast<float*>(&Mu);
+#pragma unroll
+          for (int q = 0; q < (int)(sizeof(XiMats) / sizeof(float)); q++)
+            mu[q] = __int_as_float(__builtin_amdgcn_readfirstlane((int)S.view[q]));
+        }
+        __syncthreads();
+        tick(3, tk);
+        // ---- pass 2: coefficients
+        for (int rb = role; rb < nblk; rb += NB) {
+          const int pos = rb * ASSOC_THREADS + tid;
+          CoeffRowHead ch;
+          ch.nnz = pos < D->N ? reinterpret_cast<const unsigned*>(wb + row_off_nnz(Npad))[pos] : 0u;
+          ch.x = reinterpret_cast<const float4*>(wb + row_off_xp4(Npad))[pos];
+          ch.e_n = EllEntry{0.f, 0.f, 0.f, 0.f};
+          if (ch.nnz > 0u) ch.e_n = D->ell[pos];
+          if (rb != role) __syncthreads();
+          coeff_rows<false>(P, D, h.iv.ell, S.c, Mu, ch, rb, 0, 1);
+        }
+        tick(4, tk);
+        arrive(&sy->arrive_b);
+        tick(5, tk);
+        if (ticks) atomicAdd(&g_res_ticks[8], 1ull);
+      } else {
+        // ---- tail block: twist after pass 1 ...
+        if (!wait_arrivals(&sy->arrive_a)) {
+          aborted = true;
+          break;
+        }
+        tick(9, tk);
+        float twist[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // (only thread 0 of the update reads it)
+        if (wave == 0) twist_finalize<true>(D, nblk, sy->xi, tag_xi, twist);  // partials: sc1 loads, served by this XCD's L2
+        tick(10, tk);
+        // ... the scalar state in flight while pass 2 runs (the previous update's write-back is this block's own)
+        unsigned hot_regs[2] = {0u, 0u};
+        if (tid < 64) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          hot_regs[0] = ld_x<true>(reinterpret_cast<const unsigned*>(st) + tid);
+          if (tid + 64 < HOT_DWORDS) hot_regs[1] = ld_x<true>(reinterpret_cast<const unsigned*>(st) + tid + 64);
+        }
+        // ... then the update after pass 2
+        if (!wait_arrivals(&sy->arrive_b)) {
+          aborted = true;
+          break;
+        }
+        tick(11, tk);
+        const UpdDesc upd = load_upd_desc(D);
+        const int flags = ((u == U - 1) ? 2 : 0) | (U << 8) | 1;
+        __shared__ unsigned long long s_tpub;
+        if (tid == 0) s_tpub = 0ull;
+        ResidentPublish pub{sy->head, tag_head + 2u, ticks ? &s_tpub : nullptr};
+        update_body<false, true, true, ResidentPublish>(upd, P, flags, nblk, S.u, twist, hot_regs, 0ull, pub);
+        if (tid == 0) st->res_iters += 1u;
+        if (ticks) {
+          const unsigned long long t1 = now();
+          const unsigned long long tp = s_tpub ? s_tpub : t1;
+          atomicAdd(&g_res_ticks[12], tp - tk);
+          atomicAdd(&g_res_ticks[13], t1 - tp);
+          atomicAdd(&g_res_ticks[14], 1ull);
+        }
+        __syncthreads();
+      }
+    }
+    if (aborted && is_tail && tid == 0) {  // tell the host: this pair must be served by the two-kernel graphs
+      st->want_full = 3;
+      *D0->want_out = 3;
+    }
+  }
+  // ---- leave: the last block of the launch resets the placement counters for the next launch of this stream
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned l = __hip_atomic_fetch_add(&teams->left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (l == gridDim.x - 1) {
+#pragma unroll
+      for (int x = 0; x < 8; x++) __hip_atomic_store(&teams->joined[x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&teams->left, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
