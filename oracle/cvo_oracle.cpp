@@ -375,6 +375,7 @@ inline unsigned se_row_grid(const OracleParams& P, const CloudView& X, int i, co
 struct PersistentGrid {
   TargetGrid G;
   double cell = 0;
+  double ymax = 0;  // largest |coordinate| of the initial targets (sizes the rounding allowance of the frame change)
   bool valid = false;
 };
 void se_kernel_impl(const OracleParams& P, const CloudView& X, const CloudView& Y, int K, float ell,
@@ -394,11 +395,13 @@ void se_kernel_impl(const OracleParams& P, const CloudView& X, const CloudView& 
       if (!pg->valid || rad > pg->cell || rad < 0.4 * pg->cell) {
         pg->valid = build_grid(*Y0, rad, pg->G);
         pg->cell = rad;
+        pg->ymax = 0;
+        for (int j = 0; j < m; j++)
+          for (int c = 0; c < 3; c++) pg->ymax = std::max(pg->ymax, (double)std::fabs(Y0->p(j)[c]));
       }
       if (pg->valid) {
         G = &pg->G;
-        for (int j = 0; j < m; j++)
-          for (int c = 0; c < 3; c++) ymax = std::max(ymax, (double)std::fabs(Y0->p(j)[c]));
+        ymax = pg->ymax;
         slack = 1e-5 * (ymax + 1.0) + 1e-5;  // float transform of the targets + the float (R, T) <-> (R^T, -R^T T) pair
       }
     } else if (rad > 0 && build_grid(Y, rad, local)) {

@@ -24,7 +24,7 @@ def run_single(name, builder, kw, max_it=0):
     for mode in ("two-kernel", "resident"):
         gpu = CvoGPU(params=P)
         if mode == "resident":
-            gpu.set_option("RESIDENT", "1")
+            gpu.set_option(os.environ.get("PROBE_ALT", "RESIDENT"), "1")
         for k, v in opts.items():
             gpu.set_option(k, v)
         da, db = gpu.upload(a), gpu.upload(b)

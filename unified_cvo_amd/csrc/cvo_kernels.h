@@ -27,6 +27,15 @@
 #pragma once
 #include "cvo_device.h"
 
+// These kernels are written for gfx950 only: v_permlane16_swap / v_permlane32_swap (xor16_sum, xor32_sum), the
+// XCC_ID hardware register, kernel-argument preloading, and - in k_assoc / k_coeff - waves that RETURN while the first
+// wave of their block goes on to further __syncthreads(): on gfx9 an s_barrier counts only the waves of the workgroup
+// that are still alive (a terminated wave is taken out of the barrier's count), which is outside what the HIP
+// programming model promises.  The device pass refuses any other target instead of miscompiling quietly.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "unified_cvo_amd kernels target gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 // min. waves per SIMD the register allocator is asked to leave room for (__launch_bounds__ second argument)
 #ifndef CVO_COEFF_WAVES
 #define CVO_COEFF_WAVES 1
