@@ -483,7 +483,10 @@ struct FlowOut {
 FlowOut compute_flow_impl(const OracleParams& P, const CloudView& X, const CloudView& Y, int K,
                           const float* mat, const int* ind) {
   const int n = X.n;
-  std::vector<double> om(3 * (size_t)n), vv(3 * (size_t)n);
+  static thread_local std::vector<double> flow_buf;  // (reused across iterations; workers get raw pointers)
+  flow_buf.resize(6 * (size_t)n);
+  double* const om = flow_buf.data();
+  double* const vv = om + 3 * (size_t)n;
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < n; i++) {
     const float* px = X.p(i);
@@ -581,10 +584,24 @@ Coefs poly_coeff_impl(const OracleParams& P, const CloudView& X, const CloudView
                       const float* mat, const int* ind, const float omega[3], const float v[3]) {
   const int n = X.n, m = Y.n;
   XiMats M = xi_mats(omega, v);
-  std::vector<XiZ> xz(m);
+  // compute_step_size_xi runs over ALL targets upstream (CvoGPU.cu:953-998); the "best-effort CPU" variant evaluates it
+  // per nonzero instead (the same function of the same inputs: identical values, O(nnz) instead of O(M))
+  const bool per_entry = g_use_grid != 0;
+  // (buffers of the calling thread, reused across iterations; the OpenMP workers get raw pointers: a thread_local
+  // named inside a parallel region would be the WORKER's own, empty, instance)
+  static thread_local std::vector<XiZ> xz_buf;
+  static thread_local std::vector<double> coef_buf;
+  if (!per_entry) xz_buf.resize(m);
+  coef_buf.resize(4 * (size_t)n);
+  XiZ* const xz = xz_buf.data();
+  double* const Bv = coef_buf.data();
+  double* const Cv = Bv + n;
+  double* const Dv = Cv + n;
+  double* const Ev = Dv + n;
+  if (!per_entry) {
 #pragma omp parallel for schedule(static)
-  for (int j = 0; j < m; j++) xz[j] = xi_point(M, omega, v, Y.p(j));
-  std::vector<double> Bv(n), Cv(n), Dv(n), Ev(n);
+    for (int j = 0; j < m; j++) xz[j] = xi_point(M, omega, v, Y.p(j));
+  }
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < n; i++) {
     double Bi = 0, Ci = 0, Di = 0, Ei = 0;
@@ -598,7 +615,8 @@ Coefs poly_coeff_impl(const OracleParams& P, const CloudView& X, const CloudView
       float temp_coef = (float)(1 / (2.0 * temp_ell * temp_ell));
       const float* py = Y.p(idx);
       float dfx = px[0] - py[0], dfy = px[1] - py[1], dfz = px[2] - py[2];
-      const XiZ& z = xz[idx];
+      const XiZ zloc = per_entry ? xi_point(M, omega, v, py) : XiZ{};
+      const XiZ& z = per_entry ? zloc : xz[idx];
       float beta_ij = (float)(-2.0 * temp_coef * (double)dot3_dev(z.xiz.x, z.xiz.y, z.xiz.z, dfx, dfy, dfz));
       float gamma_ij =
           (-temp_coef) * (z.normxiz2 + dot3_dev(2.0f * z.xi2z.x, 2.0f * z.xi2z.y, 2.0f * z.xi2z.z, dfx, dfy, dfz));
