@@ -96,22 +96,6 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # The step ends with an RCCL all-gather of the poses whatever the world size is: a plain `python bench.py --gpus 1`
-    # forms a one-rank process group too, so that the timed region contains what `config.parallelism` says it does.
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if "MASTER_PORT" not in os.environ:
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-    use_dist = True
-    try:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    except Exception as e:  # noqa: BLE001
-        if world > 1:
-            raise
-        use_dist = False
-        log(f"[bench] one-rank RCCL process group failed to initialise ({e}): the step runs without the all-gather")
     # host threads this rank may use (uploads, CPU baseline): the box's usable CPUs are shared by the local ranks
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     n_threads = max(1, available_cpus() // local_world)
@@ -131,6 +115,24 @@ def main():
     src, tgt = both[:len(host_clouds)], both[len(host_clouds):]
     t_h2d = time.time() - t_up
     inits = [q[3] for q in pairs]
+    # (after the first upload: RCCL's start-up threads otherwise compete with the upload pool for the host cores and
+    # the one-off `uploaded in` figure doubles)
+    # The step ends with an RCCL all-gather of the poses whatever the world size is: a plain `python bench.py --gpus 1`
+    # forms a one-rank process group too, so that the timed region contains what `config.parallelism` says it does.
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    use_dist = True
+    try:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    except Exception as e:  # noqa: BLE001
+        if world > 1:
+            raise
+        use_dist = False
+        log(f"[bench] one-rank RCCL process group failed to initialise ({e}): the step runs without the all-gather")
     pose_buf = torch.zeros(hi - lo, 16, dtype=torch.float32, device=dev)
     kw = dict(max_iterations=args.max_iterations) if args.max_iterations > 0 else {}
 
