@@ -153,3 +153,15 @@ def test_config5_per_gpu_shape_64_pairs_of_10k(oracle):
     o = oracle.align(op, _ocloud(oracle, cs[0][1]), _ocloud(oracle, cs[0][2]), inits[0])
     assert full.iterations == o["iterations"] == 2000 and full.ret == o["ret"] == 0
     assert cases.max_abs_diff(full.transform, o["transform"]) <= TOL_POSE_CLAMPED
+
+
+def test_single_iteration_and_prefix_at_40k(oracle):
+    """Beyond BASELINE's sizes (the north_star quotes N ~ 5k-20k; 40k x 40k = 157 row blocks, a 200 MB candidate
+    bitmap): one association pass bit-exact against the oracle's literal scan, then a 40-iteration prefix."""
+    from test_gpu_parity import _single_iteration, _prefix
+    P, src, tgt, init = cases.config2(n=40000)
+    _single_iteration(oracle, P, src, tgt, init)
+    g, o = _prefix(oracle, P, src, tgt, init, 40)
+    for a, b in zip(g.trace, o["trace"]):
+        _cmp_trace(a, b)
+    assert cases.max_abs_diff(g.transform, o["transform"]) <= 1e-6
