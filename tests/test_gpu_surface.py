@@ -362,3 +362,101 @@ def test_override_state_is_validated():
         with pytest.raises(CvoError):
             gpu.align(src, tgt, init, max_iterations=2, **bad)
     assert gpu.align(src, tgt, init, max_iterations=2, K0=16, ell0=0.3).iterations == 2
+
+
+# ---- the hoisted arithmetic of the row loops (round 4): bit-for-bit against the plain forms, on the device ----
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def _hoisted_pairs(gpu, op, operands, per_item):
+    """operands: (n, per_item) doubles; returns (plain, hoisted) as flat arrays in operand order."""
+    out = gpu.debug_scalar_math(op, operands)
+    return out[:, 0:16:2].reshape(-1), out[:, 1:16:2].reshape(-1)
+
+
+@pytest.mark.gpu
+def test_hoisted_division_is_the_ieee_division_bit_for_bit():
+    """exp(-d2 / (2.0 l l)) (CvoGPU.cu:552): the per-pair IEEE double division with its row-only part hoisted
+    (rcp_refined once per row, div_by per candidate: 3 instructions instead of 12).  10^7 random operand pairs from the
+    real ranges - d2 in [0, d2_thres], l in [ell_min, 1.2 ell_0] x the range factor - are divided both ways ON THE
+    DEVICE and compared bit for bit; numpy's (correctly rounded) division is the third opinion."""
+    gpu = CvoGPU()
+    rs = np.random.default_rng(41)
+    n_items = 1_250_000                                           # x 8 operand pairs = 10^7
+    l = rs.uniform(0.02, 1.2 * 0.95 * 1.3, (n_items, 8)).astype(np.float32)      # lengthscales incl. range_ell
+    den = 2.0 * l.astype(np.float64) * l.astype(np.float64)                       # (2.0 * l) * l, exact in double
+    thr = (-2.0 * l.astype(np.float64) ** 2 * np.log(1e-3 / 0.01)).astype(np.float32)
+    d2 = (rs.uniform(0, 1, (n_items, 8)) ** 2 * thr).astype(np.float32)           # squared distances below the cut-off
+    num = -d2.astype(np.float64)
+    ops = np.empty((n_items, 16))
+    ops[:, 0::2] = num
+    ops[:, 1::2] = den
+    plain, hoisted = _hoisted_pairs(gpu, 8, ops, 8)
+    nz = num.reshape(-1) != 0                                     # (-0 / d = -0 plain, +0 hoisted: exp() maps both to 1)
+    assert np.array_equal(_bits(plain)[nz], _bits(hoisted)[nz])
+    assert np.all(hoisted[~nz] == 0.0)
+    assert np.array_equal(_bits(plain), _bits(num.reshape(-1) / den.reshape(-1)))  # the device division IS correctly rounded
+    # edges of the float-derived operand space: tiniest / largest float numerators, extreme lengthscales
+    edge_n = -np.array([1.4e-45, 1.1754944e-38, 1e-30, 1e-10, 1.0, 3.0e3, 1e20, 3.4e38], np.float32).astype(np.float64)
+    for dd in (2.0 * 1e-8 ** 2, 2.0 * 1e-3 ** 2, 0.0098, 2.0, 2.0 * 5e3 ** 2, 2.0 * np.float64(np.float32(1e15)) ** 2):
+        ops = np.zeros((1, 16))
+        ops[0, 0::2] = edge_n
+        ops[0, 1::2] = dd
+        plain, hoisted = _hoisted_pairs(gpu, 8, ops, 8)
+        assert np.array_equal(_bits(plain), _bits(hoisted)), dd
+        assert np.array_equal(_bits(plain), _bits(edge_n / dd)), dd
+
+
+@pytest.mark.gpu
+def test_hoisted_division_by_six_is_the_ieee_division_bit_for_bit():
+    """beta^3 / 6.0 (CvoGPU.cu:1072): float cubes promoted to double, divided by the literal 6.0 - with the reciprocal
+    folded (Markstein correction) vs the 12-instruction IEEE sequence, 10^7 operands over 60 decades plus edges."""
+    gpu = CvoGPU()
+    rs = np.random.default_rng(43)
+    n_items = 1_250_000
+    beta = (rs.normal(size=(n_items, 8)) * 10.0 ** rs.uniform(-30, 12, (n_items, 8))).astype(np.float32)
+    with np.errstate(over="ignore", under="ignore"):
+        cube = (beta * beta * beta).astype(np.float64)            # float products, as the kernel forms them
+    cube = np.where(np.isfinite(cube), cube, 1.0)
+    ops = np.zeros((n_items, 16))
+    ops[:, :8] = cube
+    plain, hoisted = _hoisted_pairs(gpu, 9, ops, 8)
+    nz = cube.reshape(-1) != 0
+    assert np.array_equal(_bits(plain)[nz], _bits(hoisted)[nz])
+    assert np.all(hoisted[~nz] == 0.0)
+    assert np.array_equal(_bits(plain), _bits(cube.reshape(-1) / 6.0))
+    edge = np.zeros((1, 16))
+    edge[0, :8] = np.array([1.4e-45, -1.4e-45, 1.1754944e-38, 3.4028235e38, -3.4028235e38, 6.0, 1.0, -2.5e-20], np.float32)
+    plain, hoisted = _hoisted_pairs(gpu, 9, edge, 8)
+    assert np.array_equal(_bits(plain), _bits(hoisted))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", [10, 11])
+def test_restated_exp_is_the_device_library_exp_bit_for_bit(op):
+    """exp_ocml (the device library's double exp restated with three-operand FMAs and SGPR-resident constants;
+    op 11: the variant for non-positive arguments, without the overflow clamp) against exp() itself on the device, bit
+    for bit: 10^7 arguments where the kernels evaluate it (log(sp_thres / sigma^2) .. 0) plus the whole double range."""
+    gpu = CvoGPU()
+    rs = np.random.default_rng(47 + op)
+    n_items = 1_250_000
+    x = -rs.uniform(0, 1, (n_items, 8)) ** 2 * 12.0               # the kernels' range, dense near 0
+    x[: n_items // 8] = -10.0 ** rs.uniform(-300, 3.1, (n_items // 8, 8))          # every magnitude down to underflow
+    if op == 10:
+        x[n_items // 8: n_items // 4] = rs.uniform(-760, 720, (n_items // 4 - n_items // 8, 8))   # incl. overflow / gradual underflow
+    ops = np.zeros((n_items, 16))
+    ops[:, :8] = x
+    plain, hoisted = _hoisted_pairs(gpu, op, ops, 8)
+    assert np.array_equal(_bits(plain), _bits(hoisted))
+    edge = np.zeros((1, 16))
+    edge[0, :8] = [0.0, -0.0, -745.2, -708.4, -1074.9, -1075.1, -np.inf, -1e308] if op == 11 else \
+        [0.0, 709.7, 709.9, 1023.9, 1024.1, np.inf, -np.inf, np.nan]
+    e_plain, e_hoisted = _hoisted_pairs(gpu, op, edge, 8)
+    assert np.array_equal(_bits(e_plain), _bits(e_hoisted))
+    # and the library function itself stays within 1 ulp of glibc's (numpy), the difference DESIGN.md section 4 allows
+    xs = ops[:, :8].reshape(-1)
+    sel = (xs > -700) & (xs < 700)
+    ref = np.exp(xs[sel])
+    assert np.max(np.abs(plain[sel] - ref) / np.spacing(ref)) <= 1.0

@@ -560,8 +560,10 @@ class CvoGPU:
         return b.value, it.value, ce.value
 
     def debug_scalar_math(self, op, items):
-        """Runs one of the device's scalar routines (k_scalar_math ops 0-6) on `items` (n x <=16 doubles); returns
-        n x 16 doubles.  op 7 (indicator windows): items = [window, threshold, x_0, ...], returns the n decisions."""
+        """Runs one of the device's scalar routines (k_scalar_math ops 0-6, 8-11) on `items` (n x <=16 doubles); returns
+        n x 16 doubles.  op 7 (indicator windows): items = [window, threshold, x_0, ...], returns the n decisions.
+        ops 8-11 (hoisted division / exp against the plain forms): eight operands per item, out[:, 2l] plain,
+        out[:, 2l+1] hoisted."""
         dp = C.POINTER(C.c_double)
         if op == 7:
             a = np.ascontiguousarray(items, np.float64).reshape(-1)

@@ -307,6 +307,76 @@ __device__ __forceinline__ float compute_range_ell(float ell, float dist) {
   return (float)(((double)dist / 500.0 + 1.0) * (double)ell);
 }
 
+// ---- double-precision division and exp() of the row loops, restated so that their loop-invariant parts can be hoisted ----
+//
+// The reference evaluates `exp(-d2 / (2.0 * l * l))` per pair (CvoGPU.cu:552: double division, double exp) and
+// `beta^3 / 6.0` per nonzero (CvoGPU.cu:1072).  hipcc expands an IEEE double division into 12 VALU instructions -
+// v_div_scale x2, v_rcp_f64, two Newton steps (4 FMAs), q = n r, e = fma(-d, q, n), v_div_fmas (= fma(e, r, q)),
+// v_div_fixup - of which the first nine depend on the DENOMINATOR only whenever v_div_scale leaves its operands
+// alone, i.e. away from zero / denormal / huge operands and quotients.  rcp_refined() is that denominator part,
+// instruction for instruction; div_by() is the numerator part.  Together they return what `n / d` returns, bit for bit,
+// for every pair of operands the scaling and fix-up instructions would pass through unchanged - which the row
+// constants (l in [ell_min, 1.2 ell_0] (1 + range / 500), den = 2 l^2) and the numerators (squared distances below the
+// cut-off, float cubes) are.  cvo_debug_scalar_math ops 8 / 9 compare the two forms bit for bit on caller-supplied
+// operands (tests/test_gpu_surface.py: 10^7 random operands from the real ranges, plus the edges); a numerator of +-0
+// gives +0 here and -0 there, which exp() maps to the same 1.0 and the coefficient sums absorb (x + (+-0) = x).
+// Theory for the constant case: with r = RN(1/d), q = RN(n r) is within one ulp of n / d and RN(q + r * RN(n - d q)) is
+// the correctly rounded quotient (Markstein's theorem; Muller et al., Handbook of Floating-Point Arithmetic, 4.7).
+__device__ __forceinline__ double rcp_refined(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+__device__ __forceinline__ double div_by(double n, double d, double r) {
+  const double q = n * r;
+  const double e = __builtin_fma(-d, q, n);
+  return __builtin_fma(e, r, q);
+}
+
+// exp(double) of the ROCm device library (ocml expD_base, what `exp()` compiled to inside the row loops), restated
+// operation for operation with the library's constants so that the kernel value stays bit-identical to the `exp()`
+// the previous rounds shipped (and the oracle's glibc exp within the 1 ulp DESIGN.md section 4 states):
+//   n = rint(x log2 e);  r = fma(-ln2_lo, n, fma(-ln2_hi, n, x));  p = degree-11 Horner in r, closed by two fma(r, p, 1);
+//   z = ldexp(p, n);  x > 1024 -> inf, x < -1075 -> 0.
+// The Horner steps come out as three-operand v_fma_f64 (addends in SGPR pairs, ExpConsts): the compiler's own choice was the
+// two-address v_fmac_f64 with a v_mov_b64 of the constant in front of every step (9 extra instructions per call) and
+// 18 VGPRs of constants.  NONPOS: the caller guarantees x <= 0 (or NaN), which makes the overflow clamp dead.
+// cvo_debug_scalar_math op 10 compares both variants with exp() bit for bit.
+// The nine Horner addends, pinned to SGPR pairs ONCE, in front of the row loop (make_exp_consts): a step `fma(r, p, c)`
+// whose addend lives in scalar registers can only be the three-operand v_fma_f64 (the two-address v_fmac_f64 wants its
+// addend in the destination VGPR), and nothing of the pinning is left inside the loop.
+struct ExpConsts {
+  double c[9];
+  double c11, c10;  // the first step, fma(r, c11, c10): one of its two constants in a VGPR pair (one SGPR operand per VOP3)
+};
+__device__ __forceinline__ ExpConsts make_exp_consts() {
+  ExpConsts k = {{0x1.71dee623fde64p-19, 0x1.a01997c89e6b0p-16, 0x1.a01a014761f6ep-13, 0x1.6c16c1852b7b0p-10,
+                  0x1.1111111122322p-7, 0x1.55555555502a1p-5, 0x1.5555555555511p-3, 0x1.000000000000bp-1, 1.0},
+                 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22};
+#pragma unroll
+  for (int q = 0; q < 8; q++) asm("" : "+s"(k.c[q]));  // (1.0 is an inline constant)
+  asm("" : "+v"(k.c11));
+  asm("" : "+s"(k.c10));
+  return k;
+}
+template <bool NONPOS>
+__device__ __forceinline__ double exp_ocml(double x, const ExpConsts& k) {
+  const double n = __builtin_rint(x * 0x1.71547652b82fep+0);
+  double r = __builtin_fma(-0x1.62e42fefa39efp-1, n, x);
+  r = __builtin_fma(-0x1.abc9e3b39803fp-56, n, r);
+  double p = __builtin_fma(r, k.c11, k.c10);
+#pragma unroll
+  for (int q = 0; q < 9; q++) p = __builtin_fma(r, p, k.c[q]);
+  p = __builtin_fma(r, p, 1.0);
+  double z = __builtin_ldexp(p, (int)n);
+  if (!NONPOS) z = x > 1024.0 ? __builtin_inf() : z;
+  z = x < -1075.0 ? 0.0 : z;
+  return z;
+}
+
 // The matrices of compute_step_size_xi (CvoGPU.cu:953-998), which depend only on (omega, v).
 struct XiMats {
   M3 m2, m3, m4;

@@ -790,7 +790,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.nbc = S->d.nblk_coeff;
   S->geom.npb = S->d.Mpad / PREP_THREADS + (S->d.NGpad * ROWS_PER_GROUP + PREP_THREADS - 1) / PREP_THREADS;
   S->geom.idx16 = M < 65536;
-  S->geom.general = dp.use_col || dp.use_sem || dp.use_geotype;
+  // (the non-isotropic kernel of mode 2 lives in the GENERAL instantiations only: single evaluations, never the loop)
+  S->geom.general = dp.use_col || dp.use_sem || dp.use_geotype || dp.mode == 2;
   S->geom.instr = dp.kernel_clock || dp.phase_ticks;
   S->geom.verify = dp.verify_lists != 0;
   // XCD-resident lean iterations (k_resident): calls with FEW pairs in flight (an iteration is a chain of latencies
@@ -1935,7 +1936,7 @@ int cvo_align_association(cvo_ctx* ctx, int pair, int* row_ptr, int* col, float*
 }
 
 int cvo_debug_scalar_math(cvo_ctx* ctx, int op, int n, const double* in, double* out) {
-  if (!ctx || !in || !out || n <= 0 || op < 0 || op > 7) return fail(ctx, CVO_E_INVALID, "cvo_debug_scalar_math: bad argument");
+  if (!ctx || !in || !out || n <= 0 || op < 0 || op > 11) return fail(ctx, CVO_E_INVALID, "cvo_debug_scalar_math: bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t n_in = op == 7 ? (size_t)n + 2 : 16 * (size_t)n, n_out = op == 7 ? (size_t)n : 16 * (size_t)n;
   double *d_in = nullptr, *d_out = nullptr;
@@ -2010,7 +2011,7 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
   const int n_pairs = ctx->last_pairs, G = ctx->last_groups;
   const bool idx16 = ctx->last_M < 65536;
   const DevParams& dp = ctx->last_params;
-  const bool general = dp.use_col || dp.use_sem || dp.use_geotype;
+  const bool general = dp.use_col || dp.use_sem || dp.use_geotype || dp.mode == 2;
   const bool instr = dp.kernel_clock || dp.phase_ticks;
   const int nba = (ctx->last_N + ASSOC_THREADS - 1) / ASSOC_THREADS;
   float out[2] = {0.f, 0.f};

@@ -397,6 +397,9 @@ __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs
 // ------------------------------------------------------------------------------------------
 struct RowData {
   float x, y, z, l, d2_thres;
+  // denominator of the geometric kernel's exponent, 2.0 * l * l (CvoGPU.cu:552), and its refined reciprocal: the part of
+  // the per-pair IEEE division that depends on the row only (rcp_refined / div_by, cvo_device.h)
+  double den, rcp;
 };
 // per-row constants of fill_in_A_mat_gpu (CvoGPU.cu:504-510)
 __device__ __forceinline__ RowData make_row(const DevParams& P, const float4 x, float ell) {
@@ -405,7 +408,23 @@ __device__ __forceinline__ RowData make_row(const DevParams& P, const float4 x, 
   float thr = 1.f;
   if (P.use_geo) thr = (float)(-2.0 * l * l * (double)P.log_geo);
   if (P.mode == 2) thr = P.d2_cull;  // non-isotropic kernel: no cut-off of its own, this one only steers the scan
-  return RowData{x.x, x.y, x.z, l, thr};
+  const double den = 2.0 * l * l;
+  return RowData{x.x, x.y, x.z, l, thr, den, rcp_refined(den)};
+}
+// The colour and semantic kernels' exponent denominators (2.0 * c_ell^2, 2.0 * s_ell^2: the same for every pair of a
+// call) with their refined reciprocals; evaluated once per thread, outside the row loops.
+struct FeatDen {
+  double c_den, c_rcp, s_den, s_rcp;
+  ExpConsts ek;  // (rides along: every evaluation of a pair needs it)
+};
+__device__ __forceinline__ FeatDen make_feat_den(const DevParams& P) {
+  FeatDen f;
+  f.c_den = 2.0 * P.c2;
+  f.c_rcp = rcp_refined(f.c_den);
+  f.s_den = P.mode == 2 ? 2.0 * P.s_ell_sq : 2.0 * P.s_ell * P.s_ell;
+  f.s_rcp = rcp_refined(f.s_den);
+  f.ek = make_exp_consts();
+  return f;
 }
 struct Pose {  // the transform applied to the target cloud this iteration (update_tf, CvoGPU.cu:94-112)
   float Ri[9], Ti[3];
@@ -440,8 +459,8 @@ __device__ __forceinline__ IterView load_iter_view(const PairState* st) {
 // i = the row's sorted position, j = the target's sorted position.
 // The pair arithmetic for an already transformed target yt (everything of CvoGPU.cu:528-573 but the transform).
 template <bool GENERAL>
-__device__ __forceinline__ bool eval_pair_yt(const DevParams& P, const PairDesc* __restrict__ D, int i, const RowData& r, int j,
-                                             const float4 yt, float& a_out) {
+__device__ __forceinline__ bool eval_pair_yt(const DevParams& P, const PairDesc* __restrict__ D, const FeatDen& F, int i,
+                                             const RowData& r, int j, const float4 yt, float& a_out) {
   float sk = 1, ck = 1, k = 1, geo_sim = 1;
   if (GENERAL && P.use_geotype) {  // compute_geometric_type_ip, CvoGPU.cu:203-215
     const float2 ga = D->xgeo[i], gb = D->ygeo[j];
@@ -451,19 +470,19 @@ __device__ __forceinline__ bool eval_pair_yt(const DevParams& P, const PairDesc*
     geo_sim = dab * dab / (n2a * n2b);
     if ((double)geo_sim < 0.01) return false;
   }
-  if (P.use_geo && P.mode == 2) {
+  if (GENERAL && P.use_geo && P.mode == 2) {  // (the host launches the GENERAL instantiations for mode 2)
     // mahananobis_distance (CvoGPU.cu:152-171): dist = a - b, (dist^T * kernel_inv) * dist; no cut-off (236-238, 279-284)
     const float d0 = r.x - yt.x, d1 = r.y - yt.y, d2v = r.z - yt.z;
     const float r0 = dot3_dev(d0, d1, d2v, P.kinv[0], P.kinv[3], P.kinv[6]);
     const float r1 = dot3_dev(d0, d1, d2v, P.kinv[1], P.kinv[4], P.kinv[7]);
     const float r2 = dot3_dev(d0, d1, d2v, P.kinv[2], P.kinv[5], P.kinv[8]);
     const float d2 = dot3_dev(r0, r1, r2, d0, d1, d2v);
-    k = (float)((double)P.sigma2 * exp((double)(-d2) / 2.0));
+    k = (float)((double)P.sigma2 * exp_ocml<false>((double)(-d2) / 2.0, F.ek));  // (an indefinite kernel can make -d2 positive)
   } else if (P.use_geo) {
     const float dx = yt.x - r.x, dy = yt.y - r.y, dz = yt.z - r.z;
     const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-    if (d2 < r.d2_thres)
-      k = (float)((double)P.sigma2 * exp((double)(-d2) / (2.0 * r.l * r.l)));
+    if (d2 < r.d2_thres)  // exp(-d2 / (2.0 * l * l)), CvoGPU.cu:552; d2 >= 0, so the exponent is <= 0
+      k = (float)((double)P.sigma2 * exp_ocml<true>(div_by((double)(-d2), r.den, r.rcp), F.ek));
     else
       return false;
   }
@@ -476,8 +495,8 @@ __device__ __forceinline__ bool eval_pair_yt(const DevParams& P, const PairDesc*
     tmp = a0.z - b0.z; res = __builtin_fmaf(tmp, tmp, res);
     tmp = a0.w - b0.w; res = __builtin_fmaf(tmp, tmp, res);
     tmp = a1.x - b1.x; res = __builtin_fmaf(tmp, tmp, res);
-    if (res < P.d2_c_thres)
-      ck = (float)((double)P.c_sigma2 * exp((double)(-res) / (2.0 * P.c2)));
+    if (res < P.d2_c_thres)  // (res is a sum of squares: exponent <= 0)
+      ck = (float)((double)P.c_sigma2 * exp_ocml<true>(div_by((double)(-res), F.c_den, F.c_rcp), F.ek));
     else
       return false;
   }
@@ -494,9 +513,8 @@ __device__ __forceinline__ bool eval_pair_yt(const DevParams& P, const PairDesc*
         tmp = a.w - b.w; res = __builtin_fmaf(tmp, tmp, res);
       }
     }
-    if (res < P.d2_s_thres)
-      sk = P.mode == 2 ? (float)((double)(P.s_sigma * P.s_sigma) * exp((double)(-res) / (2.0 * P.s_ell_sq)))
-                       : (float)((double)(P.s_sigma * P.s_sigma) * exp((double)(-res) / (2.0 * P.s_ell * P.s_ell)));
+    if (res < P.d2_s_thres)  // (F.s_den: 2.0 * s_ell^2 kept in float for mode 2, 2.0 * s_ell * s_ell otherwise)
+      sk = (float)((double)(P.s_sigma * P.s_sigma) * exp_ocml<true>(div_by((double)(-res), F.s_den, F.s_rcp), F.ek));
     else
       return false;
   }
@@ -507,12 +525,12 @@ __device__ __forceinline__ bool eval_pair_yt(const DevParams& P, const PairDesc*
 // pair arithmetic.  (The gates of a pair - geometric type, distance, colour, semantics - only ever reject: the order in
 // which they are tested does not reach a result.)
 template <bool GENERAL>
-__device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __restrict__ D, const Pose& pose, int i,
-                                          const RowData& r, int j, const float4 y0, float& a_out, float4& yt_out) {
+__device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __restrict__ D, const FeatDen& F, const Pose& pose,
+                                          int i, const RowData& r, int j, const float4 y0, float& a_out, float4& yt_out) {
   const V3 ytv = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
   const float4 yt = make_float4(ytv.x, ytv.y, ytv.z, 0.f);
   yt_out = yt;
-  return eval_pair_yt<GENERAL>(P, D, i, r, j, yt, a_out);
+  return eval_pair_yt<GENERAL>(P, D, F, i, r, j, yt, a_out);
 }
 // ------------------------------------------------------------------------------------------
 // k_assoc: ordered association + flow, one thread per (sorted) source row.
@@ -533,18 +551,20 @@ struct RowAcc {
   float o0 = 0, o1 = 0, o2 = 0, v0 = 0, v1 = 0, v2 = 0;
   double asum = 0;
   unsigned nnz = 0;
+  EllEntry* slot = nullptr;  // where the row's next nonzero goes: D->ell + nnz * N + pos, advanced by N per nonzero
 };
 
 // One pair (i, j) that passed the geometric cut-off, with its transformed target: the rest of CvoGPU.cu:528-589 (kernel
 // values, a > sp_thres, ELL store) + the flow terms of 758-782.
 template <bool GENERAL>
-__device__ __forceinline__ void visit_pair_yt(const DevParams& P, const PairDesc* __restrict__ D, int i, int pos, int N,
-                                              const RowData& r, const V3& pxe, int j, const float4 yt, RowAcc& A) {
+__device__ __forceinline__ void visit_pair_yt(const DevParams& P, const PairDesc* __restrict__ D, const FeatDen& F, int i, int pos,
+                                              int N, const RowData& r, const V3& pxe, int j, const float4 yt, RowAcc& A) {
   float a;
-  if (!eval_pair_yt<GENERAL>(P, D, i, r, j, yt, a)) return;
+  if (!eval_pair_yt<GENERAL>(P, D, F, i, r, j, yt, a)) return;
   if (a > P.sp_thres) {
-    D->ell[(size_t)A.nnz * N + pos] = EllEntry{a, yt.x, yt.y, yt.z};
+    *A.slot = EllEntry{a, yt.x, yt.y, yt.z};
     if (P.keep_columns) D->ell_j[(size_t)A.nnz * N + pos] = D->yorder[j];  // (list entries are sorted positions)
+    A.slot += N;
     A.nnz++;
     const V3 pye{yt.x, yt.y, yt.z};
     const V3 cr = cross_dev(pxe, pye);
@@ -953,6 +973,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
   const int pos = bx * ASSOC_THREADS + threadIdx.x;  // position in k_list's count-ordered row windows
   const int K = iv.K;
   RowAcc A;
+  A.slot = D->ell + pos;
   unsigned long long ncand = 0;
   unsigned overflowed = 0;
   unsigned long long tt1 = 0, tt2 = 0;
@@ -966,6 +987,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
       const int i = head.ip;
       const float4 x = head.x;
       const RowData r = make_row(P, x, iv.ell);
+      const FeatDen F = make_feat_den(P);
       const V3 pxe{x.x, x.y, x.z};
       const Pose& pose = iv.pose;
       const IdxT* cj = reinterpret_cast<const IdxT*>(D->cand_j) + pos;
@@ -989,7 +1011,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
         // iteration, +5 % for the 64-pair batch: most waves hold rows of one to three candidates, where the exp already
         // runs once or twice per wave either way, and the second loop and its LDS traffic are pure overhead.)
         const V3 ytv = transform_point(pose.Ri, pose.Ti, ycur.x, ycur.y, ycur.z);
-        visit_pair_yt<GENERAL>(P, D, i, pos, N, r, pxe, j, make_float4(ytv.x, ytv.y, ytv.z, 0.f), A);
+        visit_pair_yt<GENERAL>(P, D, F, i, pos, N, r, pxe, j, make_float4(ytv.x, ytv.y, ytv.z, 0.f), A);
       }
       D->nnz_row[pos] = A.nnz;
       if (INSTR) tt2 = __builtin_readcyclecounter();
@@ -1128,6 +1150,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
   unsigned nnz_max = 0;
   if (n_ovf > 0) {
     const Pose pose = load_pose(st);
+    const FeatDen F = make_feat_den(P);
     for (int q = blockIdx.x * DENSE_WAVES + wave; q < n_ovf; q += DENSE_BLOCKS * DENSE_WAVES) {
       // a position of k_list's ordering (all per-row outputs are stored by position); dense regime: every row
       const int r_sorted = all_dense ? q : D->ovf_rows[q];
@@ -1151,7 +1174,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
           const int j = j0 + 64 * h + lane;
           if (j < M) {
             const float4 y0 = D->y4[j];
-            ok[h] = eval_pair<GENERAL>(P, D, pose, i, r, GENERAL ? D->yinv[j] : 0, y0, a[h], yt[h]) && (a[h] > P.sp_thres);
+            ok[h] = eval_pair<GENERAL>(P, D, F, pose, i, r, GENERAL ? D->yinv[j] : 0, y0, a[h], yt[h]) && (a[h] > P.sp_thres);
           }
         }
         int nstaged = 0;
@@ -1286,8 +1309,9 @@ __device__ __forceinline__ void coeff_entry(const XiMats& M, const float4 x, flo
       (-temp_coef) * (epsil_const + dot3_dev(2.0f * xi4z.x, 2.0f * xi4z.y, 2.0f * xi4z.z, dfx, dfy, dfz));
   Bi += (double)(A_ij * beta_ij);
   Ci += (double)A_ij * ((double)gamma_ij + (double)(beta_ij * beta_ij) / 2.0);
+  // beta^3 / 6.0 (CvoGPU.cu:1072): the IEEE division with its constant half folded (rcp_refined / div_by, cvo_device.h)
   Di += (double)A_ij * ((double)__builtin_fmaf(beta_ij, gamma_ij, delta_ij) +
-                        (double)(beta_ij * beta_ij * beta_ij) / 6.0);
+                        div_by((double)(beta_ij * beta_ij * beta_ij), 6.0, rcp_refined(6.0)));
   Ei += (double)A_ij * ((double)__builtin_fmaf(beta_ij, delta_ij, epsil_ij) +
                         1 / 2.0 * beta_ij * beta_ij * gamma_ij + 1 / 2.0 * gamma_ij * gamma_ij +
                         1 / 24.0 * beta_ij * beta_ij * beta_ij * beta_ij);
@@ -2299,6 +2323,7 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
   const int N = D->N, M = D->M, K = st->K;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const Pose pose = load_pose(st);
+  const FeatDen F = make_feat_den(P);
   unsigned checked = 0;
   for (int pos = blockIdx.x * 4 + wave; pos < N; pos += gridDim.x * 4) {
     const int i = D->ip[pos];
@@ -2311,7 +2336,7 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
       float a = 0.f;
       float4 yt;
       bool ok = false;
-      if (j < M) ok = eval_pair<GENERAL>(P, D, pose, i, r, GENERAL ? D->yinv[j] : 0, D->y4[j], a, yt) && (a > P.sp_thres);
+      if (j < M) ok = eval_pair<GENERAL>(P, D, F, pose, i, r, GENERAL ? D->yinv[j] : 0, D->y4[j], a, yt) && (a > P.sp_thres);
       const unsigned long long m = __ballot(ok);
       const unsigned rank = nnz + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
       const bool keep = ok && rank < (unsigned)K;
@@ -2355,6 +2380,12 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
 //   op 6  update_tf              in: R[9], T[3]                  out: Rinv[9], Tinv[3]
 //   op 7  indicator windows      ONE item: in = {window, threshold, x_0 .. x_{n-1}}, out[k] = decision of sample k
 //                                (indicator_update on a scratch PairState, exactly as the update calls it)
+// The hoisted arithmetic of the row loops against the compiler's / the device library's own forms (eight operands per
+// item, lane l takes operand l; out[2 l] = the plain form, out[2 l + 1] = the hoisted form - the tests compare the BITS):
+//   op 8  n / d  vs  div_by(n, d, rcp_refined(d))            in: {n_l, d_l} pairs (in[2 l], in[2 l + 1])
+//   op 9  x / 6.0  vs  div_by(x, 6.0, rcp_refined(6.0))      in: x_l (in[l])
+//   op 10 exp(x)  vs  exp_ocml<false>(x)                     in: x_l
+//   op 11 exp(x)  vs  exp_ocml<true>(x)   (x <= 0)           in: x_l
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_scalar_math(int op, int n, const double* __restrict__ in, double* __restrict__ out,
                                                     PairState* scratch) {
@@ -2371,6 +2402,27 @@ __global__ __launch_bounds__(64) void k_scalar_math(int op, int n, const double*
   }
   const double* a = in + 16 * (size_t)blockIdx.x;
   double* o = out + 16 * (size_t)blockIdx.x;
+  if (op >= 8 && op <= 11) {
+    if (lane >= 8) return;
+    double plain, hoisted;
+    if (op == 8) {
+      const double nn = a[2 * lane], dd = a[2 * lane + 1];
+      plain = nn / dd;
+      hoisted = div_by(nn, dd, rcp_refined(dd));
+    } else if (op == 9) {
+      const double x = a[lane];
+      plain = x / 6.0;
+      hoisted = div_by(x, 6.0, rcp_refined(6.0));
+    } else {
+      const double x = a[lane];
+      const ExpConsts ek = make_exp_consts();
+      plain = exp(x);
+      hoisted = op == 10 ? exp_ocml<false>(x, ek) : exp_ocml<true>(x, ek);
+    }
+    o[2 * lane] = plain;
+    o[2 * lane + 1] = hoisted;
+    return;
+  }
   if (op == 0 || op == 1) {
     const double coef[4] = {a[0], a[1], a[2], a[3]};
     double re[3], im[3];
