@@ -15,6 +15,8 @@ from unified_cvo_amd import CvoGPU  # noqa: E402
 
 NP = int(os.environ.get("PROBE_PAIRS", "64"))
 REPS = int(os.environ.get("PROBE_REPS", "3"))
+from unified_cvo_amd import build as _hipbuild  # noqa: E402
+RESIDENT_LIB = _hipbuild.build_resident()  # k_resident is not part of the default library
 opts = {k[4:]: v for k, v in os.environ.items() if k.startswith("RES_")}   # RES_RESIDENT_BLOCKS=12 -> option
 
 
@@ -22,7 +24,7 @@ def run_single(name, builder, kw, max_it=0):
     P, a, b, init = builder(**kw)
     out = {}
     for mode in ("two-kernel", "resident"):
-        gpu = CvoGPU(params=P)
+        gpu = CvoGPU(params=P, library=RESIDENT_LIB)
         if mode == "resident":
             gpu.set_option(os.environ.get("PROBE_ALT", "RESIDENT"), "1")
         for k, v in opts.items():
@@ -57,7 +59,7 @@ def run_batch(n_pairs, n=10000, max_it=0):
     P = cs[0][0]
     out = {}
     for mode in ("two-kernel", "resident"):
-        gpu = CvoGPU(params=P)
+        gpu = CvoGPU(params=P, library=RESIDENT_LIB)
         if mode == "resident":
             gpu.set_option("RESIDENT", "1")
         for k, v in opts.items():

@@ -461,6 +461,13 @@ def test_lean_graph_waits_do_not_change_results(monkeypatch):
     assert np.array_equal(a.transform, c.transform)
 
 
+def _resident_library():
+    """lib/libcvo_hip_resident.so: the same sources built with -DCVO_WITH_RESIDENT (__graft_entry__.build() makes it in
+    the build container; built here if it did not travel)."""
+    from unified_cvo_amd import build as hipbuild
+    return hipbuild.LIB_RESIDENT if os.path.exists(hipbuild.LIB_RESIDENT) else hipbuild.build_resident()
+
+
 @pytest.mark.parametrize("builder,kw,n_it", [(cases.config2, dict(n=10000), 700), (cases.config2, dict(n=5000), 500),
                                              (cases.config3, dict(n=6000), 400), (cases.config4, dict(n=10000), 10000)])
 def test_resident_iteration_is_bit_identical(builder, kw, n_it):
@@ -472,7 +479,9 @@ def test_resident_iteration_is_bit_identical(builder, kw, n_it):
     ref_gpu = CvoGPU(params=P)
     ref = ref_gpu.align(src, tgt, init, max_iterations=n_it)
     assert ref_gpu.debug_resident_ticks()[1] == 0             # the default path is the two-kernel iteration
-    gpu = CvoGPU(params=P)
+    with pytest.raises(CvoError):                             # ... and the product library does not even contain the kernel
+        ref_gpu.set_option("RESIDENT", "1")
+    gpu = CvoGPU(params=P, library=_resident_library())
     gpu.set_option("RESIDENT", "1")
     for _ in range(2):
         r = gpu.align(src, tgt, init, max_iterations=n_it)
@@ -487,7 +496,7 @@ def test_resident_iteration_small_batch_is_bit_identical():
     pairs = [cases.config2(n=5000 + 300 * p, pair_id=p) for p in range(8)]
     P = pairs[0][0]
     ref = CvoGPU(params=P).align_batch([p[1] for p in pairs], [p[2] for p in pairs], [p[3] for p in pairs], max_iterations=300)
-    gpu = CvoGPU(params=P)
+    gpu = CvoGPU(params=P, library=_resident_library())
     gpu.set_option("RESIDENT", "1")
     res = gpu.align_batch([p[1] for p in pairs], [p[2] for p in pairs], [p[3] for p in pairs], max_iterations=300)
     assert gpu.debug_resident_ticks()[1] > 0

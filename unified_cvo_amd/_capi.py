@@ -136,19 +136,20 @@ EXPORTED = [
     "cvo_ctx_set_option", "cvo_debug_resident_ticks",
 ]
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    """Loads libcvo_hip.so (once).  Raises if the HIP extension has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def lib(path=None):
+    """Loads libcvo_hip.so (once; `path`: another build of the same C-ABI, e.g. build.LIB_RESIDENT).  Raises if the
+    HIP extension has not been built."""
+    path = os.path.abspath(path) if path else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -m unified_cvo_amd.build` "
+            f"{path} is missing: build it with `python -m unified_cvo_amd.build` "
             "(there is no CPU fallback for the hot path)")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, ip, fp = C.c_void_p, C.c_int, C.POINTER(C.c_float)
     L.cvo_version.restype = C.c_char_p
     L.cvo_params_default.argtypes = [C.POINTER(cvo_params_t)]
@@ -198,5 +199,5 @@ def lib():
     L.cvo_debug_device_memory.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     for name in EXPORTED:
         getattr(L, name)  # AttributeError here = the library does not export what the header declares
-    _lib = L
+    _libs[path] = L
     return L

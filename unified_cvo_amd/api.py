@@ -260,8 +260,8 @@ class AlignResult:
 class CvoGPU:
     """cvo::CvoGPU(yaml) over the HIP backend."""
 
-    def __init__(self, param_file=None, params=None, device=0):
-        self.L = _capi.lib()
+    def __init__(self, param_file=None, params=None, device=0, library=None):
+        self.L = _capi.lib(library)  # (library: another build of the same C-ABI, e.g. build.LIB_RESIDENT)
         if params is not None:
             self.params = params
         elif param_file is not None:

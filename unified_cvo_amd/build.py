@@ -13,6 +13,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcvo_hip.so")
+# The same sources with -DCVO_WITH_RESIDENT: the XCD-resident iteration (k_resident), an experiment that lost to the two
+# launches it replaces (ROUND_LOG.md round 3).  Not part of the product library; the tests that keep it honest load this one.
+LIB_RESIDENT = os.path.join(LIBDIR, "libcvo_hip_resident.so")
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
@@ -60,26 +63,39 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(p) > t for p in sources() + headers())
+
+
+def _compile(lib, defines, verbose):
+    os.makedirs(LIBDIR, exist_ok=True)
+    extra = os.environ.get("CVO_EXTRA_HIPCC_FLAGS", "").split()  # (experiments: -DCVO_ASSOC_WAVES=6 ...)
+    cmd = [_hipcc()] + HIPCC_FLAGS + defines + extra + ["-I", os.path.join(ROOT, "include"), "-o", lib] + sources()
+    if verbose:
+        print("[unified_cvo_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return lib
 
 
 def build(force=False, verbose=True):
     """Compile every HIP source for gfx950 into unified_cvo_amd/lib/libcvo_hip.so."""
     if not force and not needs_build():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    extra = os.environ.get("CVO_EXTRA_HIPCC_FLAGS", "").split()  # (experiments: -DCVO_ASSOC_WAVES=6 ...)
-    cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-I", os.path.join(ROOT, "include"), "-o", LIB] + sources()
-    if verbose:
-        print("[unified_cvo_amd.build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return LIB
+    return _compile(LIB, [], verbose)
+
+
+def build_resident(force=False, verbose=True):
+    """The variant with k_resident compiled in (lib/libcvo_hip_resident.so), for tests/ and scripts/resident_probe.py."""
+    if not force and not needs_build(LIB_RESIDENT):
+        return LIB_RESIDENT
+    return _compile(LIB_RESIDENT, ["-DCVO_WITH_RESIDENT"], verbose)
 
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
+    if "--resident" in sys.argv:
+        print(build_resident(force="--force" in sys.argv))

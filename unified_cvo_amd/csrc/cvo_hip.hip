@@ -514,12 +514,13 @@ void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags) {
   launch_coeff(g.stream, g.instr, g.nba, g.csplit, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0));
 }
 
+#ifdef CVO_WITH_RESIDENT
 // U lean iterations of every pair of the sub-batch in one launch (k_resident).  Grid: 8 XCDs x ceil(n_pairs / 8) pairs x
 // res_nb blocks; the blocks place themselves (see the kernel), so only the total matters.
 void launch_resident(cvo_ctx* c, const LaunchGeom& g, int U) {
   const int ppx = (g.n_pairs + 7) / 8;
   const dim3 grid((unsigned)(8 * ppx * (g.res_nb + 1))), blk(ASSOC_THREADS);  // res_nb row blocks + the tail block per pair
-  const int packed = (U & 0xff) | (g.res_nb << 8) | (int)((unsigned)g.n_pairs << 20);
+  const int packed = (U & 0xff) | (g.res_nb << 8) | (int)((unsigned)g.n_pairs << 20);  // (setup_batch: lean_U <= 255 or no resident launches)
   const int nblk_split = g.nba | (g.csplit << 14) | ((g.p0 & 7) << 20);
   const PairDesc* descs = c->d_descs + g.p0;
   PairState* st = c->d_states + g.p0;
@@ -541,6 +542,8 @@ void launch_resident(cvo_ctx* c, const LaunchGeom& g, int U) {
 #undef CVO_LAUNCH_RESIDENT
 }
 
+#endif  // CVO_WITH_RESIDENT
+
 // A chunk of U iterations.  Full: every iteration can rebuild its candidate list and serve overflow rows.
 // Lean: rebuild opportunities only every lean_U iterations; pairs that need more wait for a full chunk.
 void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U) {
@@ -551,6 +554,7 @@ void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U)
     }
     return;
   }
+#ifdef CVO_WITH_RESIDENT
   if (g.res_nb > 0) {  // the lean iterations between two rebuild opportunities in ONE launch
     for (int u = 0; u < U; u += lean_U) {
       launch_rebuild(c, g);
@@ -558,6 +562,7 @@ void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U)
     }
     return;
   }
+#endif
   for (int u = 0; u < U; u++) {
     if (u % lean_U == 0) launch_rebuild(c, g);
     const bool last = (u % lean_U == lean_U - 1) || u == U - 1;
@@ -806,7 +811,9 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   // section 3, ROUND_LOG.md round 3 have the numbers (an L2-local hop is 260 ns, a reduce + broadcast among the blocks of
   // a pair 1.5 - 2 us: what a launch boundary plus its cold prologue cost).  Kept because it is bit-identical, bounded
   // and the harness for any further in-launch experiment; tests/test_gpu_parity.py runs it.
+#ifdef CVO_WITH_RESIDENT
   if (mode == 0 && ctx_opt_on(ctx, "RESIDENT") && !ctx->resident_off && !dp.kernel_clock && !S->geom.verify && S->geom.csplit == 1 &&
+      dp.lean_U <= 255 &&  // (the launch packs its iteration count into eight bits)
       (n_pairs <= 16 || ctx_opt(ctx, "RESIDENT_BLOCKS"))) {
     const int per_group = (n_pairs + S->G - 1) / S->G, ppx = (per_group + 7) / 8;
     int nb = std::max(1, 48 / (S->G * ppx) - 1);
@@ -817,6 +824,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     while (nb > 1 && (long)S->G * ppx * (nb + 1) > 64) nb--;
     if ((long)S->G * ppx * (nb + 1) <= 64) S->geom.res_nb = nb;
   }
+#endif
   ctx->last_resident_nb = S->geom.res_nb;
   ctx->last_xorder = sources[0]->h_order;
   ctx->last_groups = S->G;
@@ -988,6 +996,11 @@ int cvo_ctx_set_option(cvo_ctx* ctx, const char* name, const char* value) {
   bool known = false;
   for (const char* k : kOptionNames) known = known || std::strcmp(k, name) == 0;
   if (!known) return fail(ctx, CVO_E_INVALID, std::string("cvo_ctx_set_option: unknown option ") + name);
+#ifndef CVO_WITH_RESIDENT
+  if ((std::strcmp(name, "RESIDENT") == 0 || std::strcmp(name, "RESIDENT_BLOCKS") == 0) && value && atoi(value) != 0)
+    return fail(ctx, CVO_E_UNSUPPORTED, "this library was built without the XCD-resident iteration (k_resident): build "
+                                        "libcvo_hip_resident.so (unified_cvo_amd/build.py, -DCVO_WITH_RESIDENT)");
+#endif
   if (value)
     ctx->opt[name] = value;
   else
@@ -1437,6 +1450,11 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     for (; ch < chunk_cap && !all_done; ch++) {
       const int slot = ch & 1;
       const int Uc = ch < n_early_chunks ? U : U_late;
+      if (ctx_opt(ctx, "VERBOSE") && atoi(ctx_opt(ctx, "VERBOSE")) >= 3) {
+        fprintf(stderr, "[cvo] chunk %d (%d iterations): graphs", ch, Uc);
+        for (int g = 0; g < G; g++) fprintf(stderr, " %s", graph_next[g] == 0 ? "full" : (graph_next[g] == 1 ? "lean" : "short"));
+        fprintf(stderr, "\n");
+      }
       for (int g = 0; g < G; g++) {
         const int v = graph_next[g];
         (v ? n_lean_launch : n_full_launch)++;
@@ -1970,11 +1988,15 @@ int cvo_debug_scalar_math(cvo_ctx* ctx, int op, int n, const double* in, double*
 // function; out[16].  Also reports how many blocks per pair the last call's resident launches used (*blocks_per_pair).
 int cvo_debug_resident_ticks(cvo_ctx* ctx, unsigned long long* out, int* blocks_per_pair) {
   if (!ctx || !out) return CVO_E_INVALID;
+#ifdef CVO_WITH_RESIDENT
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_res_ticks), sizeof(unsigned long long) * 16));
   unsigned long long zero[16] = {};
   HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_res_ticks), zero, sizeof zero));
+#else
+  for (int q = 0; q < 16; q++) out[q] = 0ull;  // (a library built without k_resident: no resident launch ever ran)
+#endif
   if (blocks_per_pair) *blocks_per_pair = ctx->last_resident_nb;
   return CVO_OK;
 }

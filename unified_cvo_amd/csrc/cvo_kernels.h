@@ -1965,7 +1965,9 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_resident: up to U optimiser iterations of every pair of a (small) sub-batch in ONE launch - the lean iterations
+// k_resident (compiled only with -DCVO_WITH_RESIDENT; slower than the two launches on every configuration, kept as
+// the harness of the in-launch experiments - ROUND_LOG.md round 3): up to U optimiser iterations of every pair of a
+// (small) sub-batch in ONE launch - the lean iterations
 // between two rebuild opportunities, which the two-kernel path runs as U x [k_assoc, k_coeff].  For calls with few
 // pairs in flight (one frame pair at a time is the reference's own use: frame-to-frame tracking), where an iteration
 // is a chain of latencies - two launch gaps, two cold prologues, two last-block elections - and not throughput.
@@ -1997,6 +1999,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
 // sub-batch streams together at or below 1.5 blocks of 256 threads per CU; __launch_bounds__(256, 2) guarantees 2 (the
 // whole register file for two blocks: rows, twist and update code share one allocation without spilling).
 // ------------------------------------------------------------------------------------------
+#ifdef CVO_WITH_RESIDENT  // opt-in build (unified_cvo_amd/build.py: build_resident): not part of the default library
 __device__ __forceinline__ unsigned xcc_id() {
   unsigned v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
@@ -2235,7 +2238,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, 2) void k_resident(const PairDesc* _
         for (int rb = role; rb < nblk; rb += NB) {
           const int pos = rb * ASSOC_THREADS + tid;
           CoeffRowHead ch;
-          ch.nnz = pos < D->N ? reinterpret_cast<const unsigned*>(wb + row_off_nnz(Npad))[pos] : 0u;
+          ch.nnz = pos < D->N ? D->nnz_row[pos] : 0u;  // (the base pass 1 stored through: no second, restrict-qualified view)
           ch.x = reinterpret_cast<const float4*>(wb + row_off_xp4(Npad))[pos];
           ch.e_n = EllEntry{0.f, 0.f, 0.f, 0.f};
           if (ch.nnz > 0u) ch.e_n = D->ell[pos];
@@ -2286,8 +2289,11 @@ __global__ __launch_bounds__(ASSOC_THREADS, 2) void k_resident(const PairDesc* _
         __syncthreads();
       }
     }
-    if (aborted && is_tail && tid == 0) {  // tell the host: this pair must be served by the two-kernel graphs
-      st->want_full = 3;
+    // tell the host: this pair must be served by the two-kernel graphs.  Published by the tail block AND by the
+    // pair's first row block: if the dispatcher did not deal this pair a tail block (self-placement assumes it hands
+    // every XCD ppx * (NB + 1) blocks), the row blocks still time out, and one of them must say so.
+    if (aborted && (is_tail || role == 0) && tid == 0) {
+      if (is_tail) st->want_full = 3;
       *D0->want_out = 3;
     }
   }
@@ -2302,6 +2308,8 @@ __global__ __launch_bounds__(ASSOC_THREADS, 2) void k_resident(const PairDesc* _
     }
   }
 }
+
+#endif  // CVO_WITH_RESIDENT
 
 // ------------------------------------------------------------------------------------------
 // k_verify (CVO_VERIFY_LISTS=1): the self-check of the candidate-list reuse.  After the association of an iteration
