@@ -460,3 +460,37 @@ def test_restated_exp_is_the_device_library_exp_bit_for_bit(op):
     sel = (xs > -700) & (xs < 700)
     ref = np.exp(xs[sel])
     assert np.max(np.abs(plain[sel] - ref) / np.spacing(ref)) <= 1.0
+
+
+@pytest.mark.gpu
+def test_hoisted_float_division_is_the_ieee_division_bit_for_bit():
+    """omega_i / c, v_i / d (CvoGPU.cu:784-787): IEEE float divisions by a call-wide constant with the denominator's half
+    hoisted (fdiv_prepare / fdiv_hoisted) - licensed per wave by fdiv_operands_safe, which this test also pins: wherever
+    it accepts a numerator the hoisted quotient equals the plain one bit for bit (and numpy's), and it accepts every
+    zero and every magnitude in [2^-100, 2^60)."""
+    gpu = CvoGPU()
+    rs = np.random.default_rng(53)
+    n_items = 1_250_000
+    num = (rs.normal(size=(n_items, 8)) * 10.0 ** rs.uniform(-44, 30, (n_items, 8))).astype(np.float32)
+    num[:1000] = (rs.normal(size=(1000, 8)) * 10.0 ** rs.uniform(-3, 3, (1000, 8))).astype(np.float32)   # the flows' usual range
+    num[1000:1010] = 0.0
+    den = np.where(rs.uniform(size=(n_items, 8)) < 0.5, 7.0, 2.0 ** rs.uniform(-20, 20, (n_items, 8))).astype(np.float32)
+    den *= np.where(rs.uniform(size=den.shape) < 0.2, -1, 1).astype(np.float32)
+    ops = np.empty((n_items, 16))
+    ops[:, 0::2] = num
+    ops[:, 1::2] = den
+    plain, hoisted = _hoisted_pairs(gpu, 12, ops, 8)
+    plain32, hoisted32 = plain.astype(np.float32), hoisted.astype(np.float32)
+    nf, df = num.reshape(-1), den.reshape(-1)
+    with np.errstate(all="ignore"):
+        ref = (nf / df).astype(np.float32)
+    assert np.array_equal(plain32.view(np.uint32), ref.view(np.uint32))          # the device's plain division is IEEE
+    refused = (hoisted == -1.0) & (plain != -1.0)
+    mag = np.abs(nf.astype(np.float64))
+    must_accept = (mag == 0) | ((mag >= 2.0 ** -100) & (mag < 2.0 ** 59))
+    assert not np.any(refused & must_accept)
+    assert np.all(refused[(mag != 0) & ((mag < 2.0 ** -101) | (mag >= 2.0 ** 61))])
+    ok = ~refused & (nf != 0)
+    assert ok.sum() > 4_000_000
+    assert np.array_equal(plain32[ok].view(np.uint32), hoisted32[ok].view(np.uint32))
+    assert np.all(hoisted32[~refused & (nf == 0)] == 0.0)

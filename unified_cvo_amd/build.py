@@ -94,6 +94,12 @@ def build_resident(force=False, verbose=True):
     return _compile(LIB_RESIDENT, ["-DCVO_WITH_RESIDENT"], verbose)
 
 
+def build_variant(name, defines, verbose=True):
+    """An experiment build of the same sources (lib/libcvo_hip_<name>.so) with extra -D switches: scripts/exp_time.py
+    times it next to the product library and checks that the poses stay bit-identical."""
+    return _compile(os.path.join(LIBDIR, f"libcvo_hip_{name}.so"), list(defines), verbose)
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)

@@ -58,6 +58,7 @@ struct DevParams {
   int verify_lists;  // CVO_VERIFY_LISTS: k_verify re-derives every row with the literal scan after each association
   int keep_columns;  // write ell_j (the column of every ELL entry): exports, traces, the self-check and the single
                      // evaluations need it, the optimiser loop itself never reads it (4 of 20 bytes per nonzero)
+  int fast_div_cd;  // 2^-20 <= |c|, |d| <= 2^20: the per-row float divisions by c and d may take their hoisted form (fdiv_hoisted)
   int debug_no_motion_bound;  // CVO_DEBUG_NO_MOTION_BOUND (tests only): the update pretends no target ever moves, so
                               // lists outlive their validity - what CVO_VERIFY_LISTS exists to catch
 };
@@ -84,6 +85,7 @@ struct PairState {
   double dist;
   double asum;  // sum of kernel values (mode 1)
   unsigned long long ncand;
+  unsigned long long ncand_list;  // candidates held by the current lists, summed over the rows (k_prep zeroes, k_list adds)
   unsigned long long noverflow;  // rows that took k_assoc's literal path
   unsigned long long ncand_total;  // candidate pairs evaluated exactly, summed over the iterations (statistics)
   int n_trace;
@@ -302,11 +304,6 @@ __device__ __forceinline__ V3 transform_point_pose_vec(const float* T, float x, 
           __builtin_fmaf(T[8], x, T[9] * y) + __builtin_fmaf(T[10], z, T[11])};
 }
 
-// compute_range_ell (CvoGPU.cu:86-90)
-__device__ __forceinline__ float compute_range_ell(float ell, float dist) {
-  return (float)(((double)dist / 500.0 + 1.0) * (double)ell);
-}
-
 // ---- double-precision division and exp() of the row loops, restated so that their loop-invariant parts can be hoisted ----
 //
 // The reference evaluates `exp(-d2 / (2.0 * l * l))` per pair (CvoGPU.cu:552: double division, double exp) and
@@ -334,6 +331,46 @@ __device__ __forceinline__ double div_by(double n, double d, double r) {
   const double q = n * r;
   const double e = __builtin_fma(-d, q, n);
   return __builtin_fma(e, r, q);
+}
+
+// The same for the IEEE FLOAT division by a wave-uniform denominator (omega_i / c, v_i / d per row, CvoGPU.cu:784-787):
+// hipcc's 12-instruction sequence is v_div_scale x2, v_rcp_f32, ONE Newton step, q = n r, two residual corrections, the
+// second one inside v_div_fmas, v_div_fixup.  fdiv_prepare() is the denominator's part, fdiv_hoisted() the numerator's
+// (5 instructions); identical to `n / d` wherever the scale / fix-up instructions pass their operands through, which for
+// 2^-20 <= |d| <= 2^20 means: n == 0 (up to the sign of the zero, see div_by), or 2^-100 <= |n| < 2^60.  The caller
+// checks exactly that (fdiv_operands_safe) and takes the plain division otherwise.  cvo_debug_scalar_math op 12.
+struct FDivU {
+  float d, r;
+};
+__device__ __forceinline__ FDivU fdiv_prepare(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  r = __builtin_fmaf(e, r, r);
+  return FDivU{d, r};
+}
+__device__ __forceinline__ float fdiv_hoisted(float n, const FDivU& u) {
+  float q = n * u.r;
+  float e = __builtin_fmaf(-u.d, q, n);
+  q = __builtin_fmaf(e, u.r, q);
+  e = __builtin_fmaf(-u.d, q, n);
+  return __builtin_fmaf(e, u.r, q);
+}
+// every one of six numerators is zero or has 2^-100 <= |n| < 2^60 (and none is inf / NaN): frexp's exponent is 0 for a
+// zero and e with |n| in [2^(e-1), 2^e) otherwise, denormals included; the sum of the magnitudes bounds each of them
+// from above and turns inf / NaN into a failed comparison
+__device__ __forceinline__ bool fdiv_operands_safe(const float (&n)[6]) {
+  const float s = ((__builtin_fabsf(n[0]) + __builtin_fabsf(n[1])) + (__builtin_fabsf(n[2]) + __builtin_fabsf(n[3]))) +
+                  (__builtin_fabsf(n[4]) + __builtin_fabsf(n[5]));
+  int emin = __builtin_amdgcn_frexp_expf(n[0]);
+#pragma unroll
+  for (int q = 1; q < 6; q++) emin = min(emin, __builtin_amdgcn_frexp_expf(n[q]));
+  return s < 0x1p60f && emin >= -99;
+}
+
+// compute_range_ell (CvoGPU.cu:86-90): (dist / 500.0 + 1.0) * ell in double; the division with its constant half folded
+// (dist is a float square root: >= 0, never denormal as a double)
+__device__ __forceinline__ float compute_range_ell(float ell, float dist) {
+  return (float)((div_by((double)dist, 500.0, rcp_refined(500.0)) + 1.0) * (double)ell);
 }
 
 // exp(double) of the ROCm device library (ocml expD_base, what `exp()` compiled to inside the row loops), restated

@@ -335,6 +335,10 @@ DevParams make_dev_params(const cvo_ctx* ctx, const cvo_params_t& p) {
   d.use_sem = p.is_using_semantics != 0;
   d.use_range_ell = p.is_using_range_ell != 0;
   d.use_geotype = p.is_using_geometric_type != 0;
+  {
+    auto mid = [](float v) { const float a = std::fabs(v); return std::isfinite(v) && a >= 0x1p-20f && a <= 0x1p20f; };
+    d.fast_div_cd = mid(p.c) && mid(p.d) ? 1 : 0;
+  }
   d.skin_frac = 2.0f;
   d.lean_skin = 1.3f;
   d.dense_regime = ctx_opt(ctx, "NO_DENSE_REGIME") ? 0 : 1;
@@ -1954,7 +1958,7 @@ int cvo_align_association(cvo_ctx* ctx, int pair, int* row_ptr, int* col, float*
 }
 
 int cvo_debug_scalar_math(cvo_ctx* ctx, int op, int n, const double* in, double* out) {
-  if (!ctx || !in || !out || n <= 0 || op < 0 || op > 11) return fail(ctx, CVO_E_INVALID, "cvo_debug_scalar_math: bad argument");
+  if (!ctx || !in || !out || n <= 0 || op < 0 || op > 12) return fail(ctx, CVO_E_INVALID, "cvo_debug_scalar_math: bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t n_in = op == 7 ? (size_t)n + 2 : 16 * (size_t)n, n_out = op == 7 ? (size_t)n : 16 * (size_t)n;
   double *d_in = nullptr, *d_out = nullptr;

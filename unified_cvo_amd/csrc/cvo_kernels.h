@@ -552,7 +552,15 @@ struct RowAcc {
   double asum = 0;
   unsigned nnz = 0;
   EllEntry* slot = nullptr;  // where the row's next nonzero goes: D->ell + nnz * N + pos, advanced by N per nonzero
+  float4* stage = nullptr;   // this thread's column of the block's LDS staging area (AssocShared::stage)
 };
+// ELL entries a row parks in LDS before they are stored (see assoc_phase).  Six: 24.6 KB of LDS per block; 4 / 5 / 6 / 7 / 8
+// slots measured 63.6 / 63.3 / 62.9 / 63.8 / 64.9 ms per step (the early iterations have ~8 nonzeros per row, the
+// steady state 2-3; beyond 6 the LDS footprint costs more occupancy than the longer rows gain).
+#ifndef CVO_ELL_STAGE_SLOTS
+#define CVO_ELL_STAGE_SLOTS 6
+#endif
+constexpr int ELL_STAGE = CVO_ELL_STAGE_SLOTS;
 
 // One pair (i, j) that passed the geometric cut-off, with its transformed target: the rest of CvoGPU.cu:528-589 (kernel
 // values, a > sp_thres, ELL store) + the flow terms of 758-782.
@@ -562,7 +570,15 @@ __device__ __forceinline__ void visit_pair_yt(const DevParams& P, const PairDesc
   float a;
   if (!eval_pair_yt<GENERAL>(P, D, F, i, r, j, yt, a)) return;
   if (a > P.sp_thres) {
-    *A.slot = EllEntry{a, yt.x, yt.y, yt.z};
+    // The row's first ELL_STAGE nonzeros are parked in the thread's own LDS column and leave after the loop as
+    // write-through stores (assoc_phase); only rows longer than that store from inside the loop.
+    if (A.nnz < (unsigned)ELL_STAGE)
+      A.stage[A.nnz * ASSOC_THREADS] = make_float4(a, yt.x, yt.y, yt.z);
+    else
+      *A.slot = EllEntry{a, yt.x, yt.y, yt.z};
+#ifdef CVO_EXP_DOUBLE_ELL
+    if (A.nnz < 64u) reinterpret_cast<EllEntry*>(D->ell_j)[(size_t)A.nnz * N + pos] = EllEntry{a, yt.x, yt.y, yt.z};
+#endif
     if (P.keep_columns) D->ell_j[(size_t)A.nnz * N + pos] = D->yorder[j];  // (list entries are sorted positions)
     A.slot += N;
     A.nnz++;
@@ -753,9 +769,13 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
   {
     const bool ov = rr < N && cnt_all > ASSOC_CAP;
     const unsigned long long m = __ballot(ov);
+    // statistic: candidate pairs the association evaluates per iteration while these lists live (one returnless atomic
+    // per wave and rebuild instead of a wave reduction in every wave of every k_assoc launch)
+    const unsigned wsum = wave_sum_u32(rr < N ? (unsigned)min(cnt_all, 0x3ffffff) : 0u);
     if ((tid & 63) == 0) {
       st_x<true>(D->ovf_bits + (pos >> 6), m);
       if (m) atomicAdd(&D->st->n_ovf, __builtin_popcountll(m));
+      if (wsum) (void)__hip_atomic_fetch_add(&D->st->ncand_list, (unsigned long long)wsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every wave drains its own stores, see flow_gate)
@@ -960,7 +980,10 @@ __device__ __forceinline__ double block_reduce_lds(BlockRedShared<NC>& S, const 
 }
 
 struct AssocShared {
-  BlockRedShared<7> red;
+  union {
+    BlockRedShared<7> red;                   // after the row loop
+    float4 stage[ELL_STAGE][ASSOC_THREADS];  // during it: the rows' first ELL entries, one column per thread
+  };
   unsigned long long cnt[ASSOC_THREADS / 64][4];
 };
 
@@ -974,14 +997,13 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
   const int K = iv.K;
   RowAcc A;
   A.slot = D->ell + pos;
-  unsigned long long ncand = 0;
+  A.stage = &S.stage[0][threadIdx.x];
   unsigned overflowed = 0;
   unsigned long long tt1 = 0, tt2 = 0;
   if (pos < N) {
     const int j1s = head.j1;  // (the first list slot exists whatever the count is)
     const int j2s = (int)(reinterpret_cast<const IdxT*>(D->cand_j) + pos)[N];
     const int cnt = head.cnt;
-    ncand = (unsigned long long)cnt;
     overflowed = cnt > ASSOC_CAP ? 1u : 0u;
     if (!overflowed) {
       const int i = head.ip;
@@ -1014,6 +1036,23 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
         visit_pair_yt<GENERAL>(P, D, F, i, pos, N, r, pxe, j, make_float4(ytv.x, ytv.y, ytv.z, 0.f), A);
       }
       D->nnz_row[pos] = A.nnz;
+      {
+        // The ELL entries leave now, back to back, as WRITE-THROUGH (sc1) 16-byte stores.  A dependent kernel boundary
+        // costs its ~1.5 us plus (bytes the predecessor left dirty in the XCDs' L2s) / 6 TB/s (MI355X_MICROARCH.md): the
+        // 5.7 MB of ELL entries a 16-pair launch used to leave behind as plain stores put ~0.9 us in front of every
+        // k_coeff; written through they drain while the other waves still work, and the row loop's wait for its
+        // prefetched loads (vmcnt(0): flat addresses) no longer includes a store acknowledgement.  Measured with
+        // scripts/exp_time.py: 66.2 -> 63.6 ms per step (4 slots; 62.9 with 6); a plain second copy of every entry (twice the dirty bytes)
+        // costs 14 ms, sc1 stores from inside the loop 2 ms (profiles/r4/ell_store_experiments.txt).
+        const unsigned ns = min(A.nnz, (unsigned)ELL_STAGE);
+        EllEntry* dst = D->ell + pos;
+        for (unsigned q = 0; q < ns; q++) {
+          const float4 e4 = A.stage[q * ASSOC_THREADS];  // (own LDS column: no barrier)
+          const f32x4 ev = {e4.x, e4.y, e4.z, e4.w};
+          asm volatile("flat_store_dwordx4 %0, %1 sc1" ::"v"(dst), "v"(ev) : "memory");
+          dst += N;
+        }
+      }
       if (INSTR) tt2 = __builtin_readcyclecounter();
     }
   }
@@ -1022,20 +1061,40 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
     g_phase_ticks[0][blockIdx.x & 8191][2] = tt2;
   }
   // per-row (omega_i / c, v_i / d) cast to double, then reduced in double (CvoGPU.cu:784-787, 824-825)
-  const double red[7] = {(double)(A.o0 / P.c), (double)(A.o1 / P.c), (double)(A.o2 / P.c), (double)(A.v0 / P.d),
-                         (double)(A.v1 / P.d), (double)(A.v2 / P.d), A.asum};
+  // (six IEEE float divisions per row by two call-wide constants: 72 of a wave's ~500 VALU instructions as the compiler
+  // expands them, 30 + 16 with the denominators' halves hoisted and the operand check that licenses it)
+  float fq[6];
+  {
+    const float fn[6] = {A.o0, A.o1, A.o2, A.v0, A.v1, A.v2};
+    const bool safe = P.fast_div_cd != 0 && fdiv_operands_safe(fn);
+    if (__ballot(!safe) == 0ull) {
+      const FDivU uc = fdiv_prepare(P.c), ud = fdiv_prepare(P.d);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        fq[q] = fdiv_hoisted(fn[q], uc);
+        fq[3 + q] = fdiv_hoisted(fn[3 + q], ud);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        fq[q] = fn[q] / P.c;
+        fq[3 + q] = fn[3 + q] / P.d;
+      }
+    }
+  }
+  const double red[7] = {(double)fq[0], (double)fq[1], (double)fq[2], (double)fq[3], (double)fq[4], (double)fq[5], A.asum};
   constexpr int NW = ASSOC_THREADS / 64;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned long long nn = wave_sum_u32(A.nnz);  // 64 rows x K_max
   const unsigned mx = wave_max_u32(A.nnz);
-  const unsigned long long nc = wave_sum_u32((unsigned)min(ncand, 0x3ffffffull));
   const unsigned long long nov = (unsigned long long)__builtin_popcountll(__ballot(overflowed != 0));
   if (lane == 0) {
     S.cnt[wave][0] = nn;
     S.cnt[wave][1] = mx;
-    S.cnt[wave][2] = nc;
+    S.cnt[wave][2] = 0ull;  // (the candidate statistic is a property of the lists: k_list leaves it in PairState::ncand_list)
     S.cnt[wave][3] = nov;
   }
+  __syncthreads();  // (the staging columns share their LDS with the reduction: every thread has drained its own)
   const double tot = block_reduce_lds<7>(S.red, red);  // (its barrier also covers S.cnt)
   if (threadIdx.x < 56 && (threadIdx.x & 7) == 0) {
     st_x<!LOCAL>(D->flow_part + (size_t)bx * 8 + (threadIdx.x >> 3), tot);  // read by another block of this launch (flow_gate)
@@ -1343,7 +1402,8 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
       const float d2_sqrt = sqrtf(dot3_dev(x.x, x.y, x.z, x.x, x.y, x.z));
       temp_ell = compute_range_ell(temp_ell, d2_sqrt);
     }
-    const float temp_coef = (float)(1 / (2.0 * temp_ell * temp_ell));
+    const double cden = 2.0 * temp_ell * temp_ell;
+    const float temp_coef = (float)div_by(1.0, cden, rcp_refined(cden));  // 1 / (2.0 * ell * ell), CvoGPU.cu:1060
     EllEntry e_n = h.e_n;
     for (unsigned s = (unsigned)q; s < nnz; s += (unsigned)nsplit) {
       const EllEntry e = e_n;
@@ -1538,8 +1598,8 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
       const unsigned nnz = (unsigned)s_n[0], max_nnz = (unsigned)s_n[1];
       st->nnz = nnz;
       st->max_nnz = max_nnz;
-      st->ncand = s_n[2];
-      st->ncand_total += s_n[2];
+      st->ncand = st->ncand_list;  // candidates of the current lists (k_list), evaluated exactly in this iteration
+      st->ncand_total += st->ncand_list;
       st->noverflow = s_n[3];
       st->K_last = st->K;  // the stride upstream wrote this iteration's A matrix with (gpu_association_to_cpu)
       if (P.mode != 0) {  // single evaluation: A_sum (SparseKernelMat.cu:62-68)
@@ -2394,6 +2454,8 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
 //   op 9  x / 6.0  vs  div_by(x, 6.0, rcp_refined(6.0))      in: x_l (in[l])
 //   op 10 exp(x)  vs  exp_ocml<false>(x)                     in: x_l
 //   op 11 exp(x)  vs  exp_ocml<true>(x)   (x <= 0)           in: x_l
+//   op 12 (float) n / d  vs  fdiv_hoisted(n, fdiv_prepare(d)) in: {n_l, d_l} pairs; out[2 l + 1] = NaN-boxed -1 (as a
+//         double: -1.0) where fdiv_operands_safe refuses the operand (the kernel then divides the plain way)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_scalar_math(int op, int n, const double* __restrict__ in, double* __restrict__ out,
                                                     PairState* scratch) {
@@ -2410,6 +2472,14 @@ __global__ __launch_bounds__(64) void k_scalar_math(int op, int n, const double*
   }
   const double* a = in + 16 * (size_t)blockIdx.x;
   double* o = out + 16 * (size_t)blockIdx.x;
+  if (op == 12) {
+    if (lane >= 8) return;
+    const float nn = (float)a[2 * lane], dd = (float)a[2 * lane + 1];
+    const float six[6] = {nn, 0.f, 0.f, 0.f, 0.f, 0.f};
+    o[2 * lane] = (double)(nn / dd);
+    o[2 * lane + 1] = fdiv_operands_safe(six) ? (double)fdiv_hoisted(nn, fdiv_prepare(dd)) : -1.0;
+    return;
+  }
   if (op >= 8 && op <= 11) {
     if (lane >= 8) return;
     double plain, hoisted;
@@ -2500,7 +2570,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
   const PairState* st = D->st;
   if (!st->rebuild) return;  // k_update: the bitmap of an earlier iteration still covers this one
   if (st->all_dense) {  // dense regime: no operands to prepare, only the overflow list to reset for k_list
-    if (blockIdx.x == 0 && threadIdx.x == 0) D->st->n_ovf = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      D->st->n_ovf = 0;
+      D->st->ncand_list = 0ull;
+    }
     return;
   }
   const DevParams P = *Pp;
@@ -2573,7 +2646,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
   const int rs = (blockIdx.x - ntb) * PREP_THREADS + tid;
   if (rs >= D->NGpad * ROWS_PER_GROUP) return;  // whole waves drop out together (NGpad*4 is a multiple of 256)
   const float ell = st->ell;  // == st->ell_build: a rebuild always uses the current lengthscale
-  if (rs == 0) D->st->n_ovf = 0;  // k_list refills the overflow list of k_assoc_dense
+  if (rs == 0) {  // k_list refills the overflow list of k_assoc_dense and the lists' candidate count
+    D->st->n_ovf = 0;
+    D->st->ncand_list = 0ull;
+  }
   // per-row skin = skin_rot * rho_i + skin_tr (+ rounding slack), see PairState / update_body
   const float skin_rot = st->skin_rot, skin_tr = st->skin_tr;
   const float tb_norm = sqrtf(__builtin_fmaf(st->Tinv[2], st->Tinv[2], __builtin_fmaf(st->Tinv[1], st->Tinv[1], st->Tinv[0] * st->Tinv[0])));
