@@ -165,3 +165,43 @@ def test_single_iteration_and_prefix_at_40k(oracle):
     for a, b in zip(g.trace, o["trace"]):
         _cmp_trace(a, b)
     assert cases.max_abs_diff(g.transform, o["transform"]) <= 1e-6
+
+
+def _ip_and_angles(gpu, oracle, P, src, tgt, poses):
+    """inner_product_gpu (CvoGPU.cu:1719-1778) and function_angle, approximate and exact (CvoGPU.cu:1814-1846), against
+    the oracle at every pose in `poses`."""
+    op, ox, oy = oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt)
+    for T in poses:
+        ip_g = gpu.inner_product_gpu(src, tgt, T, P.ell_init)
+        ip_o = oracle.inner_product(op, ox, oy, T, P.ell_init)
+        assert ip_o > 0 and ip_g == pytest.approx(ip_o, rel=TOL_IP_REL)
+        for approximate in (True, False):
+            fa_g = gpu.function_angle(src, tgt, T, P.ell_init, approximate)
+            fa_o = oracle.function_angle(op, ox, oy, T, P.ell_init, approximate)
+            assert fa_g == pytest.approx(fa_o, rel=TOL_IP_REL)
+
+
+def test_config3_literal_10k_full_length(oracle):
+    """BASELINE.json configs[2] at its literal size AND length: 10k x 10k clouds with 5-channel colour,
+    cvo_intensity_params_gpu.yaml, the whole loop of /root/reference/src/cvo/CvoGPU.cu:1387-1533 to its 5000th iteration
+    (MAX_ITER of that file; the run ends clamped at min_step), final pose within 2e-4 of the oracle's; then the overlap
+    queries of the reference drivers at the initial and the final pose."""
+    P, src, tgt, init = cases.config3(n=10000)
+    gpu = CvoGPU(params=P)
+    g = gpu.align(src, tgt, init)
+    o = oracle.align(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt), init)
+    assert g.iterations == o["iterations"] == P.MAX_ITER == 5000 and g.ret == o["ret"] == 0
+    assert cases.max_abs_diff(g.transform, o["transform"]) <= TOL_POSE_CLAMPED
+    final = np.linalg.inv(g.transform.astype(np.float64)).astype(np.float32)
+    _ip_and_angles(gpu, oracle, P, src, tgt, (init, final))
+
+
+def test_config4_literal_10k_overlap_queries(oracle):
+    """BASELINE.json configs[3] (10k x 10k, colour + 19-class semantics, warm start): inner_product_gpu and both
+    function_angle flavours at the initial and the final pose of the full-size run."""
+    P, src, tgt, init = cases.config4(n=10000)
+    gpu = CvoGPU(params=P)
+    g = gpu.align(src, tgt, init)
+    assert g.ret == 0 and g.iterations < P.MAX_ITER
+    final = np.linalg.inv(g.transform.astype(np.float64)).astype(np.float32)
+    _ip_and_angles(gpu, oracle, P, src, tgt, (init, final))
