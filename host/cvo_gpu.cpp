@@ -234,6 +234,79 @@ std::vector<int> CvoGPU::align_batch(const std::vector<const CvoPointCloud*>& so
   return rets;
 }
 
+CvoGPU::ResidentClouds::~ResidentClouds() {
+  for (cvo_cloud* h : handles)
+    if (h) cvo_cloud_free(h);
+}
+
+std::unique_ptr<CvoGPU::ResidentClouds> CvoGPU::upload_clouds(const std::vector<const CvoPointCloud*>& clouds,
+                                                              int host_threads) const {
+  std::lock_guard<std::mutex> lk(call_mutex);
+  const int k = (int)clouds.size();
+  // what CvoPointCloud_to_gpu builds per point (upstream CvoGPU_impl.cu:206-263), for all clouds, then ONE parallel upload
+  std::vector<std::vector<float>> xyz(k), feat(k), label(k), geo(k);
+  std::vector<int> n(k);
+  std::vector<const float*> px(k), pf(k), pl(k), pg(k);
+  for (int c = 0; c < k; c++) {
+    const CvoPointCloud& pc = *clouds[c];
+    n[c] = pc.num_points();
+    xyz[c].resize(3 * (size_t)n[c]);
+    for (int i = 0; i < n[c]; i++)
+      for (int d = 0; d < 3; d++) xyz[c][3 * (size_t)i + d] = pc.positions()[i][d];
+    const MatXf& F = pc.features();
+    if (F.rows() == n[c] && F.cols() > 0) {
+      feat[c].assign(CVO_FEATURE_DIMENSIONS * (size_t)n[c], 0.f);
+      for (int i = 0; i < n[c]; i++)
+        for (int d = 0; d < CVO_FEATURE_DIMENSIONS && d < F.cols(); d++) feat[c][CVO_FEATURE_DIMENSIONS * (size_t)i + d] = F(i, d);
+    }
+    const MatXf& L = pc.labels();
+    if (pc.num_classes() > 0 && L.rows() == n[c]) {
+      label[c].assign(CVO_NUM_CLASSES * (size_t)n[c], 0.f);
+      for (int i = 0; i < n[c]; i++)
+        for (int d = 0; d < pc.num_classes() && d < CVO_NUM_CLASSES; d++) label[c][CVO_NUM_CLASSES * (size_t)i + d] = L(i, d);
+    }
+    const std::vector<float>& g = pc.geometric_types();
+    if (!g.empty()) {
+      geo[c].assign(2 * (size_t)n[c], 0.f);
+      for (size_t i = 0; i < geo[c].size() && i < g.size(); i++) geo[c][i] = g[i];
+    }
+    px[c] = xyz[c].data();
+    pf[c] = feat[c].empty() ? nullptr : feat[c].data();
+    pl[c] = label[c].empty() ? nullptr : label[c].data();
+    pg[c] = geo[c].empty() ? nullptr : geo[c].data();
+  }
+  std::unique_ptr<ResidentClouds> out(new ResidentClouds());
+  out->handles.assign(k, nullptr);
+  if (k)
+    check(ctx, cvo_cloud_upload_many(ctx, k, n.data(), px.data(), pf.data(), pl.data(), pg.data(), host_threads, out->handles.data()),
+          "cvo_cloud_upload_many");
+  return out;
+}
+
+std::vector<int> CvoGPU::align_batch(const ResidentClouds& sources, const ResidentClouds& targets, const std::vector<Mat4f>& inits,
+                                     std::vector<Mat4f>& transforms, double* seconds) const {
+  std::lock_guard<std::mutex> lk(call_mutex);
+  const int n = sources.size();
+  if (targets.size() != n || (int)inits.size() != n) throw std::runtime_error("align_batch: size mismatch");
+  std::vector<float> init(16 * (size_t)n), out(16 * (size_t)n);
+  for (int i = 0; i < n; i++) std::copy(inits[i].data(), inits[i].data() + 16, &init[16 * (size_t)i]);
+  std::vector<cvo_align_info_t> infos(n);
+  transforms.resize(n);
+  std::vector<int> rets(n);
+  if (n == 0) return rets;
+  check(ctx, cvo_align_batch(ctx, &params, n, sources.handles.data(), targets.handles.data(), init.data(), out.data(), infos.data(),
+                             nullptr),
+        "cvo_align_batch");
+  for (int i = 0; i < n; i++) {
+    std::copy(&out[16 * (size_t)i], &out[16 * (size_t)i] + 16, transforms[i].data());
+    rets[i] = infos[i].ret;
+  }
+  if (seconds) *seconds = infos[0].seconds;
+  return rets;
+}
+
+std::string CvoGPU::advice() const { return cvo_ctx_advice(ctx); }
+
 float CvoGPU::inner_product_gpu(const CvoPointCloud& a, const CvoPointCloud& b, const Mat4f& T, float ell) const {
   std::lock_guard<std::mutex> lk(call_mutex);  // (see CvoGPU.hpp: the const entry points share one context)
   if (a.num_points() == 0 || b.num_points() == 0) return 0.f;

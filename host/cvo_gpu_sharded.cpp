@@ -30,6 +30,12 @@ struct CvoGPUSharded::Impl {
   std::vector<float*> send, recv;             // device buffers: this device's poses / everybody's
   std::vector<int*> send_ret, recv_ret;
   int cap_per = 0;                            // pairs per device the buffers hold
+  // upload_batch(): the resident shards
+  std::vector<std::unique_ptr<CvoGPU::ResidentClouds>> res_src, res_tgt;
+  int res_n = -1;
+  std::vector<int> solve_and_gather(int n, const std::vector<const CvoPointCloud*>* sources,
+                                    const std::vector<const CvoPointCloud*>* targets, const std::vector<Mat4f>& inits,
+                                    std::vector<Mat4f>& transforms, double* seconds, int read_from);
 
   void reserve(int per) {
     if (per <= cap_per) return;
@@ -101,6 +107,44 @@ std::vector<int> CvoGPUSharded::align_batch(const std::vector<const CvoPointClou
                                             int read_from) {
   const int n = (int)sources.size();
   if ((int)targets.size() != n || (int)inits.size() != n) throw std::runtime_error("align_batch: size mismatch");
+  return impl->solve_and_gather(n, &sources, &targets, inits, transforms, seconds, read_from);
+}
+
+void CvoGPUSharded::upload_batch(const std::vector<const CvoPointCloud*>& sources,
+                                 const std::vector<const CvoPointCloud*>& targets, int host_threads_per_device) {
+  const int n = (int)sources.size();
+  if ((int)targets.size() != n) throw std::runtime_error("upload_batch: size mismatch");
+  const int D = (int)impl->devices.size();
+  const ShardPlan plan(n, D);
+  impl->res_src.clear();
+  impl->res_tgt.clear();
+  impl->res_src.resize(D);
+  impl->res_tgt.resize(D);
+  for (int d = 0; d < D; d++) {
+    hip_ok(hipSetDevice(impl->devices[d]), "hipSetDevice");
+    const int lo = plan.lo(d), hi = plan.hi(d);
+    std::vector<const CvoPointCloud*> s(sources.begin() + lo, sources.begin() + std::max(lo, hi)),
+        t(targets.begin() + lo, targets.begin() + std::max(lo, hi));
+    impl->res_src[d] = impl->gpus[d]->upload_clouds(s, host_threads_per_device);
+    impl->res_tgt[d] = impl->gpus[d]->upload_clouds(t, host_threads_per_device);
+  }
+  impl->res_n = n;
+}
+
+std::vector<int> CvoGPUSharded::align_resident(const std::vector<Mat4f>& inits, std::vector<Mat4f>& transforms, double* seconds,
+                                               int read_from) {
+  if (impl->res_n < 0) throw std::runtime_error("align_resident: upload_batch first");
+  if ((int)inits.size() != impl->res_n) throw std::runtime_error("align_resident: size mismatch");
+  return impl->solve_and_gather(impl->res_n, nullptr, nullptr, inits, transforms, seconds, read_from);
+}
+
+std::string CvoGPUSharded::advice() const { return impl->gpus[0]->advice(); }
+
+std::vector<int> CvoGPUSharded::Impl::solve_and_gather(int n, const std::vector<const CvoPointCloud*>* sources_p,
+                                                       const std::vector<const CvoPointCloud*>* targets_p,
+                                                       const std::vector<Mat4f>& inits, std::vector<Mat4f>& transforms,
+                                                       double* seconds, int read_from) {
+  Impl* const impl = this;
   const int D = (int)impl->devices.size();
   if (read_from < 0 || read_from >= D) throw std::runtime_error("align_batch: read_from out of range");
   transforms.assign(n, Mat4f::Identity());
@@ -121,9 +165,15 @@ std::vector<int> CvoGPUSharded::align_batch(const std::vector<const CvoPointClou
         std::vector<int> rr(per, 0);
         for (int q = 0; q < per; q++) std::memcpy(&poses[16 * (size_t)q], Mat4f::Identity().data(), sizeof(float) * 16);
         if (hi > lo) {
-          std::vector<const CvoPointCloud*> s(sources.begin() + lo, sources.begin() + hi), t(targets.begin() + lo, targets.begin() + hi);
           std::vector<Mat4f> in(inits.begin() + lo, inits.begin() + hi), out;
-          const std::vector<int> r = impl->gpus[d]->align_batch(s, t, in, out, nullptr);
+          std::vector<int> r;
+          if (sources_p) {
+            std::vector<const CvoPointCloud*> s(sources_p->begin() + lo, sources_p->begin() + hi),
+                t(targets_p->begin() + lo, targets_p->begin() + hi);
+            r = impl->gpus[d]->align_batch(s, t, in, out, nullptr);
+          } else {
+            r = impl->gpus[d]->align_batch(*impl->res_src[d], *impl->res_tgt[d], in, out, nullptr);
+          }
           for (int q = 0; q < hi - lo; q++) {
             std::memcpy(&poses[16 * (size_t)q], out[q].data(), sizeof(float) * 16);
             rr[q] = r[q];

@@ -4,6 +4,7 @@
 // an array of the 192-byte CvoPoint record instead of pcl::PointCloud<CvoPoint> (UnifiedCvo/pcl_interop.hpp forwards
 // pcl clouds where PCL exists).  The multi-frame overloads (Ceres IRLS) are out of scope.
 #pragma once
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -48,6 +49,26 @@ class CvoGPU {
   std::vector<int> align_batch(const std::vector<const CvoPointCloud*>& sources,
                                const std::vector<const CvoPointCloud*>& targets, const std::vector<Mat4f>& inits,
                                std::vector<Mat4f>& transforms, double* seconds = nullptr) const;
+  // New: clouds that stay on the device across calls.  Upstream converts and uploads both clouds inside every align()
+  // (CvoPointCloud_to_gpu, CvoGPU_impl.cu:206-285); a frame pipeline that matches a frame against several partners, or
+  // a host that prepares batch k + 1 while batch k is being solved, uploads once (in parallel, cvo_cloud_upload_many).
+  class ResidentClouds {
+   public:
+    ~ResidentClouds();
+    ResidentClouds(const ResidentClouds&) = delete;
+    ResidentClouds& operator=(const ResidentClouds&) = delete;
+    int size() const { return (int)handles.size(); }
+
+   private:
+    friend class CvoGPU;
+    ResidentClouds() = default;
+    std::vector<cvo_cloud*> handles;
+  };
+  std::unique_ptr<ResidentClouds> upload_clouds(const std::vector<const CvoPointCloud*>& clouds, int host_threads = 0) const;
+  std::vector<int> align_batch(const ResidentClouds& sources, const ResidentClouds& targets, const std::vector<Mat4f>& inits,
+                               std::vector<Mat4f>& transforms, double* seconds = nullptr) const;
+  // cvo_ctx_advice of this object's context ("" = nothing to report; see include/cvo_hip.h, hardware queues)
+  std::string advice() const;
 
   float function_angle(const CvoPointCloud& source_points, const CvoPointCloud& target_points,
                        const Mat4f& T_target_frame_to_source_frame, float ell, bool is_approximate = true,

@@ -31,6 +31,15 @@ class CvoGPUSharded {
   std::vector<int> align_batch(const std::vector<const CvoPointCloud*>& sources,
                                const std::vector<const CvoPointCloud*>& targets, const std::vector<Mat4f>& inits,
                                std::vector<Mat4f>& transforms, double* seconds = nullptr, int read_from = 0);
+  // The same with the clouds kept on their devices across calls (CvoGPU::ResidentClouds): upload_batch() shards and
+  // uploads n pairs once, align_resident() solves them from `inits` as often as the caller likes - what a frame
+  // pipeline does that prepares batch k + 1 while batch k is solved, and what `cvo_align_sharded --bench` times.
+  void upload_batch(const std::vector<const CvoPointCloud*>& sources, const std::vector<const CvoPointCloud*>& targets,
+                    int host_threads_per_device = 0);
+  std::vector<int> align_resident(const std::vector<Mat4f>& inits, std::vector<Mat4f>& transforms, double* seconds = nullptr,
+                                  int read_from = 0);
+  // cvo_ctx_advice of device 0's context ("" = nothing to report)
+  std::string advice() const;
   // which device pair p of an n-pair batch runs on
   int device_of(int p, int n) const;
 

@@ -150,6 +150,14 @@ typedef struct cvo_align_opts_t {
 int cvo_ctx_create(int device, cvo_ctx** out);
 void cvo_ctx_destroy(cvo_ctx* ctx);
 const char* cvo_last_error(const cvo_ctx* ctx);
+/* Hardware queues.  A batch (cvo_align_batch, CvoGPUSharded) runs on four sub-batch HIP streams that must sit on four
+ * different hardware queues; HIP deals streams onto GPU_MAX_HW_QUEUES queues (default 4, read once at the process's
+ * first HIP call) and the upload stream, RCCL and the host application bring streams of their own.  The library
+ * therefore puts GPU_MAX_HW_QUEUES=8 into the environment when it is LOADED, unless the variable is already set
+ * (CVO_NO_HW_QUEUE_HINT=1 disables this).  If HIP was initialised earlier, or the variable says less than 8,
+ * cvo_ctx_create leaves an advisory text here ("" = nothing to report) and prints it once per process on stderr
+ * (CVO_QUIET=1 silences the print).  Nothing but speed depends on it. */
+const char* cvo_ctx_advice(const cvo_ctx* ctx);
 /* Tuning / diagnostic switches of a context (none changes a result; the list is in unified_cvo_amd/csrc/cvo_hip.hip,
  * kOptionNames, and DESIGN.md).  A context reads CVO_<NAME> from the environment ONCE, in cvo_ctx_create; afterwards
  * only this call changes them (value NULL = unset), so no library call depends on the process environment while it

@@ -2,6 +2,7 @@
 import glob
 import os
 import subprocess
+import sys
 import warnings
 
 import numpy as np
@@ -357,3 +358,72 @@ def test_shard_plan_partition_and_gather_arithmetic():
         counts = [hi - lo for lo, hi in (sharding.shard_range(n, 8, r) for r in range(8))]
         line = [l for l in out if l.startswith(f"D=8 n={n} ")][0]
         assert line.endswith("counts=" + ",".join(map(str, counts)))
+
+
+def test_library_load_sets_the_hardware_queue_hint():
+    """The hardware-queue contract (include/cvo_hip.h, cvo_ctx_advice): loading the library puts GPU_MAX_HW_QUEUES=8 into
+    the process environment - HIP reads it at the process's first HIP call - unless the variable is already set or
+    CVO_NO_HW_QUEUE_HINT is.  No GPU needed: nothing here calls HIP."""
+    code = ("import ctypes, os, sys; sys.path.insert(0, %r); from unified_cvo_amd import _capi; _capi.lib(); "
+            "g = ctypes.CDLL(None).getenv; g.restype = ctypes.c_char_p; print(g(b'GPU_MAX_HW_QUEUES'))" % cases.ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "CVO_NO_HW_QUEUE_HINT")}
+    run = lambda e: subprocess.check_output([sys.executable, "-c", code], env=e, text=True).strip()  # noqa: E731
+    assert run(env) == "b'8'"
+    assert run(dict(env, GPU_MAX_HW_QUEUES="3")) == "b'3'"          # an explicit choice is left alone
+    assert run(dict(env, CVO_NO_HW_QUEUE_HINT="1")) == "None"
+
+
+@pytest.mark.gpu
+def test_hardware_queue_advice_channel():
+    """cvo_ctx_advice: silent when the process has 8 hardware queues, a text (and one stderr line) below that."""
+    code = ("import sys; sys.path.insert(0, %r); from unified_cvo_amd import CvoGPU; print('ADVICE[' + CvoGPU().advice() + ']')"
+            % cases.ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "CVO_NO_HW_QUEUE_HINT", "CVO_QUIET")}
+    ok = subprocess.run([sys.executable, "-c", code], env=env, text=True, capture_output=True)
+    assert "ADVICE[]" in ok.stdout and "[cvo] advice" not in ok.stderr          # the load-time hint did its job
+    low = subprocess.run([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="2"), text=True, capture_output=True)
+    assert "ADVICE[GPU_MAX_HW_QUEUES is 2" in low.stdout and "[cvo] advice: GPU_MAX_HW_QUEUES is 2" in low.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_runs_the_headline_batch_at_the_c_abi_speed(tmp_path):
+    """the C++ host of the multi-GPU mode (cvo::CvoGPUSharded, RCCL communicator alive, one
+    device here) solves BASELINE.json's per-GPU headline workload - 64 resident 10k x 10k pairs, 2000 iterations - within
+    10 % of cvo_align_batch called directly, in a process that sets NO environment variable (the library's load-time
+    hardware-queue hint is all it gets), and returns bit-identical poses."""
+    import time
+    from unified_cvo_amd import CvoGPU
+    shard = os.path.join(HOST, "cvo_align_sharded")
+    yaml = os.path.join(cases.CONFIGS, "geometric_gpu.yaml")
+    NP = 64
+    pairs = [cases.config2(n=10000, pair_id=p) for p in range(NP)]
+    args = []
+    for p, (_, src, tgt, _) in enumerate(pairs):
+        _write_xyz_pcd(tmp_path / f"s{p}.pcd", src.device_arrays()[0])
+        _write_xyz_pcd(tmp_path / f"t{p}.pcd", tgt.device_arrays()[0])
+        args += [str(tmp_path / f"s{p}.pcd"), str(tmp_path / f"t{p}.pcd")]
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "CVO_NO_HW_QUEUE_HINT")}
+    out = subprocess.check_output([shard, "--bench", "5", yaml, "0", "1"] + args, text=True, env=env)
+    lines = [l.split() for l in out.strip().splitlines()]
+    bench = [l for l in lines if l and l[0] == "bench"][0]
+    assert bench[:7] == ["bench", "devices", "1", "pairs", str(NP), "reps", "5"]
+    ms_cpp = float(bench[bench.index("min") + 1])
+    assert not [l for l in lines if l and l[0] == "advice"]
+    P = pairs[0][0]
+    gpu = CvoGPU(params=P)
+    both = gpu.upload_many([a[1] for a in pairs] + [a[2] for a in pairs])
+    inits = [np.eye(4, dtype=np.float32)] * NP
+    gpu.align_batch(both[:NP], both[NP:], inits)
+    best = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        res = gpu.align_batch(both[:NP], both[NP:], inits)
+        best = min(best, time.perf_counter() - t0)
+    ms_py = best * 1e3
+    print(f"headline batch: C++ host (CvoGPUSharded, RCCL) {ms_cpp:.2f} ms, cvo_align_batch via ctypes {ms_py:.2f} ms")
+    assert ms_cpp <= 1.10 * ms_py, (ms_cpp, ms_py)
+    plines = [l for l in lines if l and l[0] == "pair"]
+    assert len(plines) == NP
+    for p, (l, r) in enumerate(zip(plines, res)):
+        T = np.array([float(v) for v in l[7:23]], np.float32).reshape(4, 4).T
+        assert np.array_equal(T, r.transform), p

@@ -133,7 +133,7 @@ EXPORTED = [
     "cvo_debug_kernel_clock",
     "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
     "cvo_align_association", "cvo_debug_scalar_math", "cvo_debug_verified_rows", "cvo_debug_device_memory", "cvo_cloud_upload_many",
-    "cvo_ctx_set_option", "cvo_debug_resident_ticks",
+    "cvo_ctx_set_option", "cvo_debug_resident_ticks", "cvo_ctx_advice",
 ]
 
 _libs = {}
@@ -160,6 +160,8 @@ def lib(path=None):
     L.cvo_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.cvo_last_error.argtypes = [vp]
     L.cvo_last_error.restype = C.c_char_p
+    L.cvo_ctx_advice.argtypes = [vp]
+    L.cvo_ctx_advice.restype = C.c_char_p
     L.cvo_ctx_stream.argtypes = [vp]
     L.cvo_ctx_stream.restype = vp
     L.cvo_ctx_synchronize.argtypes = [vp]

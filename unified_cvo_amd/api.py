@@ -559,6 +559,11 @@ class CvoGPU:
         self._check(self.L.cvo_debug_list_builds(self.ctx, C.byref(b), C.byref(it), C.byref(ce)))
         return b.value, it.value, ce.value
 
+    def advice(self):
+        """Performance-relevant observations about the process set-up (cvo_ctx_advice): "" when there is nothing to say,
+        e.g. a text about GPU_MAX_HW_QUEUES when HIP was initialised with fewer than 8 hardware queues."""
+        return self.L.cvo_ctx_advice(self.ctx).decode()
+
     def debug_scalar_math(self, op, items):
         """Runs one of the device's scalar routines (k_scalar_math ops 0-6, 8-11) on `items` (n x <=16 doubles); returns
         n x 16 doubles.  op 7 (indicator windows): items = [window, threshold, x_0, ...], returns the n decisions.
