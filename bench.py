@@ -21,10 +21,6 @@ import time
 
 import numpy as np
 
-# The batch is enqueued on 4 HIP streams; RCCL adds streams of its own.  HIP maps streams onto 4 hardware
-# queues by default, and sharing a queue serialises two of our sub-batches (measured: 0.37 s instead of
-# 0.25 s per step under torchrun).  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # Per-pair kernel durations inside the timed loop (roofline.avg_launch_ms) come from the instrumented instantiation of the
 # per-iteration kernels (cvo_align_opts_t.kernel_clock); it costs ~3 % of a step, so only the LAST timed step runs it -
 # the other steps run the production kernels.  CVO_KERNEL_CLOCK=0 in the environment switches the instrumented step off
@@ -35,9 +31,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
 C_CULL_FLOPS = 8               # flops per pair test
+N_SIMD = 256 * 4               # MI355X: 256 CUs x 4 SIMDs, each issuing one VALU wave-instruction per >= 4 cycles
+SHADER_CLOCK_HZ = 2.4e9        # peak engine clock
 
 
 def available_cpus():
@@ -54,6 +53,15 @@ def available_cpus():
     except Exception:
         pass
     return n
+
+
+def _getenv_c(name):
+    """The C environment (what HIP and the library's load-time hint see; os.environ is Python's start-up snapshot)."""
+    import ctypes
+    g = ctypes.CDLL(None).getenv
+    g.restype = ctypes.c_char_p
+    v = g(name.encode())
+    return v.decode() if v else None
 
 
 def log(*a):
@@ -82,7 +90,12 @@ def main():
     import torch
     import torch.distributed as dist
     import cases
-    from unified_cvo_amd import CvoGPU, sharding
+    from unified_cvo_amd import CvoGPU, sharding, _capi
+    # The hardware-queue contract lives in the library (include/cvo_hip.h, cvo_ctx_advice): loading it puts
+    # GPU_MAX_HW_QUEUES=8 into the environment unless the caller chose a value.  HIP reads the variable at the process's
+    # first HIP call, so the library is loaded HERE - after `import torch` (the process must end up with ONE HIP runtime:
+    # torch's), before torch touches the GPU; the bench line reports what the context found (config.hardware_queues).
+    _capi.lib()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -203,13 +216,13 @@ def main():
         bytes_pass = (n * 12 + n * 12) * ppl            # one pass over one iteration's inputs, geometric payload
         pair_tests_iter = 2.0 * float(n) * float(n)     # two passes over N x M per iteration and pair
         pair_rate = pair_tests_iter * iters_total * args.steps / elapsed if args.steps else 0.0
-        valu_peak_pairs = FP32_VALU_PEAK_TFLOPS * 1e12 / C_CULL_FLOPS
         executed_tests = float(tiles) * rpt * tpt + 2.0 * float(cand_evals)   # scan tiles + both passes over the lists
         executed_frac = executed_tests / (pair_tests_iter * max(float(iters_total), 1.0))
         # HBM traffic per launch comes from PMC passes (rocprofv3 --pmc, scripts/profile_round.sh), which cannot run
         # inside this process: profiles/kernel_traffic.json carries them together with the hash of the kernel sources they
         # were measured on, and is only reported while that hash matches the library that runs here (else null).
         traffic, traffic_note = {}, "profiles/kernel_traffic.json missing"
+        valu_insts_per_step = None
         tpath = os.path.join(ROOT, "profiles", "kernel_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -223,6 +236,7 @@ def main():
                 else:
                     traffic = tj.get("hbm_bytes_per_launch", {})
                     traffic_note = tj.get("source", "")
+                    valu_insts_per_step = tj.get("valu_wave_insts_per_step")
             except Exception as e:  # noqa: BLE001
                 traffic_note = f"unreadable: {e}"
         if not traffic:
@@ -258,15 +272,20 @@ def main():
             "pairs_per_launch": ppl, "sub_batches": n_groups, "timed_at_iteration": mid_iters,
             "step_traffic_gbs": step_traffic_gbs,
             "other_kernels": [other, kernel_entry("cvo_dev::k_scan", scan_ms, round(builds / max(iters_total, 1), 5))],
-            # The path is an all-pairs accumulation with O(N+M) compulsory bytes: HBM is not the binding roof
-            # (SURVEY.md 8(d)).  The VALU view: algorithmic pair tests per second of the whole job against the FP32
-            # vector roof for the 8-flop cull test.  Bounding-box culling and candidate-list reuse skip almost all of
-            # the N*M tests, so the algorithmic rate exceeds the roof; `executed_fraction` is the share really run.
-            "valu": {"algorithmic_pair_tests_per_s": pair_rate, "peak_pair_tests_per_s": valu_peak_pairs,
-                     "algorithmic_frac_of_roof": round(pair_rate / valu_peak_pairs, 4),
+            # The path is an all-pairs accumulation with O(N+M) compulsory bytes; which resource binds
+            # is a measurement.  `valu_issue_utilisation`: VALU wave-instructions of ONE step (SQ_INSTS_VALU summed over every
+            # kernel and launch of one cvo_align_batch of this workload: PMC pass of scripts/profile_round.sh, keyed to the
+            # kernel-source hash like `traffic`) x 4 cycles (a wave64 instruction occupies its 16-lane SIMD for at least four)
+            # / (1024 SIMDs x 2.4 GHz x the measured step time): the share of the chip's VALU issue slots the step uses, a
+            # lower bound where instructions take more than one pass.  Bounding-box culling and candidate-list reuse skip
+            # almost all of the 2 N M algorithmic pair tests: `executed_fraction_of_pair_tests` is the share really run.
+            "valu": {"valu_issue_utilisation": (round(valu_insts_per_step * 4.0 / (N_SIMD * SHADER_CLOCK_HZ * (elapsed / args.steps)), 4)
+                                                if valu_insts_per_step else None),
+                     "valu_wave_insts_per_step": valu_insts_per_step,
+                     "simds": N_SIMD, "clock_hz": SHADER_CLOCK_HZ,
+                     "algorithmic_pair_tests_per_s": pair_rate,
                      "executed_fraction_of_pair_tests": round(executed_frac, 6),
-                     "list_builds_per_iteration": round(builds / max(iters_total, 1), 5),
-                     "flops_per_pair_test": C_CULL_FLOPS, "peak_tflops": FP32_VALU_PEAK_TFLOPS},
+                     "list_builds_per_iteration": round(builds / max(iters_total, 1), 5)},
         }
         cpu_baseline = None
         if not args.no_cpu_baseline and world == 1:
@@ -349,6 +368,42 @@ def main():
                 gsp.close()
                 log(f"[bench] single pair, {name}: {best.iterations} iterations, {best.seconds*1e3:.2f} ms "
                     f"({best.seconds*1e6/max(best.iterations,1):.2f} us/iteration)")
+        # ---- the other two entry points of the path: inner_product_gpu (CvoGPU.cu:1719-1778) and function_angle
+        # (CvoGPU.cu:1814-1846; exact = three inner products) - the loop-closure / overlap queries of the reference drivers.
+        # One pass of the association over resident clouds, the candidate structure built from scratch in every call
+        # (k_prep, k_scan, k_list, k_assoc [+ k_assoc_dense], k_update); wall time per call, median of 9.
+        overlap_queries = []
+        if world == 1 and args.max_iterations <= 0 and not args.no_single_pair:
+            for name, builder, kw2, extra_bytes in (("config2 shape at 10k x 10k xyz", cases.config2, dict(n=10000), 0),
+                                                    ("config3: 10k x 10k + 5-channel colour", cases.config3, dict(n=10000), 5 * 4),
+                                                    ("config4: 10k x 10k + colour + 19-class semantics", cases.config4, dict(n=10000), (5 + 19) * 4)):
+                Pc, a_, b_, init_ = builder(**kw2)
+                gq = CvoGPU(params=Pc, device=local_rank)
+                da, db = gq.upload(a_), gq.upload(b_)
+
+                def med(fn, reps=9):
+                    fn()
+                    ts = []
+                    for _ in range(reps):
+                        t1 = time.perf_counter()
+                        fn()
+                        ts.append(time.perf_counter() - t1)
+                    return sorted(ts)[len(ts) // 2] * 1e3
+
+                ip_ms = med(lambda: gq.inner_product_gpu(da, db, init_, Pc.ell_init))
+                fa_ms = med(lambda: gq.function_angle(da, db, init_, Pc.ell_init, True))
+                fe_ms = med(lambda: gq.function_angle(da, db, init_, Pc.ell_init, False))
+                one_pass = (12 + extra_bytes) * (a_.num_points() + b_.num_points())   # the loop's per-iteration bytes / 2
+                overlap_queries.append({"config": name, "inner_product_gpu_ms": round(ip_ms, 4),
+                                        "function_angle_approximate_ms": round(fa_ms, 4), "function_angle_exact_ms": round(fe_ms, 4),
+                                        "algorithmic_bytes_one_pass": one_pass,
+                                        "achieved_gbs": round(one_pass / (ip_ms * 1e-3) / 1e9, 3),
+                                        "frac_of_hbm_peak": round(one_pass / (ip_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)})
+                log(f"[bench] overlap queries, {name}: inner_product_gpu {ip_ms:.3f} ms, function_angle {fa_ms:.3f} (approximate) / "
+                    f"{fe_ms:.3f} (exact) ms per call")
+                da.free()
+                db.free()
+                gq.close()
         upload_ms_per_cloud = t_h2d * 1e3 / max(2 * len(host_clouds), 1)
         # PCIe-inclusive, as a frame pipeline runs it: while the GPU solves batch k the host threads order and upload
         # batch k + 1 (cvo_cloud_upload_many on its own streams); every step pays for fresh inputs, the timed region
@@ -401,9 +456,11 @@ def main():
                        "timed_steps": (f"{args.steps} steps; the LAST one runs the instrumented instantiation of the per-iteration "
                                        "kernels (device clock per launch, ~3 % slower), the others the production kernels"
                                        if CLOCK_LAST_STEP else f"{args.steps} steps, production kernels"),
-                       "host_threads_per_rank": n_threads},
+                       "host_threads_per_rank": n_threads,
+                       "hardware_queues": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES") or _getenv_c("GPU_MAX_HW_QUEUES"),
+                                           "advice": gpu.advice()}},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "single_pair": single_pair,
-            "pcie_inclusive": pcie_inclusive,
+            "overlap_queries": overlap_queries, "pcie_inclusive": pcie_inclusive,
         }
         h2d_rate = (2 * n * 16 * 1.0) * B / max(t_h2d, 1e-9) / 1e9
         log(f"[bench] inputs: generated in {t_gen:.2f}s, uploaded in {t_h2d:.3f}s ({h2d_rate:.2f} GB/s incl. host-side k-d ordering on {n_threads} threads); "

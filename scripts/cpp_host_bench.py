@@ -34,7 +34,6 @@ for label, env in (("no environment variable set (the library's load-time hint)"
     adv = [l[:120] for l in r.stdout.splitlines() if l.startswith("advice ")]
     print(f"C++ host, {label}:\n    {line[0] if line else r.stderr[-400:]}" + (f"\n    {adv[0]} ..." if adv else ""), flush=True)
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from unified_cvo_amd import CvoGPU  # noqa: E402
 gpu = CvoGPU(params=pairs[0][0])
 both = gpu.upload_many([a[1] for a in pairs] + [a[2] for a in pairs])

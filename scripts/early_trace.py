@@ -3,7 +3,6 @@
 import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import cases
 from unified_cvo_amd import CvoGPU
 P = cases.load_params("geometric_gpu")

@@ -27,7 +27,13 @@ if "--traffic" in sys.argv:
         k = max((q for q in raw if q.startswith(prefix)), key=lambda q: raw[q]["FETCH_SIZE"]["launches"])  # (template arguments vary)
         return int((2 * raw[k]["FETCH_SIZE"]["avg_per_launch"] + raw[k]["WRITE_SIZE"]["avg_per_launch"]) * 1024)
 
-    kt = {"points": 10000, "pairs": 16,
+    # VALU wave-instructions of the whole batch call the counters were collected on = one step of bench.py: every kernel,
+    # every launch (early-exit launches included)
+    valu_total = int(sum(v["SQ_INSTS_VALU"]["launches"] * v["SQ_INSTS_VALU"]["avg_per_launch"] for k, v in raw.items()
+                         if "SQ_INSTS_VALU" in v and "k_hold" not in k))
+    kt = {"points": 10000, "pairs": 16, "valu_wave_insts_per_step": valu_total,
+          "valu_wave_insts_per_launch": {k.replace("cvo_dev::", "").split("<")[0]: int(v["SQ_INSTS_VALU"]["avg_per_launch"])
+                                         for k, v in raw.items() if "SQ_INSTS_VALU" in v and "k_hold" not in k},
           "hbm_bytes_per_launch": {"k_coeff": hbm("cvo_dev::k_coeff"), "k_assoc": hbm("cvo_dev::k_assoc<"), "k_scan": hbm("cvo_dev::k_scan<")},
           "correction": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE counts 64 B per "
                         "128-B request; WRITE_SIZE uncalibrated)",

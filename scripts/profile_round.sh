@@ -11,7 +11,6 @@ cd /tmp && export TMPDIR=/tmp
 cat > /tmp/one_batch.py <<PY
 import os, sys
 sys.path.insert(0, "$R"); sys.path.insert(0, "$R/tests")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import cases
 from unified_cvo_amd import CvoGPU
 P = cases.load_params("geometric_gpu")

@@ -13,7 +13,6 @@ import time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np  # noqa: E402
 import cases  # noqa: E402
 from unified_cvo_amd import CvoGPU  # noqa: E402
