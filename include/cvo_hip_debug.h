@@ -56,6 +56,10 @@ int cvo_debug_verified_rows(cvo_ctx* ctx, unsigned long long* rows);
  * set, since the last call of this function (layout: g_res_ticks in unified_cvo_amd/csrc/cvo_kernels.h), and the
  * blocks per pair of the last call's resident launches (0 = the call used the two-kernel iteration). */
 int cvo_debug_resident_ticks(cvo_ctx* ctx, unsigned long long out[16], int* blocks_per_pair);
+/* The spatial (k-d) ordering of a resident cloud: out[r] = original index of the point at sorted position r (n entries).
+ * Computed on the device at upload (k_kd_order) for clouds of 8 .. 16384 finite points, on the host otherwise and under
+ * CVO_ORDER=host / virtual / CVO_NO_SORT; no result depends on it. */
+int cvo_debug_cloud_order(const cvo_cloud* cloud, int* out);
 /* Free / total bytes of the context's device (hipMemGetInfo), for leak checks without a second HIP runtime in the process. */
 int cvo_debug_device_memory(cvo_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 #ifdef __cplusplus

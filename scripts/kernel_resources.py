@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 from unified_cvo_amd import build as B  # noqa: E402
 
 flags = [f for f in B.HIPCC_FLAGS if f not in ("-shared",)]
-cmd = [B._hipcc()] + flags + ["-I", os.path.join(ROOT, "include"), "-c", B.sources()[0], "-o", "/tmp/_kres.o",
+cmd = [B._hipcc()] + flags + os.environ.get("CVO_EXTRA_HIPCC_FLAGS", "").split() + ["-I", os.path.join(ROOT, "include"), "-c", B.sources()[0], "-o", "/tmp/_kres.o",
                               "-Rpass-analysis=kernel-resource-usage"]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur, rows = None, {}

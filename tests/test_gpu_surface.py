@@ -494,3 +494,64 @@ def test_hoisted_float_division_is_the_ieee_division_bit_for_bit():
     assert ok.sum() > 4_000_000
     assert np.array_equal(plain32[ok].view(np.uint32), hoisted32[ok].view(np.uint32))
     assert np.all(hoisted32[~refused & (nf == 0)] == 0.0)
+
+
+# ---- the spatial ordering computed on the device (k_kd_order, round 4) ----
+
+def _leaf_sets(order):
+    """Every aligned run of four sorted positions is one leaf of the k-d ordering: its point set, order-free."""
+    n = len(order)
+    pad = (-n) % 4
+    o = np.concatenate([order, np.full(pad, -1, order.dtype)]).reshape(-1, 4)
+    return np.sort(o, axis=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [9, 700, 4999, 10000, 16384])
+def test_device_kd_ordering_equals_its_host_twin(n):
+    """k_kd_order (one block per cloud: level-wise bitonic sorts of (segment, coordinate, point) keys in LDS) against
+    the host recursion with the same rule (CVO_ORDER=virtual: std::nth_element, split axis from the root box halved per
+    level): the same points in every leaf - every aligned run of 4 - hence in every aligned run of 64 and 512; inside a
+    leaf the two leave their points in different (irrelevant) orders."""
+    src, _, _ = synth.geometric_pair(n, 7)
+    pc = CvoPointCloud.from_xyz(src)
+    dev = CvoGPU()
+    d = dev.upload(pc).debug_order()
+    assert np.array_equal(np.sort(d), np.arange(n))
+    host = CvoGPU()
+    host.set_option("ORDER", "virtual")
+    h = host.upload(pc).debug_order()
+    assert np.array_equal(_leaf_sets(d), _leaf_sets(h))
+    # and the aligned runs of 64 really are compact: their boxes are far smaller than the cloud's
+    x = src[d][: (n // 64) * 64].reshape(-1, 64, 3)
+    if len(x):
+        run_vol = np.prod(x.max(axis=1) - x.min(axis=1), axis=1).mean()
+        assert run_vol < 4.0 * (64.0 / n) * np.prod(src.max(axis=0) - src.min(axis=0))   # (a random 64-subset spans ~all of it)
+
+
+@pytest.mark.gpu
+def test_result_does_not_depend_on_where_the_ordering_runs():
+    """Device ordering (default), host ordering with per-segment boxes (CVO_ORDER=host), its level-axes twin and no
+    ordering at all: bit-identical poses, with colour and semantic attributes riding along (they are gathered into
+    spatial order by the same kernel)."""
+    for builder, kw in ((cases.config2, dict(n=3000)), (cases.config4, dict(n=2000))):
+        P, src, tgt, init = builder(**kw)
+        ref = CvoGPU(params=P).align(src, tgt, init, max_iterations=150)
+        for opt, val in (("ORDER", "host"), ("ORDER", "virtual"), ("NO_SORT", "1")):
+            g = CvoGPU(params=P)
+            g.set_option(opt, val)
+            r = g.align(src, tgt, init, max_iterations=150)
+            assert r.iterations == ref.iterations and np.array_equal(r.transform, ref.transform), (opt, val)
+
+
+@pytest.mark.gpu
+def test_large_and_odd_clouds_are_ordered_on_the_host():
+    """Above KD_MAX_POINTS (16384) and for non-finite coordinates the upload falls back to the host ordering / the
+    identity: same API, valid permutations, usable clouds."""
+    gpu = CvoGPU()
+    src, tgt, _ = synth.geometric_pair(20000, 3)
+    o = gpu.upload(CvoPointCloud.from_xyz(src)).debug_order()
+    assert np.array_equal(np.sort(o), np.arange(20000))
+    bad = src[:100].copy()
+    bad[17, 1] = np.nan
+    assert np.array_equal(gpu.upload(CvoPointCloud.from_xyz(bad)).debug_order(), np.arange(100))

@@ -133,7 +133,7 @@ EXPORTED = [
     "cvo_debug_kernel_clock",
     "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
     "cvo_align_association", "cvo_debug_scalar_math", "cvo_debug_verified_rows", "cvo_debug_device_memory", "cvo_cloud_upload_many",
-    "cvo_ctx_set_option", "cvo_debug_resident_ticks", "cvo_ctx_advice",
+    "cvo_ctx_set_option", "cvo_debug_resident_ticks", "cvo_ctx_advice", "cvo_debug_cloud_order",
 ]
 
 _libs = {}
@@ -199,6 +199,7 @@ def lib(path=None):
     L.cvo_debug_scalar_math.argtypes = [vp, ip, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.cvo_debug_verified_rows.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.cvo_debug_device_memory.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.cvo_debug_cloud_order.argtypes = [vp, C.POINTER(C.c_int)]
     for name in EXPORTED:
         getattr(L, name)  # AttributeError here = the library does not export what the header declares
     _libs[path] = L

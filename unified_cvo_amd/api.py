@@ -187,6 +187,12 @@ class DeviceCloud:
             self.gpu.L.cvo_cloud_free(self.handle)
             self.handle = None
 
+    def debug_order(self):
+        """The cloud's spatial (k-d) ordering: original index of the point at every sorted position."""
+        out = np.zeros(max(self.n, 1), np.int32)
+        self.gpu._check(self.gpu.L.cvo_debug_cloud_order(self.handle, out.ctypes.data_as(C.POINTER(C.c_int))))
+        return out[:self.n]
+
     def __del__(self):
         try:
             self.free()

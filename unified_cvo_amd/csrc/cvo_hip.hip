@@ -99,12 +99,15 @@ static const char* const kOptionNames[] = {
     "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
     "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
     "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "RESIDENT",
-    "RESIDENT_BLOCKS"};
+    "RESIDENT_BLOCKS", "ORDER"};
 
 struct cvo_ctx {
   int device = 0;
   std::map<std::string, std::string> opt;  // see kOptionNames
   std::mutex upload_mutex;                 // cvo_cloud_upload / _aos192 share upload_stream and the error string
+  std::mutex kd_mutex;                     // the ordering launches of concurrent uploads share upload_stream and d_kd_jobs
+  KdJob* d_kd_jobs = nullptr;              // job descriptors of the running k_kd_order launch
+  int kd_jobs_cap = 0;
   hipStream_t stream = nullptr;
   hipStream_t upload_stream = nullptr;  // cvo_cloud_upload copies here (never waits for, nor delays, the solver's streams)
   std::string err;
@@ -951,6 +954,21 @@ void cvo_params_default(cvo_params_t* p) {
   p->multiframe_least_squares_num_threads = 24;
 }
 
+// The streams of a context - group 0 (= the context's stream), seven more sub-batch streams, the upload stream - are
+// handed back to a per-device pool when the context is destroyed and reused, in the same roles, by the next context of
+// that device.  HIP deals streams onto hardware queues as they are first used; a context created after another one had
+// been DESTROYED found its four sub-batch streams sharing queues (214 ms instead of 64 ms per headline step,
+// scripts/upload_probe.py) however carefully it ordered their creation.  Streams that are never destroyed keep the
+// queues the first context's careful order gave them.  Contexts alive at the same time still get streams of their own.
+namespace {
+struct StreamSet {
+  hipStream_t g[cvo_ctx::MAX_GROUPS] = {};
+  hipStream_t upload = nullptr;
+};
+std::mutex g_stream_pool_mutex;
+std::map<int, std::vector<StreamSet>> g_stream_pool;
+}  // namespace
+
 int cvo_ctx_create(int device, cvo_ctx** out) {
   if (!out) return CVO_E_INVALID;
   *out = nullptr;
@@ -961,7 +979,20 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
   c->device = device;
   for (const char* name : kOptionNames)  // the ONLY place the library reads the environment
     if (const char* v = std::getenv((std::string("CVO_") + name).c_str())) c->opt[name] = v;
-  bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+  bool pooled = false;
+  {
+    std::lock_guard<std::mutex> lk(g_stream_pool_mutex);
+    auto& pool = g_stream_pool[device];
+    if (!pool.empty()) {
+      const StreamSet ss = pool.back();
+      pool.pop_back();
+      for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++) c->gstream[g] = ss.g[g];
+      c->stream = ss.g[0];
+      c->upload_stream = ss.upload;
+      pooled = true;
+    }
+  }
+  bool ok = (pooled || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess) &&
             hipMalloc(&c->d_params, sizeof(DevParams)) == hipSuccess &&
             hipMalloc(&c->d_teams, sizeof(ResidentTeams) * cvo_ctx::MAX_GROUPS) == hipSuccess &&
             // (cleared on the context's own stream: a synchronous hipMemset would run on the NULL stream, whose hardware
@@ -988,7 +1019,7 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
   }
   c->gstream[0] = c->stream;
   for (int g = 0; ok && g < cvo_ctx::MAX_GROUPS; g++) {
-    if (g) ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess;
+    if (g && !pooled) ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 2; i++) ok = ok && hipEventCreateWithFlags(&c->ev_chk[i][g], hipEventDisableTiming) == hipSuccess;
   }
@@ -1002,7 +1033,10 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
     ok = ok && hipGetLastError() == hipSuccess;
   }
   for (int g = 0; ok && g < 4; g++) ok = ok && hipStreamSynchronize(c->gstream[g]) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
+  if (!pooled) ok = ok && hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
+  // k_kd_order keeps the keys of a whole cloud in LDS: up to 128 KB of dynamic shared memory
+  ok = ok && hipFuncSetAttribute((const void*)k_kd_order, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(sizeof(unsigned long long) * KD_MAX_POINTS)) == hipSuccess;
   if (!ok) {
     cvo_ctx_destroy(c);
     return CVO_E_HIP;
@@ -1020,17 +1054,32 @@ void cvo_ctx_destroy(cvo_ctx* c) {
   free_workspace(c);
   if (c->d_params) (void)hipFree(c->d_params);
   if (c->d_teams) (void)hipFree(c->d_teams);
+  if (c->d_kd_jobs) (void)hipFree(c->d_kd_jobs);
   for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++) {
     for (int i = 0; i < 2; i++)
       if (c->ev_chk[i][g]) (void)hipEventDestroy(c->ev_chk[i][g]);
     if (c->ev_join[g]) (void)hipEventDestroy(c->ev_join[g]);
-    if (g && c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
-  if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
+  if (c->upload_stream) (void)hipStreamSynchronize(c->upload_stream);
+  {  // a complete set goes back to the device's pool (see StreamSet); a partial one (failed creation) is destroyed
+    bool complete = c->upload_stream != nullptr;
+    for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++) complete = complete && c->gstream[g] != nullptr;
+    if (complete) {
+      StreamSet ss;
+      for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++) ss.g[g] = c->gstream[g];
+      ss.upload = c->upload_stream;
+      std::lock_guard<std::mutex> lk(g_stream_pool_mutex);
+      g_stream_pool[c->device].push_back(ss);
+    } else {
+      for (int g = 1; g < cvo_ctx::MAX_GROUPS; g++)
+        if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
+      if (c->stream) (void)hipStreamDestroy(c->stream);
+      if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
+    }
+  }
   delete c;
 }
 
@@ -1070,7 +1119,9 @@ struct KdPoint {
   float c[3];
   int i;
 };
-static void kd_split(KdPoint* pts, int lo, int hi) {
+// vext != nullptr: the split axis comes from the root box's extents, halved once per split along that axis - one axis
+// per level, what k_kd_order does on the device (option ORDER=virtual: the host twin of the device ordering)
+static void kd_split(KdPoint* pts, int lo, int hi, const float* vext = nullptr) {
   const int n = hi - lo;
   if (n <= 4) return;
   const int unit = n > 512 ? 512 : (n > 64 ? 64 : 4);
@@ -1078,27 +1129,36 @@ static void kd_split(KdPoint* pts, int lo, int hi) {
   if (left >= n) left -= unit;
   if (left <= 0) return;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int k = lo; k < hi; k++)
+  if (!vext)
+    for (int k = lo; k < hi; k++)
+      for (int c = 0; c < 3; c++) {
+        const float v = pts[k].c[c];
+        mn[c] = std::min(mn[c], v);
+        mx[c] = std::max(mx[c], v);
+      }
+  else
     for (int c = 0; c < 3; c++) {
-      const float v = pts[k].c[c];
-      mn[c] = std::min(mn[c], v);
-      mx[c] = std::max(mx[c], v);
+      mn[c] = 0.f;
+      mx[c] = vext[c];
     }
   int axis = 0;
   for (int c = 1; c < 3; c++)
     if (mx[c] - mn[c] > mx[axis] - mn[axis]) axis = c;
+  float vnext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+  vnext[axis] *= 0.5f;
   // the records themselves are permuted (no index indirection in the comparator: ~4x faster at 10k points)
   std::nth_element(pts + lo, pts + lo + left, pts + hi, [axis](const KdPoint& a, const KdPoint& b) {
     return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.i < b.i);
   });
-  kd_split(pts, lo, lo + left);
-  kd_split(pts, lo + left, hi);
+  kd_split(pts, lo, lo + left, vext ? vnext : nullptr);
+  kd_split(pts, lo + left, hi, vext ? vnext : nullptr);
 }
 
-static void spatial_order(const float* x4, int n, std::vector<int>& order, bool no_sort) {
+static void spatial_order(const float* x4, int n, std::vector<int>& order, bool no_sort, bool level_axes) {
   order.resize(n);
   for (int i = 0; i < n; i++) order[i] = i;
   if (n < 8 || no_sort) return;
+
   std::vector<KdPoint> pts((size_t)n);
   for (int i = 0; i < n; i++) {
     for (int c = 0; c < 3; c++) {
@@ -1108,7 +1168,18 @@ static void spatial_order(const float* x4, int n, std::vector<int>& order, bool 
     }
     pts[i].i = i;
   }
-  kd_split(pts.data(), 0, n);
+  if (level_axes) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < n; i++)
+      for (int c = 0; c < 3; c++) {
+        mn[c] = std::min(mn[c], pts[i].c[c]);
+        mx[c] = std::max(mx[c], pts[i].c[c]);
+      }
+    const float ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    kd_split(pts.data(), 0, n, ext);
+  } else {
+    kd_split(pts.data(), 0, n);
+  }
   for (int r = 0; r < n; r++) order[r] = pts[r].i;
 }
 
@@ -1124,7 +1195,15 @@ struct HostCloud {
   const char* geo;   size_t geo_stride;    // 2 floats, or NULL
 };
 
-static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t stream, cvo_cloud** out) {
+// A cloud whose spatial ordering runs on the device (k_kd_order): staged and copied, not yet ordered.  The staging
+// buffer lives until the caller has synchronised the stream the copy was enqueued on.
+struct StagedCloud {
+  cvo_cloud* c = nullptr;
+  KdJob job{};          // job.n == 0: ordered on the host, nothing left to do
+  std::vector<char> stage;
+};
+
+static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t stream, StagedCloud* sc) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int n = h.n;
   cvo_cloud* c = new cvo_cloud();
@@ -1132,17 +1211,39 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
   c->device = ctx->device;
   c->n = n;
   const size_t nn = (size_t)std::max(n, 1);
+  // Where the ordering runs: on the device for clouds k_kd_order holds in LDS (the host then only stages, allocates and
+  // copies: ~0.1 ms of CPU per 10k cloud instead of 1.2), on this thread otherwise (tiny, huge or non-finite clouds,
+  // CVO_NO_SORT, CVO_ORDER=host).
+  bool finite = true;
+  for (int i = 0; i < n && finite; i++) {
+    const float* p = reinterpret_cast<const float*>(h.xyz + (size_t)i * h.xyz_stride);
+    finite = std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]);
+  }
+  const char* ord = ctx_opt(ctx, "ORDER");
+  const bool device_order = n >= 8 && n <= KD_MAX_POINTS && finite && ctx_opt(ctx, "NO_SORT") == nullptr &&
+                            !(ord && (std::strcmp(ord, "host") == 0 || std::strcmp(ord, "virtual") == 0));
   size_t off = 0;
   auto take = [&](size_t bytes) {
     const size_t o = off;
     off = align_up(off + bytes, 256);
     return o;
   };
-  const size_t o_x4 = take(sizeof(float4) * nn), o_xs4 = take(sizeof(float4) * nn), o_order = take(sizeof(int) * nn),
-               o_inv = take(sizeof(int) * nn);
+  // (device ordering: the caller's arrays go up in ORIGINAL order - x4 stays, the raw attribute arrays are scratch - and
+  // the kernel writes the spatially ordered ones; host ordering: everything is staged in its final form)
+  const size_t o_x4 = take(sizeof(float4) * nn);
+  const size_t o_rawf = device_order && h.feat ? take(sizeof(float) * FD * nn) : 0, o_rawl = device_order && h.label ? take(sizeof(float) * NC * nn) : 0,
+               o_rawg = device_order && h.geo ? take(sizeof(float) * 2 * nn) : 0;
+  const size_t up_bytes_device = off;
+  const size_t o_xs4 = take(sizeof(float4) * nn), o_order = take(sizeof(int) * nn), o_inv = take(sizeof(int) * nn);
   const size_t o_feat = h.feat ? take(sizeof(float4) * 2 * nn) : 0, o_label = h.label ? take(sizeof(float4) * 5 * nn) : 0,
                o_geo = h.geo ? take(sizeof(float2) * nn) : 0;
-  std::vector<char> stage(off, 0);  // (pageable: the copy below is synchronous with respect to this thread only)
+  int NP = KD_THREADS;
+  while (NP < n) NP *= 2;
+  const size_t o_segpos = device_order ? take(sizeof(unsigned short) * (size_t)NP) : 0,
+               o_seglo = device_order ? take(sizeof(unsigned short) * 2 * KD_MAX_SEGS) : 0;
+  const size_t up_bytes = device_order ? up_bytes_device : off;
+  std::vector<char>& stage = sc->stage;
+  stage.assign(up_bytes, 0);  // (pageable: kept alive by the caller until the stream has been synchronised)
   float* x4 = reinterpret_cast<float*>(&stage[o_x4]);
   double sx = 0, sy = 0, sz = 0, r2max = 0;
   for (int i = 0; i < n; i++) {
@@ -1164,30 +1265,45 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
     c->cz = (float)(sz / n);
   }
   if (!std::isfinite(c->cx) || !std::isfinite(c->cy) || !std::isfinite(c->cz)) c->cx = c->cy = c->cz = 0.f;
-  std::vector<int> order;
-  spatial_order(x4, n, order, ctx_opt(ctx, "NO_SORT") != nullptr);
-  // colour, class distributions and geometric types are kept in SPATIAL order only (position r holds the attributes of
-  // point order[r]): the kernels index them by sorted position, like the coordinates they gather per candidate
-  if (h.feat) {
-    float* f8 = reinterpret_cast<float*>(&stage[o_feat]);
-    for (int r = 0; r < n; r++) std::memcpy(&f8[FD_PAD * (size_t)r], h.feat + (size_t)order[r] * h.feat_stride, sizeof(float) * FD);
+  if (device_order) {
+    if (h.feat) {
+      float* f = reinterpret_cast<float*>(&stage[o_rawf]);
+      for (int i = 0; i < n; i++) std::memcpy(&f[FD * (size_t)i], h.feat + (size_t)i * h.feat_stride, sizeof(float) * FD);
+    }
+    if (h.label) {
+      float* l = reinterpret_cast<float*>(&stage[o_rawl]);
+      for (int i = 0; i < n; i++) std::memcpy(&l[NC * (size_t)i], h.label + (size_t)i * h.label_stride, sizeof(float) * NC);
+    }
+    if (h.geo) {
+      float* g = reinterpret_cast<float*>(&stage[o_rawg]);
+      for (int i = 0; i < n; i++) std::memcpy(&g[2 * (size_t)i], h.geo + (size_t)i * h.geo_stride, sizeof(float) * 2);
+    }
+  } else {
+    std::vector<int> order;
+    spatial_order(x4, n, order, ctx_opt(ctx, "NO_SORT") != nullptr, ord && std::strcmp(ord, "virtual") == 0);
+    // colour, class distributions and geometric types are kept in SPATIAL order only (position r holds the attributes of
+    // point order[r]): the kernels index them by sorted position, like the coordinates they gather per candidate
+    if (h.feat) {
+      float* f8 = reinterpret_cast<float*>(&stage[o_feat]);
+      for (int r = 0; r < n; r++) std::memcpy(&f8[FD_PAD * (size_t)r], h.feat + (size_t)order[r] * h.feat_stride, sizeof(float) * FD);
+    }
+    if (h.label) {
+      float* l20 = reinterpret_cast<float*>(&stage[o_label]);
+      for (int r = 0; r < n; r++) std::memcpy(&l20[NC_PAD * (size_t)r], h.label + (size_t)order[r] * h.label_stride, sizeof(float) * NC);
+    }
+    if (h.geo) {
+      float* g2 = reinterpret_cast<float*>(&stage[o_geo]);
+      for (int r = 0; r < n; r++) std::memcpy(&g2[2 * (size_t)r], h.geo + (size_t)order[r] * h.geo_stride, sizeof(float) * 2);
+    }
+    float* xs = reinterpret_cast<float*>(&stage[o_xs4]);
+    for (int r = 0; r < n; r++) std::memcpy(&xs[4 * (size_t)r], &x4[4 * (size_t)order[r]], 16);
+    if (n > 0) std::memcpy(&stage[o_order], order.data(), sizeof(int) * (size_t)n);
+    {
+      int* inv = reinterpret_cast<int*>(&stage[o_inv]);
+      for (int r = 0; r < n; r++) inv[order[r]] = r;
+    }
+    c->h_order = std::move(order);
   }
-  if (h.label) {
-    float* l20 = reinterpret_cast<float*>(&stage[o_label]);
-    for (int r = 0; r < n; r++) std::memcpy(&l20[NC_PAD * (size_t)r], h.label + (size_t)order[r] * h.label_stride, sizeof(float) * NC);
-  }
-  if (h.geo) {
-    float* g2 = reinterpret_cast<float*>(&stage[o_geo]);
-    for (int r = 0; r < n; r++) std::memcpy(&g2[2 * (size_t)r], h.geo + (size_t)order[r] * h.geo_stride, sizeof(float) * 2);
-  }
-  float* xs = reinterpret_cast<float*>(&stage[o_xs4]);
-  for (int r = 0; r < n; r++) std::memcpy(&xs[4 * (size_t)r], &x4[4 * (size_t)order[r]], 16);
-  if (n > 0) std::memcpy(&stage[o_order], order.data(), sizeof(int) * (size_t)n);
-  {
-    int* inv = reinterpret_cast<int*>(&stage[o_inv]);
-    for (int r = 0; r < n; r++) inv[order[r]] = r;
-  }
-  c->h_order = std::move(order);
   hipError_t e = hipMalloc(&c->slab, off);
   c->slab_bytes = off;
   if (e != hipSuccess) {
@@ -1202,14 +1318,87 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
   c->label = h.label ? (float4*)(c->slab + o_label) : nullptr;
   c->geo = h.geo ? (float2*)(c->slab + o_geo) : nullptr;
   if (n > 0) {
-    e = hipMemcpyAsync(c->slab, stage.data(), off, hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    e = hipMemcpyAsync(c->slab, stage.data(), up_bytes, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) {
       cvo_cloud_free(c);
       return fail(ctx, CVO_E_HIP, std::string("cloud upload: ") + hipGetErrorString(e));
     }
   }
-  *out = c;
+  sc->c = c;
+  sc->job = KdJob{};
+  if (device_order) {
+    KdJob& J = sc->job;
+    J.n = n;
+    J.NP = NP;
+    J.x4 = c->x4;
+    J.seg_of_pos = (unsigned short*)(c->slab + o_segpos);
+    J.seg_lo = (unsigned short*)(c->slab + o_seglo);
+    J.order = c->order;
+    J.inv = c->inv;
+    J.xs4 = c->xs4;
+    J.raw_feat = h.feat ? (const float*)(c->slab + o_rawf) : nullptr;
+    J.feat = c->feat;
+    J.raw_label = h.label ? (const float*)(c->slab + o_rawl) : nullptr;
+    J.label = c->label;
+    J.raw_geo = h.geo ? (const float*)(c->slab + o_rawg) : nullptr;
+    J.geo = c->geo;
+    c->h_order.assign((size_t)n, 0);
+  }
+  return CVO_OK;
+}
+
+// Second half of an upload: the copies of `clouds` have been enqueued (and, for upload_many, completed) - order the
+// clouds that asked for it with ONE launch of k_kd_order (a block per cloud) on the context's upload stream, bring the
+// permutations back (exports map rows through them), synchronise.  On error every cloud of the list is released.
+static int finish_uploads(cvo_ctx* ctx, std::vector<StagedCloud>& clouds) {
+  std::vector<KdJob> jobs;
+  int np_max = 0;
+  for (auto& sc : clouds)
+    if (sc.c && sc.job.n > 0) {
+      jobs.push_back(sc.job);
+      np_max = std::max(np_max, sc.job.NP);
+    }
+  hipError_t e = hipSuccess;
+  std::lock_guard<std::mutex> lk(ctx->kd_mutex);
+  if (!jobs.empty()) {
+    if ((int)jobs.size() > ctx->kd_jobs_cap) {
+      if (ctx->d_kd_jobs) (void)hipFree(ctx->d_kd_jobs);
+      ctx->d_kd_jobs = nullptr;
+      ctx->kd_jobs_cap = 0;
+      e = hipMalloc(&ctx->d_kd_jobs, sizeof(KdJob) * jobs.size());
+      if (e == hipSuccess) ctx->kd_jobs_cap = (int)jobs.size();
+    }
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(ctx->d_kd_jobs, jobs.data(), sizeof(KdJob) * jobs.size(), hipMemcpyHostToDevice, ctx->upload_stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_kd_order, dim3((unsigned)jobs.size()), dim3(KD_THREADS), sizeof(unsigned long long) * (size_t)np_max,
+                         ctx->upload_stream, (const KdJob*)ctx->d_kd_jobs);
+      e = hipGetLastError();
+    }
+    for (auto& sc : clouds)
+      if (e == hipSuccess && sc.c && sc.job.n > 0)
+        e = hipMemcpyAsync(sc.c->h_order.data(), sc.c->order, sizeof(int) * (size_t)sc.job.n, hipMemcpyDeviceToHost, ctx->upload_stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->upload_stream);
+  if (e != hipSuccess) {
+    for (auto& sc : clouds) {
+      if (sc.c) cvo_cloud_free(sc.c);
+      sc.c = nullptr;
+    }
+    return fail(ctx, CVO_E_HIP, std::string("cloud upload (ordering): ") + hipGetErrorString(e));
+  }
+  return CVO_OK;
+}
+
+// One cloud on the context's upload stream (cvo_cloud_upload, cvo_cloud_upload_aos192).
+static int upload_one(cvo_ctx* ctx, const HostCloud& h, cvo_cloud** out) {
+  std::lock_guard<std::mutex> lk(ctx->upload_mutex);
+  std::vector<StagedCloud> one(1);
+  int rc = upload_host_cloud(ctx, h, ctx->upload_stream, &one[0]);
+  if (rc != CVO_OK) return rc;
+  rc = finish_uploads(ctx, one);
+  if (rc != CVO_OK) return rc;
+  *out = one[0].c;
   return CVO_OK;
 }
 
@@ -1218,8 +1407,7 @@ int cvo_cloud_upload(cvo_ctx* ctx, int n, const float* xyz, const float* feat, c
   if (!ctx || !out || n < 0 || (n > 0 && !xyz)) return fail(ctx, CVO_E_INVALID, "cvo_cloud_upload: bad argument");
   const HostCloud h{n, (const char*)xyz, 12, (const char*)feat, sizeof(float) * FD, (const char*)label, sizeof(float) * NC,
                     (const char*)geotype, 8};
-  std::lock_guard<std::mutex> lk(ctx->upload_mutex);
-  return upload_host_cloud(ctx, h, ctx->upload_stream, out);
+  return upload_one(ctx, h, out);
 }
 
 // n_clouds clouds from a pool of host threads (each cloud: spatial ordering on its thread, one allocation, one copy on
@@ -1238,11 +1426,16 @@ static int upload_many_impl(cvo_ctx* ctx, int n_clouds, const int* n, const floa
   std::vector<int> rcs(T, CVO_OK);
   std::vector<std::string> errs(T);
   std::atomic<int> next(0);
+  std::vector<StagedCloud> staged((size_t)n_clouds);
   auto work_body = [&](int t) {
-    hipStream_t s = nullptr;
-    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    // Every thread copies on the context's ONE upload stream (enqueueing from several threads is legal; a pageable
+    // source makes each copy synchronous for its thread anyway).  No temporary streams: HIP deals streams onto hardware
+    // queues in creation order, and streams created between two contexts used to push a later context's sub-batch
+    // streams onto shared queues (3x slower batches, scripts/upload_probe.py).
+    hipStream_t s = ctx->upload_stream;
+    if (hipSetDevice(ctx->device) != hipSuccess) {
       rcs[t] = CVO_E_HIP;
-      errs[t] = "cvo_cloud_upload_many: stream creation failed";
+      errs[t] = "cvo_cloud_upload_many: hipSetDevice failed";
       return;
     }
     cvo_ctx local;  // error text of this thread (the shared context's string is not thread-safe)
@@ -1254,17 +1447,16 @@ static int upload_many_impl(cvo_ctx* ctx, int n_clouds, const int* n, const floa
       const HostCloud h{n[q], (const char*)xyz[q], 12, (const char*)(feat ? feat[q] : nullptr), sizeof(float) * FD,
                         (const char*)(label ? label[q] : nullptr), sizeof(float) * NC,
                         (const char*)(geotype ? geotype[q] : nullptr), 8};
-      cvo_cloud* c = nullptr;
-      const int rc = upload_host_cloud(&local, h, s, &c);
+      const int rc = upload_host_cloud(&local, h, s, &staged[q]);
       if (rc != CVO_OK) {
         rcs[t] = rc;
         errs[t] = local.err;
         break;
       }
-      c->ctx = ctx;
-      out[q] = c;
+      staged[q].c->ctx = ctx;
+      out[q] = staged[q].c;
     }
-    (void)hipStreamDestroy(s);
+    // (the ordering kernel of the call is launched on the same stream: it runs after every copy)
   };
   auto work = [&](int t) {  // (bad_alloc of a staging buffer etc. must not leave a worker or cross the C ABI)
     try {
@@ -1292,7 +1484,10 @@ static int upload_many_impl(cvo_ctx* ctx, int n_clouds, const int* n, const floa
       }
       return fail(ctx, rcs[t], errs[t]);
     }
-  return CVO_OK;
+  const int rc = finish_uploads(ctx, staged);  // the spatial ordering of all clouds: one kernel launch
+  if (rc != CVO_OK)
+    for (int q = 0; q < n_clouds; q++) out[q] = nullptr;
+  return rc;
 }
 
 int cvo_cloud_upload_many(cvo_ctx* ctx, int n_clouds, const int* n, const float* const* xyz, const float* const* feat,
@@ -1315,8 +1510,7 @@ int cvo_cloud_upload_aos192(cvo_ctx* ctx, int n, const void* pts, cvo_cloud** ou
   // label_distribution@44, geometric_type@120, sizeof = 192: read in place, record by record.
   const char* b = (const char*)pts;
   const HostCloud h{n, b, 192, b + 20, 192, b + 44, 192, b + 120, 192};
-  std::lock_guard<std::mutex> lk(ctx->upload_mutex);
-  return upload_host_cloud(ctx, h, ctx->upload_stream, out);
+  return upload_one(ctx, h, out);
 }
 
 // ---- multi-frame edge kernel ---------------------------------------------------------
@@ -2043,6 +2237,12 @@ int cvo_debug_resident_ticks(cvo_ctx* ctx, unsigned long long* out, int* blocks_
   for (int q = 0; q < 16; q++) out[q] = 0ull;  // (a library built without k_resident: no resident launch ever ran)
 #endif
   if (blocks_per_pair) *blocks_per_pair = ctx->last_resident_nb;
+  return CVO_OK;
+}
+
+int cvo_debug_cloud_order(const cvo_cloud* c, int* out) {
+  if (!c || !out) return CVO_E_INVALID;
+  for (int r = 0; r < c->n; r++) out[r] = c->h_order[r];
   return CVO_OK;
 }
 
