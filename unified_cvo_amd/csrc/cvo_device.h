@@ -47,6 +47,8 @@ struct DevParams {
   float rebuild_shrink;  // rebuild when ell < rebuild_shrink * ell_build (the lists would be (1/shrink)^3 too long)
   int lean_U;            // iterations between two rebuild opportunities in the lean graph
   int lean_U2;           // ... and in the short lean graph (motion too fast for lean_U, slow enough for a list to last lean_U2)
+  int calm_U;            // a pair whose list outlives this many more iterations at its current speed reports itself calm
+                         // (want = -1): the host may give it one rebuild opportunity per chunk (0 = never)
   int shrink_align;      // optional (ell-shrink) rebuilds wait for an iteration count with (k & shrink_align) == 0:
                          // 63 when several pairs share a sub-batch (their rebuilds then share a pass), 0 otherwise
   float skin_min, skin_max;  // clamp of the skin (fractions of the cut-off radius) before skin_frac
@@ -99,7 +101,7 @@ struct PairState {
   // get a thin skin; only the farthest rows pay for the whole motion bound.
   float skin_rot, skin_tr;
   int n_builds;
-  int want_full, n_stalls;  // host hint: 2 = this pair needs the graph with per-iteration rebuild / dense kernels,
+  int want_full, n_stalls;  // host hint: 4 / 2 = this pair needs the graph with per-iteration rebuild (4: and the dense kernel), -1 = calm,
                             // 1 = the short lean graph (a rebuild opportunity every lean_U2 iterations), 0 = the lean graph
   int all_dense;
   float skin_scale;  // backs the skin off while rows overflow their lists (see update_body)
@@ -111,6 +113,7 @@ struct PairState {
   // block that finishes the pair's work in the launch, [0] k_assoc (lean graph; its last interval is left in
   // clk_last_assoc by the flow gate and added by the update) / [1] k_coeff, summed over clk_n iterations
   unsigned clk_last_assoc, clk_n[2];
+  float last_used, last_rate;  // list reuse: share of the motion allowance used since the build / used per iteration (statistics)
   int K_last;  // num_neighbors of the last EXECUTED iteration: the row stride upstream wrote its A matrix with (0: none ran)
   unsigned long long clk_sum[2];
   // ---- everything above is the "hot" prefix k_update stages through LDS ----

@@ -99,7 +99,7 @@ static const char* const kOptionNames[] = {
     "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
     "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
     "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "RESIDENT",
-    "RESIDENT_BLOCKS", "ORDER"};
+    "RESIDENT_BLOCKS", "ORDER", "NO_NODENSE", "CALM_U"};
 
 struct cvo_ctx {
   int device = 0;
@@ -135,9 +135,9 @@ struct cvo_ctx {
   hipEvent_t ev_chk[2][MAX_GROUPS] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
   // graph cache (one per group)
-  // [group][0 = full chunk, 1 = lean chunk, 2 = short lean chunk; + 3 for the instrumented kernels (CVO_KERNEL_CLOCK /
+  // [group][0 = full chunk, 1 = lean chunk, 2 = short lean chunk, 3 = full chunk without k_assoc_dense, 4 = calm chunk (lean, one rebuild opportunity); + 5 for the instrumented kernels (CVO_KERNEL_CLOCK /
   // CVO_PHASE_TICKS), cached side by side so that a caller can time single steps of a loop without re-capturing]
-  static constexpr int GRAPH_VARIANTS = 12;  // ... x 2 chunk lengths (the early chunks of a call are shorter)
+  static constexpr int GRAPH_VARIANTS = 20;  // ... x 2 chunk lengths (the early chunks of a call are shorter)
   hipGraphExec_t graph_exec[MAX_GROUPS][GRAPH_VARIANTS] = {};
   GraphKey graph_key[MAX_GROUPS][GRAPH_VARIANTS] = {};
   int last_chunks = 0, last_lean_launches = 0, last_full_launches = 0;
@@ -416,7 +416,7 @@ void choose_scan_config(const cvo_ctx* ctx, int n_pairs, int NG, int Mpad, int* 
   *gpb_out = gpb;
 }
 
-void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const DevParams* dp, const int* st, int force) {
+void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const DevParams* dp, const PairState* st, int force) {
   switch (T) {
     case 1: hipLaunchKernelGGL(k_scan<1>, grid, dim3(256), 0, s, descs, dp, st, force); break;
     case 2: hipLaunchKernelGGL(k_scan<2>, grid, dim3(256), 0, s, descs, dp, st, force); break;
@@ -429,7 +429,7 @@ void launch_scan(hipStream_t s, int T, dim3 grid, const PairDesc* descs, const D
 inline dim3 row_grid(int nblk, int n_pairs) { return dim3((unsigned)(nblk * ((n_pairs + 7) / 8 * 8))); }
 
 void launch_list(hipStream_t s, bool idx16, int N, int n_pairs, const PairDesc* descs, const DevParams* dp,
-                 const int* st) {
+                 const PairState* st) {
   const int nblk = (N + LIST_THREADS - 1) / LIST_THREADS;
   const dim3 blk(LIST_THREADS), grid = row_grid(nblk, n_pairs);
   if (idx16)
@@ -513,6 +513,7 @@ void launch_dense(hipStream_t s, bool general, int N, int n_pairs, const PairDes
 struct LaunchGeom {
   int n_pairs, p0, T, gx, gy, nba, nbc, npb, N, csplit;
   int group = 0;        // sub-batch index (its stream, its ResidentTeams)
+  int horizon_cap = 1 << 20;  // the lean graph's period (DevParams::lean_U)
   int res_nb = 0;       // k_resident: blocks per pair (0 = the lean graphs use the two-kernel iteration)
   bool idx16, general, instr, verify;
   hipStream_t stream;
@@ -527,10 +528,10 @@ void launch_init(cvo_ctx* c, const LaunchGeom& g) {
 // The rebuild kernels: no-ops (early exit) unless k_update flagged the pair's candidate list as expired.
 void launch_rebuild(cvo_ctx* c, const LaunchGeom& g) {
   const PairDesc* descs = c->d_descs + g.p0;
-  const int* st = c->d_status + g.p0;
-  hipLaunchKernelGGL(k_prep, dim3(g.npb, g.n_pairs), dim3(PREP_THREADS), 0, g.stream, descs, c->d_params, st);
-  launch_scan(g.stream, g.T, dim3(g.gx, g.gy, g.n_pairs), descs, c->d_params, st, 0);
-  launch_list(g.stream, g.idx16, g.N, g.n_pairs, descs, c->d_params, st);
+  const PairState* states = c->d_states + g.p0;
+  hipLaunchKernelGGL(k_prep, dim3(g.npb, g.n_pairs), dim3(PREP_THREADS), 0, g.stream, descs, c->d_params, states);
+  launch_scan(g.stream, g.T, dim3(g.gx, g.gy, g.n_pairs), descs, c->d_params, states, 0);
+  launch_list(g.stream, g.idx16, g.N, g.n_pairs, descs, c->d_params, states);
 }
 
 // One optimiser iteration over the current lists: association, [overflow rows], coefficients + update (the last
@@ -577,7 +578,17 @@ void launch_resident(cvo_ctx* c, const LaunchGeom& g, int U) {
 
 // A chunk of U iterations.  Full: every iteration can rebuild its candidate list and serve overflow rows.
 // Lean: rebuild opportunities only every lean_U iterations; pairs that need more wait for a full chunk.
+// lean_U == 0: the full chunk WITHOUT k_assoc_dense - a rebuild opportunity in every iteration with the full graph's
+// rebuild rule (no horizon), but a pair whose rows overflow their lists waits (and asks for the dense kernel: want = 4).
+// Large clouds run their fast first iterations here: the dense kernel, launched for nothing, is 5 us + a launch gap.
 void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U) {
+  if (lean && lean_U == 0) {
+    for (int u = 0; u < U; u++) {
+      launch_rebuild(c, g);
+      launch_core(c, g, true, 2);
+    }
+    return;
+  }
   if (!lean) {
     for (int u = 0; u < U; u++) {
       launch_rebuild(c, g);
@@ -597,7 +608,9 @@ void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U)
   for (int u = 0; u < U; u++) {
     if (u % lean_U == 0) launch_rebuild(c, g);
     const bool last = (u % lean_U == lean_U - 1) || u == U - 1;
-    launch_core(c, g, true, (last ? 2 : 0) | (lean_U << 8));
+    // (horizon of the rebuild rule: the lean graph's period even in a calm chunk, whose one opportunity per chunk is a bet
+    // on the list outliving the linear prediction - a pair that loses it waits for the next chunk)
+    launch_core(c, g, true, (last ? 2 : 0) | (std::min(lean_U, g.horizon_cap) << 8));
   }
 }
 
@@ -696,6 +709,12 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   dp.groups_per_block = S->gpb;
   dp.lean_U = 8;
   if (const char* e = ctx_opt(ctx, "LEAN_U")) dp.lean_U = std::max(1, atoi(e));
+  // Calm pairs (see PairState::want_full).  In the end game the pose jitters around its optimum: the motion PER ITERATION
+  // stays at ~10 % of a list's allowance while the allowance used SINCE THE BUILD stays below 5 % for hundreds of
+  // iterations (CVO_VERBOSE=2 prints both), so a linear "outlives the next 64 iterations" test never fires.  Four
+  // iterations of linear margin it is: 62.3 -> 61.4 ms per headline step, single pairs -1.5 ... -2.5 %, no additional waits.
+  dp.calm_U = 4;
+  if (const char* e = ctx_opt(ctx, "CALM_U")) dp.calm_U = std::max(0, atoi(e));
   dp.lean_U2 = 2;
   if (const char* e = ctx_opt(ctx, "LEAN_U2")) dp.lean_U2 = std::max(0, atoi(e));  // 0 = no short lean graph
   if (dp.lean_U2 >= dp.lean_U) dp.lean_U2 = 0;
@@ -838,6 +857,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   // run side by side: row blocks per pair = what keeps the total at or below 1.5 blocks of 256 threads per CU (the
   // kernel is built for 2).
   S->geom.res_nb = 0;
+  S->geom.horizon_cap = std::max(1, dp.lean_U);
   // OFF by default (option RESIDENT=1): measured on MI355X it does not beat the two launches it replaces - DESIGN.md
   // section 3, ROUND_LOG.md round 3 have the numbers (an L2-local hop is 260 ns, a reduce + broadcast among the blocks of
   // a pair 1.5 - 2 us: what a launch boundary plus its cold prologue cost).  Kept because it is bit-identical, bounded
@@ -1630,10 +1650,10 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     const int lean_U = std::max(1, std::min(dp.lean_U, U));
     bool resident_broken = false;
     const int lean_U2 = std::max(0, std::min(dp.lean_U2, U));
-    auto lean_period = [&](int v) { return v == 2 ? lean_U2 : lean_U; };
-    const int v_instr = S.geom.instr ? 3 : 0;  // the instrumented kernels have their own cached graphs
+    auto lean_period = [&](int v, int Uc) { return v == 4 ? Uc : (v == 3 ? 0 : (v == 2 ? lean_U2 : lean_U)); };
+    const int v_instr = S.geom.instr ? 5 : 0;  // the instrumented kernels have their own cached graphs
     auto get_graph = [&](int g, int v, int Uc) -> int {
-      const int vi = v + v_instr + (Uc != U ? 6 : 0);
+      const int vi = v + v_instr + (Uc != U ? 10 : 0);
       GraphKey key;
       key.n_pairs = geom[g].n_pairs;
       key.p0 = geom[g].p0;
@@ -1645,7 +1665,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       key.npb = S.geom.npb;
       key.idx16 = S.geom.idx16 ? 1 : 0;
       key.general = S.geom.general ? 1 : 0;
-      key.U = Uc * 256 + lean_period(v);
+      key.U = Uc * 256 + lean_period(v, Uc) + (v == 3 ? 128 : 0);
       key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0) | (geom[g].res_nb << 2);
       key.arena = geom[g].arena.base;
       key.stride256 = geom[g].arena.stride256;
@@ -1657,7 +1677,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       }
       hipGraph_t gr = nullptr;
       HIP_TRY(ctx, hipStreamBeginCapture(geom[g].stream, hipStreamCaptureModeThreadLocal));
-      launch_chunk(ctx, geom[g], Uc, v != 0, lean_period(v));
+      launch_chunk(ctx, geom[g], Uc, v != 0, lean_period(v, Uc));
       // (the capture is always ended, whatever the launches reported: a stream left in capture mode would poison
       // every later call on this context)
       const hipError_t e_launch = hipGetLastError();
@@ -1678,8 +1698,12 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     const int n_chunks = (max_iter + U - 1) / U;
     const int chunk_cap = 4 * n_chunks + 16;
     const bool allow_lean = ctx_opt(ctx, "NO_LEAN") == nullptr;
-    int graph_next[cvo_ctx::MAX_GROUPS];  // 0 = full, 1 = lean, 2 = short lean
-    for (int g = 0; g < G; g++) graph_next[g] = 0;  // the first iterations move fast: full graph
+    int graph_next[cvo_ctx::MAX_GROUPS];  // 0 = full, 1 = lean, 2 = short lean, 3 = full without the dense kernel
+    // the first iterations move fast: full graph - for large clouds without the dense kernel (rows that overflow their
+    // lists are a small-cloud / huge-lengthscale matter; a pair that has some waits two chunks for the real full graph)
+    const bool start_nodense = allow_lean && S.N > 4096 && ctx_opt(ctx, "NO_NODENSE") == nullptr;
+    const bool allow_calm = dp.calm_U > 0;
+    for (int g = 0; g < G; g++) graph_next[g] = start_nodense ? 3 : 0;
     bool all_done = false;
     int ch = 0;
     int n_lean_launch = 0, n_full_launch = 0;
@@ -1691,7 +1715,8 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       const int Uc = ch < n_early_chunks ? U : U_late;
       if (ctx_opt(ctx, "VERBOSE") && atoi(ctx_opt(ctx, "VERBOSE")) >= 3) {
         fprintf(stderr, "[cvo] chunk %d (%d iterations): graphs", ch, Uc);
-        for (int g = 0; g < G; g++) fprintf(stderr, " %s", graph_next[g] == 0 ? "full" : (graph_next[g] == 1 ? "lean" : "short"));
+        for (int g = 0; g < G; g++)
+          fprintf(stderr, " %s", graph_next[g] == 0 ? "full" : (graph_next[g] == 1 ? "lean" : (graph_next[g] == 2 ? "short" : (graph_next[g] == 3 ? "full-nodense" : "calm"))));
         fprintf(stderr, "\n");
       }
       for (int g = 0; g < G; g++) {
@@ -1701,10 +1726,10 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
           rc = get_graph(g, v, Uc);
           if (rc != CVO_OK) return rc;
           const auto tl = now();
-          HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g][v + v_instr + (Uc != U ? 6 : 0)], geom[g].stream));
+          HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g][v + v_instr + (Uc != U ? 10 : 0)], geom[g].stream));
           t_launch += ms_since(tl);
         } else {
-          launch_chunk(ctx, geom[g], Uc, v != 0, lean_period(v));
+          launch_chunk(ctx, geom[g], Uc, v != 0, lean_period(v, Uc));
           HIP_TRY(ctx, hipGetLastError());
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status[slot] + geom[g].p0, ctx->d_status + geom[g].p0,
@@ -1723,10 +1748,10 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
         all_done = true;
         for (int p = 0; p < n_pairs; p++) all_done = all_done && ctx->h_status[ws][p] != 0;
         for (int g = 0; g < G; g++) {
-          int want = 0;  // the most demanding unfinished pair of the group decides: 2 = full, 1 = short lean, 0 = lean
+          int want = -1;  // the most demanding unfinished pair of the group decides: 4 / 2 = full, 1 = short lean, 0 = lean, -1 = calm
           for (int p = geom[g].p0; p < geom[g].p0 + geom[g].n_pairs; p++)
             if (ctx->h_status[ws][p] == 0) want = std::max(want, ctx->h_status[ws][ctx->cap_pairs + p]);
-          if (want >= 3) {  // a resident launch timed out: its pairs are served by the two-kernel graphs from now on
+          if (want == 3) {  // a resident launch timed out: its pairs are served by the two-kernel graphs from now on
             want = 2;
             if (!resident_broken)
               fprintf(stderr, "[cvo] warning: a resident launch timed out (blocks of a pair not co-resident); this context "
@@ -1735,7 +1760,8 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
             for (int q = 0; q < G; q++) geom[q].res_nb = 0;  // (graphs are keyed on it: the next ones are captured anew)
           }
           if (want == 1 && lean_U2 <= 0) want = 2;
-          graph_next[g] = !allow_lean ? 0 : (want >= 2 ? 0 : (want == 1 ? 2 : 1));
+          // want: 0 lean, 1 short lean, 2 a rebuild opportunity in every iteration, 4 the dense kernel as well
+          graph_next[g] = !allow_lean ? 0 : (want >= 4 ? 0 : (want >= 2 ? (start_nodense ? 3 : 0) : (want == 1 ? 2 : (want == 0 || !allow_calm ? 1 : 4))));
           if (ctx_opt(ctx, "VERBOSE") && atoi(ctx_opt(ctx, "VERBOSE")) >= 2 && ch < 12) {
             int nw = 0;
             for (int p = geom[g].p0; p < geom[g].p0 + geom[g].n_pairs; p++) nw += ctx->h_status[ws][ctx->cap_pairs + p] != 0;
@@ -1790,6 +1816,11 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       stalls += ctx->h_states[p].n_stalls;
       its += ctx->h_states[p].status ? ctx->h_states[p].iterations : ctx->h_states[p].k;
     }
+    if (atoi(ctx_opt(ctx, "VERBOSE")) >= 2)
+      for (int p = 0; p < std::min(n_pairs, 4); p++)
+        fprintf(stderr, "[cvo]   pair %d: k %d, list allowance used %.3f, per iteration %.5f, want %d, builds %d, ell %.4f (built at %.4f)\n", p,
+                ctx->h_states[p].k, ctx->h_states[p].last_used, ctx->h_states[p].last_rate, ctx->h_states[p].want_full,
+                ctx->h_states[p].n_builds, ctx->h_states[p].ell, ctx->h_states[p].ell_build);
     fprintf(stderr, "[cvo] %d pairs, %d groups: %d chunks (%d full + %d lean group launches), iterations %ld, list builds %ld, waits %ld, %.3f ms\n",
             n_pairs, G, ctx->last_chunks, ctx->last_full_launches, ctx->last_lean_launches, its, builds, stalls, ms);
   }
@@ -2416,7 +2447,7 @@ int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms) {
     for (int g = 0; g < G; g++) {
       const int p0 = (int)((long)n_pairs * g / G), p1 = (int)((long)n_pairs * (g + 1) / G);
       launch_scan(ctx->stream, dp.T, dim3(ctx->last_gx, ctx->last_gy, p1 - p0), ctx->d_descs + p0, ctx->d_params,
-                  ctx->d_status + p0, variant);
+                  ctx->d_states + p0, variant);
     }
   };
   sweep();  // warm-up

@@ -40,8 +40,12 @@
 #ifndef CVO_COEFF_WAVES
 #define CVO_COEFF_WAVES 1
 #endif
+// k_assoc, geometry-only instantiation: 6 (68 VGPRs, no spills; the GENERAL one needs 121 and would spill: it stays at 1; with its 24.6 KB of LDS per block six blocks = six waves per SIMD fit a CU anyway).
+// The batch is throughput-bound above ~64 pairs (scripts/scale_probe.py): 62.2 vs 63.0 ms per step at 64 pairs, 111.9
+// vs 114.1 at 128.  k_coeff stays at 1: its register count comes from the update it carries in its last block (93), and
+// asking for 6 / 8 waves spills 68 / 140 bytes there (64.0 / 67.2 ms).
 #ifndef CVO_ASSOC_WAVES
-#define CVO_ASSOC_WAVES 1
+#define CVO_ASSOC_WAVES 6
 #endif
 
 namespace cvo_dev {
@@ -209,15 +213,20 @@ constexpr int SCAN_TILE_CAP = 128;  // (row group, slice) tiles a wave queues in
 
 template <int T>
 __global__ __launch_bounds__(256) void k_scan(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
-                                              const int* __restrict__ status, int force) {
+                                              const PairState* __restrict__ states, int force) {
   constexpr int RG = ROWS_PER_GROUP;
   // per-wave tile queue: the row operands of every overlapping group, fetched by the lane that found it
   __shared__ f32x4 s_rows[4][SCAN_TILE_CAP][RG];
   __shared__ int s_tile_g[4][SCAN_TILE_CAP];
-  if (!force && status[blockIdx.z] != 0) return;
+  // (the three rebuild kernels run as rebuild OPPORTUNITIES - every lean_U iterations in the lean graphs - and mostly
+  // find nothing to do: what they branch on comes from the kernel-argument state array in ONE round of scalar loads,
+  // not through status[] -> descriptor -> state pointer -> flag)
+  {
+    const PairState* __restrict__ st0 = states + blockIdx.z;  // == D->st
+    const int status_v = st0->status, rebuild_v = st0->rebuild, dense_v = st0->all_dense;
+    if (!force && (status_v != 0 || !rebuild_v || dense_v)) return;  // finished / the bitmap is still a superset / dense regime
+  }
   const PairDesc* __restrict__ D = descs + blockIdx.z;
-  if (!force && !D->st->rebuild) return;  // the bitmap of an earlier iteration is still a superset
-  if (!force && D->st->all_dense) return;  // dense regime: k_list sends every row to k_assoc_dense, no bitmap needed
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int slice = blockIdx.x * 4 + wave;
@@ -611,13 +620,16 @@ constexpr int LIST_THREADS = 256;
 template <typename IdxT, int ASSOC_CAP>
 __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restrict__ descs,
                                                         const DevParams* __restrict__ Pp,
-                                                        const int* __restrict__ status, int nblk, int n_pairs) {
+                                                        const PairState* __restrict__ states, int nblk, int n_pairs) {
   constexpr int ASSOC_STRIDE = ASSOC_CAP + 1;  // odd stride: conflict-free per-thread lists
   PairBlock pb;
   if (!pair_block(nblk, n_pairs, pb)) return;
-  if (status[pb.pair] != 0) return;
+  {
+    const PairState* __restrict__ st0 = states + pb.pair;  // == D->st (see k_scan)
+    const int status_v = st0->status, rebuild_v = st0->rebuild;
+    if (status_v != 0 || !rebuild_v) return;
+  }
   const PairDesc* __restrict__ D = descs + pb.pair;
-  if (!D->st->rebuild) return;
   const int N = D->N;
   const int T = Pp->T;
   const int rbw = D->rbw;
@@ -1118,7 +1130,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
 // INSTR = true is the instrumented instantiation (CVO_KERNEL_CLOCK / CVO_PHASE_TICKS); the production one carries no
 // time stamps at all.
 template <typename IdxT, int ASSOC_CAP, bool GENERAL, bool INSTR>
-__global__ __launch_bounds__(ASSOC_THREADS, CVO_ASSOC_WAVES) void k_assoc(const PairDesc* __restrict__ descs,
+__global__ __launch_bounds__(ASSOC_THREADS, GENERAL ? 1 : CVO_ASSOC_WAVES) void k_assoc(const PairDesc* __restrict__ descs,
                                                           const DevParams* __restrict__ Pp,
                                                           const PairState* __restrict__ states,
                                                           const char* __restrict__ arena, int lean_nblk_pairs,
@@ -1752,6 +1764,8 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
       auto share = [&](float used, float allowance) { return used <= 0.f ? 0.f : (allowance > 0.f ? used * frcp(allowance) : __builtin_inff()); };
       const float used = fmaxf(share(rot_b, st->skin_rot), share(tr_b, st->skin_tr));
       const float rate = fmaxf(share(rot_1, st->skin_rot), share(tr_1, st->skin_tr));
+      st->last_used = used;
+      st->last_rate = rate;
       // the list is unusable for the coming iteration ...
       // (A list built for a larger ell stays a superset: rebuilding it after ell has shrunk only sheds candidates.  That
       // rebuild is optional, so it waits for a rebuild opportunity - flagged in the middle of a lean period it would
@@ -1793,7 +1807,9 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         // rebuilds; s ~ 1.5 sqrt(step / radius) balances the two for this kernel set.  The lean graph only has a
         // rebuild opportunity every lean_U iterations, so it needs s >= ~1.3 lean_U step / radius; when that is
         // too much (fast motion) or rows overflow their lists, ask the host for the full graph.
-        int want_full = 2;
+        // 2 = a rebuild opportunity in every iteration; 4 = and k_assoc_dense (rows that overflowed the lists of the last
+        // build, or the dense regime): the host has a full graph without the dense kernel for large clouds
+        int want_full = (st->n_ovf > 0 || st->all_dense) ? 4 : 2;
         float s = 0.f;
         // rows that overflow their lists fall back to the literal scan over all targets (k_assoc_dense): fine for a few
         // rows or a small cloud, ruinous if a generous skin pushes many rows of a large one over the edge - the skin
@@ -1832,13 +1848,17 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         if (!dry) *D.want_out = want_full;
         st->n_builds = INIT ? 1 : st->n_builds + 1;
         st->rebuild = 1;  // cleared by k_list once bitmap and lists are current
-      } else if (st->want_full && st->n_ovf == 0) {  // has the motion slowed down enough for a leaner graph?
+      } else if (st->n_ovf == 0) {  // has the motion slowed down enough for a leaner graph?
         const float c = fminf(P.lean_skin, 1.3f);
         int want = st->want_full;
         if (used + c * (float)P.lean_U * rate <= 1.f)
           want = 0;
         else if (P.lean_U2 > 0 && used + c * (float)P.lean_U2 * rate <= 1.f)
           want = min(want, 1);
+        // -1 = calm: at the current speed the list outlives P.calm_U more iterations - the host may run this pair on the
+        // lean graph with ONE rebuild opportunity per chunk (the opportunities are three launches each, and in the end
+        // game - the step clamped at min_step, rebuilds only when ell has decayed - nearly all of them find nothing to do)
+        if (want == 0 && P.calm_U > 0 && used + c * (float)P.calm_U * rate <= 1.f) want = -1;
         if (want != st->want_full) {
           st->want_full = want;
           if (!dry) *D.want_out = want;
@@ -1964,8 +1984,8 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
       if (pb.bx == 0 && cq == 0 && threadIdx.x == 0) {
         st->n_stalls++;
         if (ovf > 0) {
-          st->want_full = 2;
-          *D->want_out = 2;
+          st->want_full = 4;
+          *D->want_out = 4;
         }
       }
       return;
@@ -2259,8 +2279,8 @@ __global__ __launch_bounds__(ASSOC_THREADS, 2) void k_resident(const PairDesc* _
           // (the update of the previous iteration, if it ran in this launch, is this block's own: program order)
           st->n_stalls += U - u;
           if (h.stop == 3) {
-            st->want_full = 2;
-            *D->want_out = 2;
+            st->want_full = 4;
+            *D->want_out = 4;
           }
         }
         break;
@@ -2564,11 +2584,13 @@ constexpr int PREP_THREADS = 512;
 
 __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restrict__ descs,
                                                         const DevParams* __restrict__ Pp,
-                                                        const int* __restrict__ status) {
-  if (status[blockIdx.y] != 0) return;
+                                                        const PairState* __restrict__ states) {
+  const PairState* st = states + blockIdx.y;  // == D->st (see k_scan)
+  {
+    const int status_v = st->status, rebuild_v = st->rebuild;
+    if (status_v != 0 || !rebuild_v) return;  // finished / the bitmap of an earlier iteration still covers this one
+  }
   const PairDesc* __restrict__ D = descs + blockIdx.y;
-  const PairState* st = D->st;
-  if (!st->rebuild) return;  // k_update: the bitmap of an earlier iteration still covers this one
   if (st->all_dense) {  // dense regime: no operands to prepare, only the overflow list to reset for k_list
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       D->st->n_ovf = 0;
