@@ -55,6 +55,7 @@ struct DevParams {
   float skin_blend;          // share of the pooled motion budget both the rotation and the translation allowance get on top of their own
   int dense_regime;      // 0: never switch a pair to the all-rows-dense regime (CVO_NO_DENSE_REGIME)
   float lean_skin;       // skin of the lean graph in units of (lean_U x the motion of one iteration)
+  float horizon_margin;  // a list is renewed at a rebuild opportunity if it would not outlive (this x iterations to the next one) at its current speed
   int kernel_clock;  // CVO_KERNEL_CLOCK: accumulate per-pair kernel durations in PairState::clk_*
   int phase_ticks;  // CVO_PHASE_TICKS: leave per-block phase timestamps (g_phase_ticks) for cvo_debug_time_kernels
   int verify_lists;  // CVO_VERIFY_LISTS: k_verify re-derives every row with the literal scan after each association

@@ -99,7 +99,7 @@ static const char* const kOptionNames[] = {
     "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
     "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
     "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "RESIDENT",
-    "RESIDENT_BLOCKS", "ORDER", "NO_NODENSE", "CALM_U"};
+    "RESIDENT_BLOCKS", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN"};
 
 struct cvo_ctx {
   int device = 0;
@@ -366,8 +366,13 @@ DevParams make_dev_params(const cvo_ctx* ctx, const cvo_params_t& p) {
     auto mid = [](float v) { const float a = std::fabs(v); return std::isfinite(v) && a >= 0x1p-20f && a <= 0x1p20f; };
     d.fast_div_cd = mid(p.c) && mid(p.d) ? 1 : 0;
   }
-  d.skin_frac = 2.0f;
-  d.lean_skin = 1.3f;
+  // List-reuse knobs, re-tuned in round 4 (scripts/skin_sweep.py, profiles/r4/skin_sweep.txt): the linear "outlives the
+  // next h iterations at the current speed" predictions are pessimistic once the pose jitters around its optimum (the
+  // allowance used since a build stays at a few percent while every iteration moves ~10 % of it), so thinner skins and
+  // a smaller margin win on every configuration: headline batch 62.05 -> 60.6 ms, config 3 single pair 21.5 -> 18.8 us
+  // per iteration.  (Round-2 values: 2.0 / 1.3 / 1.25.)
+  d.skin_frac = 1.0f;
+  d.lean_skin = 0.5f;
   d.dense_regime = ctx_opt(ctx, "NO_DENSE_REGIME") ? 0 : 1;
   d.skin_blend = 0.25f;
   if (const char* e = ctx_opt(ctx, "SKIN_BLEND")) d.skin_blend = std::min(1.f, std::max(0.f, (float)atof(e)));
@@ -375,7 +380,9 @@ DevParams make_dev_params(const cvo_ctx* ctx, const cvo_params_t& p) {
   d.skin_max = 0.25f;
   if (const char* e = ctx_opt(ctx, "SKIN_MIN")) d.skin_min = std::max(0.f, (float)atof(e));
   if (const char* e = ctx_opt(ctx, "SKIN_MAX")) d.skin_max = std::max(d.skin_min, (float)atof(e));
-  if (const char* e = ctx_opt(ctx, "LEAN_SKIN")) d.lean_skin = std::max(1.3f, (float)atof(e));
+  if (const char* e = ctx_opt(ctx, "LEAN_SKIN")) d.lean_skin = std::max(0.1f, (float)atof(e));
+  d.horizon_margin = 0.3f;
+  if (const char* e = ctx_opt(ctx, "HORIZON_MARGIN")) d.horizon_margin = std::max(0.f, (float)atof(e));
   d.rebuild_shrink = 0.9f;
   if (const char* e = ctx_opt(ctx, "SKIN")) d.skin_frac = std::max(0.f, (float)atof(e));
   d.phase_ticks = ctx_opt(ctx, "PHASE_TICKS") ? 1 : 0;

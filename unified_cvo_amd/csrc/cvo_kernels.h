@@ -1777,12 +1777,12 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
                               ((st->k & P.shrink_align) == 0 || ell_next < 0.85f * P.rebuild_shrink * st->ell_build);
       bool rebuild = INIT || P.mode != 0 || !(used <= 1.f) || ell_next > st->ell_build || shrink_now;
       // ... or would expire before the next rebuild opportunity of the lean graph
-      if (trio_follows && horizon > 0 && !(used + 1.25f * (float)horizon * rate <= 1.f)) rebuild = true;
+      if (trio_follows && horizon > 0 && !(used + P.horizon_margin * (float)horizon * rate <= 1.f)) rebuild = true;
       // ... and, in a batch, at the common iteration counts of the optional rebuilds: a list that would not survive
       // until the next of them is renewed now, together with the other pairs' (the pass runs anyway), instead of
       // putting work into a pass of its own some opportunities later
       if (trio_follows && horizon > 0 && P.shrink_align > 0 && (st->k & P.shrink_align) == 0 &&
-          !(used + 1.25f * (float)(P.shrink_align + 1) * rate <= 1.f))
+          !(used + P.horizon_margin * (float)(P.shrink_align + 1) * rate <= 1.f))
         rebuild = true;
       // Dense regime (rows sitting on K_max, e.g. the first iterations of an outdoor pair at a large ell): when most
       // rows overflow their lists anyway, lists are pointless - every row goes to k_assoc_dense (the reference's
