@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-rnd = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r3"
+rnd = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r4"
 src = os.path.join(ROOT, "gpurun_out", rnd + "_prof") + "/"
 dst = os.path.join(ROOT, "profiles", rnd) + "/"
 KT = os.path.join(ROOT, "profiles", "kernel_traffic.json")
@@ -46,7 +46,8 @@ if "--traffic" in sys.argv:
     sys.exit(0)
 
 os.makedirs(dst, exist_ok=True)
-for f in ("bench_kernel_stats.csv", "configs.json", "xcd_exchange.txt", "resident_probe.txt", "stress.txt"):
+for f in ("bench_kernel_stats.csv", "configs.json", "stress.txt", "cpp_host_bench.txt", "upload_probe.txt", "scale_probe.txt",
+          "perf_probe.txt", "pmc_summary.txt"):
     if os.path.exists(src + f):
         shutil.copy(src + f, dst + f)
 for f in ("bench_n1.json", "bench_under_rocprof.json", "bench_torchrun_n1.json"):

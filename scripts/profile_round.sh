@@ -1,9 +1,9 @@
 # The round's profile set, run on the GPU box (gpurun): bench line, rocprofv3 kernel trace of the same command, PMC
 # passes (one counter group per pass, no trace domains), every BASELINE config next to the oracle.
-#   ROUND=r3 bash scripts/profile_round.sh      -> gpurun_out/r3_prof/ ; then scripts/install_profiles.py r3 (here)
+#   ROUND=r4 bash scripts/profile_round.sh      -> gpurun_out/r4_prof/ ; then scripts/install_profiles.py r4 (here)
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/${ROUND:-r3}_prof
+O=$R/gpurun_out/${ROUND:-r4}_prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # PMC: the headline batch itself (one cvo_align_batch of 64 x 10k x 10k, 2000 iterations; launches of 16 pairs), not
@@ -27,7 +27,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_IN
 done
 python $R/scripts/summarize_pmc.py $O/pmc_summary_raw.json /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 /tmp/pmc4 /tmp/pmc5 > $O/pmc_summary.txt
 # the PMC traffic of THIS build goes into profiles/kernel_traffic.json before the bench run, which reports it
-python $R/scripts/install_profiles.py ${ROUND:-r3} --traffic
+python $R/scripts/install_profiles.py ${ROUND:-r4} --traffic
 timeout 600 python $R/bench.py --gpus 1 --steps 10 --warmup 3 > $O/bench_n1.json 2> $O/bench_n1.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-single-pair --no-pipeline > $O/bench_under_rocprof.json 2> $O/rocprof.log
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
@@ -35,9 +35,14 @@ cd $R && timeout 600 python scripts/run_configs.py $O/configs.json > $O/configs.
 # the same bench command under torchrun with ONE rank (what the driver does for N > 1, at N = 1): RCCL cost per step
 cd $R && timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
   bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-single-pair --no-pipeline > $O/bench_torchrun_n1.json 2> $O/bench_torchrun_n1.log
-# premise check of the XCD-resident iteration and the resident kernel itself against the two-kernel iteration
-timeout 300 $R/scripts/ubench/xcd_exchange > $O/xcd_exchange.txt 2>&1
-(PROBE_REPS=3 timeout 300 python $R/scripts/resident_probe.py single; RES_PHASE_TICKS=1 PROBE_REPS=2 timeout 300 python $R/scripts/resident_probe.py single; PROBE_REPS=2 timeout 300 python $R/scripts/resident_probe.py batch16) > $O/resident_probe.txt 2>&1
+# the C++ host of the multi-GPU mode on the headline workload, with and without the library's hardware-queue hint
+timeout 600 python $R/scripts/cpp_host_bench.py > $O/cpp_host_bench.txt 2> $O/cpp_host_bench.log
+# what an upload costs (ordering on the device vs on the host) and the PCIe-inclusive pipeline with 2 upload threads
+timeout 600 python $R/scripts/upload_probe.py > $O/upload_probe.txt 2>&1
+# where latency-bound turns into throughput-bound: the batch at 1 ... 128 pairs
+timeout 600 python $R/scripts/scale_probe.py > $O/scale_probe.txt 2>&1
+# the early phase: first 16 / 64 / 256 iterations of the batch, single pairs
+timeout 600 python $R/scripts/perf_probe.py $O/perf_probe.json > $O/perf_probe.txt 2>&1
 # run-to-run reproducibility under load
 timeout 900 python $R/scripts/stress_repeat.py ${STRESS_BATCH:-100} ${STRESS_SINGLE:-40} > $O/stress.txt 2>&1
 tail -3 $O/bench_n1.log
