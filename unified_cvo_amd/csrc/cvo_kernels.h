@@ -616,6 +616,10 @@ __device__ __forceinline__ void visit_pair_yt(const DevParams& P, const PairDesc
 // overflow list of k_assoc_dense (also cached).
 // ------------------------------------------------------------------------------------------
 constexpr int LIST_THREADS = 256;
+#ifndef CVO_LIST_RB
+#define CVO_LIST_RB 8
+#endif
+constexpr int LIST_RB = CVO_LIST_RB;  // candidates ranked per sweep of a row's list in k_list (2 / 4 / 8 / 16: 59.7 / 59.5 / 59.1 / 59.5 ms per step)
 
 template <typename IdxT, int ASSOC_CAP>
 __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restrict__ descs,
@@ -747,12 +751,12 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
         }
       }
       // original indices: independent gathers, four in flight
-      for (int k0 = 0; k0 < cnt; k0 += 4) {
-        int jj[4];
+      for (int k0 = 0; k0 < cnt; k0 += LIST_RB) {
+        int jj[LIST_RB];
 #pragma unroll
-        for (int u = 0; u < 4; u++) jj[u] = yorder[(int)list[min(k0 + u, cnt - 1)]];
+        for (int u = 0; u < LIST_RB; u++) jj[u] = yorder[(int)list[min(k0 + u, cnt - 1)]];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < LIST_RB; u++)
           if (k0 + u < cnt) list[k0 + u] = (IdxT)jj[u];
       }
       // ascending original j (the order of the reference's first-K truncation and float accumulation): every entry
@@ -760,15 +764,29 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
       // an insertion sort's chain of dependent shifts
       // the list entry is the target's sorted position (gathered while the rank is counted), the ORDER is that of the
       // original indices
+      // (LIST_RB candidates per round: their position gathers are in flight together, and one pass over the list ranks all
+      // of them - a dependent global load and a list sweep per CANDIDATE sat on every thread's serial chain before.  Packing
+      // (original index, position) into one LDS word instead removes the gather altogether and is 2 % faster for a lone
+      // pair, but the doubled LDS - 69 KB per block, two blocks per CU - costs the 64-pair batch 3 %: measured, not kept.)
       IdxT* out = reinterpret_cast<IdxT*>(D->cand_j);
       const int* yinv = D->yinv;
-      for (int k = 0; k < cnt; k++) {
-        const int j = (int)list[k];
-        const int entry = yinv[j];
-        int rank = 0;
-#pragma unroll 4
-        for (int m2 = 0; m2 < cnt; m2++) rank += ((int)list[m2] < j) ? 1 : 0;
-        out[(size_t)rank * N + pos] = (IdxT)entry;
+      for (int k0 = 0; k0 < cnt; k0 += LIST_RB) {
+        int j[LIST_RB], entry[LIST_RB], rank[LIST_RB];
+#pragma unroll
+        for (int u = 0; u < LIST_RB; u++) {
+          j[u] = (int)list[min(k0 + u, cnt - 1)];
+          rank[u] = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < LIST_RB; u++) entry[u] = yinv[j[u]];
+        for (int m2 = 0; m2 < cnt; m2++) {
+          const int v = (int)list[m2];
+#pragma unroll
+          for (int u = 0; u < LIST_RB; u++) rank[u] += (v < j[u]) ? 1 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < LIST_RB; u++)
+          if (k0 + u < cnt) out[(size_t)rank[u] * N + pos] = (IdxT)entry[u];
       }
     }
   }
