@@ -402,7 +402,22 @@ void se_kernel_impl(const OracleParams& P, const CloudView& X, const CloudView& 
       if (pg->valid) {
         G = &pg->G;
         ymax = pg->ymax;
-        slack = 1e-5 * (ymax + 1.0) + 1e-5;  // float transform of the targets + the float (R, T) <-> (R^T, -R^T T) pair
+        // The grid is queried at R x + T while the exact test measures |R^T (y0 - T) - x| (float transform of the targets,
+        // float (R, T) <-> (R^T, -R^T T) pair): the two distances differ by the rounding of the float transform and by
+        // however far the float R has drifted from orthonormality over the iterations so far - |R^T R - I|_F times the
+        // extent of whatever it multiplies (source points, targets, T).  Both measured here, in double, per call.
+        double xmax = 0, tmax = 0, drift = 0;
+        for (int i = 0; i < n; i++)
+          for (int c = 0; c < 3; c++) xmax = std::max(xmax, (double)std::fabs(X.p(i)[c]));
+        for (int c = 0; c < 3; c++) tmax = std::max(tmax, (double)std::fabs(Tpose[c]));
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++) {
+            double d = (a == b) ? -1.0 : 0.0;
+            for (int c = 0; c < 3; c++) d += (double)Rpose[3 * c + a] * (double)Rpose[3 * c + b];
+            drift += d * d;
+          }
+        drift = std::sqrt(drift);
+        slack = 1e-5 * (ymax + xmax + tmax + 1.0) + 1e-5 + 2.0 * drift * (ymax + xmax + tmax + 1.0);
       }
     } else if (rad > 0 && build_grid(Y, rad, local)) {
       G = &local;

@@ -736,10 +736,20 @@ def test_lidar_flavour_single_feature(oracle):
     assert cases.max_abs_diff(g.transform, o["transform"]) < 1e-6
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("CVO_FUZZ_SEEDS", "48"))))
+FUZZ_SEEDS = int(os.environ.get("CVO_FUZZ_SEEDS", "48"))
+FUZZ_OUTCOMES = {}   # seed -> followed the oracle strictly to the last recorded iteration (filled by _fuzz_one)
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS))
 def test_randomised_trajectories(oracle, seed):
     """Randomised sizes / parameters / initial guesses: every recorded iteration (counts, ell, K, twist, B..E, step,
     pose) must follow the oracle through list rebuilds, waits, ordered truncation and the overflow path."""
+    _fuzz_one(oracle, seed)
+
+
+def _fuzz_one(oracle, seed):
+    if seed in FUZZ_OUTCOMES:
+        return FUZZ_OUTCOMES[seed]
     rs = np.random.default_rng(100 + seed)
     kind = seed % 3
     n = int(rs.integers(150, 1800))
@@ -794,17 +804,24 @@ def test_randomised_trajectories(oracle, seed):
         # After a one-ulp separation the two runs are two valid trajectories of the same optimiser: the north_star
         # tolerance applies, relaxed to 2 * min_step where the prefix ends clamped at min_step (two
         # implementations can sit on opposite phases of the +-min_step jitter).
-        assert cases.max_abs_diff(g.transform, o["transform"]) <= max(TOL_POSE_CLAMPED, 2.0 * P.min_step), (seed, compared)
+        # (the 2 * min_step allowance only where a run really ends on the clamp; 1e-3 at most otherwise)
+        clamped = any(abs(t.trace[-1].step - P.min_step) <= 1e-6 * P.min_step for t in (g, _Obj(o)))
+        tol = max(TOL_POSE_CLAMPED, 2.0 * P.min_step) if clamped else min(max(TOL_POSE_CLAMPED, 2.0 * P.min_step), 1e-3)
+        assert cases.max_abs_diff(g.transform, o["transform"]) <= tol, (seed, compared, clamped)
+    return strict
 
 
-FUZZ_OUTCOMES = {}
+class _Obj:
+    def __init__(self, d):
+        self.trace = d["trace"]
 
 
-def test_randomised_trajectories_mostly_strict():
+def test_randomised_trajectories_mostly_strict(oracle):
     """At most 10 % of the fuzz seeds may leave the strict per-iteration comparison (a one-ulp exp() difference between
-    ocml and glibc); everything else must have followed the oracle bit-for-decision to the last recorded iteration."""
-    if len(FUZZ_OUTCOMES) < 10:
-        pytest.skip("runs after test_randomised_trajectories")
+    ocml and glibc); everything else must have followed the oracle bit-for-decision to the last recorded iteration.
+    Self-contained: seeds the parametrised test has not run in this session (-k selections, xdist) are run here."""
+    for seed in range(FUZZ_SEEDS):
+        _fuzz_one(oracle, seed)
     loose = sorted(s for s, ok in FUZZ_OUTCOMES.items() if not ok)
     print(f"fuzz: {len(loose)} of {len(FUZZ_OUTCOMES)} seeds left the strict comparison: {loose}")
     assert len(loose) <= 0.10 * len(FUZZ_OUTCOMES), loose
