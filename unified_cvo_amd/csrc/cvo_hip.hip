@@ -529,7 +529,7 @@ struct LaunchGeom {
 
 void launch_init(cvo_ctx* c, const LaunchGeom& g) {
   hipLaunchKernelGGL(k_update<true>, dim3(g.n_pairs), dim3(64), 0, g.stream, c->d_descs + g.p0, c->d_params,
-                     c->d_status + g.p0, 0);
+                     c->d_status + 2 * g.p0, 0);
 }
 
 // The rebuild kernels: no-ops (early exit) unless k_update flagged the pair's candidate list as expired.
@@ -546,7 +546,7 @@ void launch_rebuild(cvo_ctx* c, const LaunchGeom& g) {
 // update_body.
 void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags) {
   const PairDesc* descs = c->d_descs + g.p0;
-  const int* st = c->d_status + g.p0;
+  const int* st = c->d_status + 2 * g.p0;  // the sub-batch's status words (see setup_batch)
   launch_assoc(g.stream, g.idx16, g.general, g.instr, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, lean ? 1 : 0);
   if (!lean) launch_dense(g.stream, g.general, g.N, g.n_pairs, descs, c->d_params, st);
   if (g.verify) launch_verify(g.stream, g.general, g.N, g.n_pairs, descs, c->d_params, st, lean ? 1 : 0);
@@ -802,8 +802,15 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.coef_part = (double*)(base + S->L.coef_part);
     D.st = ctx->d_states + p;
     D.trace = trace_cap > 0 ? (cvo_trace_t*)(base + S->L.trace) : nullptr;
-    D.status_out = ctx->d_status + p;
-    D.want_out = ctx->d_status + ctx->cap_pairs + p;
+    {
+      // status / requested-graph mirrors the host polls: every sub-batch owns ONE contiguous block [status[n_g] | want[n_g]]
+      // at 2 * p0(g), fetched with one copy per chunk (two copies per chunk and stream were two 5 us blits)
+      int g = 0;
+      while (g + 1 < S->G && (int)((long)n_pairs * (g + 1) / S->G) <= p) g++;
+      const int p0 = (int)((long)n_pairs * g / S->G), p1 = (int)((long)n_pairs * (g + 1) / S->G);
+      D.status_out = ctx->d_status + 2 * p0 + (p - p0);
+      D.want_out = ctx->d_status + 2 * p0 + (p1 - p0) + (p - p0);
+    }
     D.gate = (int*)(base + S->L.gate);
     D.gate_flow = (int*)(base + S->L.gate_flow);
     D.done = (int*)(base + S->L.done);
@@ -1741,11 +1748,8 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
           launch_chunk(ctx, geom[g], Uc, v != 0, lean_period(v, Uc));
           HIP_TRY(ctx, hipGetLastError());
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status[slot] + geom[g].p0, ctx->d_status + geom[g].p0,
-                                    sizeof(int) * (size_t)geom[g].n_pairs, hipMemcpyDeviceToHost, geom[g].stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status[slot] + ctx->cap_pairs + geom[g].p0,
-                                    ctx->d_status + ctx->cap_pairs + geom[g].p0, sizeof(int) * (size_t)geom[g].n_pairs,
-                                    hipMemcpyDeviceToHost, geom[g].stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status[slot] + 2 * geom[g].p0, ctx->d_status + 2 * geom[g].p0,
+                                    sizeof(int) * 2 * (size_t)geom[g].n_pairs, hipMemcpyDeviceToHost, geom[g].stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_chk[slot][g], geom[g].stream));
       }
       // keep one chunk of speculation in flight: inspect the chunk before this one
@@ -1755,11 +1759,13 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
         for (int g = 0; g < G; g++) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_chk[ws][g]));
         t_wait += ms_since(tw);
         all_done = true;
-        for (int p = 0; p < n_pairs; p++) all_done = all_done && ctx->h_status[ws][p] != 0;
         for (int g = 0; g < G; g++) {
+          const int* hs = ctx->h_status[ws] + 2 * geom[g].p0;  // [status[n_g] | want[n_g]]
+          const int ng = geom[g].n_pairs;
+          for (int q = 0; q < ng; q++) all_done = all_done && hs[q] != 0;
           int want = -1;  // the most demanding unfinished pair of the group decides: 4 / 2 = full, 1 = short lean, 0 = lean, -1 = calm
-          for (int p = geom[g].p0; p < geom[g].p0 + geom[g].n_pairs; p++)
-            if (ctx->h_status[ws][p] == 0) want = std::max(want, ctx->h_status[ws][ctx->cap_pairs + p]);
+          for (int q = 0; q < ng; q++)
+            if (hs[q] == 0) want = std::max(want, hs[ng + q]);
           if (want == 3) {  // a resident launch timed out: its pairs are served by the two-kernel graphs from now on
             want = 2;
             if (!resident_broken)
@@ -1773,7 +1779,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
           graph_next[g] = !allow_lean ? 0 : (want >= 4 ? 0 : (want >= 2 ? (start_nodense ? 3 : 0) : (want == 1 ? 2 : (want == 0 || !allow_calm ? 1 : 4))));
           if (ctx_opt(ctx, "VERBOSE") && atoi(ctx_opt(ctx, "VERBOSE")) >= 2 && ch < 12) {
             int nw = 0;
-            for (int p = geom[g].p0; p < geom[g].p0 + geom[g].n_pairs; p++) nw += ctx->h_status[ws][ctx->cap_pairs + p] != 0;
+            for (int q = 0; q < ng; q++) nw += hs[ng + q] != 0;
             fprintf(stderr, "[cvo] after chunk %d group %d: %d of %d pairs ask for the full graph\n", ch - 1, g, nw, geom[g].n_pairs);
           }
         }
@@ -1788,7 +1794,8 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       for (int g = 0; g < G; g++) HIP_TRY(ctx, hipStreamSynchronize(geom[g].stream));
       const int ws = (ch - 1) & 1;
       bool fin = true;
-      for (int p = 0; p < n_pairs; p++) fin = fin && ctx->h_status[ws][p] != 0;
+      for (int g = 0; g < G; g++)
+        for (int q = 0; q < geom[g].n_pairs; q++) fin = fin && ctx->h_status[ws][2 * geom[g].p0 + q] != 0;
       if (!fin && ch >= chunk_cap) return fail(ctx, CVO_E_HIP, "cvo_align_batch: optimiser loop did not terminate");
     }
   }
