@@ -23,7 +23,9 @@ for name, builder, kw, oracle_cap in (
         ("config2 5k x 5k xyz (cvo_geometric_params_gpu)", cases.config2, dict(n=5000), 0),
         ("config2-shape 10k x 10k xyz", cases.config2, dict(n=10000), 0),
         ("config3 10k x 10k + 5-ch colour (cvo_intensity_params_gpu, HEAD side + overrides)", cases.config3, dict(n=10000), 0),
-        ("config4 10k x 10k + 19-class semantics (cvo_semantic_params_img_gpu0, warm start)", cases.config4, dict(n=10000), 0)):
+        ("config4 10k x 10k + 19-class semantics (cvo_semantic_params_img_gpu0, warm start)", cases.config4, dict(n=10000), 0),
+        ("clustered street scene 10k x 10k xyz (NOT a BASELINE config: synth.scene_pair, density varies > 100x, rows on the K cap)",
+         cases.scene, dict(n=10000), 0)):
     P, src, tgt, init = builder(**kw)
     gpu = CvoGPU(params=P)
     ds, dt = gpu.upload(src), gpu.upload(tgt)

@@ -24,6 +24,15 @@ def config2(n=5000, pair_id=0, m=None):
     return p, CvoPointCloud.from_xyz(src), CvoPointCloud.from_xyz(tgt), np.eye(4, dtype=np.float32)
 
 
+def scene(n=10000, pair_id=0):
+    """A clustered street-scene pair (synth.scene_pair: ground, facades, small dense objects; local density varies by
+    more than 100x), cvo_geometric_params_gpu.yaml, identity init.  Not a BASELINE.json config: the evidence that the
+    candidate-list machinery does not depend on the uniform density of the synthetic slab."""
+    p = load_params("geometric_gpu")
+    src, tgt, _ = synth.scene_pair(n, pair_id)
+    return p, CvoPointCloud.from_xyz(src), CvoPointCloud.from_xyz(tgt), np.eye(4, dtype=np.float32)
+
+
 def config3(n=10000, pair_id=0):
     """Colour clouds, cvo_intensity_params_gpu.yaml (HEAD side + documented overrides), identity init."""
     p = load_params("intensity_gpu")

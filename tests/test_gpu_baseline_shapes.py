@@ -205,3 +205,22 @@ def test_config4_literal_10k_overlap_queries(oracle):
     assert g.ret == 0 and g.iterations < P.MAX_ITER
     final = np.linalg.inv(g.transform.astype(np.float64)).astype(np.float32)
     _ip_and_angles(gpu, oracle, P, src, tgt, (init, final))
+
+
+def test_clustered_scene_full_length(oracle):
+    """Not a BASELINE.json config: a clustered street-scene pair (cases.scene: ground plane, facades, small dense objects;
+    local density varies by more than 100x, the first iterations have thousands of rows beyond the candidate-list
+    capacity, some on the K = 512 cap of CvoGPU.cu:558).  10k x 10k, the whole loop: same iteration count and return
+    code as the oracle, final pose within 2e-4; one association pass at the initial ell bit-exact (ordered first-K
+    truncation on most rows); overlap queries at the final pose."""
+    from test_gpu_parity import _single_iteration
+    P, src, tgt, init = cases.scene(n=10000)
+    _, _, (_, _, nz) = _single_iteration(oracle, P, src, tgt, init)
+    assert (nz == P.nearest_neighbors_max).sum() >= 10 and (nz > 64).sum() > 2000 and np.median(nz) < 64   # clustered
+    gpu = CvoGPU(params=P)
+    g = gpu.align(src, tgt, init)
+    o = oracle.align(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt), init)
+    assert g.iterations == o["iterations"] and g.ret == o["ret"]
+    assert cases.max_abs_diff(g.transform, o["transform"]) <= TOL_POSE_CLAMPED
+    final = np.linalg.inv(g.transform.astype(np.float64)).astype(np.float32)
+    _ip_and_angles(gpu, oracle, P, src, tgt, (final,))

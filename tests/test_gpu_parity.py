@@ -124,7 +124,8 @@ def _prefix(oracle, P, src, tgt, init, n_it, gpu=None):
 
 
 @pytest.mark.parametrize("builder,kw,n_it", [(cases.config2, dict(n=2000), 120), (cases.config3, dict(n=1500), 80),
-                                             (cases.config4, dict(n=2000), 80), (cases.config1, {}, 150)])
+                                             (cases.config4, dict(n=2000), 80), (cases.config1, {}, 150),
+                                             (cases.scene, dict(n=3000), 150)])
 def test_trajectory_prefix(oracle, builder, kw, n_it):
     """Per-iteration state over a prefix of the optimisation (config 1 runs on the neighbour cap throughout)."""
     P, src, tgt, init = builder(**kw)
@@ -134,7 +135,7 @@ def test_trajectory_prefix(oracle, builder, kw, n_it):
     assert cases.max_abs_diff(g.transform, o["transform"]) <= 1e-6
 
 
-@pytest.mark.parametrize("builder,n_it", [(cases.config3, 220), (cases.config4, 220), (cases.config2, 220)])
+@pytest.mark.parametrize("builder,n_it", [(cases.config3, 220), (cases.config4, 220), (cases.config2, 220), (cases.scene, 100)])
 def test_trajectory_prefix_full_size_10k(oracle, builder, n_it):
     """BASELINE.json configs 3 / 4 (and the 10k geometric shape of config 5) at their FULL size: every iteration of a
     220-iteration prefix - the fast first iterations with their list rebuilds, then the lean graph - must take the

@@ -315,6 +315,8 @@ def test_device_indicator_windows_vs_deque(window, thr):
     ("config4", cases.config4, dict(n=10000), 320),
     ("config2-5k", cases.config2, dict(n=5000), 400),
     ("config1", cases.config1, {}, 1200),
+    ("scene-10k", cases.scene, dict(n=10000), 400),     # clustered: thousands of rows over the list capacity / on the K cap
+    ("scene-3k", cases.scene, dict(n=3000), 2000),
 ])
 def test_verify_lists_full_size(monkeypatch, name, builder, kw, n_it):
     """Every row of every iteration - including the fast-moving first 30, where lists live for one or two iterations,

@@ -195,6 +195,7 @@ constexpr unsigned RESIDENT_TIMEOUT_TICKS = 5000000u;  // s_memrealtime runs at 
 struct PairDesc {
   // ---- read by the per-iteration kernels (k_assoc, k_coeff): kept together at the front ----
   int N, M, nblk_assoc, nblk_coeff;  // nblk_coeff = nblk_assoc * csplit partials of the coefficient phase
+  int dense_blocks;                  // blocks of k_assoc_dense for this pair (dense_blocks_for: the launch's grid x)
   // k_list orders the rows of every 256-row window by candidate count; POSITION = index in that order
   int* cand_cnt;   // [N] candidates of the row at each position
   void* cand_j;    // [ASSOC_CAP][N] cached candidate lists by position, u16 or i32: the targets' SORTED positions, in
@@ -206,8 +207,8 @@ struct PairDesc {
   EllEntry* ell;              // ELL kernel matrix [K_max][N] by POSITION: value + transformed target, ascending ORIGINAL j in a row
   int* ell_j;                 // [K_max][N]: the column (ORIGINAL j) of every entry
   unsigned* nnz_row;          // nonzeros[N], by position
-  double* flow_part;          // [nblk_assoc + DENSE_BLOCKS][8]: omega(3), v(3), sum a, pad (row blocks, then k_assoc_dense)
-  unsigned long long* cnt_part;  // [nblk_assoc + DENSE_BLOCKS][4]: nnz, max, candidates, overflow rows
+  double* flow_part;          // [nblk_assoc + DENSE_BLOCKS_MAX][8]: omega(3), v(3), sum a, pad (row blocks, then k_assoc_dense)
+  unsigned long long* cnt_part;  // [nblk_assoc + DENSE_BLOCKS_MAX][4]: nnz, max, candidates, overflow rows
   double* coef_part;          // [nblk_assoc * COEFF_SPLIT_MAX][4]: B C D E
   int* done;        // [1] k_coeff: blocks that stored their partials (monotonic; the last one runs the update)
   int csplit, pad_csplit;  // k_coeff: blocks per row block; block q of a row block takes the ELL slots s = q (mod csplit)
@@ -258,8 +259,22 @@ struct PairDesc {
 
 constexpr int COEFF_SPLIT_MAX = 32;
 constexpr int ROWS_PER_GROUP = 4;
-constexpr int DENSE_BLOCKS = 64;  // k_assoc_dense blocks per pair (one overflow row per wave at a time)
-// (4 waves per block; 8 for small clouds, where the dense regime sends every row here: see launch_dense)
+// k_assoc_dense blocks per pair (one overflow row per wave at a time; 4 waves per block, 8 for small clouds, where the
+// dense regime sends every row here: see launch_dense).  A batch launches few per pair (its pairs fill the chip and
+// most of them have no overflow rows at all); a pair solved alone gets enough waves to fill it by itself: clustered
+// clouds put thousands of rows on this path (profiles/r4/scene.txt).
+constexpr int DENSE_BLOCKS_MIN = 64;
+constexpr int DENSE_BLOCKS_MAX = 1024;
+inline int dense_waves_for(int N) { return N <= 4096 ? 8 : 4; }
+inline int dense_blocks_for(int N, int pairs_in_launch) {
+  const int waves_pair = 8192 / (pairs_in_launch < 1 ? 1 : pairs_in_launch);  // 1024 SIMDs x 8 wave slots
+  int nb = waves_pair / dense_waves_for(N);
+  const int rows = (N + dense_waves_for(N) - 1) / dense_waves_for(N);          // one row per wave is the most there is to do
+  if (nb > rows) nb = rows;
+  if (nb > DENSE_BLOCKS_MAX) nb = DENSE_BLOCKS_MAX;
+  if (nb < DENSE_BLOCKS_MIN) nb = DENSE_BLOCKS_MIN;
+  return nb;
+}
 
 // ---- arithmetic conventions (DESIGN.md "Numerics") ------------------------------------------
 __device__ __forceinline__ float dot3_dev(float a0, float a1, float a2, float b0, float b1, float b2) {

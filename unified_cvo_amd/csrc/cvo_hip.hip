@@ -248,8 +248,8 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.rsync = take(sizeof(ResidentSync));
   L.rowperm = take(sizeof(int) * (size_t)N);
   L.iorig = take(sizeof(int) * (size_t)N);
-  L.flow_part = take(sizeof(double) * 8 * (size_t)(nba + DENSE_BLOCKS));
-  L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)(nba + DENSE_BLOCKS));
+  L.flow_part = take(sizeof(double) * 8 * (size_t)(nba + DENSE_BLOCKS_MAX));
+  L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)(nba + DENSE_BLOCKS_MAX));
   L.coef_part = take(sizeof(double) * 4 * (size_t)nbc * COEFF_SPLIT_MAX);
   L.trace = take(sizeof(cvo_trace_t) * (size_t)std::max(trace_capacity, 0));
   L.total = off;
@@ -501,10 +501,11 @@ void launch_verify(hipStream_t s, bool general, int N, int n_pairs, const PairDe
     hipLaunchKernelGGL(k_verify<false>, grid, dim3(256), 0, s, descs, dp, st, lean);
 }
 
-void launch_dense(hipStream_t s, bool general, int N, int n_pairs, const PairDesc* descs, const DevParams* dp, const int* st) {
+void launch_dense(hipStream_t s, bool general, int N, int n_pairs, int dense_blocks, const PairDesc* descs, const DevParams* dp,
+                  const int* st) {
   // small clouds can have every row here (dense regime): twice the waves; large ones mostly launch it for nothing
-  const dim3 grid(DENSE_BLOCKS, n_pairs);
-  if (N <= 4096) {
+  const dim3 grid(dense_blocks, n_pairs);
+  if (dense_waves_for(N) == 8) {
     if (general)
       hipLaunchKernelGGL((k_assoc_dense<true, 8>), grid, dim3(512), 0, s, descs, dp, st);
     else
@@ -519,6 +520,7 @@ void launch_dense(hipStream_t s, bool general, int N, int n_pairs, const PairDes
 
 struct LaunchGeom {
   int n_pairs, p0, T, gx, gy, nba, nbc, npb, N, csplit;
+  int dense_blocks = DENSE_BLOCKS_MIN;  // k_assoc_dense grid x = PairDesc::dense_blocks of every pair of the launch
   int group = 0;        // sub-batch index (its stream, its ResidentTeams)
   int horizon_cap = 1 << 20;  // the lean graph's period (DevParams::lean_U)
   int res_nb = 0;       // k_resident: blocks per pair (0 = the lean graphs use the two-kernel iteration)
@@ -548,7 +550,7 @@ void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags) {
   const PairDesc* descs = c->d_descs + g.p0;
   const int* st = c->d_status + 2 * g.p0;  // the sub-batch's status words (see setup_batch)
   launch_assoc(g.stream, g.idx16, g.general, g.instr, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, lean ? 1 : 0);
-  if (!lean) launch_dense(g.stream, g.general, g.N, g.n_pairs, descs, c->d_params, st);
+  if (!lean) launch_dense(g.stream, g.general, g.N, g.n_pairs, g.dense_blocks, descs, c->d_params, st);
   if (g.verify) launch_verify(g.stream, g.general, g.N, g.n_pairs, descs, c->d_params, st, lean ? 1 : 0);
   launch_coeff(g.stream, g.instr, g.nba, g.csplit, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0));
 }
@@ -753,6 +755,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.nslices = S->d.Mpad / (64 * S->T);
     D.rbw = (int)align_up((size_t)(S->d.Mpad / (64 * S->T) + 31) / 32, 4);
     D.nblk_assoc = S->d.nblk_assoc;
+    D.dense_blocks = dense_blocks_for(N, n_pairs);
     // coefficient phase: small clouds get several blocks per row block (see coeff_rows); a function of the pair's own
     // size only, so that a pair is reduced in the same order whether it is solved alone or inside a batch
     D.csplit = coeff_split(X->n);
@@ -851,6 +854,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.gy = S->gy;
   S->geom.nba = S->d.nblk_assoc;
   S->geom.N = N;
+  S->geom.dense_blocks = dense_blocks_for(N, n_pairs);
   S->geom.arena.base = ctx->arena;
   S->geom.arena.stride256 = (unsigned)(S->L.total >> 8);
   S->geom.arena.Npad = S->d.Npad;
@@ -1678,7 +1682,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       key.gy = S.gy;
       key.nba = S.d.nblk_assoc;
       key.nbc = S.d.nblk_coeff * 64 + S.geom.csplit;
-      key.npb = S.geom.npb;
+      key.npb = S.geom.npb + (S.geom.dense_blocks << 20);  // (npb < 2^20: Mpad / 256 + rows / 256)
       key.idx16 = S.geom.idx16 ? 1 : 0;
       key.general = S.geom.general ? 1 : 0;
       key.U = Uc * 256 + lean_period(v, Uc) + (v == 3 ? 128 : 0);

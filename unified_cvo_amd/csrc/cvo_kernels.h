@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
   if (n_ovf > 0) {
     const Pose pose = load_pose(st);
     const FeatDen F = make_feat_den(P);
-    for (int q = blockIdx.x * DENSE_WAVES + wave; q < n_ovf; q += DENSE_BLOCKS * DENSE_WAVES) {
+    for (int q = blockIdx.x * DENSE_WAVES + wave; q < n_ovf; q += (int)gridDim.x * DENSE_WAVES) {
       // a position of k_list's ordering (all per-row outputs are stored by position); dense regime: every row
       const int r_sorted = all_dense ? q : D->ovf_rows[q];
       const int i = D->ip[r_sorted];
@@ -1360,7 +1360,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
     cp[3] = 0;
   }
   // full graph: the twist of the iteration from the partials of k_assoc (an earlier launch) and of this kernel
-  if (P.mode == 0) flow_gate(D, DENSE_BLOCKS, D->nblk_assoc + DENSE_BLOCKS);
+  if (P.mode == 0) flow_gate(D, (int)gridDim.x, D->nblk_assoc + (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1931,7 +1931,7 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
     for (int q = threadIdx.x; q < (int)(sizeof(ResidentSync) / 8); q += 64) reinterpret_cast<unsigned long long*>(D->rsync)[q] = 0ull;
   const DevParams P = *Pp;
   __shared__ UpdateShared U;
-  update_body<INIT, false>(load_upd_desc(D), P, flags, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS, U, nullptr,
+  update_body<INIT, false>(load_upd_desc(D), P, flags, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + D->dense_blocks, U, nullptr,
                            nullptr);
 }
 
@@ -2037,7 +2037,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   }
   const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && !replay, st, 1);
   const UpdDesc upd = load_upd_desc(D);
-  const int n_flow_upd = ((flags & 1) || ovf == 0) ? D->nblk_assoc : D->nblk_assoc + DENSE_BLOCKS;  // (see k_assoc_dense)
+  const int n_flow_upd = ((flags & 1) || ovf == 0) ? D->nblk_assoc : D->nblk_assoc + D->dense_blocks;  // (see k_assoc_dense)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partial stores before the counter, see flow_gate
   __syncthreads();
   if (threadIdx.x == 0) {

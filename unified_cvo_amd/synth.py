@@ -55,6 +55,41 @@ def geometric_pair(n, pair_id=0, m=None, noise=0.01):
     return src.astype(np.float32), tgt[perm].astype(np.float32), perm
 
 
+def scene_pair(n, pair_id=0, m=None, noise=0.01):
+    """A clustered frame pair (not part of BASELINE.json: the uniform slab of geometric_pair has 2-3 neighbours per point
+    everywhere).  A street scene as a forward-looking depth sensor samples it: a ground plane (55 % of the points, image
+    sampling: density falls with the square of the depth), two facades (25 %), a dozen small dense objects - poles,
+    boxes (20 %); local density varies by more than 100x between a nearby object and the far ground.  Same motion,
+    noise and target permutation as geometric_pair."""
+    m = n if m is None else m
+    nn = max(n, m)
+    rs = np.random.default_rng(6000 + pair_id)
+    n_ground, n_wall = int(0.55 * nn), int(0.25 * nn)
+    n_obj = nn - n_ground - n_wall
+    # ground y = -1.6: uniform in the IMAGE (u, v) -> depth z = h / v, lateral x = u z
+    v = rs.uniform(1.6 / 40.0, 1.6 / 2.5, n_ground)
+    z = 1.6 / v
+    u = rs.uniform(-0.6, 0.6, n_ground)
+    ground = np.stack([u * z, np.full(n_ground, -1.6) + rs.normal(0, 0.02, n_ground), z], axis=1)
+    # facades x = +-7 (depth again image-sampled), 0 .. 6 m high
+    zw = 1.0 / rs.uniform(1.0 / 40.0, 1.0 / 4.0, n_wall)
+    side = np.where(rs.random(n_wall) < 0.5, -7.0, 7.0)
+    wall = np.stack([side + rs.normal(0, 0.03, n_wall), rs.uniform(-1.6, 4.4, n_wall), zw], axis=1)
+    # objects: a dozen boxes / poles of 0.3 .. 1.5 m, points on them ~ uniformly
+    k = 12
+    centres = np.stack([rs.uniform(-5.5, 5.5, k), np.full(k, -1.6), rs.uniform(4.0, 25.0, k)], axis=1)
+    sizes = np.stack([rs.uniform(0.15, 0.8, k), rs.uniform(0.8, 2.5, k), rs.uniform(0.15, 0.8, k)], axis=1)
+    which = rs.integers(0, k, n_obj)
+    obj = centres[which] + np.stack([rs.uniform(-1, 1, n_obj), rs.uniform(0, 1, n_obj), rs.uniform(-1, 1, n_obj)], axis=1) * sizes[which]
+    pts = np.concatenate([ground, wall, obj], axis=0)[rs.permutation(nn)]
+    src = pts[:n]
+    rt = np.random.default_rng(7000 + pair_id)
+    T = gt_motion()
+    tgt = pts[:m] @ T[:3, :3].T + T[:3, 3] + rt.normal(0.0, noise, (m, 3))
+    perm = rt.permutation(m)
+    return src.astype(np.float32), tgt[perm].astype(np.float32), perm
+
+
 def colour_features(xyz, rng, noise=0.0):
     """5 channels: rgb = 0.5 + 0.5 sin(w_c . xyz + phi_c), 2 gradient channels ~ N(0.5, 0.05)."""
     w = np.array([[0.9, 0.3, 0.2], [0.2, 1.1, 0.4], [0.5, 0.6, 0.8]])
