@@ -62,6 +62,8 @@ struct DevParams {
   int keep_columns;  // write ell_j (the column of every ELL entry): exports, traces, the self-check and the single
                      // evaluations need it, the optimiser loop itself never reads it (4 of 20 bytes per nonzero)
   int fast_div_cd;  // 2^-20 <= |c|, |d| <= 2^20: the per-row float divisions by c and d may take their hoisted form (fdiv_hoisted)
+  int long_lists;  // overflow rows keep a cached sorted candidate list of up to LONG_CAP entries (PairDesc::long_j)
+  unsigned long long call_serial;  // process-wide serial of this align call: generation tag of the cached long lists
   int debug_no_motion_bound;  // CVO_DEBUG_NO_MOTION_BOUND (tests only): the update pretends no target ever moves, so
                               // lists outlive their validity - what CVO_VERIFY_LISTS exists to catch
 };
@@ -105,7 +107,9 @@ struct PairState {
   int want_full, n_stalls;  // host hint: 4 / 2 = this pair needs the graph with per-iteration rebuild (4: and the dense kernel), -1 = calm,
                             // 1 = the short lean graph (a rebuild opportunity every lean_U2 iterations), 0 = the lean graph
   int all_dense;
-  float skin_scale;  // backs the skin off while rows overflow their lists (see update_body)
+  float skin_scale;  // backs the skin off while rows fall back to the literal scan (see update_body)
+  int n_scan;        // rows of the last build beyond every list (more than LONG_CAP candidates, or ASSOC_CAP without long
+                     // lists): k_assoc_dense scans all targets for them (filled by k_list, reset by k_prep)
   // all_dense = dense regime: every row is served by k_assoc_dense, no lists (see update_body)
   // A_sparsity_indicator_ell_update FIFOs (CvoGPU.cu:1167-1285): bookkeeping here, storage below
   int s_head, s_size, e_head, e_size;
@@ -211,7 +215,9 @@ struct PairDesc {
   unsigned long long* cnt_part;  // [nblk_assoc + DENSE_BLOCKS_MAX][4]: nnz, max, candidates, overflow rows
   double* coef_part;          // [nblk_assoc * COEFF_SPLIT_MAX][4]: B C D E
   int* done;        // [1] k_coeff: blocks that stored their partials (monotonic; the last one runs the update)
-  int csplit, pad_csplit;  // k_coeff: blocks per row block; block q of a row block takes the ELL slots s = q (mod csplit)
+  int csplit, csplit_heavy;  // k_coeff: blocks per row block; block q of a row block takes the ELL slots s = q (mod csplit).
+                             // csplit_heavy >= csplit: while the pair has overflow rows (rows of hundreds of nonzeros; only
+                             // the full graph runs such a pair) - a function of the pair's own state, so that batch == solo
   const float4* xfeat;
   const float4* yfeat;
   const float4* xlabel;
@@ -248,6 +254,11 @@ struct PairDesc {
   int* ovf_rows;   // [N]: positions of rows with more candidates than a list holds (handled by k_assoc_dense)
   unsigned long long* ovf_bits;  // [ceil(N / 64)]: bit p % 64 of word p / 64 <=> position p overflows (k_list's blocks ->
                                  // its last block, coherent stores / loads)
+  // Long lists: the candidates of an overflow row (more than ASSOC_CAP, at most LONG_CAP), as the targets' sorted
+  // positions in ascending ORIGINAL index, [overflow index q][LONG_CAP]; built and consumed by k_assoc_dense, valid while
+  // long_stamp[q] == (call_serial << 24 | n_builds).  Null when positions do not fit 16 bits or CVO_NO_LONG_LISTS is set.
+  unsigned short* long_j;
+  unsigned long long* long_stamp;  // [N]
   PairState* st;
   cvo_trace_t* trace;
   int* status_out;  // mirror of st->status for cheap host polling
@@ -259,13 +270,13 @@ struct PairDesc {
 
 constexpr int COEFF_SPLIT_MAX = 32;
 constexpr int ROWS_PER_GROUP = 4;
-// k_assoc_dense blocks per pair (one overflow row per wave at a time; 4 waves per block, 8 for small clouds, where the
-// dense regime sends every row here: see launch_dense).  A batch launches few per pair (its pairs fill the chip and
+// k_assoc_dense blocks per pair (one overflow row per wave at a time; 4 waves per block).  A batch launches few per pair (its pairs fill the chip and
 // most of them have no overflow rows at all); a pair solved alone gets enough waves to fill it by itself: clustered
 // clouds put thousands of rows on this path (profiles/r4/scene.txt).
+constexpr int LONG_CAP = 1024;  // candidates a cached long list holds (rows beyond it are scanned literally)
 constexpr int DENSE_BLOCKS_MIN = 64;
 constexpr int DENSE_BLOCKS_MAX = 1024;
-inline int dense_waves_for(int N) { return N <= 4096 ? 8 : 4; }
+inline int dense_waves_for(int) { return 4; }
 inline int dense_blocks_for(int N, int pairs_in_launch) {
   const int waves_pair = 8192 / (pairs_in_launch < 1 ? 1 : pairs_in_launch);  // 1024 SIMDs x 8 wave slots
   int nb = waves_pair / dense_waves_for(N);

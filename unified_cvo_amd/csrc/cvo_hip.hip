@@ -72,7 +72,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, done, rsync, cand_cnt, rowperm, iorig, xp4, ip, cand_j, ell, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, done, rsync, cand_cnt, rowperm, iorig, long_j, long_stamp, xp4, ip, cand_j, ell, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -99,7 +99,7 @@ static const char* const kOptionNames[] = {
     "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
     "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
     "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "RESIDENT",
-    "RESIDENT_BLOCKS", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN"};
+    "RESIDENT_BLOCKS", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS"};
 
 struct cvo_ctx {
   int device = 0;
@@ -207,7 +207,7 @@ struct Dims {
   int Mpad, nchunks, rbw_max, nblk_assoc, nblk_coeff, NG, NGpad, Npad;
 };
 
-PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
+PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, bool long_lists, Dims* d) {
   const int Mpad = (int)align_up((size_t)M, 512);
   const int nchunks = Mpad / 64;
   const int rbw_max = (int)align_up((size_t)(nchunks + 31) / 32, 4);  // slice bits per row, enough for T = 1
@@ -248,6 +248,8 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, Dims* d) {
   L.rsync = take(sizeof(ResidentSync));
   L.rowperm = take(sizeof(int) * (size_t)N);
   L.iorig = take(sizeof(int) * (size_t)N);
+  L.long_stamp = take(sizeof(unsigned long long) * (size_t)N);
+  L.long_j = long_lists ? take(sizeof(unsigned short) * (size_t)N * LONG_CAP) : 0;
   L.flow_part = take(sizeof(double) * 8 * (size_t)(nba + DENSE_BLOCKS_MAX));
   L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)(nba + DENSE_BLOCKS_MAX));
   L.coef_part = take(sizeof(double) * 4 * (size_t)nbc * COEFF_SPLIT_MAX);
@@ -318,6 +320,15 @@ int ensure_workspace(cvo_ctx* c, int n_pairs, size_t bytes_per_pair) {
     drop_graphs(c);
   }
   return CVO_OK;
+}
+
+int coeff_split(int n);
+// blocks per row block while a pair has overflow rows (PairDesc::csplit_heavy): ~1000 blocks per pair
+int coeff_split_heavy(int n) {
+  const int nba = (n + ASSOC_THREADS - 1) / ASSOC_THREADS;
+  int s = coeff_split(n);
+  while (s < COEFF_SPLIT_MAX && nba * (2 * s) <= 1024) s *= 2;
+  return s;
 }
 
 int coeff_split(int n) {
@@ -503,23 +514,16 @@ void launch_verify(hipStream_t s, bool general, int N, int n_pairs, const PairDe
 
 void launch_dense(hipStream_t s, bool general, int N, int n_pairs, int dense_blocks, const PairDesc* descs, const DevParams* dp,
                   const int* st) {
-  // small clouds can have every row here (dense regime): twice the waves; large ones mostly launch it for nothing
   const dim3 grid(dense_blocks, n_pairs);
-  if (dense_waves_for(N) == 8) {
-    if (general)
-      hipLaunchKernelGGL((k_assoc_dense<true, 8>), grid, dim3(512), 0, s, descs, dp, st);
-    else
-      hipLaunchKernelGGL((k_assoc_dense<false, 8>), grid, dim3(512), 0, s, descs, dp, st);
-  } else {
-    if (general)
-      hipLaunchKernelGGL((k_assoc_dense<true, 4>), grid, dim3(256), 0, s, descs, dp, st);
-    else
-      hipLaunchKernelGGL((k_assoc_dense<false, 4>), grid, dim3(256), 0, s, descs, dp, st);
-  }
+  if (general)
+    hipLaunchKernelGGL((k_assoc_dense<true, 4>), grid, dim3(256), 0, s, descs, dp, st);  // (dense_waves_for)
+  else
+    hipLaunchKernelGGL((k_assoc_dense<false, 4>), grid, dim3(256), 0, s, descs, dp, st);
 }
 
 struct LaunchGeom {
   int n_pairs, p0, T, gx, gy, nba, nbc, npb, N, csplit;
+  int csplit_heavy = 1;  // k_coeff grid of the graph with the dense kernel (the only one that runs pairs with overflow rows)
   int dense_blocks = DENSE_BLOCKS_MIN;  // k_assoc_dense grid x = PairDesc::dense_blocks of every pair of the launch
   int group = 0;        // sub-batch index (its stream, its ResidentTeams)
   int horizon_cap = 1 << 20;  // the lean graph's period (DevParams::lean_U)
@@ -552,7 +556,7 @@ void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags) {
   launch_assoc(g.stream, g.idx16, g.general, g.instr, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, lean ? 1 : 0);
   if (!lean) launch_dense(g.stream, g.general, g.N, g.n_pairs, g.dense_blocks, descs, c->d_params, st);
   if (g.verify) launch_verify(g.stream, g.general, g.N, g.n_pairs, descs, c->d_params, st, lean ? 1 : 0);
-  launch_coeff(g.stream, g.instr, g.nba, g.csplit, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0));
+  launch_coeff(g.stream, g.instr, g.nba, lean ? g.csplit : g.csplit_heavy, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0));
 }
 
 #ifdef CVO_WITH_RESIDENT
@@ -625,6 +629,7 @@ void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U)
 
 struct BatchSetup {
   int N, M, T, gpb, gx, gy, G;
+  bool long_lists = false;
   Dims d;
   PairLayout L;
   LaunchGeom geom;
@@ -679,7 +684,9 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   // (the update reduces an iteration's nonzero count in 32 bits: rows x nearest_neighbors_max must fit)
   if ((unsigned long long)N * (unsigned long long)std::max(params->nearest_neighbors_max, 1) >= (1ull << 32))
     return fail(ctx, CVO_E_INVALID, "source rows x nearest_neighbors_max must stay below 2^32");
-  S->L = make_layout(N, M, Kmax, trace_cap, &S->d);
+  // overflow rows keep sorted candidate lists of their own (PairDesc::long_j) when sorted positions fit 16 bits
+  S->long_lists = mode == 0 && M <= 65535 && ctx_opt(ctx, "NO_LONG_LISTS") == nullptr;
+  S->L = make_layout(N, M, Kmax, trace_cap, S->long_lists, &S->d);
   {
     size_t free_b = 0, total_b = 0;
     const size_t need = S->L.total * (size_t)n_pairs;
@@ -716,6 +723,11 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   }
   dp.T = S->T;
   dp.groups_per_block = S->gpb;
+  dp.long_lists = S->long_lists ? 1 : 0;
+  {
+    static std::atomic<unsigned long long> g_call_serial{1};  // never repeats inside a process: see PairDesc::long_stamp
+    dp.call_serial = g_call_serial.fetch_add(1);
+  }
   dp.lean_U = 8;
   if (const char* e = ctx_opt(ctx, "LEAN_U")) dp.lean_U = std::max(1, atoi(e));
   // Calm pairs (see PairState::want_full).  In the end game the pose jitters around its optimum: the motion PER ITERATION
@@ -759,6 +771,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     // coefficient phase: small clouds get several blocks per row block (see coeff_rows); a function of the pair's own
     // size only, so that a pair is reduced in the same order whether it is solved alone or inside a batch
     D.csplit = coeff_split(X->n);
+    D.csplit_heavy = coeff_split_heavy(X->n);
     D.nblk_coeff = S->d.nblk_assoc * D.csplit;
     D.NG = (X->n + ROWS_PER_GROUP - 1) / ROWS_PER_GROUP;
     D.NGpad = S->d.NGpad;
@@ -796,6 +809,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.xp4 = (float4*)(base + S->L.xp4);
     D.ip = (int*)(base + S->L.ip);
     D.iorig = (int*)(base + S->L.iorig);
+    D.long_j = S->long_lists ? (unsigned short*)(base + S->L.long_j) : nullptr;
+    D.long_stamp = (unsigned long long*)(base + S->L.long_stamp);
     D.cand_j = (void*)(base + S->L.cand_j);
     D.ell = (EllEntry*)(base + S->L.ell);
     D.ell_j = (int*)(base + S->L.ell_j);
@@ -860,6 +875,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.arena.Npad = S->d.Npad;
   S->geom.csplit = 1;
   for (int p = 0; p < n_pairs; p++) S->geom.csplit = std::max(S->geom.csplit, coeff_split(sources[p]->n));
+  S->geom.csplit_heavy = 1;
+  for (int p = 0; p < n_pairs; p++) S->geom.csplit_heavy = std::max(S->geom.csplit_heavy, coeff_split_heavy(sources[p]->n));
   S->geom.nbc = S->d.nblk_coeff;
   S->geom.npb = S->d.Mpad / PREP_THREADS + (S->d.NGpad * ROWS_PER_GROUP + PREP_THREADS - 1) / PREP_THREADS;
   S->geom.idx16 = M < 65536;
@@ -1684,7 +1701,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       key.nbc = S.d.nblk_coeff * 64 + S.geom.csplit;
       key.npb = S.geom.npb + (S.geom.dense_blocks << 20);  // (npb < 2^20: Mpad / 256 + rows / 256)
       key.idx16 = S.geom.idx16 ? 1 : 0;
-      key.general = S.geom.general ? 1 : 0;
+      key.general = (S.geom.general ? 1 : 0) | (S.geom.csplit_heavy << 1);
       key.U = Uc * 256 + lean_period(v, Uc) + (v == 3 ? 128 : 0);
       key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0) | (geom[g].res_nb << 2);
       key.arena = geom[g].arena.base;

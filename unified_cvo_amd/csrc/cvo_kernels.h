@@ -799,12 +799,15 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
   {
     const bool ov = rr < N && cnt_all > ASSOC_CAP;
     const unsigned long long m = __ballot(ov);
+    // ... and which of them are beyond a long list as well (k_assoc_dense scans all targets for those)
+    const unsigned long long m_scan = (Pp->long_lists && !D->st->all_dense) ? __ballot(ov && cnt_all > LONG_CAP) : m;
     // statistic: candidate pairs the association evaluates per iteration while these lists live (one returnless atomic
     // per wave and rebuild instead of a wave reduction in every wave of every k_assoc launch)
     const unsigned wsum = wave_sum_u32(rr < N ? (unsigned)min(cnt_all, 0x3ffffff) : 0u);
     if ((tid & 63) == 0) {
       st_x<true>(D->ovf_bits + (pos >> 6), m);
       if (m) atomicAdd(&D->st->n_ovf, __builtin_popcountll(m));
+      if (m_scan) atomicAdd(&D->st->n_scan, __builtin_popcountll(m_scan));
       if (wsum) (void)__hip_atomic_fetch_add(&D->st->ncand_list, (unsigned long long)wsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -1214,12 +1217,81 @@ __global__ __launch_bounds__(ASSOC_THREADS, GENERAL ? 1 : CVO_ASSOC_WAVES) void 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_assoc_dense: the rows k_assoc could not list (more than ASSOC_CAP candidates).  One wave per row at
-// a time runs the reference's literal ordered scan over ALL targets (CvoGPU.cu:522-590), 64 targets per
-// step: lanes evaluate the exact pair arithmetic in parallel, a ballot + prefix count gives every hit its
-// ELL slot in ascending j (so the first-K truncation and its early exit are exact), and the float flow
-// accumulation of compute_flow_gpu_no_eigen is replayed serially in lane (= j) order with v_readlane.
+// k_assoc_dense: the rows k_assoc could not list (more than ASSOC_CAP candidates).  One wave per row at a time, 64
+// candidates per lane step: lanes evaluate the exact pair arithmetic in parallel, a ballot + prefix count gives every
+// hit its ELL slot in ascending j (so the first-K truncation and its early exit are exact), and the float flow
+// accumulation of compute_flow_gpu_no_eigen is replayed serially in lane (= j) order.
+//   * rows with at most LONG_CAP candidates walk a LONG LIST: the row's candidates from the bitmap, sorted by original
+//     target index (the order of the reference's scan, CvoGPU.cu:522-590).  The wave that owns the row builds the list
+//     the first time it meets the row after a rebuild (decode, bitonic sort of (j << 16 | position) keys in LDS) and
+//     leaves it in HBM for the iterations that follow - a clustered cloud has thousands of rows with a few hundred
+//     neighbours each, and scanning all M targets for each of them cost 60x the slab's iteration (profiles/r4/scene.txt);
+//   * the others (and every row in the dense regime) run the literal ordered scan over ALL targets.
 // ------------------------------------------------------------------------------------------
+// The candidates of sorted row rr from the bitmap -> keys[0 .. cnt) = (original index << 16 | sorted position), ascending.
+__device__ __forceinline__ int build_long_list(const PairDesc* __restrict__ D, const int T, const int rr, unsigned* keys,
+                                               const int lane) {
+  const int N = D->N;
+  const int rbw = D->rbw;
+  const unsigned* rb = D->rowbits + (size_t)rr * rbw;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int cnt = 0;
+  const int wpr = 32 * T;  // mask words behind one word of slice bits
+  for (int w = 0; w < rbw; w++) {
+    const unsigned f = rb[w];  // (uniform)
+    if (f == 0) continue;
+    for (int h = 0; h < wpr; h += 64) {
+      // lane l: mask word h + l of this group = slice w * 32 + (h + l) / T, word (h + l) % T
+      const int l2 = h + lane;
+      const int sl = w * 32 + l2 / T;
+      unsigned long long m = 0;
+      if (l2 < wpr && ((f >> (l2 / T)) & 1u)) m = D->masks[((size_t)sl * N + rr) * T + (l2 % T)];
+      unsigned long long todo = __ballot(m != 0ull);
+      while (todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const unsigned long long mm = lane_u64(m, l);
+        const int chunk = w * wpr + h + l;  // == sl * T + t of lane l
+        if ((mm >> lane) & 1ull) {
+          const int idx = cnt + __builtin_popcountll(mm & lt);
+          if (idx < LONG_CAP) keys[idx] = (unsigned)(chunk * 64 + lane);
+        }
+        cnt += __builtin_popcountll(mm);
+      }
+    }
+  }
+  cnt = min(cnt, LONG_CAP);  // (the caller only comes here with a count that fits)
+  __builtin_amdgcn_wave_barrier();
+  int p2 = 64;
+  while (p2 < cnt) p2 <<= 1;
+  const int* yorder = D->yorder;
+  for (int k = lane; k < p2; k += 64) {
+    unsigned key = 0xffffffffu;
+    if (k < cnt) {
+      const unsigned p = keys[k];
+      key = ((unsigned)yorder[p] << 16) | p;
+    }
+    keys[k] = key;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // bitonic sort, ascending (the LDS operations of one wave complete in order; the barriers only pin the compiler)
+  for (int k = 2; k <= p2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < (p2 >> 1); t += 64) {
+        const int i1 = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int i2 = i1 | j;
+        const unsigned a = keys[i1], b = keys[i2];
+        const bool up = (i1 & k) == 0;
+        if ((a > b) == up) {
+          keys[i1] = b;
+          keys[i2] = a;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  return cnt;
+}
+
 template <bool GENERAL, int DENSE_WAVES>
 __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
                                                      const int* __restrict__ status) {
@@ -1234,12 +1306,15 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
   if (n_ovf == 0 && P.mode == 0) return;  // nothing to add: k_assoc has finished the twist, the update skips these slots
   const bool all_dense = st->all_dense != 0;
   __shared__ float2 s_hits[DENSE_WAVES][128][6];  // per wave: the hits of one step, compacted ({flow term, value} per component)
+  __shared__ unsigned s_keys[DENSE_WAVES][LONG_CAP];  // per wave: the long list being built (sort keys)
   double red[7] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long nnz_sum = 0;
   unsigned nnz_max = 0;
   if (n_ovf > 0) {
     const Pose pose = load_pose(st);
     const FeatDen F = make_feat_den(P);
+    const bool long_lists = !all_dense && P.long_lists != 0 && D->long_j != nullptr;
+    const unsigned long long gen = (P.call_serial << 24) | (unsigned long long)((unsigned)st->n_builds & 0xffffffu);
     for (int q = blockIdx.x * DENSE_WAVES + wave; q < n_ovf; q += (int)gridDim.x * DENSE_WAVES) {
       // a position of k_list's ordering (all per-row outputs are stored by position); dense regime: every row
       const int r_sorted = all_dense ? q : D->ovf_rows[q];
@@ -1247,23 +1322,49 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
       const float4 x = D->xp4[r_sorted];
       const RowData r = make_row(P, x, st->ell);
       const V3 pxe{x.x, x.y, x.z};
+      // where this row's candidates come from: its long list (built now if it is not the current one) or all targets
+      int n_cand = M;
+      bool listed = false, fresh = false;
+      const unsigned short* lj = nullptr;
+      if (long_lists) {
+        const int cnt = __float_as_int(x.w);  // (k_list keeps the row's candidate count next to its coordinates)
+        if (cnt <= LONG_CAP) {
+          listed = true;
+          n_cand = cnt;
+          lj = D->long_j + (size_t)q * LONG_CAP;
+          if (D->long_stamp[q] != gen) {
+            n_cand = build_long_list(D, P.T, D->rowperm[r_sorted], s_keys[wave], lane);
+            fresh = true;
+            unsigned short* out = D->long_j + (size_t)q * LONG_CAP;
+            for (int k = lane; k < n_cand; k += 64) out[k] = (unsigned short)(s_keys[wave][k] & 0xffffu);
+            if (lane == 0) D->long_stamp[q] = gen;
+          }
+        }
+      }
       unsigned nnz = 0;
-      // Two chunks of 64 targets per step: their (independent) evaluations overlap in the pipeline; if the first one
+      // Two chunks of 64 candidates per step: their (independent) evaluations overlap in the pipeline; if the first one
       // already fills the row, the second was evaluated for nothing.  Hits are compacted into LDS in ascending j
       // (slot = rank inside the step), then lanes 0..5 replay the reference's ordered float accumulation, one
       // component each (one LDS read + one FMA per hit and lane; lane 6 carries the double sum of the values).
       float acc = 0.f;   // lanes 0..2: omega_i, lanes 3..5: v_i  (CvoGPU.cu:779-780)
       double asum = 0;   // lane 6
-      for (int j0 = 0; j0 < M && nnz < (unsigned)K; j0 += 128) {
+      for (int j0 = 0; j0 < n_cand && nnz < (unsigned)K; j0 += 128) {
         float a[2] = {0.f, 0.f};
         float4 yt[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
         bool ok[2] = {false, false};
+        int col[2] = {0, 0};
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-          const int j = j0 + 64 * h + lane;
-          if (j < M) {
-            const float4 y0 = D->y4[j];
-            ok[h] = eval_pair<GENERAL>(P, D, F, pose, i, r, GENERAL ? D->yinv[j] : 0, y0, a[h], yt[h]) && (a[h] > P.sp_thres);
+          const int c = j0 + 64 * h + lane;
+          if (c < n_cand) {
+            if (listed) {  // list entries are sorted positions: coordinates and features from the spatially ordered arrays
+              const int p = fresh ? (int)(s_keys[wave][c] & 0xffffu) : (int)lj[c];
+              col[h] = p;
+              ok[h] = eval_pair<GENERAL>(P, D, F, pose, i, r, p, D->ys4[p], a[h], yt[h]) && (a[h] > P.sp_thres);
+            } else {
+              col[h] = c;
+              ok[h] = eval_pair<GENERAL>(P, D, F, pose, i, r, GENERAL ? D->yinv[c] : 0, D->y4[c], a[h], yt[h]) && (a[h] > P.sp_thres);
+            }
           }
         }
         int nstaged = 0;
@@ -1275,7 +1376,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
           const bool keep = ok[h] && rank < (unsigned)K;  // `if (num_inds == num_neighbors) break;`
           if (keep) {
             D->ell[(size_t)rank * N + r_sorted] = EllEntry{a[h], yt[h].x, yt[h].y, yt[h].z};
-            if (P.keep_columns) D->ell_j[(size_t)rank * N + r_sorted] = j0 + 64 * h + lane;
+            if (P.keep_columns) D->ell_j[(size_t)rank * N + r_sorted] = listed ? D->yorder[col[h]] : col[h];
             // flow terms of this lane's pair (CvoGPU.cu:767-769)
             const V3 pye{yt[h].x, yt[h].y, yt[h].z};
             const V3 cr = cross_dev(pxe, pye);
@@ -1808,7 +1909,13 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
       // thinned out (mean nonzeros per row below 12, far from the 32 / 64 a list holds).
       if (!INIT && P.mode == 0 && P.dense_regime) {
         const bool was = st->all_dense != 0;
-        const bool now = was ? (unsigned long long)st->nnz >= 12ull * (unsigned long long)D.N : 2 * st->n_ovf > D.N;
+        // (with long lists an overflow row costs what its candidates cost: the literal scan of everything only pays when
+        // most rows are beyond even those, when the target cloud is small - 2048 targets are 32 lane steps, no bitmap, no
+        // sort, no rebuilds: the demo pair on its K cap - or when the rows see a third of it anyway)
+        const bool now = was ? (unsigned long long)st->nnz >= 12ull * (unsigned long long)D.N
+                             : (2 * st->n_scan > D.N ||
+                                (2 * st->n_ovf > D.N &&
+                                 (D.M <= 2048 || 3ull * st->ncand_list > (unsigned long long)D.N * (unsigned long long)D.M)));
         if (now != was) {
           st->all_dense = now ? 1 : 0;
           rebuild = true;
@@ -1829,11 +1936,11 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         // build, or the dense regime): the host has a full graph without the dense kernel for large clouds
         int want_full = (st->n_ovf > 0 || st->all_dense) ? 4 : 2;
         float s = 0.f;
-        // rows that overflow their lists fall back to the literal scan over all targets (k_assoc_dense): fine for a few
+        // rows beyond every list fall back to the literal scan over all targets (k_assoc_dense): fine for a few
         // rows or a small cloud, ruinous if a generous skin pushes many rows of a large one over the edge - the skin
-        // backs off by halves while the last build left overflow rows and recovers slowly afterwards
+        // backs off by halves while the last build left such rows and recovers slowly afterwards
         if (INIT) st->skin_scale = 1.f;
-        else if (st->n_ovf > 0 && !st->all_dense) st->skin_scale = fmaxf(0.5f * st->skin_scale, 1.f / 64.f);
+        else if (st->n_scan > 0 && !st->all_dense) st->skin_scale = fmaxf(0.5f * st->skin_scale, 1.f / 64.f);
         else st->skin_scale = fminf(1.f, 1.1f * st->skin_scale);
         if (!INIT && P.mode == 0 && P.use_geo && radius > 0.f && P.skin_frac > 0.f && !st->all_dense) {
           const float rel = step_move * frcp(radius);
@@ -1966,7 +2073,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     head.e_n = EllEntry{0.f, 0.f, 0.f, 0.f};
     if (cq == 0) head.e_n = reinterpret_cast<const EllEntry*>(wb + row_off_ell(Npad))[pos];
   }
-  const int csplit = D->csplit;
+  const int csplit_light = D->csplit, csplit_heavy = D->csplit_heavy;
   PairState* const st = states + pb.pair;  // == D->st, without the dependent pointer load
   // The state as this launch found it, through a read-only view so that the loads are scalar (only the block that
   // finishes last writes the state, after every block has read it); one burst together with what the row loop
@@ -1974,6 +2081,8 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   const PairState* __restrict__ st_in = states + pb.pair;
   const int status_v = st_in->status, rebuild_v = st_in->rebuild, ovf = st_in->n_ovf;
   const DevParams P = *Pp;
+  // rows with hundreds of nonzeros (a pair with overflow rows: clustered clouds, the K cap) are spread over more blocks
+  const int csplit = (ovf > 0 && !(flags & 1)) ? csplit_heavy : csplit_light;
   // the twist and its matrices (twist_finalize): wave-uniform scalar loads
   XiMats Mu;
   {
@@ -2036,14 +2145,17 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     if (threadIdx.x + 64 < HOT_DWORDS) hot_regs[1] = reinterpret_cast<const unsigned*>(st)[threadIdx.x + 64];
   }
   const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && !replay, st, 1);
-  const UpdDesc upd = load_upd_desc(D);
+  UpdDesc upd = load_upd_desc(D);
+  upd.nblk_coeff = nblk * csplit;
   const int n_flow_upd = ((flags & 1) || ovf == 0) ? D->nblk_assoc : D->nblk_assoc + D->dense_blocks;  // (see k_assoc_dense)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partial stores before the counter, see flow_gate
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int done = __hip_atomic_fetch_add(D->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int nwork = nblk * csplit;  // blocks of this pair that store a partial
-    s_last = replay ? (done % nwork == nwork - 1) : (done == (epoch + 1) * nwork - 1);
+    // the counter advances by nblk * COEFF_SPLIT_MAX per iteration whatever the split of the iteration is (splits are
+    // powers of two): each of the nblk * csplit blocks that store a partial adds its share
+    const unsigned share = (unsigned)(COEFF_SPLIT_MAX / csplit), per_it = (unsigned)(nblk * COEFF_SPLIT_MAX);
+    const unsigned done = (unsigned)__hip_atomic_fetch_add(D->done, (int)share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + share;
+    s_last = replay ? (done % per_it == 0u) : (done == (unsigned)(epoch + 1) * per_it);
   }
   __syncthreads();
   const unsigned long long tt3 = INSTR ? __builtin_readcyclecounter() : 0ull;
@@ -2612,6 +2724,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
   if (st->all_dense) {  // dense regime: no operands to prepare, only the overflow list to reset for k_list
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       D->st->n_ovf = 0;
+      D->st->n_scan = 0;
       D->st->ncand_list = 0ull;
     }
     return;
@@ -2688,6 +2801,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PairDesc* __restric
   const float ell = st->ell;  // == st->ell_build: a rebuild always uses the current lengthscale
   if (rs == 0) {  // k_list refills the overflow list of k_assoc_dense and the lists' candidate count
     D->st->n_ovf = 0;
+    D->st->n_scan = 0;
     D->st->ncand_list = 0ull;
   }
   // per-row skin = skin_rot * rho_i + skin_tr (+ rounding slack), see PairState / update_body
