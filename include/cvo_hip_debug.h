@@ -42,6 +42,10 @@ int cvo_debug_kernel_clock(cvo_ctx* ctx, float* ms_assoc, float* ms_coeff, unsig
  * (re)built by k_scan, the optimiser iterations run, and the candidate pairs k_assoc evaluated exactly. */
 int cvo_debug_list_builds(cvo_ctx* ctx, unsigned long long* builds, unsigned long long* iterations,
                           unsigned long long* candidate_evaluations);
+/* How the last list build of pair `pair` of the last align call classed its rows: rows beyond the 64-entry candidate
+ * lists (served by k_assoc_dense), those of them beyond a long list as well (literal scan of all targets), and whether
+ * the pair ended in the dense regime (no lists at all). */
+int cvo_debug_row_classes(cvo_ctx* ctx, int pair, int* overflow_rows, int* scanned_rows, int* dense_regime);
 /* Number of candidate pairs in the bitmap the last iteration used (superset of nnz). */
 int cvo_debug_last_candidates(cvo_ctx* ctx, unsigned long long* out);
 /* Runs the device's scalar restatements of the reference's host-side maths (cubic roots of poly_solver_order3,

@@ -332,6 +332,57 @@ def test_verify_lists_full_size(monkeypatch, name, builder, kw, n_it):
     assert builds < iters                                    # lists really were reused while being verified
 
 
+def _blob_pair(n_blob=3000, n_bg=5000, seed=5):
+    """A tight ball of n_blob points (every one of them sees the whole ball: far more candidates than a long list holds)
+    in a sparse background of n_bg points, moved by the usual ground-truth motion."""
+    from unified_cvo_amd import synth
+    rs = np.random.default_rng(seed)
+    blob = rs.normal(0.0, 0.05, (n_blob, 3)) + np.array([0.5, -0.3, 6.0])
+    bg = np.stack([rs.uniform(-8, 8, n_bg), rs.uniform(-2, 3, n_bg), rs.uniform(2, 30, n_bg)], axis=1)
+    pts = np.concatenate([blob, bg])[rs.permutation(n_blob + n_bg)]
+    T = synth.gt_motion()
+    tgt = (pts @ T[:3, :3].T + T[:3, 3] + rs.normal(0, 0.01, pts.shape))[rs.permutation(len(pts))]
+    return CvoPointCloud.from_xyz(pts.astype(np.float32)), CvoPointCloud.from_xyz(tgt.astype(np.float32))
+
+
+def test_long_lists_three_row_classes(monkeypatch):
+    """One pair with all three kinds of rows at once - listed (<= 64 candidates), long-listed (<= 1024, the cached
+    index-sorted lists of k_assoc_dense) and scanned literally (the 3000-point blob) - re-derived row by row on the device,
+    and bit-identical to the same call with CVO_NO_LONG_LISTS=1 (every overflow row scanned, as in round 3)."""
+    P = cases.load_params("geometric_gpu")
+    src, tgt = _blob_pair()
+    init = np.eye(4, dtype=np.float32)
+    n_it = 60
+    monkeypatch.setenv("CVO_VERIFY_LISTS", "1")
+    gpu = CvoGPU(params=P)
+    g = gpu.align(src, tgt, init, max_iterations=n_it)
+    assert g.iterations == n_it and gpu.debug_verified_rows() == n_it * src.num_points()
+    n_ovf, n_scan, dense = gpu.debug_row_classes()
+    assert not dense and n_scan >= 2500 and n_ovf > n_scan          # blob rows are scanned, others walk long lists
+    monkeypatch.delenv("CVO_VERIFY_LISTS")
+    monkeypatch.setenv("CVO_NO_LONG_LISTS", "1")
+    ref = CvoGPU(params=P)
+    r = ref.align(src, tgt, init, max_iterations=n_it)
+    assert np.array_equal(r.transform, g.transform) and (r.final_ell, r.final_num_neighbors) == (g.final_ell, g.final_num_neighbors)
+    o2, s2, _ = ref.debug_row_classes()
+    assert s2 == o2                                                   # without long lists every overflow row is scanned
+
+
+def test_long_lists_survive_across_calls():
+    """The cached long lists carry a generation tag (call serial, list build): a second call on the same context and
+    workspace - same pair, then another pair of the same size - never reads a list of the call before."""
+    P, src, tgt, init = cases.scene(n=3000)
+    gpu = CvoGPU(params=P)
+    a = gpu.align(src, tgt, init, max_iterations=120)
+    b = gpu.align(src, tgt, init, max_iterations=120)
+    assert np.array_equal(a.transform, b.transform)
+    assert gpu.debug_row_classes()[0] > 0
+    P2, src2, tgt2, _ = cases.scene(n=3000, pair_id=1)
+    fresh = CvoGPU(params=P).align(src2, tgt2, init, max_iterations=120)
+    reused = gpu.align(src2, tgt2, init, max_iterations=120)
+    assert np.array_equal(fresh.transform, reused.transform)
+
+
 def test_verify_lists_catches_a_broken_skin(monkeypatch):
     """The check is not vacuous: with the motion bound disabled (CVO_DEBUG_NO_MOTION_BOUND: lists are never rebuilt for
     motion) the first fast iterations lose pairs and the call fails with CVO_E_VERIFY."""

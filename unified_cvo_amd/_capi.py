@@ -131,7 +131,7 @@ EXPORTED = [
     "cvo_align", "cvo_align_ex", "cvo_align_batch", "cvo_batch_poses_to_device", "cvo_inner_product",
     "cvo_function_angle", "cvo_association", "cvo_association_non_isotropic", "cvo_cloud_transformed", "cvo_edge_kernel_matrix", "cvo_debug_last_ell", "cvo_debug_time_scan", "cvo_debug_time_kernels",
     "cvo_debug_kernel_clock",
-    "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
+    "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_row_classes", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
     "cvo_align_association", "cvo_debug_scalar_math", "cvo_debug_verified_rows", "cvo_debug_device_memory", "cvo_cloud_upload_many",
     "cvo_ctx_set_option", "cvo_debug_resident_ticks", "cvo_ctx_advice", "cvo_debug_cloud_order",
 ]
@@ -192,6 +192,7 @@ def lib(path=None):
     L.cvo_debug_kernel_clock.argtypes = [vp, fp, fp, C.POINTER(C.c_ulonglong)]
     L.cvo_debug_last_candidates.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.cvo_debug_list_builds.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    L.cvo_debug_row_classes.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cvo_debug_last_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cvo_debug_scan_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cvo_align_association.argtypes = [vp, ip, C.POINTER(C.c_int), C.POINTER(C.c_int), fp, C.c_size_t,

@@ -565,6 +565,12 @@ class CvoGPU:
         self._check(self.L.cvo_debug_list_builds(self.ctx, C.byref(b), C.byref(it), C.byref(ce)))
         return b.value, it.value, ce.value
 
+    def debug_row_classes(self, pair=0):
+        """(overflow rows, rows scanned literally, dense regime) of pair `pair` as its last list build left them."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.L.cvo_debug_row_classes(self.ctx, pair, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, bool(c.value)
+
     def advice(self):
         """Performance-relevant observations about the process set-up (cvo_ctx_advice): "" when there is nothing to say,
         e.g. a text about GPU_MAX_HW_QUEUES when HIP was initialised with fewer than 8 hardware queues."""

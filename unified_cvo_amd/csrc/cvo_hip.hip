@@ -2449,6 +2449,15 @@ int cvo_debug_list_builds(cvo_ctx* ctx, unsigned long long* builds, unsigned lon
   return CVO_OK;
 }
 
+int cvo_debug_row_classes(cvo_ctx* ctx, int pair, int* overflow_rows, int* scanned_rows, int* dense_regime) {
+  if (!ctx || pair < 0 || pair >= ctx->last_pairs) return fail(ctx, CVO_E_INVALID, "cvo_debug_row_classes: bad argument");
+  const PairState& st = ctx->h_states[pair];
+  if (overflow_rows) *overflow_rows = st.n_ovf;
+  if (scanned_rows) *scanned_rows = st.n_scan;
+  if (dense_regime) *dense_regime = st.all_dense;
+  return CVO_OK;
+}
+
 int cvo_debug_scan_stats(cvo_ctx* ctx, unsigned long long* tiles, int* rows_per_tile, int* targets_per_tile) {
   if (!ctx || !tiles || ctx->last_pairs < 1) return fail(ctx, CVO_E_INVALID, "cvo_debug_scan_stats: bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
