@@ -76,6 +76,8 @@ struct PairLayout {  // byte offsets of one pair's workspace inside the arena
       coef_part, trace, total;
 };
 
+static const char* const kGraphNames[8] = {"full", "lean", "short", "full-nodense", "calm", "lean+dense", "short+dense", "calm+dense"};
+
 struct GraphKey {
   int n_pairs = 0, p0 = 0, T = 0, gx = 0, gy = 0, nba = 0, nbc = 0, npb = 0, idx16 = 0, general = 0, U = 0, flags = 0;
   const void* arena = nullptr;  // kernel arguments of the row-block kernels (ArenaArg)
@@ -137,7 +139,7 @@ struct cvo_ctx {
   // graph cache (one per group)
   // [group][0 = full chunk, 1 = lean chunk, 2 = short lean chunk, 3 = full chunk without k_assoc_dense, 4 = calm chunk (lean, one rebuild opportunity); + 5 for the instrumented kernels (CVO_KERNEL_CLOCK /
   // CVO_PHASE_TICKS), cached side by side so that a caller can time single steps of a loop without re-capturing]
-  static constexpr int GRAPH_VARIANTS = 20;  // ... x 2 chunk lengths (the early chunks of a call are shorter)
+  static constexpr int GRAPH_VARIANTS = 32;  // 8 graphs (see cvo_align_batch) x instrumented or not  // ... x 2 chunk lengths (the early chunks of a call are shorter)
   hipGraphExec_t graph_exec[MAX_GROUPS][GRAPH_VARIANTS] = {};
   GraphKey graph_key[MAX_GROUPS][GRAPH_VARIANTS] = {};
   int last_chunks = 0, last_lean_launches = 0, last_full_launches = 0;
@@ -550,13 +552,18 @@ void launch_rebuild(cvo_ctx* c, const LaunchGeom& g) {
 // One optimiser iteration over the current lists: association, [overflow rows], coefficients + update (the last
 // block of k_coeff).  Lean: no k_assoc_dense, pairs with overflow rows or an expired list wait.  `flags` see
 // update_body.
-void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags) {
+// `dense`: a lean graph that runs k_assoc_dense all the same (pairs with overflow rows / in the dense regime that need
+// no rebuild opportunity in every iteration).
+void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags, bool dense = false) {
   const PairDesc* descs = c->d_descs + g.p0;
   const int* st = c->d_status + 2 * g.p0;  // the sub-batch's status words (see setup_batch)
-  launch_assoc(g.stream, g.idx16, g.general, g.instr, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, lean ? 1 : 0);
-  if (!lean) launch_dense(g.stream, g.general, g.N, g.n_pairs, g.dense_blocks, descs, c->d_params, st);
-  if (g.verify) launch_verify(g.stream, g.general, g.N, g.n_pairs, descs, c->d_params, st, lean ? 1 : 0);
-  launch_coeff(g.stream, g.instr, g.nba, lean ? g.csplit : g.csplit_heavy, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0));
+  const bool lean_dense = lean && dense;
+  launch_assoc(g.stream, g.idx16, g.general, g.instr, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena,
+               (lean ? 1 : 0) | (lean_dense ? 4 : 0));
+  if (!lean || dense) launch_dense(g.stream, g.general, g.N, g.n_pairs, g.dense_blocks, descs, c->d_params, st);
+  if (g.verify) launch_verify(g.stream, g.general, g.N, g.n_pairs, descs, c->d_params, st, (lean ? 1 : 0) | (lean_dense ? 4 : 0));
+  launch_coeff(g.stream, g.instr, g.nba, (lean && !dense) ? g.csplit : g.csplit_heavy, g.n_pairs, descs, c->d_params,
+               c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0) | (lean_dense ? 32 : 0));
 }
 
 #ifdef CVO_WITH_RESIDENT
@@ -594,7 +601,7 @@ void launch_resident(cvo_ctx* c, const LaunchGeom& g, int U) {
 // lean_U == 0: the full chunk WITHOUT k_assoc_dense - a rebuild opportunity in every iteration with the full graph's
 // rebuild rule (no horizon), but a pair whose rows overflow their lists waits (and asks for the dense kernel: want = 4).
 // Large clouds run their fast first iterations here: the dense kernel, launched for nothing, is 5 us + a launch gap.
-void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U) {
+void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U, bool dense = false) {
   if (lean && lean_U == 0) {
     for (int u = 0; u < U; u++) {
       launch_rebuild(c, g);
@@ -610,7 +617,7 @@ void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U)
     return;
   }
 #ifdef CVO_WITH_RESIDENT
-  if (g.res_nb > 0) {  // the lean iterations between two rebuild opportunities in ONE launch
+  if (g.res_nb > 0 && !dense) {  // the lean iterations between two rebuild opportunities in ONE launch
     for (int u = 0; u < U; u += lean_U) {
       launch_rebuild(c, g);
       launch_resident(c, g, std::min(lean_U, U - u));
@@ -623,7 +630,7 @@ void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U)
     const bool last = (u % lean_U == lean_U - 1) || u == U - 1;
     // (horizon of the rebuild rule: the lean graph's period even in a calm chunk, whose one opportunity per chunk is a bet
     // on the list outliving the linear prediction - a pair that loses it waits for the next chunk)
-    launch_core(c, g, true, (last ? 2 : 0) | (std::min(lean_U, g.horizon_cap) << 8));
+    launch_core(c, g, true, (last ? 2 : 0) | (std::min(lean_U, g.horizon_cap) << 8), dense);
   }
 }
 
@@ -1687,10 +1694,18 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     const int lean_U = std::max(1, std::min(dp.lean_U, U));
     bool resident_broken = false;
     const int lean_U2 = std::max(0, std::min(dp.lean_U2, U));
-    auto lean_period = [&](int v, int Uc) { return v == 4 ? Uc : (v == 3 ? 0 : (v == 2 ? lean_U2 : lean_U)); };
-    const int v_instr = S.geom.instr ? 5 : 0;  // the instrumented kernels have their own cached graphs
+    // graphs: 0 full (rebuild opportunity + k_assoc_dense in every iteration), 1 lean, 2 short lean, 3 full without the
+    // dense kernel, 4 calm; 5 / 6 / 7 = lean / short lean / calm WITH the dense kernel (pairs with overflow rows, or in
+    // the dense regime, whose lists live long enough)
+    auto lean_base = [](int v) { return v >= 5 ? (v == 7 ? 4 : v - 4) : v; };
+    auto lean_period = [&](int v, int Uc) {
+      const int b = lean_base(v);
+      return b == 4 ? Uc : (b == 3 ? 0 : (b == 2 ? lean_U2 : lean_U));
+    };
+    const int v_instr = S.geom.instr ? 8 : 0;  // the instrumented kernels have their own cached graphs
+    auto graph_index = [&](int v, int Uc) { return v + v_instr + (Uc != U ? 16 : 0); };
     auto get_graph = [&](int g, int v, int Uc) -> int {
-      const int vi = v + v_instr + (Uc != U ? 10 : 0);
+      const int vi = graph_index(v, Uc);
       GraphKey key;
       key.n_pairs = geom[g].n_pairs;
       key.p0 = geom[g].p0;
@@ -1703,7 +1718,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       key.idx16 = S.geom.idx16 ? 1 : 0;
       key.general = (S.geom.general ? 1 : 0) | (S.geom.csplit_heavy << 1);
       key.U = Uc * 256 + lean_period(v, Uc) + (v == 3 ? 128 : 0);
-      key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0) | (geom[g].res_nb << 2);
+      key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0) | (geom[g].res_nb << 2) | (v << 24);
       key.arena = geom[g].arena.base;
       key.stride256 = geom[g].arena.stride256;
       key.Npad = geom[g].arena.Npad;
@@ -1714,7 +1729,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       }
       hipGraph_t gr = nullptr;
       HIP_TRY(ctx, hipStreamBeginCapture(geom[g].stream, hipStreamCaptureModeThreadLocal));
-      launch_chunk(ctx, geom[g], Uc, v != 0, lean_period(v, Uc));
+      launch_chunk(ctx, geom[g], Uc, v != 0, lean_period(v, Uc), v >= 5);
       // (the capture is always ended, whatever the launches reported: a stream left in capture mode would poison
       // every later call on this context)
       const hipError_t e_launch = hipGetLastError();
@@ -1753,7 +1768,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       if (ctx_opt(ctx, "VERBOSE") && atoi(ctx_opt(ctx, "VERBOSE")) >= 3) {
         fprintf(stderr, "[cvo] chunk %d (%d iterations): graphs", ch, Uc);
         for (int g = 0; g < G; g++)
-          fprintf(stderr, " %s", graph_next[g] == 0 ? "full" : (graph_next[g] == 1 ? "lean" : (graph_next[g] == 2 ? "short" : (graph_next[g] == 3 ? "full-nodense" : "calm"))));
+          fprintf(stderr, " %s", kGraphNames[graph_next[g]]);
         fprintf(stderr, "\n");
       }
       for (int g = 0; g < G; g++) {
@@ -1763,10 +1778,10 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
           rc = get_graph(g, v, Uc);
           if (rc != CVO_OK) return rc;
           const auto tl = now();
-          HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g][v + v_instr + (Uc != U ? 10 : 0)], geom[g].stream));
+          HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g][graph_index(v, Uc)], geom[g].stream));
           t_launch += ms_since(tl);
         } else {
-          launch_chunk(ctx, geom[g], Uc, v != 0, lean_period(v, Uc));
+          launch_chunk(ctx, geom[g], Uc, v != 0, lean_period(v, Uc), v >= 5);
           HIP_TRY(ctx, hipGetLastError());
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status[slot] + 2 * geom[g].p0, ctx->d_status + 2 * geom[g].p0,
@@ -1784,10 +1799,18 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
           const int* hs = ctx->h_status[ws] + 2 * geom[g].p0;  // [status[n_g] | want[n_g]]
           const int ng = geom[g].n_pairs;
           for (int q = 0; q < ng; q++) all_done = all_done && hs[q] != 0;
-          int want = -1;  // the most demanding unfinished pair of the group decides: 4 / 2 = full, 1 = short lean, 0 = lean, -1 = calm
+          // the most demanding unfinished pair of the group decides the level (2 = full, 1 = short lean, 0 = lean,
+          // -1 = calm), any of them that needs k_assoc_dense gets it (want_level / want_encode, cvo_kernels.h)
+          int want = -1;
+          bool dense = false, timed_out = false;
           for (int q = 0; q < ng; q++)
-            if (hs[q] == 0) want = std::max(want, hs[ng + q]);
-          if (want == 3) {  // a resident launch timed out: its pairs are served by the two-kernel graphs from now on
+            if (hs[q] == 0) {
+              const int w = hs[ng + q];
+              timed_out = timed_out || w == 3;
+              dense = dense || w == 4 || w >= 8;
+              want = std::max(want, w == 4 || w == 3 ? 2 : (w >= 8 ? w - 9 : w));
+            }
+          if (timed_out) {  // a resident launch timed out: its pairs are served by the two-kernel graphs from now on
             want = 2;
             if (!resident_broken)
               fprintf(stderr, "[cvo] warning: a resident launch timed out (blocks of a pair not co-resident); this context "
@@ -1796,8 +1819,16 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
             for (int q = 0; q < G; q++) geom[q].res_nb = 0;  // (graphs are keyed on it: the next ones are captured anew)
           }
           if (want == 1 && lean_U2 <= 0) want = 2;
-          // want: 0 lean, 1 short lean, 2 a rebuild opportunity in every iteration, 4 the dense kernel as well
-          graph_next[g] = !allow_lean ? 0 : (want >= 4 ? 0 : (want >= 2 ? (start_nodense ? 3 : 0) : (want == 1 ? 2 : (want == 0 || !allow_calm ? 1 : 4))));
+          if (!allow_lean)
+            graph_next[g] = 0;
+          else if (want >= 2)
+            graph_next[g] = dense ? 0 : (start_nodense ? 3 : 0);
+          else if (want == 1)
+            graph_next[g] = dense ? 6 : 2;
+          else if (want == 0 || !allow_calm)
+            graph_next[g] = dense ? 5 : 1;
+          else
+            graph_next[g] = dense ? 7 : 4;
           if (ctx_opt(ctx, "VERBOSE") && atoi(ctx_opt(ctx, "VERBOSE")) >= 2 && ch < 12) {
             int nw = 0;
             for (int q = 0; q < ng; q++) nw += hs[ng + q] != 0;

@@ -1186,16 +1186,19 @@ __global__ __launch_bounds__(ASSOC_THREADS, GENERAL ? 1 : CVO_ASSOC_WAVES) void 
     const float4* a3 = D->ys4;
     const EllEntry* a4 = D->ell;
     const float e = st->ell, r0 = st->Rinv[0], t0 = st->Tinv[0];
+    // (c, d, log_geo and d2_c_thres share one 16-byte scalar load: with all four pinned none of its registers is dead, so
+    // the allocator cannot hand one to another load of this burst - that reuse put a wait, one more round trip, in the
+    // middle of it: +0.6 us per iteration for a lone pair, found in the ISA)
     asm volatile("" ::"s"(n), "s"(k), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e), "s"(r0), "s"(t0), "s"(P.sp_thres),
-                 "s"(P.log_geo));
+                 "s"(P.log_geo), "s"(P.c), "s"(P.d), "s"(P.d2_c_thres));
   }
   const bool replay = (lean & 2) != 0;  // cvo_debug_time_kernels: re-run on the state the last call left behind
   if (!replay && status_v != 0) return;
   // lean graph (no rebuild / dense kernels inside the iteration): a pair whose list has expired, or that has
   // rows for k_assoc_dense, does not advance; it waits for the next rebuild opportunity / for the host to
   // switch its group to the full graph (k_coeff skips it too and tells the host)
-  if ((lean & 1) && (rebuild_v || n_ovf_v > 0)) return;
-  pair_clock_begin(INSTR && P.kernel_clock && lean == 1 && pb.bx == 0, const_cast<PairState*>(st), 0);
+  if ((lean & 1) && (rebuild_v || (n_ovf_v > 0 && !(lean & 4)))) return;  // (bit 2: k_assoc_dense follows in this graph)
+  pair_clock_begin(INSTR && P.kernel_clock && (lean & 3) == 1 && pb.bx == 0, const_cast<PairState*>(st), 0);
   __shared__ AssocShared S;
   assoc_phase<IdxT, ASSOC_CAP, GENERAL, INSTR>(P, D, load_iter_view(st), S, pb.bx, head);
   // Everything from here on - the block's partial is on its way, the last-block counter, possibly the twist - is the
@@ -1205,8 +1208,8 @@ __global__ __launch_bounds__(ASSOC_THREADS, GENERAL ? 1 : CVO_ASSOC_WAVES) void 
   if (threadIdx.x >= 64) return;
   // lean graph, or a pair without overflow rows in the full one (k_assoc_dense then has nothing to add and leaves at
   // once): nothing else adds to the flow, the twist of the iteration can be finished here
-  if (((lean & 3) || n_ovf_v == 0) && P.mode == 0) {  // (bit 1: the timing replay includes it)
-    const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && lean == 1, st, 0);
+  if ((n_ovf_v == 0 || ((lean & 3) && !(lean & 4))) && P.mode == 0) {  // (bit 1: the timing replay includes it)
+    const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && (lean & 3) == 1, st, 0);
     const bool last = flow_gate(D, nblk, nblk);
     if (last && threadIdx.x == 0 && clk0) D->st->clk_last_assoc = pair_clock_ticks(clk0);  // added up by the update
   }
@@ -1304,6 +1307,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n_ovf = st->n_ovf;
   if (n_ovf == 0 && P.mode == 0) return;  // nothing to add: k_assoc has finished the twist, the update skips these slots
+  if (st->rebuild) return;  // (lean graphs with this kernel: the pair waits for its rebuild opportunity, see k_assoc)
   const bool all_dense = st->all_dense != 0;
   __shared__ float2 s_hits[DENSE_WAVES][128][6];  // per wave: the hits of one step, compacted ({flow term, value} per component)
   __shared__ unsigned s_keys[DENSE_WAVES][LONG_CAP];  // per wave: the long list being built (sort keys)
@@ -1600,6 +1604,13 @@ __device__ __forceinline__ UpdDesc load_upd_desc(const PairDesc* __restrict__ D)
 // sum (the lean graph has no k_assoc_dense, so its slots are not read).
 // RES: called from the resident kernel - counts, state and indicator FIFOs were (or may have been) written by OTHER
 // blocks of the SAME launch, so they are read with L1-bypassing loads as well.
+// PairState::want_full, the graph a pair asks the host for: a LEVEL - 2 = a rebuild opportunity in every iteration,
+// 1 = every lean_U2 iterations (short lean graph), 0 = every lean_U (lean graph), -1 = calm, one per chunk - and whether
+// k_assoc_dense has to run (overflow rows / the dense regime).  Encoded as: level without the dense kernel; 4 = level 2
+// with it; 8 + (level + 1) = a leaner level with it.  (3 is the resident launch's time-out, see k_resident.)
+__device__ __forceinline__ int want_level(int w) { return w == 4 ? 2 : (w >= 8 ? w - 9 : w); }
+__device__ __forceinline__ int want_encode(int level, bool dense) { return !dense ? level : (level >= 2 ? 4 : 9 + level); }
+
 struct NoEarlyPublish {
   __device__ __forceinline__ void operator()(int, int, float, const float*, const float*) const {}
 };
@@ -1860,6 +1871,10 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
       // instructions per IEEE sqrtf / division on the serial tail.)
       auto fsqrt = [](float x) { return __builtin_amdgcn_sqrtf(x); };
       auto frcp = [](float x) { return __builtin_amdgcn_rcpf(x); };
+      // how the last build classed the rows, the regime and the request in force: read here, once, so that the decisions
+      // at the end of this block do not each start with a staging-area round trip of their own
+      const int c_ovf = st->n_ovf, c_scan = st->n_scan, c_want = st->want_full;
+      int c_dense = st->all_dense;
       const float ell_next = st->ell;
       const float radius = ell_next * fsqrt(fmaxf(-2.f * P.log_geo, 0.f));  // cut-off radius for l = ell
       float dr = 0, dt = 0, dr1 = 0, dt1 = 0;
@@ -1908,22 +1923,23 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
       // literal ordered scan), nothing is rebuilt while that lasts, and the pair returns to lists once the rows have
       // thinned out (mean nonzeros per row below 12, far from the 32 / 64 a list holds).
       if (!INIT && P.mode == 0 && P.dense_regime) {
-        const bool was = st->all_dense != 0;
+        const bool was = c_dense != 0;
         // (with long lists an overflow row costs what its candidates cost: the literal scan of everything only pays when
         // most rows are beyond even those, when the target cloud is small - 2048 targets are 32 lane steps, no bitmap, no
         // sort, no rebuilds: the demo pair on its K cap - or when the rows see a third of it anyway)
         const bool now = was ? (unsigned long long)st->nnz >= 12ull * (unsigned long long)D.N
-                             : (2 * st->n_scan > D.N ||
-                                (2 * st->n_ovf > D.N &&
+                             : (2 * c_scan > D.N ||
+                                (2 * c_ovf > D.N &&
                                  (D.M <= 2048 || 3ull * st->ncand_list > (unsigned long long)D.N * (unsigned long long)D.M)));
         if (now != was) {
-          st->all_dense = now ? 1 : 0;
+          c_dense = now ? 1 : 0;
+          st->all_dense = c_dense;
           rebuild = true;
         } else if (now) {
           rebuild = false;
         }
       }
-      early(done ? 1 : (rebuild ? 2 : (st->n_ovf > 0 ? 3 : 0)), st->K, st->ell, Ri, Ti);
+      early(done ? 1 : (rebuild ? 2 : (c_ovf > 0 ? 3 : 0)), st->K, st->ell, Ri, Ti);
       if (rebuild) {
         for (int q = 0; q < 9; q++) st->Rb[q] = Ri[q];
         for (int q = 0; q < 3; q++) st->Tb[q] = Ti[q];
@@ -1934,23 +1950,27 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         // too much (fast motion) or rows overflow their lists, ask the host for the full graph.
         // 2 = a rebuild opportunity in every iteration; 4 = and k_assoc_dense (rows that overflowed the lists of the last
         // build, or the dense regime): the host has a full graph without the dense kernel for large clouds
-        int want_full = (st->n_ovf > 0 || st->all_dense) ? 4 : 2;
+        // (overflow rows as the LAST build left them: a pair that gains its first ones in a graph without the dense kernel
+        // waits there and asks for it, see k_coeff)
+        const bool dense_rows = c_ovf > 0 || c_dense != 0;
+        int want_full = 2;
         float s = 0.f;
         // rows beyond every list fall back to the literal scan over all targets (k_assoc_dense): fine for a few
         // rows or a small cloud, ruinous if a generous skin pushes many rows of a large one over the edge - the skin
         // backs off by halves while the last build left such rows and recovers slowly afterwards
         if (INIT) st->skin_scale = 1.f;
-        else if (st->n_scan > 0 && !st->all_dense) st->skin_scale = fmaxf(0.5f * st->skin_scale, 1.f / 64.f);
+        else if (c_scan > 0 && !c_dense) st->skin_scale = fmaxf(0.5f * st->skin_scale, 1.f / 64.f);
         else st->skin_scale = fminf(1.f, 1.1f * st->skin_scale);
-        if (!INIT && P.mode == 0 && P.use_geo && radius > 0.f && P.skin_frac > 0.f && !st->all_dense) {
+        if (!INIT && P.mode == 0 && P.use_geo && radius > 0.f && P.skin_frac > 0.f && !c_dense) {
           const float rel = step_move * frcp(radius);
           s = st->skin_scale * P.skin_frac * fminf(fmaxf(1.5f * fsqrt(rel), P.skin_min), P.skin_max);
           const float s_lean = fmaxf(s, P.lean_skin * (float)P.lean_U * rel);
           const float s_lean2 = fmaxf(s, P.lean_skin * (float)P.lean_U2 * rel);
-          if (s_lean <= 0.5f && st->n_ovf == 0) {
+          // (rows that walk long lists cost what their candidates cost, whatever the skin; rows scanned literally do not)
+          if (s_lean <= 0.5f && c_scan == 0) {
             s = s_lean;
             want_full = 0;
-          } else if (P.lean_U2 > 0 && s_lean2 <= 0.5f && st->n_ovf == 0) {
+          } else if (P.lean_U2 > 0 && s_lean2 <= 0.5f && c_scan == 0) {
             s = s_lean2;  // too fast for lean_U iterations between rebuilds, slow enough for lean_U2
             want_full = 1;
           } else if (!(s >= 2.f * rel)) {
@@ -1969,13 +1989,15 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
           st->skin_tr = life * ((1.f - bl) * tr_1 + bl * step_move);
           if (!(st->skin_rot == st->skin_rot) || !(st->skin_tr == st->skin_tr)) st->skin_rot = st->skin_tr = 0.f;
         }
+        if (c_dense) want_full = -1;  // dense regime: nothing is rebuilt until the pair leaves it
+        want_full = want_encode(want_full, dense_rows);
         st->want_full = want_full;
         if (!dry) *D.want_out = want_full;
         st->n_builds = INIT ? 1 : st->n_builds + 1;
         st->rebuild = 1;  // cleared by k_list once bitmap and lists are current
-      } else if (st->n_ovf == 0) {  // has the motion slowed down enough for a leaner graph?
+      } else if (c_scan == 0 && !c_dense) {  // has the motion slowed down enough for a leaner graph?
         const float c = fminf(P.lean_skin, 1.3f);
-        int want = st->want_full;
+        int want = want_level(c_want);
         if (used + c * (float)P.lean_U * rate <= 1.f)
           want = 0;
         else if (P.lean_U2 > 0 && used + c * (float)P.lean_U2 * rate <= 1.f)
@@ -1984,7 +2006,8 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         // lean graph with ONE rebuild opportunity per chunk (the opportunities are three launches each, and in the end
         // game - the step clamped at min_step, rebuilds only when ell has decayed - nearly all of them find nothing to do)
         if (want == 0 && P.calm_U > 0 && used + c * (float)P.calm_U * rate <= 1.f) want = -1;
-        if (want != st->want_full) {
+        want = want_encode(want, c_ovf > 0);
+        if (want != c_want) {
           st->want_full = want;
           if (!dry) *D.want_out = want;
         }
@@ -2027,7 +2050,7 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
                                                const int* __restrict__ status, int flags) {
   if (!INIT && status[blockIdx.x] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.x;
-  if (!INIT && (flags & 1) && (D->st->rebuild || D->st->n_ovf > 0)) return;  // lean graph: the pair is waiting (k_assoc)
+  if (!INIT && (flags & 1) && (D->st->rebuild || (D->st->n_ovf > 0 && !(flags & 32)))) return;  // lean graph: the pair is waiting (k_assoc)
   if (INIT && threadIdx.x == 0) {  // the pair's cross-block counters start at zero
     *D->gate = 0;
     *D->gate_flow = 0;
@@ -2038,7 +2061,7 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
     for (int q = threadIdx.x; q < (int)(sizeof(ResidentSync) / 8); q += 64) reinterpret_cast<unsigned long long*>(D->rsync)[q] = 0ull;
   const DevParams P = *Pp;
   __shared__ UpdateShared U;
-  update_body<INIT, false>(load_upd_desc(D), P, flags, (flags & 1) ? D->nblk_assoc : D->nblk_assoc + D->dense_blocks, U, nullptr,
+  update_body<INIT, false>(load_upd_desc(D), P, flags, ((flags & 1) && !(flags & 32)) ? D->nblk_assoc : D->nblk_assoc + D->dense_blocks, U, nullptr,
                            nullptr);
 }
 
@@ -2046,7 +2069,7 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
 // k_coeff: coefficient phase + (align loop) the update.  The block of a pair that finishes last runs update_body:
 // one launch less on the critical path of every iteration, and no block ever waits for another one.  Partials
 // cross blocks inside the launch, hence the coherent stores / loads (st_x / ld_x).
-// flags: bit 0 = lean graph, the rest see update_body.
+// flags: bit 0 = lean graph, bit 5 = ... with k_assoc_dense in every iteration, the rest see update_body.
 // ------------------------------------------------------------------------------------------
 template <bool INSTR>
 __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const PairDesc* __restrict__ descs,
@@ -2081,8 +2104,6 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   const PairState* __restrict__ st_in = states + pb.pair;
   const int status_v = st_in->status, rebuild_v = st_in->rebuild, ovf = st_in->n_ovf;
   const DevParams P = *Pp;
-  // rows with hundreds of nonzeros (a pair with overflow rows: clustered clouds, the K cap) are spread over more blocks
-  const int csplit = (ovf > 0 && !(flags & 1)) ? csplit_heavy : csplit_light;
   // the twist and its matrices (twist_finalize): wave-uniform scalar loads
   XiMats Mu;
   {
@@ -2100,17 +2121,26 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     const EllEntry* a3 = D->ell;
     const int a4 = D->M;
     const float e = st_in->ell;
-    asm volatile("" ::"s"(n), "s"(nb), "s"(ep), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e), "s"(csplit), "s"(P.mode),
-                 "s"(P.sp_thres), "s"(Mu.omega[0]), "s"(Mu.m2.m[0][0]), "s"(Mu.m4.m[2][2]), "s"(Mu.v[2]));
+    const int k_line = st_in->K;  // (rides in the 16-byte load of status / rebuild / n_ovf: pinned so that none of its
+                                  // registers is dead and reused inside the burst, see k_assoc)
+    asm volatile("" ::"s"(n), "s"(nb), "s"(ep), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e), "s"(csplit_light),
+                 "s"(csplit_heavy), "s"(status_v), "s"(rebuild_v), "s"(ovf), "s"(k_line), "s"(P.mode), "s"(P.sp_thres), "s"(P.use_range_ell),
+                 "s"(Mu.omega[0]), "s"(Mu.m2.m[0][0]), "s"(Mu.m4.m[2][2]), "s"(Mu.v[2]));
+    // (nothing computed from these values - the slice count below is the first - may be scheduled into the middle of
+    // the burst, where it would need a wait of its own: one more round trip)
+    __builtin_amdgcn_sched_barrier(0);
   }
+  // rows with hundreds of nonzeros (a pair with overflow rows: clustered clouds, the K cap) are spread over more blocks
+  // (both counts are requested in the burst above: a load that depends on the branch would be one more round trip)
+  const int csplit = (ovf > 0 && (!(flags & 1) || (flags & 32))) ? csplit_heavy : csplit_light;
   if (cq >= csplit) return;
   const bool replay = (flags & 8) != 0;  // cvo_debug_time_kernels: same work, nothing written back
   if (!replay && status_v != 0) return;
   if (flags & 1) {
-    if (rebuild_v || ovf > 0) {  // waiting, see k_assoc; tell the host which graph this pair needs
+    if (rebuild_v || (ovf > 0 && !(flags & 32))) {  // waiting, see k_assoc; tell the host which graph this pair needs
       if (pb.bx == 0 && cq == 0 && threadIdx.x == 0) {
         st->n_stalls++;
-        if (ovf > 0) {
+        if (ovf > 0 && !(flags & 32)) {
           st->want_full = 4;
           *D->want_out = 4;
         }
@@ -2147,13 +2177,13 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && !replay, st, 1);
   UpdDesc upd = load_upd_desc(D);
   upd.nblk_coeff = nblk * csplit;
-  const int n_flow_upd = ((flags & 1) || ovf == 0) ? D->nblk_assoc : D->nblk_assoc + D->dense_blocks;  // (see k_assoc_dense)
+  const int n_flow_upd = (((flags & 1) && !(flags & 32)) || ovf == 0) ? D->nblk_assoc : D->nblk_assoc + D->dense_blocks;  // (see k_assoc_dense)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partial stores before the counter, see flow_gate
   __syncthreads();
   if (threadIdx.x == 0) {
     // the counter advances by nblk * COEFF_SPLIT_MAX per iteration whatever the split of the iteration is (splits are
     // powers of two): each of the nblk * csplit blocks that store a partial adds its share
-    const unsigned share = (unsigned)(COEFF_SPLIT_MAX / csplit), per_it = (unsigned)(nblk * COEFF_SPLIT_MAX);
+    const unsigned share = (unsigned)COEFF_SPLIT_MAX >> __builtin_ctz((unsigned)csplit), per_it = (unsigned)(nblk * COEFF_SPLIT_MAX);
     const unsigned done = (unsigned)__hip_atomic_fetch_add(D->done, (int)share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + share;
     s_last = replay ? (done % per_it == 0u) : (done == (unsigned)(epoch + 1) * per_it);
   }
@@ -2536,7 +2566,7 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
   if (status[blockIdx.y] != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.y;
   PairState* st = D->st;
-  if (lean && (st->rebuild || st->n_ovf > 0)) return;  // the pair did not advance in this slot (see k_assoc)
+  if ((lean & 1) && (st->rebuild || (st->n_ovf > 0 && !(lean & 4)))) return;  // the pair did not advance in this slot (see k_assoc)
   const DevParams P = *Pp;
   const int N = D->N, M = D->M, K = st->K;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
