@@ -368,6 +368,33 @@ def test_long_lists_three_row_classes(monkeypatch):
     assert s2 == o2                                                   # without long lists every overflow row is scanned
 
 
+def test_mixed_batch_with_and_without_overflow_rows(monkeypatch):
+    """Sub-batches whose pairs ask for different graphs: clustered scene pairs (overflow rows: the graphs with
+    k_assoc_dense, the heavy coefficient split) next to slab pairs (lean / calm graphs, one block per row block) and a
+    small demo-like pair in the dense regime.  Every row of every iteration is re-derived on the device, and every pair
+    ends bit-identical to the same pair solved alone - the split of a pair's coefficient reduction depends on its own
+    state only."""
+    P = cases.load_params("geometric_gpu")
+    pairs = [cases.scene(n=3000, pair_id=0), cases.config2(n=3000, pair_id=1), cases.scene(n=3000, pair_id=2),
+             cases.config2(n=3000, pair_id=3), cases.scene(n=2500, pair_id=4), cases.config2(n=2200, pair_id=5, m=3000),
+             cases.scene(n=3000, pair_id=6), cases.config2(n=3000, pair_id=7), cases.scene(n=600, pair_id=8)]
+    n_it = 300
+    monkeypatch.setenv("CVO_VERIFY_LISTS", "1")
+    gpu = CvoGPU(params=P)
+    res = gpu.align_batch([p[1] for p in pairs], [p[2] for p in pairs], [p[3] for p in pairs], max_iterations=n_it)
+    assert gpu.debug_last_geometry()[0] == 2                                     # two sub-batches
+    assert gpu.debug_verified_rows() == sum(r.iterations * p[1].num_points() for r, p in zip(res, pairs))
+    classes = [gpu.debug_row_classes(q) for q in range(len(pairs))]
+    assert any(c[0] > 0 for c in classes) and any(c[0] == 0 for c in classes)    # both kinds really were in the batch
+    monkeypatch.delenv("CVO_VERIFY_LISTS")
+    solo = CvoGPU(params=P)
+    for q, (p, r) in enumerate(zip(pairs, res)):
+        one = solo.align(p[1], p[2], p[3], max_iterations=n_it)
+        assert (one.iterations, one.ret, one.final_ell, one.final_num_neighbors) == (
+            r.iterations, r.ret, r.final_ell, r.final_num_neighbors), q
+        assert np.array_equal(one.transform, r.transform), q
+
+
 def test_long_lists_survive_across_calls():
     """The cached long lists carry a generation tag (call serial, list build): a second call on the same context and
     workspace - same pair, then another pair of the same size - never reads a list of the call before."""

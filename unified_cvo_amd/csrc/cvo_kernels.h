@@ -140,6 +140,34 @@ __device__ __forceinline__ bool pair_block(int nblk, int n_pairs, PairBlock& pb)
 // coherent with the others inside a kernel, and agent-scope fences write back / invalidate whole caches.  Relaxed
 // agent-scope atomics carry the coherence bits on the instruction itself, which is all a handful of partial
 // sums needs.  COH = false: plain accesses (the producer is an earlier kernel).
+// Address-space qualified views: pointers read out of a PairDesc are generic ("flat") to the compiler.  A flat load
+// counts against vmcnt AND lgkmcnt and the compiler waits for both counters to reach zero before it uses one: a loop
+// that prefetches (k_assoc's candidates, k_coeff's entries) or a tail that has several groups of loads in flight then
+// serialises on every use.  Re-qualified as global, the same loads are global_load with exact vmcnt(n) waits.
+#define CVO_GLOBAL __attribute__((address_space(1)))
+#define CVO_CONST __attribute__((address_space(4)))
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // plain vector: loadable from any address space
+// (float4 is a class type: its copy constructor only takes generic references)
+__device__ __forceinline__ float4 ldg_f4(const CVO_GLOBAL f32x4* p) {
+  const f32x4 v = *p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+// ... and only its xyz: a 16-byte load whose fourth register is dead gets that register handed to the next load the loop
+// issues, which then has to wait for this one (k_assoc's candidate prefetch was serialised that way)
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ float4 ldg_xyz(const CVO_GLOBAL f32x4* p) {
+  const f32x3 v = *reinterpret_cast<const CVO_GLOBAL f32x3*>(p);
+  return make_float4(v.x, v.y, v.z, 0.f);
+}
+template <typename T>
+__device__ __forceinline__ const CVO_GLOBAL T* as_global(const T* p) {
+  return (const CVO_GLOBAL T*)p;
+}
+template <bool COH, typename T>
+__device__ __forceinline__ T ld_g(const CVO_GLOBAL T* p) {
+  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
 template <bool COH, typename T>
 __device__ __forceinline__ void st_x(T* p, T v) {
   if (COH)
@@ -165,9 +193,6 @@ __device__ __forceinline__ T ld_x(const T* p) {
 // and the wave-uniform row operands use s_load (constant address space => scalar cache; xcull is
 // written by the previous kernel, k_prep, so it is read-only for the lifetime of k_scan).
 constexpr int XCULL_PAD = 32;  // rows k_scan may read past N (whole groups + prefetch)
-#define CVO_GLOBAL __attribute__((address_space(1)))
-#define CVO_CONST __attribute__((address_space(4)))
-typedef float f32x4 __attribute__((ext_vector_type(4)));  // plain vector: loadable from any address space
 
 // v_writelane_b32 with compile-time lanes: moves wave-uniform values (SGPRs: the halves of ballot
 // masks) into consecutive lanes of two VGPRs.  (The clang builtin is not declared for hipcc's host
@@ -1045,21 +1070,21 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
       const FeatDen F = make_feat_den(P);
       const V3 pxe{x.x, x.y, x.z};
       const Pose& pose = iv.pose;
-      const IdxT* cj = reinterpret_cast<const IdxT*>(D->cand_j) + pos;
+      const CVO_GLOBAL IdxT* cj = as_global(reinterpret_cast<const IdxT*>(D->cand_j)) + pos;
       // list entries are sorted positions: coordinates (and features) come from the spatially ordered arrays of the
       // target cloud - the candidates of the 64 neighbouring rows of a wave fall into a few cache lines instead of 64
-      const float4* __restrict__ ysrc = D->ys4;
+      const CVO_GLOBAL f32x4* ysrc = (const CVO_GLOBAL f32x4*)D->ys4;
       // exact evaluation in ascending original j; index and coordinates of the next candidates are in
       // flight while the current one is evaluated
       int j1 = cnt > 0 ? j1s : 0;
       int j2 = cnt > 1 ? j2s : 0;
       if (INSTR) tt1 = __builtin_readcyclecounter();
-      float4 y1 = ysrc[j1];
+      float4 y1 = ldg_xyz(ysrc + j1);
       for (int k = 0; k < cnt && A.nnz < (unsigned)K; k++) {
         const int j = j1;
         const float4 ycur = y1;
         j1 = j2;
-        if (k + 1 < cnt) y1 = ysrc[j1];
+        if (k + 1 < cnt) y1 = ldg_xyz(ysrc + j1);
         if (k + 2 < cnt) j2 = (int)cj[(size_t)(k + 2) * N];
         // (Tried in round 3: a first pass that only transforms and tests the distance, parking what passes in LDS, and
         // the kernel values in a second pass over the parked entries - bit-identical, -8 % for a lone pair's resident
@@ -1658,12 +1683,15 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     // the coherent ones so that the two round trips overlap
     // (every count of one iteration fits 32 bits - at most rows x K_max nonzeros, rows x targets candidates, checked
     // at set-up - and the block partials are read as such: the 64-bit DPP steps cost four times the instructions)
-    const unsigned* cnt32 = reinterpret_cast<const unsigned*>(D.cnt_part);
+    // (global, not flat, addresses: the two groups of loads below are then really in flight together - a flat load makes
+    // the compiler wait for vmcnt AND lgkmcnt to drain before anything that follows it)
+    const CVO_GLOBAL unsigned* cnt32 = as_global(reinterpret_cast<const unsigned*>(D.cnt_part));
+    const CVO_GLOBAL double* coef_part = as_global(D.coef_part);
     unsigned vq[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int b = bl + 16 * u;
-      vq[u] = b < nba ? ld_x<RES>(cnt32 + ((size_t)b * 4 + c) * 2) : 0u;
+      vq[u] = b < nba ? ld_g<RES>(cnt32 + ((size_t)b * 4 + c) * 2) : 0u;
     }
     if (P.mode == 0) {
       // eight (coherent) loads in flight per lane, summed in block order
@@ -1672,13 +1700,13 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
 #pragma unroll
         for (int u = 0; u < 8; u++) {
           const int b = b0 + 16 * u;
-          v[u] = b < nbc ? ld_x<COH>(D.coef_part + (size_t)b * 4 + c) : 0.0;
+          v[u] = b < nbc ? ld_g<COH>(coef_part + (size_t)b * 4 + c) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) s += v[u];
       }
     } else if (c == 0) {
-      for (int b = bl; b < nba; b += 16) s += D.flow_part[(size_t)b * 8 + 6];
+      for (int b = bl; b < nba; b += 16) s += as_global(D.flow_part)[(size_t)b * 8 + 6];
     }
     // (component 2, the candidate statistic, can exceed 32 bits for very large clouds before the dense regime engages:
     // it saturates instead of wrapping; nnz / overflow rows are bounded by the set-up check)
@@ -1691,7 +1719,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int b = b0 + 16 * u;
-        v[u] = b < nba ? ld_x<RES>(cnt32 + ((size_t)b * 4 + c) * 2) : 0u;
+        v[u] = b < nba ? ld_g<RES>(cnt32 + ((size_t)b * 4 + c) * 2) : 0u;
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) q = (c == 1) ? max(q, v[u]) : addsat(q, v[u]);
@@ -2178,6 +2206,9 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   UpdDesc upd = load_upd_desc(D);
   upd.nblk_coeff = nblk * csplit;
   const int n_flow_upd = (((flags & 1) && !(flags & 32)) || ovf == 0) ? D->nblk_assoc : D->nblk_assoc + D->dense_blocks;  // (see k_assoc_dense)
+  // (how many flow partials the update will sum: known now - left to the compiler, the two descriptor words behind it are
+  // requested after the counter's round trip, one more dependent wait on the pair's serial tail)
+  asm volatile("" ::"s"(n_flow_upd));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partial stores before the counter, see flow_gate
   __syncthreads();
   if (threadIdx.x == 0) {
