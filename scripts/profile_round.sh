@@ -43,6 +43,9 @@ timeout 600 python $R/scripts/upload_probe.py > $O/upload_probe.txt 2>&1
 timeout 600 python $R/scripts/scale_probe.py > $O/scale_probe.txt 2>&1
 # the early phase: first 16 / 64 / 256 iterations of the batch, single pairs
 timeout 600 python $R/scripts/perf_probe.py $O/perf_probe.json > $O/perf_probe.txt 2>&1
+# the clustered street scene (not a BASELINE config): us per iteration at 3000 / 10k points, and its kernels
+timeout 300 python $R/scripts/scene_probe.py 2>&1 | grep -v "chunk [0-9]" > $O/scene_probe.txt
+GRAFT_REPO_ROOT=$R timeout 300 bash $R/scripts/scene_profile.sh > /dev/null 2>&1; cp $R/gpurun_out/scene_prof/kernel_stats.csv $O/scene_kernel_stats.csv
 # run-to-run reproducibility under load
 timeout 900 python $R/scripts/stress_repeat.py ${STRESS_BATCH:-100} ${STRESS_SINGLE:-40} > $O/stress.txt 2>&1
 tail -3 $O/bench_n1.log
