@@ -261,8 +261,10 @@ struct PairDesc {
   unsigned long long* long_stamp;  // [N]
   PairState* st;
   cvo_trace_t* trace;
-  int* status_out;  // mirror of st->status for cheap host polling
+  int* status_out;  // mirror of st->status: the kernels' own early-exit word (device memory)
   int* want_out;    // mirror of st->want_full
+  int* status_host;  // the same two words in pinned HOST memory: the device writes them when they change (posted
+  int* want_host;    // writes), the host reads them after a chunk's event - no copy kernel between two chunks
   int* gate;        // [1] blocks of k_list that finished the current rebuild (the last one validates the list)
   int* gate_flow;   // [1] blocks of k_assoc / k_assoc_dense that stored their flow partial (the last one reduces them)
   ResidentSync* rsync;  // k_resident: the pair's in-launch synchronisation words

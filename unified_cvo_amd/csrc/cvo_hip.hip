@@ -127,7 +127,8 @@ struct cvo_ctx {
   int cap_pairs = 0;
   std::vector<PairDesc> h_descs;
   std::vector<PairState> h_states;
-  int* h_status[2] = {nullptr, nullptr};  // pinned
+  int* h_status[2] = {nullptr, nullptr};  // pinned; [0]: the live host mirror of the status / want words the device writes
+                                          // (PairDesc::status_host / want_host), [1]: unused slot kept for the layout
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   // A batch is split into up to MAX_GROUPS sub-batches, each enqueued on its own stream: the pairs are
   // independent, so one group's latency-bound kernels (k_update: one wave per pair) and launch tails
@@ -139,7 +140,7 @@ struct cvo_ctx {
   // graph cache (one per group)
   // [group][0 = full chunk, 1 = lean chunk, 2 = short lean chunk, 3 = full chunk without k_assoc_dense, 4 = calm chunk (lean, one rebuild opportunity); + 5 for the instrumented kernels (CVO_KERNEL_CLOCK /
   // CVO_PHASE_TICKS), cached side by side so that a caller can time single steps of a loop without re-capturing]
-  static constexpr int GRAPH_VARIANTS = 32;  // 8 graphs (see cvo_align_batch) x instrumented or not  // ... x 2 chunk lengths (the early chunks of a call are shorter)
+  static constexpr int GRAPH_VARIANTS = 48;  // 8 graphs (see cvo_align_batch) x instrumented or not x 3 chunk lengths  // ... x 2 chunk lengths (the early chunks of a call are shorter)
   hipGraphExec_t graph_exec[MAX_GROUPS][GRAPH_VARIANTS] = {};
   GraphKey graph_key[MAX_GROUPS][GRAPH_VARIANTS] = {};
   int last_chunks = 0, last_lean_launches = 0, last_full_launches = 0;
@@ -307,7 +308,8 @@ int ensure_workspace(cvo_ctx* c, int n_pairs, size_t bytes_per_pair) {
     HIP_TRY(c, hipMalloc(&c->d_states, sizeof(PairState) * (size_t)n_pairs));
     // [0, n): st->status mirrors, [n, 2n): st->want_full mirrors
     HIP_TRY(c, hipMalloc(&c->d_status, sizeof(int) * 2 * (size_t)n_pairs));
-    for (int i = 0; i < 2; i++) HIP_TRY(c, hipHostMalloc(&c->h_status[i], sizeof(int) * 2 * (size_t)n_pairs));
+    for (int i = 0; i < 2; i++)  // fine-grained: what the device writes there needs no cache maintenance to be seen
+      HIP_TRY(c, hipHostMalloc(&c->h_status[i], sizeof(int) * 2 * (size_t)n_pairs, hipHostMallocMapped | hipHostMallocCoherent));
     c->cap_pairs = n_pairs;
     drop_graphs(c);
   }
@@ -835,6 +837,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
       const int p0 = (int)((long)n_pairs * g / S->G), p1 = (int)((long)n_pairs * (g + 1) / S->G);
       D.status_out = ctx->d_status + 2 * p0 + (p - p0);
       D.want_out = ctx->d_status + 2 * p0 + (p1 - p0) + (p - p0);
+      D.status_host = ctx->h_status[0] + 2 * p0 + (p - p0);
+      D.want_host = ctx->h_status[0] + 2 * p0 + (p1 - p0) + (p - p0);
     }
     D.gate = (int*)(base + S->L.gate);
     D.gate_flow = (int*)(base + S->L.gate_flow);
@@ -865,6 +869,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_states, ctx->h_states.data(), sizeof(PairState) * (size_t)n_pairs,
                               hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int) * 2 * (size_t)ctx->cap_pairs, ctx->stream));
+  std::memset(ctx->h_status[0], 0, sizeof(int) * 2 * (size_t)ctx->cap_pairs);  // (no call is in flight on this context)
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_params, &dp, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
   S->gx = (S->d.Mpad / (64 * S->T) + 3) / 4;
   S->gy = ((int)align_up((size_t)S->d.NG, 64) + S->gpb - 1) / S->gpb;
@@ -1666,6 +1671,11 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   const bool adaptive_chunks = !(opts && opts->iters_per_launch > 0) && !ctx_opt(ctx, "FIXED_CHUNKS") && max_iter >= 512;
   const int U_late = adaptive_chunks ? 2 * U : U;
   const int n_early_chunks = adaptive_chunks ? 256 / U : 0;
+  // The first two chunks of a call are chosen blind (the host learns what a pair wants one chunk behind) and are full
+  // graphs: short ones, so that a warm-started pair whose lists outlive dozens of iterations from the start is not held
+  // on six launches per iteration for 32 of its few hundred iterations.
+  const int U_first = adaptive_chunks && !ctx_opt(ctx, "FIXED_CHUNKS") ? std::max(1, U / 4) : U;
+  const int n_first_chunks = U_first != U ? 2 : 0;
   const int graph_mode = opts ? opts->use_graph : 0;
   const bool use_graph = graph_mode != 1;
 
@@ -1703,7 +1713,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       return b == 4 ? Uc : (b == 3 ? 0 : (b == 2 ? lean_U2 : lean_U));
     };
     const int v_instr = S.geom.instr ? 8 : 0;  // the instrumented kernels have their own cached graphs
-    auto graph_index = [&](int v, int Uc) { return v + v_instr + (Uc != U ? 16 : 0); };
+    auto graph_index = [&](int v, int Uc) { return v + v_instr + (Uc == U ? 0 : (Uc == U_late && U_late != U ? 16 : 32)); };
     auto get_graph = [&](int g, int v, int Uc) -> int {
       const int vi = graph_index(v, Uc);
       GraphKey key;
@@ -1747,7 +1757,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     };
     // Chunks are enqueued until every pair has finished.  A pair advances one iteration per slot unless it is
     // waiting in a lean chunk for a rebuild / dense kernel, so the bound below is only a safety net.
-    const int n_chunks = (max_iter + U - 1) / U;
+    const int n_chunks = (max_iter + U_first - 1) / U_first;
     const int chunk_cap = 4 * n_chunks + 16;
     const bool allow_lean = ctx_opt(ctx, "NO_LEAN") == nullptr;
     int graph_next[cvo_ctx::MAX_GROUPS];  // 0 = full, 1 = lean, 2 = short lean, 3 = full without the dense kernel
@@ -1764,7 +1774,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     for (; ch < chunk_cap && !all_done; ch++) {
       const int slot = ch & 1;
-      const int Uc = ch < n_early_chunks ? U : U_late;
+      const int Uc = ch < n_first_chunks ? U_first : (ch < n_early_chunks + n_first_chunks ? U : U_late);
       if (ctx_opt(ctx, "VERBOSE") && atoi(ctx_opt(ctx, "VERBOSE")) >= 3) {
         fprintf(stderr, "[cvo] chunk %d (%d iterations): graphs", ch, Uc);
         for (int g = 0; g < G; g++)
@@ -1784,8 +1794,9 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
           launch_chunk(ctx, geom[g], Uc, v != 0, lean_period(v, Uc), v >= 5);
           HIP_TRY(ctx, hipGetLastError());
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status[slot] + 2 * geom[g].p0, ctx->d_status + 2 * geom[g].p0,
-                                    sizeof(int) * 2 * (size_t)geom[g].n_pairs, hipMemcpyDeviceToHost, geom[g].stream));
+        // (no status copy: the device keeps a mirror of every pair's two words in pinned host memory up to date, and the
+        // event's system-scope release makes what the chunk wrote visible - a copy kernel and its two boundaries per
+        // chunk and stream were 7 us of a chunk's ~300)
         HIP_TRY(ctx, hipEventRecord(ctx->ev_chk[slot][g], geom[g].stream));
       }
       // keep one chunk of speculation in flight: inspect the chunk before this one
@@ -1796,7 +1807,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
         t_wait += ms_since(tw);
         all_done = true;
         for (int g = 0; g < G; g++) {
-          const int* hs = ctx->h_status[ws] + 2 * geom[g].p0;  // [status[n_g] | want[n_g]]
+          const volatile int* hs = ctx->h_status[0] + 2 * geom[g].p0;  // [status[n_g] | want[n_g]], live (may be newer than chunk ch - 1)
           const int ng = geom[g].n_pairs;
           for (int q = 0; q < ng; q++) all_done = all_done && hs[q] != 0;
           // the most demanding unfinished pair of the group decides the level (2 = full, 1 = short lean, 0 = lean,
@@ -1844,10 +1855,9 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     ctx->last_full_launches = n_full_launch;
     if (!all_done) {  // the in-flight chunk may have finished the stragglers; otherwise report it
       for (int g = 0; g < G; g++) HIP_TRY(ctx, hipStreamSynchronize(geom[g].stream));
-      const int ws = (ch - 1) & 1;
       bool fin = true;
       for (int g = 0; g < G; g++)
-        for (int q = 0; q < geom[g].n_pairs; q++) fin = fin && ctx->h_status[ws][2 * geom[g].p0 + q] != 0;
+        for (int q = 0; q < geom[g].n_pairs; q++) fin = fin && ((volatile int*)ctx->h_status[0])[2 * geom[g].p0 + q] != 0;
       if (!fin && ch >= chunk_cap) return fail(ctx, CVO_E_HIP, "cvo_align_batch: optimiser loop did not terminate");
     }
   }
@@ -2429,6 +2439,14 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
           fprintf(stderr, "[cvo]   pair %d, updating block: entry -> counter %.0f, update %.0f ticks\n", p,
                   (double)(long long)(h[1][4096 + p][1] - h[1][4096 + p][0]),
                   (double)(long long)(h[1][4096 + p][2] - h[1][4096 + p][1]));
+      if (which) {
+        unsigned long long u[8];
+        HIP_TRY(ctx, hipMemcpyFromSymbol(u, HIP_SYMBOL(g_upd_ticks), sizeof(u)));
+        fprintf(stderr, "[cvo]   inside the update (last pair to run it): reduce %lld, step %lld, pose + distance + indicator %lld, "
+                        "update_tf + list bookkeeping %lld, rest %lld, write-back %lld ticks\n",
+                (long long)(u[1] - u[0]), (long long)(u[2] - u[1]), (long long)(u[3] - u[2]), (long long)(u[4] - u[3]),
+                (long long)(u[5] - u[4]), (long long)(u[6] - u[5]));
+      }
     }
   }
   *ms_assoc = out[0];

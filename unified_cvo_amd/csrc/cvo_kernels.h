@@ -980,6 +980,10 @@ __device__ __forceinline__ bool flow_gate(const PairDesc* __restrict__ D, int nb
 // entry / counter / exit at [1][4096 + p].  Only differences inside a block mean anything (the counters of
 // different XCDs are not aligned).  Printed by cvo_debug_time_kernels.
 __device__ unsigned long long g_phase_ticks[2][8192][4];
+// ... and inside the update (the last pair to get there wins; meant for one pair in flight): entry, partials reduced, step
+// chosen, pose / distance / indicator done (update_tf next), list bookkeeping done, state written back
+__device__ unsigned long long g_upd_ticks[8];
+#define CVO_UPD_STAMP(i) do { if (P.phase_ticks && threadIdx.x == 0) g_upd_ticks[i] = __builtin_readcyclecounter(); } while (0)
 
 // CVO_KERNEL_CLOCK (see PairState::clk_*): the first block of pair p stamps its entry (blocks are dispatched in
 // order, so it is the pair's earliest or close to it; an atomic minimum over all blocks would serialise 79 atomics per
@@ -1599,6 +1603,8 @@ struct UpdDesc {
   cvo_trace_t* trace;
   int* status_out;
   int* want_out;
+  int* status_host;
+  int* want_host;
   int nblk_coeff, N, M;
   float ymax;
   double sqrt_nm;
@@ -1612,6 +1618,8 @@ __device__ __forceinline__ UpdDesc load_upd_desc(const PairDesc* __restrict__ D)
   u.trace = D->trace;
   u.status_out = D->status_out;
   u.want_out = D->want_out;
+  u.status_host = D->status_host;
+  u.want_host = D->want_host;
   u.nblk_coeff = D->nblk_coeff;
   u.N = D->N;
   u.M = D->M;
@@ -1657,6 +1665,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
   unsigned* const s_hot = U.hot;
   const int tid = threadIdx.x;
   const bool act = tid < 64;
+  CVO_UPD_STAMP(0);
 
   // the scalar part of the state is staged through LDS: one coalesced burst in, one out, instead of
   // dozens of dependent global accesses from a single lane
@@ -1752,9 +1761,11 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     e_front = ld_x<RES>(eq + st->e_head);
     s_front = ld_x<RES>(sq + st->s_head);
   }
+  CVO_UPD_STAMP(1);
   // the step of this iteration: the cubic's real roots are searched on three lanes side by side
   float step_w = 0.f;
   if (!INIT && act && P.mode == 0) step_w = select_step<true>(s_c[0], s_c[1], s_c[2], s_c[3], P.min_step, P.max_step);
+  CVO_UPD_STAMP(2);
   if (tid == 0) {
     int done = 0;
     if (twist) {  // k_coeff: every block derived the same normalised twist
@@ -1885,6 +1896,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         }
       }
     }
+    CVO_UPD_STAMP(3);
     // update_tf (CvoGPU.cu:94-112): the transform applied next, and the returned matrix when done
     float Ri[9], Ti[3];
     update_tf(st->R, st->T, Ri, Ti);
@@ -2020,7 +2032,10 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         if (c_dense) want_full = -1;  // dense regime: nothing is rebuilt until the pair leaves it
         want_full = want_encode(want_full, dense_rows);
         st->want_full = want_full;
-        if (!dry) *D.want_out = want_full;
+        if (!dry) {
+          *D.want_out = want_full;
+          *D.want_host = want_full;
+        }
         st->n_builds = INIT ? 1 : st->n_builds + 1;
         st->rebuild = 1;  // cleared by k_list once bitmap and lists are current
       } else if (c_scan == 0 && !c_dense) {  // has the motion slowed down enough for a leaner graph?
@@ -2037,10 +2052,14 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         want = want_encode(want, c_ovf > 0);
         if (want != c_want) {
           st->want_full = want;
-          if (!dry) *D.want_out = want;
+          if (!dry) {
+            *D.want_out = want;
+            *D.want_host = want;
+          }
         }
       }
     }
+    CVO_UPD_STAMP(4);
     for (int q = 0; q < 9; q++) st->Rinv[q] = Ri[q];
     for (int q = 0; q < 3; q++) st->Tinv[q] = Ti[q];
     if (done || INIT || P.mode != 0) {  // the returned matrix (final update_tf, CvoGPU.cu:1562): only read once the pair is done
@@ -2066,11 +2085,14 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
     if (done && !dry) {
       st->status = 1;
       *D.status_out = 1;
+      *D.status_host = 1;
     }
   }
+  CVO_UPD_STAMP(5);
   __syncthreads();
   if (act && !dry)
     for (int q = tid; q < HOT_DWORDS; q += 64) reinterpret_cast<unsigned*>(gst)[q] = s_hot[q];
+  CVO_UPD_STAMP(6);
 }
 
 template <bool INIT>
@@ -2171,6 +2193,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
         if (ovf > 0 && !(flags & 32)) {
           st->want_full = 4;
           *D->want_out = 4;
+          *D->want_host = 4;
         }
       }
       return;
@@ -2472,6 +2495,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, 2) void k_resident(const PairDesc* _
           if (h.stop == 3) {
             st->want_full = 4;
             *D->want_out = 4;
+            *D->want_host = 4;
           }
         }
         break;
@@ -2566,6 +2590,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, 2) void k_resident(const PairDesc* _
     if (aborted && (is_tail || role == 0) && tid == 0) {
       if (is_tail) st->want_full = 3;
       *D0->want_out = 3;
+      *D0->want_host = 3;
     }
   }
   // ---- leave: the last block of the launch resets the placement counters for the next launch of this stream
