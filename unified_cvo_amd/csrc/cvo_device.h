@@ -108,6 +108,8 @@ struct PairState {
                             // 1 = the short lean graph (a rebuild opportunity every lean_U2 iterations), 0 = the lean graph
   int all_dense;
   float skin_scale;  // backs the skin off while rows fall back to the literal scan (see update_body)
+  int row_max;       // candidates a row may have and still be served thread-per-row by k_assoc (<= the list capacity): set by
+                     // the update when it orders a rebuild, read by k_list (who overflows) and k_assoc until the next one
   int n_scan;        // rows of the last build beyond every list (more than LONG_CAP candidates, or ASSOC_CAP without long
                      // lists): k_assoc_dense scans all targets for them (filled by k_list, reset by k_prep)
   // all_dense = dense regime: every row is served by k_assoc_dense, no lists (see update_body)

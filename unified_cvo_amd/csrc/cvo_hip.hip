@@ -101,7 +101,7 @@ static const char* const kOptionNames[] = {
     "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
     "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
     "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "RESIDENT",
-    "RESIDENT_BLOCKS", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS"};
+    "RESIDENT_BLOCKS", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS"};
 
 struct cvo_ctx {
   int device = 0;
@@ -1674,8 +1674,10 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   // The first two chunks of a call are chosen blind (the host learns what a pair wants one chunk behind) and are full
   // graphs: short ones, so that a warm-started pair whose lists outlive dozens of iterations from the start is not held
   // on six launches per iteration for 32 of its few hundred iterations.
-  const int U_first = adaptive_chunks && !ctx_opt(ctx, "FIXED_CHUNKS") ? std::max(1, U / 4) : U;
-  const int n_first_chunks = U_first != U ? 2 : 0;
+  int U_first = adaptive_chunks ? std::max(1, U / 4) : U;
+  if (adaptive_chunks && ctx_opt(ctx, "FIRST_U")) U_first = std::max(1, std::min(atoi(ctx_opt(ctx, "FIRST_U")), U));
+  int n_first_chunks = U_first != U ? 2 : 0;
+  if (U_first != U && ctx_opt(ctx, "FIRST_CHUNKS")) n_first_chunks = std::max(0, atoi(ctx_opt(ctx, "FIRST_CHUNKS")));
   const int graph_mode = opts ? opts->use_graph : 0;
   const bool use_graph = graph_mode != 1;
 

@@ -469,6 +469,7 @@ struct Pose {  // the transform applied to the target cloud this iteration (upda
 struct IterView {
   int K;
   float ell;
+  int row_max;  // PairState::row_max
   Pose pose;
 };
 __device__ __forceinline__ Pose load_pose(const PairState* st) {
@@ -483,6 +484,7 @@ __device__ __forceinline__ IterView load_iter_view(const PairState* st) {
   IterView v;
   v.K = st->K;
   v.ell = st->ell;
+  v.row_max = st->row_max;
   v.pose = load_pose(st);
   return v;
 }
@@ -664,6 +666,7 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
   const int rbw = D->rbw;
   __shared__ IdxT s_list[LIST_THREADS * ASSOC_STRIDE];
   __shared__ int s_row[LIST_THREADS];
+  const int row_max = min(D->st->row_max, ASSOC_CAP);  // rows with more candidates go to k_assoc_dense (PairState::row_max)
   const int tid = threadIdx.x;
   const int w0row = pb.bx * LIST_THREADS;
   // ---- candidates of row w0row + tid
@@ -744,7 +747,7 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
     }
     D->ip[pos] = rr;  // the row's index into the (spatially ordered) feature arrays
     D->iorig[pos] = D->xorder[rr];
-    if (cnt_all > ASSOC_CAP) {
+    if (cnt_all > row_max) {
       // more candidates than a list holds (dense regime, e.g. rows sitting on K_max): k_assoc_dense
       // evaluates these rows against all targets, 64 at a time.  Only flagged here (below, one bit per position): the
       // list itself is written in ascending position order by the block that finishes last, so that the order in
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
   // front of the gate - write back the XCD's L2 with a block's freshly written lists in it - cost 4 ms of the 74 ms
   // step: 3.5 us and more per block, four blocks per CU.)
   {
-    const bool ov = rr < N && cnt_all > ASSOC_CAP;
+    const bool ov = rr < N && cnt_all > row_max;
     const unsigned long long m = __ballot(ov);
     // ... and which of them are beyond a long list as well (k_assoc_dense scans all targets for those)
     const unsigned long long m_scan = (Pp->long_lists && !D->st->all_dense) ? __ballot(ov && cnt_all > LONG_CAP) : m;
@@ -1066,7 +1069,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
     const int j1s = head.j1;  // (the first list slot exists whatever the count is)
     const int j2s = (int)(reinterpret_cast<const IdxT*>(D->cand_j) + pos)[N];
     const int cnt = head.cnt;
-    overflowed = cnt > ASSOC_CAP ? 1u : 0u;
+    overflowed = cnt > min(iv.row_max, ASSOC_CAP) ? 1u : 0u;
     if (!overflowed) {
       const int i = head.ip;
       const float4 x = head.x;
@@ -1324,6 +1327,9 @@ __device__ __forceinline__ int build_long_list(const PairDesc* __restrict__ D, c
   return cnt;
 }
 
+// flow partials k_assoc_dense leaves for a pair with n_ovf overflow rows (4 waves per block, one row per wave at a time)
+__device__ __forceinline__ int dense_parts(int dense_blocks, int n_ovf) { return min(dense_blocks, (n_ovf + 3) >> 2); }
+
 template <bool GENERAL, int DENSE_WAVES>
 __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
                                                      const int* __restrict__ status) {
@@ -1337,6 +1343,11 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
   const int n_ovf = st->n_ovf;
   if (n_ovf == 0 && P.mode == 0) return;  // nothing to add: k_assoc has finished the twist, the update skips these slots
   if (st->rebuild) return;  // (lean graphs with this kernel: the pair waits for its rebuild opportunity, see k_assoc)
+  // one row per wave is the most there is to do: blocks beyond that leave no partial and stay out of the gate (the last
+  // block's reduction and the update read nblk_assoc + dense_parts() slots - with the whole grid's 1024 that tail alone
+  // was most of a launch that serves a few dozen rows)
+  const int n_parts = P.mode == 0 ? dense_parts((int)gridDim.x, n_ovf) : (int)gridDim.x;
+  if ((int)blockIdx.x >= n_parts) return;
   const bool all_dense = st->all_dense != 0;
   __shared__ float2 s_hits[DENSE_WAVES][128][6];  // per wave: the hits of one step, compacted ({flow term, value} per component)
   __shared__ unsigned s_keys[DENSE_WAVES][LONG_CAP];  // per wave: the long list being built (sort keys)
@@ -1494,7 +1505,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
     cp[3] = 0;
   }
   // full graph: the twist of the iteration from the partials of k_assoc (an earlier launch) and of this kernel
-  if (P.mode == 0) flow_gate(D, (int)gridDim.x, D->nblk_assoc + (int)gridDim.x);
+  if (P.mode == 0) flow_gate(D, n_parts, D->nblk_assoc + n_parts);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1993,6 +2004,10 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         // (overflow rows as the LAST build left them: a pair that gains its first ones in a graph without the dense kernel
         // waits there and asks for it, see k_coeff)
         const bool dense_rows = c_ovf > 0 || c_dense != 0;
+        // A wave of k_assoc runs as long as its longest row.  While a sixteenth of the rows overflow anyway (a clustered
+        // cloud: k_assoc_dense runs in every iteration, its long lists cost what their candidates cost), rows of more
+        // than 24 candidates join them - a wave per row, 64 candidates per step - instead of holding 63 neighbours back.
+        st->row_max = (!INIT && P.long_lists && !c_dense && 16 * c_ovf > D.N) ? 24 : ASSOC_CAP16;
         int want_full = 2;
         float s = 0.f;
         // rows beyond every list fall back to the literal scan over all targets (k_assoc_dense): fine for a few
@@ -2111,7 +2126,10 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
     for (int q = threadIdx.x; q < (int)(sizeof(ResidentSync) / 8); q += 64) reinterpret_cast<unsigned long long*>(D->rsync)[q] = 0ull;
   const DevParams P = *Pp;
   __shared__ UpdateShared U;
-  update_body<INIT, false>(load_upd_desc(D), P, flags, ((flags & 1) && !(flags & 32)) ? D->nblk_assoc : D->nblk_assoc + D->dense_blocks, U, nullptr,
+  update_body<INIT, false>(load_upd_desc(D), P, flags,
+                           ((flags & 1) && !(flags & 32)) ? D->nblk_assoc
+                                                          : D->nblk_assoc + (P.mode == 0 ? dense_parts(D->dense_blocks, D->st->n_ovf) : D->dense_blocks),
+                           U, nullptr,
                            nullptr);
 }
 
@@ -2153,6 +2171,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   // needs first, see k_assoc.
   const PairState* __restrict__ st_in = states + pb.pair;
   const int status_v = st_in->status, rebuild_v = st_in->rebuild, ovf = st_in->n_ovf;
+  const unsigned max_nnz_prev = st_in->max_nnz;  // longest row of the iteration before (this one's is not reduced yet)
   const DevParams P = *Pp;
   // the twist and its matrices (twist_finalize): wave-uniform scalar loads
   XiMats Mu;
@@ -2174,15 +2193,16 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     const int k_line = st_in->K;  // (rides in the 16-byte load of status / rebuild / n_ovf: pinned so that none of its
                                   // registers is dead and reused inside the burst, see k_assoc)
     asm volatile("" ::"s"(n), "s"(nb), "s"(ep), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e), "s"(csplit_light),
-                 "s"(csplit_heavy), "s"(status_v), "s"(rebuild_v), "s"(ovf), "s"(k_line), "s"(P.mode), "s"(P.sp_thres), "s"(P.use_range_ell),
+                 "s"(csplit_heavy), "s"(status_v), "s"(rebuild_v), "s"(ovf), "s"(k_line), "s"(max_nnz_prev), "s"(P.mode), "s"(P.sp_thres), "s"(P.use_range_ell),
                  "s"(Mu.omega[0]), "s"(Mu.m2.m[0][0]), "s"(Mu.m4.m[2][2]), "s"(Mu.v[2]));
     // (nothing computed from these values - the slice count below is the first - may be scheduled into the middle of
     // the burst, where it would need a wait of its own: one more round trip)
     __builtin_amdgcn_sched_barrier(0);
   }
-  // rows with hundreds of nonzeros (a pair with overflow rows: clustered clouds, the K cap) are spread over more blocks
+  // rows with hundreds of nonzeros (a pair with overflow rows: clustered clouds, the K cap) are spread over more blocks -
+  // while its rows really are that long (the longest row of the iteration before: the pair's own state, like n_ovf)
   // (both counts are requested in the burst above: a load that depends on the branch would be one more round trip)
-  const int csplit = (ovf > 0 && (!(flags & 1) || (flags & 32))) ? csplit_heavy : csplit_light;
+  const int csplit = (ovf > 0 && max_nnz_prev > 48u && (!(flags & 1) || (flags & 32))) ? csplit_heavy : csplit_light;
   if (cq >= csplit) return;
   const bool replay = (flags & 8) != 0;  // cvo_debug_time_kernels: same work, nothing written back
   if (!replay && status_v != 0) return;
@@ -2228,7 +2248,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && !replay, st, 1);
   UpdDesc upd = load_upd_desc(D);
   upd.nblk_coeff = nblk * csplit;
-  const int n_flow_upd = (((flags & 1) && !(flags & 32)) || ovf == 0) ? D->nblk_assoc : D->nblk_assoc + D->dense_blocks;  // (see k_assoc_dense)
+  const int n_flow_upd = (((flags & 1) && !(flags & 32)) || ovf == 0) ? D->nblk_assoc : D->nblk_assoc + dense_parts(D->dense_blocks, ovf);  // (see k_assoc_dense)
   // (how many flow partials the update will sum: known now - left to the compiler, the two descriptor words behind it are
   // requested after the counter's round trip, one more dependent wait on the pair's serial tail)
   asm volatile("" ::"s"(n_flow_upd));
@@ -2459,6 +2479,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, 2) void k_resident(const PairDesc* _
       h.stop = ui(0) != 0 ? 1 : (ui(1) != 0 ? 2 : (ui(2) > 0 ? 3 : 0));
       h.iv.K = ui(3);
       h.iv.ell = uf(4);
+      h.iv.row_max = ld_x<true>(&st->row_max);  // (changes only with a rebuild: never inside this launch)
       k0 = ui(6);
 #pragma unroll
       for (int q = 0; q < 9; q++) h.iv.pose.Ri[q] = uf(8 + q);
