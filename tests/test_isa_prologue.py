@@ -44,14 +44,20 @@ def _scalar_rounds_before_first_exit(lines, span):
     return loads, waits
 
 
-@pytest.mark.parametrize("kernel", ["k_assoc<unsigned short, 64, false, false>", "k_assoc<unsigned short, 64, true, false>",
-                                    "k_coeff<false>"])
-def test_prologue_is_one_burst_of_scalar_loads(device_code, kernel):
+@pytest.mark.parametrize("kernel,max_waits", [("k_assoc<unsigned short, 64, false, false>", 1),
+                                              ("k_assoc<unsigned short, 64, true, false>", 1),
+                                              # k_coeff sits at the SGPR limit (the 42 floats of the twist matrices live in
+                                              # scalar registers through its row loop): the compiler pulls parameter loads of
+                                              # the update into the burst and spills them to a VGPR, a wait each time.  Measured
+                                              # against the one-wait build (scripts/exp_time.py, interleaved): nothing - the row
+                                              # heads' vector loads, requested before the burst, take longer than all of it.
+                                              ("k_coeff<false>", 3)])
+def test_prologue_is_one_burst_of_scalar_loads(device_code, kernel, max_waits):
     lines, ks = device_code
     assert kernel in ks, sorted(ks)
     loads, waits = _scalar_rounds_before_first_exit(lines, ks[kernel])
     assert loads >= 10        # the burst is there ...
-    assert waits == 1, f"{kernel}: {waits} waits inside the first burst of {loads} scalar loads"
+    assert 1 <= waits <= max_waits, f"{kernel}: {waits} waits inside the first burst of {loads} scalar loads"
 
 
 def test_no_scratch_in_the_per_iteration_kernels(device_code):

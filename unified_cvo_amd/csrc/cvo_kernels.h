@@ -2202,7 +2202,12 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   // rows with hundreds of nonzeros (a pair with overflow rows: clustered clouds, the K cap) are spread over more blocks -
   // while its rows really are that long (the longest row of the iteration before: the pair's own state, like n_ovf)
   // (both counts are requested in the burst above: a load that depends on the branch would be one more round trip)
-  const int csplit = (ovf > 0 && max_nnz_prev > 48u && (!(flags & 1) || (flags & 32))) ? csplit_heavy : csplit_light;
+  // (as many slices as keep a thread's share of the longest row at ~32 entries: every slice is four more partials for the
+  // update to fetch, 128 per round trip)
+  // ... and at least ~128 blocks per pair while rows are long
+  int csplit = csplit_light;
+  if (ovf > 0 && max_nnz_prev > 48u && (!(flags & 1) || (flags & 32)))
+    while (csplit < csplit_heavy && ((unsigned)(csplit * 32) < max_nnz_prev || nblk * csplit < 128)) csplit <<= 1;
   if (cq >= csplit) return;
   const bool replay = (flags & 8) != 0;  // cvo_debug_time_kernels: same work, nothing written back
   if (!replay && status_v != 0) return;
