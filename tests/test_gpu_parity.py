@@ -429,12 +429,13 @@ def test_result_does_not_depend_on_list_reuse(monkeypatch):
 
 def test_batch_scheduling_switches_do_not_change_results(monkeypatch):
     """In a batch the optional (ell-shrink) rebuilds wait for common iteration counts, lists that would not reach the
-    next of them are renewed early, and chunks grow from 16 to 32 iterations after the first 256: scheduling only -
-    the poses are bit-identical with all of it switched off."""
+    next of them are renewed early, chunks grow from 16 to 32 iterations after the first 256 and the two blind first
+    chunks of a call are 4 iterations long: scheduling only - the poses are bit-identical with all of it switched off."""
     cs = [cases.config2(n=2000, pair_id=p) for p in range(8)]
     P = cs[0][0]
     runs = []
-    for env in ({}, {"CVO_SHRINK_ALIGN": "0"}, {"CVO_FIXED_CHUNKS": "1", "CVO_SHRINK_ALIGN": "15"}):
+    for env in ({}, {"CVO_SHRINK_ALIGN": "0"}, {"CVO_FIXED_CHUNKS": "1", "CVO_SHRINK_ALIGN": "15"},
+                {"CVO_FIRST_U": "16"}, {"CVO_FIRST_U": "2", "CVO_FIRST_CHUNKS": "6"}):   # the blind first chunks of a call
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         gpu = CvoGPU(params=P)
