@@ -48,7 +48,7 @@ del gpu, both
 
 # ---- one pair in flight, every config shape (interleaved so that graphs / workspaces are re-keyed between calls)
 singles = [("config2 10k", cases.config2(n=10000)), ("config3", cases.config3()), ("config4", cases.config4()),
-           ("config1", cases.config1())]
+           ("config1", cases.config1()), ("clustered scene 10k", cases.scene(n=10000))]
 for name, c in singles:
     g = CvoGPU(params=c[0])
     s, t = g.upload_many([c[1], c[2]])
