@@ -782,7 +782,14 @@ def _fuzz_one(oracle, seed):
     P.min_step = float(rs.choice([1e-4, 2e-3]))
     P.is_using_range_ell = int(rs.integers(0, 2))
     init = (synth.gt_motion() @ synth.warm_start_delta()).astype(np.float32) if rs.integers(0, 2) else np.eye(4, dtype=np.float32)
-    n_it = 90
+    strict = _follow_oracle(oracle, P, a, b, init, 90, seed)
+    FUZZ_OUTCOMES[seed] = strict
+    return strict
+
+
+def _follow_oracle(oracle, P, a, b, init, n_it, seed):
+    """A prefix of the optimisation, iteration by iteration against the oracle; returns whether the comparison stayed
+    strict to the last recorded iteration (see the comment on the one-ulp separations below)."""
     g, o = _prefix(oracle, P, a, b, init, n_it)
     assert g.iterations == o["iterations"] and g.ret == o["ret"]
     assert len(g.trace) == len(o["trace"])
@@ -799,7 +806,6 @@ def _fuzz_one(oracle, seed):
         compared += 1
     assert compared >= min(10, len(g.trace))
     strict = compared == len(g.trace)
-    FUZZ_OUTCOMES[seed] = strict
     if strict:
         assert cases.max_abs_diff(g.transform, o["transform"]) <= 1e-6
     else:
@@ -816,6 +822,32 @@ def _fuzz_one(oracle, seed):
 class _Obj:
     def __init__(self, d):
         self.trace = d["trace"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_clustered_trajectories(oracle, monkeypatch, seed):
+    """The same for clustered clouds (synth.scene_pair: local density varies by more than 100x): random sizes, ragged
+    pairs, lengthscales, neighbour caps and warm starts put rows on the 64-entry lists, on long lists, on the literal
+    scan and on the K cap in one pair.  Every recorded iteration follows the oracle, and a second run re-derives every
+    row of every iteration on the device (CVO_VERIFY_LISTS) and ends on the same pose."""
+    rs = np.random.default_rng(900 + seed)
+    n, m = int(rs.integers(1200, 6500)), int(rs.integers(1200, 6500))
+    src, tgt, _ = synth.scene_pair(n, 50 + seed, m=m)
+    a, b = CvoPointCloud.from_xyz(src), CvoPointCloud.from_xyz(tgt)
+    P = cases.load_params("geometric_gpu")
+    P.ell_init = float(rs.choice([0.3, 0.6, 0.95, 1.4]))
+    P.nearest_neighbors_max = int(rs.choice([40, 200, 512]))
+    P.ell_decay_start = int(rs.choice([5, 30]))
+    P.is_using_range_ell = int(rs.integers(0, 2))
+    init = (synth.gt_motion() @ synth.warm_start_delta()).astype(np.float32) if rs.integers(0, 2) else np.eye(4, dtype=np.float32)
+    n_it = 70
+    _follow_oracle(oracle, P, a, b, init, n_it, seed)
+    ref = CvoGPU(params=P).align(a, b, init, max_iterations=n_it)
+    monkeypatch.setenv("CVO_VERIFY_LISTS", "1")
+    gpu = CvoGPU(params=P)
+    chk = gpu.align(a, b, init, max_iterations=n_it)          # raises CvoError(CVO_E_VERIFY) on any mismatch
+    assert chk.iterations == ref.iterations and np.array_equal(chk.transform, ref.transform)
+    assert gpu.debug_verified_rows() >= chk.iterations * a.num_points()
 
 
 def test_randomised_trajectories_mostly_strict(oracle):
