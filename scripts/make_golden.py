@@ -49,6 +49,8 @@ if __name__ == "__main__":
         run("config2_n2000", cases.config2, n=2000),
         run("config3_n2000", cases.config3, n=2000),
         run("config4_n2000", cases.config4, n=2000),
+        # not a BASELINE config: a clustered street scene (rows on the lists, beyond them and on the K cap at once)
+        run("scene_n2500", cases.scene, n=2500),
     ]
     path = os.path.join(ROOT, "tests", "golden", "oracle_traces.json")
     with open(path, "w") as f:

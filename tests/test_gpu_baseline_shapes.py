@@ -53,12 +53,13 @@ def test_micro_fixture_full_ell(name):
 
 
 def test_every_committed_golden_trace():
-    """HIP path vs all four entries of tests/golden/oracle_traces.json (no oracle call at all): the demo pair on the
-    neighbour cap for 1000 iterations, configs 2 / 3 / 4 at n = 2000 to their own ends."""
+    """HIP path vs all five entries of tests/golden/oracle_traces.json (no oracle call at all): the demo pair on the
+    neighbour cap for 1000 iterations, configs 2 / 3 / 4 at n = 2000 and a clustered street scene at n = 2500 to their
+    own ends."""
     with open(os.path.join(cases.GOLDEN, "oracle_traces.json")) as f:
         gold = {c["name"]: c for c in json.load(f)["cases"]}
     builders = {"config1_demo_geometric_k1000": cases.config1, "config2_n2000": cases.config2,
-                "config3_n2000": cases.config3, "config4_n2000": cases.config4}
+                "config3_n2000": cases.config3, "config4_n2000": cases.config4, "scene_n2500": cases.scene}
     assert set(gold) == set(builders)
     for name, builder in builders.items():
         gc = gold[name]

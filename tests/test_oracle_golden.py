@@ -11,10 +11,11 @@ with open(os.path.join(cases.GOLDEN, "oracle_traces.json")) as f:
     GOLD = {c["name"]: c for c in json.load(f)["cases"]}
 
 BUILDERS = {"config1_demo_geometric_k1000": cases.config1, "config2_n2000": cases.config2,
-            "config3_n2000": cases.config3, "config4_n2000": cases.config4}
+            "config3_n2000": cases.config3, "config4_n2000": cases.config4, "scene_n2500": cases.scene}
 
 
-@pytest.mark.parametrize("name", ["config1_demo_geometric_k1000", "config2_n2000", "config3_n2000", "config4_n2000"])
+@pytest.mark.parametrize("name", ["config1_demo_geometric_k1000", "config2_n2000", "config3_n2000", "config4_n2000",
+                                  "scene_n2500"])
 def test_oracle_reproduces_golden(oracle, name):
     g = GOLD[name]
     P, src, tgt, init = BUILDERS[name](**g["kwargs"])
