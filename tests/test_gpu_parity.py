@@ -843,8 +843,20 @@ def test_randomised_clustered_trajectories(oracle, monkeypatch, seed):
     rs = np.random.default_rng(900 + seed)
     n, m = int(rs.integers(1200, 6500)), int(rs.integers(1200, 6500))
     src, tgt, _ = synth.scene_pair(n, 50 + seed, m=m)
-    a, b = CvoPointCloud.from_xyz(src), CvoPointCloud.from_xyz(tgt)
-    P = cases.load_params("geometric_gpu")
+    kind = seed % 3   # geometry only / + colour / + colour and semantics (k_assoc, k_assoc_dense: GENERAL instantiations)
+    if kind == 0:
+        a, b = CvoPointCloud.from_xyz(src), CvoPointCloud.from_xyz(tgt)
+        P = cases.load_params("geometric_gpu")
+    else:
+        T = synth.gt_motion()
+        back = (tgt.astype(np.float64) - T[:3, 3]) @ T[:3, :3]          # the target points before the motion (+ noise)
+        fs = synth.colour_features(src, np.random.default_rng(7100 + seed)).astype(np.float32)
+        ft = synth.colour_features(back, np.random.default_rng(7200 + seed), noise=0.01).astype(np.float32)
+        geo = np.tile(np.array([[0.0, 1.0]], np.float32), (max(n, m), 1))
+        ls = synth.checkerboard_labels(src) if kind == 2 else None
+        lt = synth.checkerboard_labels(back, flip=0.02, rng=np.random.default_rng(7300 + seed)) if kind == 2 else None
+        a, b = CvoPointCloud.from_arrays(src, fs, ls, geo[:n]), CvoPointCloud.from_arrays(tgt, ft, lt, geo[:m])
+        P = cases.load_params("intensity_gpu" if kind == 1 else "semantic_img_gpu0")
     P.ell_init = float(rs.choice([0.3, 0.6, 0.95, 1.4]))
     P.nearest_neighbors_max = int(rs.choice([40, 200, 512]))
     P.ell_decay_start = int(rs.choice([5, 30]))
