@@ -104,8 +104,9 @@ struct PairState {
   // get a thin skin; only the farthest rows pay for the whole motion bound.
   float skin_rot, skin_tr;
   int n_builds;
-  int want_full, n_stalls;  // host hint: 4 / 2 = this pair needs the graph with per-iteration rebuild (4: and the dense kernel), -1 = calm,
-                            // 1 = the short lean graph (a rebuild opportunity every lean_U2 iterations), 0 = the lean graph
+  int want_full, n_stalls;  // host hint (want_level / want_encode, cvo_kernels.h): 2 = a rebuild opportunity in every iteration,
+                            // 1 = the short lean graph (one every lean_U2 iterations), 0 = the lean graph, -1 = calm (one per
+                            // chunk); 4 = 2 with k_assoc_dense, 8 / 9 / 10 = -1 / 0 / 1 with it; 3 = a resident launch timed out
   int all_dense;
   float skin_scale;  // backs the skin off while rows fall back to the literal scan (see update_body)
   int row_max;       // candidates a row may have and still be served thread-per-row by k_assoc (<= the list capacity): set by

@@ -140,7 +140,7 @@ struct cvo_ctx {
   // graph cache (one per group)
   // [group][0 = full chunk, 1 = lean chunk, 2 = short lean chunk, 3 = full chunk without k_assoc_dense, 4 = calm chunk (lean, one rebuild opportunity); + 5 for the instrumented kernels (CVO_KERNEL_CLOCK /
   // CVO_PHASE_TICKS), cached side by side so that a caller can time single steps of a loop without re-capturing]
-  static constexpr int GRAPH_VARIANTS = 48;  // 8 graphs (see cvo_align_batch) x instrumented or not x 3 chunk lengths  // ... x 2 chunk lengths (the early chunks of a call are shorter)
+  static constexpr int GRAPH_VARIANTS = 48;  // 8 graphs (see cvo_align_batch) x instrumented or not x 3 chunk lengths
   hipGraphExec_t graph_exec[MAX_GROUPS][GRAPH_VARIANTS] = {};
   GraphKey graph_key[MAX_GROUPS][GRAPH_VARIANTS] = {};
   int last_chunks = 0, last_lean_launches = 0, last_full_launches = 0;
@@ -1663,8 +1663,8 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   const auto t_host1 = std::chrono::steady_clock::now();
 
   const int max_iter = dp.max_iter;
-  // Iterations per chunk (= per host check).  A chunk boundary costs a stream ~15 us (graph launch, the two status
-  // copies, the event), a longer chunk lets a finished or re-planned sub-batch run on for nothing: 16 iterations for
+  // Iterations per chunk (= per host check).  A chunk boundary costs a stream ~10 us (graph launch, the event; the
+  // status words reach the host by themselves), a longer chunk lets a finished or re-planned sub-batch run on for nothing: 16 iterations for
   // the first 256 (short warm-started solves end there, and the early requests change quickly), 32 afterwards.
   int U = (opts && opts->iters_per_launch > 0) ? opts->iters_per_launch : 16;
   U = std::max(1, std::min(U, std::max(1, max_iter)));
