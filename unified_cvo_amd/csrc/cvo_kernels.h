@@ -1808,9 +1808,6 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         const int k = st->k;
         const int K_used = st->K;
         const float ell_used = st->ell;
-        float R[9], T[3];
-        for (int q = 0; q < 9; q++) R[q] = st->R[q];
-        for (int q = 0; q < 3; q++) T[q] = st->T[q];
         const float* om = st->omega;
         const float* vv = st->v;
         double dist = 0;
@@ -1834,20 +1831,21 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
           const float xi[6] = {om[0], om[1], om[2], vv[0], vv[1], vv[2]};
           float dtrans[12];
           exp_sek3(xi, step, dtrans);  // CvoGPU.cu:1462
-          double dR[9], dT[3];
-          for (int i = 0; i < 3; i++) {
-            for (int j = 0; j < 3; j++) dR[3 * i + j] = (double)dtrans[4 * i + j];
-            dT[i] = (double)dtrans[4 * i + 3];
+          // (the increment stays in its twelve floats; widened where it is used: kept as doubles it held 24 registers across
+          // everything up to the - rarely taken - logarithm below, and the update's registers are what caps k_coeff's occupancy)
+          auto dRd = [&](int q) { return (double)dtrans[4 * (q / 3) + (q % 3)]; };
+          auto dTd = [&](int i) { return (double)dtrans[4 * i + 3]; };
+          // (the running pose is fetched from the staged state row by row, only now: held in registers from the top of the
+          // update it was live through Exp_SEK3, where the register count of the whole kernel peaks)
+#pragma unroll 1  // (one row's temporaries at a time)
+          for (int i = 0; i < 3; i++) {  // CvoGPU.cu:1463-1469
+            const double r0 = st->R[3 * i + 0], r1 = st->R[3 * i + 1], r2 = st->R[3 * i + 2];
+            const float tn = (float)((r0 * dTd(0) + (r1 * dTd(1) + r2 * dTd(2))) + (double)st->T[i]);
+            float rn[3];
+            for (int j = 0; j < 3; j++) rn[j] = (float)(r0 * dRd(0 + j) + (r1 * dRd(3 + j) + r2 * dRd(6 + j)));
+            st->T[i] = tn;
+            for (int j = 0; j < 3; j++) st->R[3 * i + j] = rn[j];
           }
-          float Tn[3], Rn[9];  // CvoGPU.cu:1463-1469
-          for (int i = 0; i < 3; i++) {
-            const double r0 = R[3 * i + 0], r1 = R[3 * i + 1], r2 = R[3 * i + 2];
-            Tn[i] = (float)((r0 * dT[0] + (r1 * dT[1] + r2 * dT[2])) + (double)T[i]);
-            for (int j = 0; j < 3; j++)
-              Rn[3 * i + j] = (float)(r0 * dR[0 + j] + (r1 * dR[3 + j] + r2 * dR[6 + j]));
-          }
-          for (int q = 0; q < 9; q++) st->R[q] = R[q] = Rn[q];
-          for (int q = 0; q < 3; q++) st->T[q] = T[q] = Tn[q];
           // dist = || log SE3(dR, dT) || (CvoGPU.cu:1473-1476) decides one thing: dist < eps_2.  dR / dT are the float
           // Exp_SEK3 of a unit twist times `step`, so in exact arithmetic dist = step * |xi|_6 = step; the float
           // rounding of dtrans (6e-8 per entry, entries <= 1) and of the normalisation move it by < 1e-6 + 1e-4 step.
@@ -1861,7 +1859,12 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
           if (!want_trace && theta_f >= 1e-6f && step * 0.9999f - 1e-6f > P.eps_2 && step <= 1.f)
             dist = (double)step;
           else
+          {
+            double dR[9], dT[3];
+            for (int q = 0; q < 9; q++) dR[q] = dRd(q);
+            for (int i = 0; i < 3; i++) dT[i] = dTd(i);
             dist = se3_log_norm(dR, dT);
+          }
           const float ip_curr = (float)((double)nnz / D.sqrt_nm);  // 1486 (sqrt(N * M): IEEE, evaluated on the host)
           const bool need_decay_ell = dry ? false : indicator_update(st, sq, eq, ip_curr, P.window, P.stable_thr, e_front, s_front);
           if (dist < (double)P.eps_2) {  // CvoGPU.cu:1505-1508
@@ -1896,13 +1899,15 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
             tr->omega[q] = om[q];
             tr->v[q] = vv[q];
           }
-          tr->B = B;
-          tr->C = C;
-          tr->D = Dd;
-          tr->E = E;
+          // (re-read from the staged state: eight + twelve values that would otherwise stay in registers across Exp_SEK3, the
+          // pose update and the indicator just for this optional record)
+          tr->B = st->B;
+          tr->C = st->C;
+          tr->D = st->D;
+          tr->E = st->E;
           tr->dist = dist;
-          for (int q = 0; q < 9; q++) tr->R[q] = R[q];
-          for (int q = 0; q < 3; q++) tr->T[q] = T[q];
+          for (int q = 0; q < 9; q++) tr->R[q] = st->R[q];
+          for (int q = 0; q < 3; q++) tr->T[q] = st->T[q];
           st->n_trace++;
         }
       }
