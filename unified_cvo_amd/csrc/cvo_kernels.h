@@ -1837,14 +1837,18 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
           auto dTd = [&](int i) { return (double)dtrans[4 * i + 3]; };
           // (the running pose is fetched from the staged state row by row, only now: held in registers from the top of the
           // update it was live through Exp_SEK3, where the register count of the whole kernel peaks)
-#pragma unroll 1  // (one row's temporaries at a time)
+          float Rc[9], Tc[3];  // (requested together, one LDS round trip; the rows below are kept apart by scheduling
+          for (int q = 0; q < 9; q++) Rc[q] = st->R[q];  // barriers: one row's double temporaries at a time)
+          for (int q = 0; q < 3; q++) Tc[q] = st->T[q];
+#pragma unroll
           for (int i = 0; i < 3; i++) {  // CvoGPU.cu:1463-1469
-            const double r0 = st->R[3 * i + 0], r1 = st->R[3 * i + 1], r2 = st->R[3 * i + 2];
-            const float tn = (float)((r0 * dTd(0) + (r1 * dTd(1) + r2 * dTd(2))) + (double)st->T[i]);
+            const double r0 = Rc[3 * i + 0], r1 = Rc[3 * i + 1], r2 = Rc[3 * i + 2];
+            const float tn = (float)((r0 * dTd(0) + (r1 * dTd(1) + r2 * dTd(2))) + (double)Tc[i]);
             float rn[3];
             for (int j = 0; j < 3; j++) rn[j] = (float)(r0 * dRd(0 + j) + (r1 * dRd(3 + j) + r2 * dRd(6 + j)));
             st->T[i] = tn;
             for (int j = 0; j < 3; j++) st->R[3 * i + j] = rn[j];
+            __builtin_amdgcn_sched_barrier(0);
           }
           // dist = || log SE3(dR, dT) || (CvoGPU.cu:1473-1476) decides one thing: dist < eps_2.  dR / dT are the float
           // Exp_SEK3 of a unit twist times `step`, so in exact arithmetic dist = step * |xi|_6 = step; the float
