@@ -56,10 +56,6 @@ int cvo_debug_scalar_math(cvo_ctx* ctx, int op, int n, const double* in, double*
 /* CVO_VERIFY_LISTS=1 (environment, read when a call starts): rows k_verify re-derived with the literal scan during the
  * last align call, summed over pairs and iterations (0 when the check was off). */
 int cvo_debug_verified_rows(cvo_ctx* ctx, unsigned long long* rows);
-/* XCD-resident iteration: per-phase tick sums of k_resident (100 MHz device counter) collected while CVO_PHASE_TICKS is
- * set, since the last call of this function (layout: g_res_ticks in unified_cvo_amd/csrc/cvo_kernels.h), and the
- * blocks per pair of the last call's resident launches (0 = the call used the two-kernel iteration). */
-int cvo_debug_resident_ticks(cvo_ctx* ctx, unsigned long long out[16], int* blocks_per_pair);
 /* The spatial (k-d) ordering of a resident cloud: out[r] = original index of the point at sorted position r (n entries).
  * Computed on the device at upload (k_kd_order) for clouds of 8 .. 16384 finite points, on the host otherwise and under
  * CVO_ORDER=host / virtual / CVO_NO_SORT; no result depends on it. */

@@ -463,49 +463,6 @@ def test_lean_graph_waits_do_not_change_results(monkeypatch):
     assert np.array_equal(a.transform, c.transform)
 
 
-def _resident_library():
-    """lib/libcvo_hip_resident.so: the same sources built with -DCVO_WITH_RESIDENT (__graft_entry__.build() makes it in
-    the build container; built here if it did not travel)."""
-    from unified_cvo_amd import build as hipbuild
-    return hipbuild.build_resident()   # (no-op while the library is newer than the kernel sources)
-
-
-@pytest.mark.parametrize("builder,kw,n_it", [(cases.config2, dict(n=10000), 700), (cases.config2, dict(n=5000), 500),
-                                             (cases.config3, dict(n=6000), 400), (cases.config4, dict(n=10000), 10000)])
-def test_resident_iteration_is_bit_identical(builder, kw, n_it):
-    """k_resident (option RESIDENT=1, off by default: ROUND_LOG.md round 3): the lean iterations between two rebuild
-    opportunities in ONE launch - blocks that place themselves on their pair's XCD, a tail block, data-tagged granules
-    through that XCD's L2 - reduce the same per-row-block partials with the same code in the same order as the
-    two-kernel iteration: poses, iteration counts, ell and K must be bit-identical, and the kernel must really have run."""
-    P, src, tgt, init = builder(**kw)
-    ref_gpu = CvoGPU(params=P)
-    ref = ref_gpu.align(src, tgt, init, max_iterations=n_it)
-    assert ref_gpu.debug_resident_ticks()[1] == 0             # the default path is the two-kernel iteration
-    with pytest.raises(CvoError):                             # ... and the product library does not even contain the kernel
-        ref_gpu.set_option("RESIDENT", "1")
-    gpu = CvoGPU(params=P, library=_resident_library())
-    gpu.set_option("RESIDENT", "1")
-    for _ in range(2):
-        r = gpu.align(src, tgt, init, max_iterations=n_it)
-        assert (r.iterations, r.ret, r.final_ell, r.final_num_neighbors) == (ref.iterations, ref.ret, ref.final_ell,
-                                                                             ref.final_num_neighbors)
-        assert np.array_equal(r.transform, ref.transform)
-    assert gpu.debug_resident_ticks()[1] > 0                  # row blocks per pair of the resident launches
-
-
-def test_resident_iteration_small_batch_is_bit_identical():
-    """Eight ragged pairs, one per XCD, two sub-batch streams: the self-placement serves several pairs per launch."""
-    pairs = [cases.config2(n=5000 + 300 * p, pair_id=p) for p in range(8)]
-    P = pairs[0][0]
-    ref = CvoGPU(params=P).align_batch([p[1] for p in pairs], [p[2] for p in pairs], [p[3] for p in pairs], max_iterations=300)
-    gpu = CvoGPU(params=P, library=_resident_library())
-    gpu.set_option("RESIDENT", "1")
-    res = gpu.align_batch([p[1] for p in pairs], [p[2] for p in pairs], [p[3] for p in pairs], max_iterations=300)
-    assert gpu.debug_resident_ticks()[1] > 0
-    for a, b in zip(ref, res):
-        assert a.iterations == b.iterations == 300 and np.array_equal(a.transform, b.transform)
-
-
 def test_context_options_are_validated():
     gpu = CvoGPU(params=CvoParams())
     gpu.set_option("CVO_VERBOSE", None)      # with or without the prefix; None clears

@@ -133,14 +133,14 @@ EXPORTED = [
     "cvo_debug_kernel_clock",
     "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_row_classes", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
     "cvo_align_association", "cvo_debug_scalar_math", "cvo_debug_verified_rows", "cvo_debug_device_memory", "cvo_cloud_upload_many",
-    "cvo_ctx_set_option", "cvo_debug_resident_ticks", "cvo_ctx_advice", "cvo_debug_cloud_order",
+    "cvo_ctx_set_option", "cvo_ctx_advice", "cvo_debug_cloud_order",
 ]
 
 _libs = {}
 
 
 def lib(path=None):
-    """Loads libcvo_hip.so (once; `path`: another build of the same C-ABI, e.g. build.LIB_RESIDENT).  Raises if the
+    """Loads libcvo_hip.so (once; `path`: another build of the same C-ABI, e.g. an experiment build of build.build_variant).  Raises if the
     HIP extension has not been built."""
     path = os.path.abspath(path) if path else LIB_PATH
     if path in _libs:

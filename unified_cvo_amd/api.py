@@ -267,7 +267,7 @@ class CvoGPU:
     """cvo::CvoGPU(yaml) over the HIP backend."""
 
     def __init__(self, param_file=None, params=None, device=0, library=None):
-        self.L = _capi.lib(library)  # (library: another build of the same C-ABI, e.g. build.LIB_RESIDENT)
+        self.L = _capi.lib(library)  # (library: another build of the same C-ABI, e.g. an experiment build of build.build_variant)
         if params is not None:
             self.params = params
         elif param_file is not None:
@@ -540,13 +540,6 @@ class CvoGPU:
         a, c, n = C.c_float(), C.c_float(), C.c_ulonglong()
         self._check(self.L.cvo_debug_kernel_clock(self.ctx, C.byref(a), C.byref(c), C.byref(n)))
         return a.value, c.value, n.value
-
-    def debug_resident_ticks(self):
-        """(per-phase tick sums of k_resident under CVO_PHASE_TICKS, blocks per pair of the last call's resident launches)."""
-        out = (C.c_ulonglong * 16)()
-        nb = C.c_int()
-        self._check(self.L.cvo_debug_resident_ticks(self.ctx, out, C.byref(nb)))
-        return [int(x) for x in out], nb.value
 
     def debug_last_geometry(self):
         """(sub-batches of the last call, pairs per sub-batch): the k_scan launches a profiler sees."""

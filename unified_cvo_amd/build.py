@@ -13,10 +13,6 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcvo_hip.so")
-# The same sources with -DCVO_WITH_RESIDENT: the XCD-resident iteration (k_resident), an experiment that lost to the two
-# launches it replaces (ROUND_LOG.md round 3).  Not part of the product library; the tests that keep it honest load this one.
-LIB_RESIDENT = os.path.join(LIBDIR, "libcvo_hip_resident.so")
-
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
@@ -46,7 +42,7 @@ def sources():
 
 
 def headers():
-    hs = [os.path.join(CSRC, f) for f in ("cvo_device.h", "cvo_kernels.h")]
+    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))  # cvo_device.h, cvo_kernels.h and its parts
     hs.append(os.path.join(ROOT, "include", "cvo_hip.h"))
     hs.append(os.path.join(ROOT, "include", "cvo_hip_debug.h"))
     return hs
@@ -87,13 +83,6 @@ def build(force=False, verbose=True):
     return _compile(LIB, [], verbose)
 
 
-def build_resident(force=False, verbose=True):
-    """The variant with k_resident compiled in (lib/libcvo_hip_resident.so), for tests/ and scripts/resident_probe.py."""
-    if not force and not needs_build(LIB_RESIDENT):
-        return LIB_RESIDENT
-    return _compile(LIB_RESIDENT, ["-DCVO_WITH_RESIDENT"], verbose)
-
-
 def build_variant(name, defines, verbose=True):
     """An experiment build of the same sources (lib/libcvo_hip_<name>.so) with extra -D switches: scripts/exp_time.py
     times it next to the product library and checks that the poses stay bit-identical."""
@@ -103,5 +92,3 @@ def build_variant(name, defines, verbose=True):
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
-    if "--resident" in sys.argv:
-        print(build_resident(force="--force" in sys.argv))

@@ -106,7 +106,7 @@ struct PairState {
   int n_builds;
   int want_full, n_stalls;  // host hint (want_level / want_encode, cvo_kernels.h): 2 = a rebuild opportunity in every iteration,
                             // 1 = the short lean graph (one every lean_U2 iterations), 0 = the lean graph, -1 = calm (one per
-                            // chunk); 4 = 2 with k_assoc_dense, 8 / 9 / 10 = -1 / 0 / 1 with it; 3 = a resident launch timed out
+                            // chunk); 4 = 2 with k_assoc_dense, 8 / 9 / 10 = -1 / 0 / 1 with it
   int all_dense;
   float skin_scale;  // backs the skin off while rows fall back to the literal scan (see update_body)
   int row_max;       // candidates a row may have and still be served thread-per-row by k_assoc (<= the list capacity): set by
@@ -135,10 +135,6 @@ struct PairState {
   // prefix: written by k_verify's blocks with atomics, never staged by the update.
   int verify_err, verify_k, verify_pos, verify_what;
   unsigned long long verify_rows;  // rows checked so far
-  // k_resident: iterations this pair ran inside resident launches (statistics; outside the hot prefix, bumped by the
-  // updating block with a plain read-modify-write - one writer per iteration)
-  unsigned res_iters;
-  unsigned res_pad;
 };
 
 // Everything a kernel needs to know about one frame pair.
@@ -169,35 +165,6 @@ __host__ __device__ inline size_t row_off_nnz(int Np) { return (size_t)8 * Np; }
 __host__ __device__ inline size_t row_off_xp4(int Np) { return (size_t)16 * Np; }
 __host__ __device__ inline size_t row_off_cand_j(int Np) { return (size_t)32 * Np; }
 __host__ __device__ inline size_t row_off_ell(int Np) { return (size_t)160 * Np; }
-
-// ---- XCD-resident iteration (k_resident) -------------------------------------------------------------------
-// What the blocks of ONE pair exchange inside a resident launch.  All of a pair's blocks run on one XCD (they placed
-// themselves there, see k_resident), so everything here travels through that XCD's L2: plain stores, relaxed atomics
-// for the arrival counters, L1-bypassing (sc1) loads.  Broadcasts are DATA-TAGGED GRANULES (MI355X_MICROARCH.md, R2):
-// one naturally aligned 8-byte {value, tag} per word, written by one store - a reader that finds the tag it waits for
-// has the value, no flag, no ordering between granules, one hop.
-//   head[q], tag 2 k     : what every block needs at the top of iteration k: stop word, K, ell, Rinv, Tinv
-//   xi[q],   tag 2 k + 1 : the normalised twist of iteration k and the matrices of compute_step_size_xi (XiMats)
-struct ResidentSync {
-  unsigned arrive_a;  // row blocks that stored their association partials in the running iteration (the tail block resets it)
-  unsigned arrive_b;  // ... their coefficient partials
-  unsigned abort;     // a wait timed out (blocks of a pair not co-resident - cannot happen by construction, bounded anyway)
-  unsigned pad[13];
-  unsigned long long head[16];
-  unsigned long long xi[48];
-};
-static_assert(sizeof(ResidentSync) == 64 + 128 + 384, "ResidentSync");
-constexpr int RES_HEAD_STOP = 0, RES_HEAD_K = 1, RES_HEAD_ELL = 2, RES_HEAD_RINV = 3, RES_HEAD_TINV = 12, RES_HEAD_WORDS = 15;
-// Self-placement of a resident launch's blocks: one per sub-batch stream.  joined[x] = blocks that found themselves on
-// XCD x so far (their index among them is their role); left = blocks that have exited (the last one resets the struct
-// for the next launch of this stream).
-struct ResidentTeams {
-  unsigned joined[8];
-  unsigned left;
-  unsigned pad[7];
-};
-static_assert(sizeof(ResidentTeams) == 64, "ResidentTeams");
-constexpr unsigned RESIDENT_TIMEOUT_TICKS = 5000000u;  // s_memrealtime runs at 100 MHz: 50 ms per wait
 
 struct PairDesc {
   // ---- read by the per-iteration kernels (k_assoc, k_coeff): kept together at the front ----
@@ -270,7 +237,6 @@ struct PairDesc {
   int* want_host;    // writes), the host reads them after a chunk's event - no copy kernel between two chunks
   int* gate;        // [1] blocks of k_list that finished the current rebuild (the last one validates the list)
   int* gate_flow;   // [1] blocks of k_assoc / k_assoc_dense that stored their flow partial (the last one reduces them)
-  ResidentSync* rsync;  // k_resident: the pair's in-launch synchronisation words
 };
 
 constexpr int COEFF_SPLIT_MAX = 32;

@@ -72,7 +72,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, done, rsync, cand_cnt, rowperm, iorig, long_j, long_stamp, xp4, ip, cand_j, ell, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, done, cand_cnt, rowperm, iorig, long_j, long_stamp, xp4, ip, cand_j, ell, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -100,8 +100,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static const char* const kOptionNames[] = {
     "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
     "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
-    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "RESIDENT",
-    "RESIDENT_BLOCKS", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS"};
+    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS"};
 
 struct cvo_ctx {
   int device = 0;
@@ -121,9 +120,6 @@ struct cvo_ctx {
   PairState* d_states = nullptr;
   int* d_status = nullptr;
   DevParams* d_params = nullptr;
-  ResidentTeams* d_teams = nullptr;  // [MAX_GROUPS]: self-placement counters of the resident launches, one per sub-batch stream
-  bool resident_off = false;         // a resident launch timed out on this context: two-kernel graphs from then on
-  int last_resident_nb = 0;          // blocks per pair of the last call's resident launches (0 = not used)
   int cap_pairs = 0;
   std::vector<PairDesc> h_descs;
   std::vector<PairState> h_states;
@@ -248,7 +244,6 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, bool long_lis
   L.gate = take(sizeof(int));
   L.gate_flow = take(sizeof(int));
   L.done = take(sizeof(int));
-  L.rsync = take(sizeof(ResidentSync));
   L.rowperm = take(sizeof(int) * (size_t)N);
   L.iorig = take(sizeof(int) * (size_t)N);
   L.long_stamp = take(sizeof(unsigned long long) * (size_t)N);
@@ -529,9 +524,8 @@ struct LaunchGeom {
   int n_pairs, p0, T, gx, gy, nba, nbc, npb, N, csplit;
   int csplit_heavy = 1;  // k_coeff grid of the graph with the dense kernel (the only one that runs pairs with overflow rows)
   int dense_blocks = DENSE_BLOCKS_MIN;  // k_assoc_dense grid x = PairDesc::dense_blocks of every pair of the launch
-  int group = 0;        // sub-batch index (its stream, its ResidentTeams)
+  int group = 0;        // sub-batch index (its stream)
   int horizon_cap = 1 << 20;  // the lean graph's period (DevParams::lean_U)
-  int res_nb = 0;       // k_resident: blocks per pair (0 = the lean graphs use the two-kernel iteration)
   bool idx16, general, instr, verify;
   hipStream_t stream;
   ArenaArg arena;  // of pair p0
@@ -568,36 +562,6 @@ void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags, bool den
                c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0) | (lean_dense ? 32 : 0));
 }
 
-#ifdef CVO_WITH_RESIDENT
-// U lean iterations of every pair of the sub-batch in one launch (k_resident).  Grid: 8 XCDs x ceil(n_pairs / 8) pairs x
-// res_nb blocks; the blocks place themselves (see the kernel), so only the total matters.
-void launch_resident(cvo_ctx* c, const LaunchGeom& g, int U) {
-  const int ppx = (g.n_pairs + 7) / 8;
-  const dim3 grid((unsigned)(8 * ppx * (g.res_nb + 1))), blk(ASSOC_THREADS);  // res_nb row blocks + the tail block per pair
-  const int packed = (U & 0xff) | (g.res_nb << 8) | (int)((unsigned)g.n_pairs << 20);  // (setup_batch: lean_U <= 255 or no resident launches)
-  const int nblk_split = g.nba | (g.csplit << 14) | ((g.p0 & 7) << 20);
-  const PairDesc* descs = c->d_descs + g.p0;
-  PairState* st = c->d_states + g.p0;
-  ResidentTeams* teams = c->d_teams + g.group;
-#define CVO_LAUNCH_RESIDENT(IDX, CAP, GEN)                                                                              \
-  hipLaunchKernelGGL((k_resident<IDX, CAP, GEN>), grid, blk, 0, g.stream, descs, c->d_params, st, g.arena.base, teams, packed, \
-                     nblk_split, g.arena.stride256, g.arena.Npad)
-  if (g.idx16) {
-    if (g.general)
-      CVO_LAUNCH_RESIDENT(unsigned short, ASSOC_CAP16, true);
-    else
-      CVO_LAUNCH_RESIDENT(unsigned short, ASSOC_CAP16, false);
-  } else {
-    if (g.general)
-      CVO_LAUNCH_RESIDENT(int, ASSOC_CAP32, true);
-    else
-      CVO_LAUNCH_RESIDENT(int, ASSOC_CAP32, false);
-  }
-#undef CVO_LAUNCH_RESIDENT
-}
-
-#endif  // CVO_WITH_RESIDENT
-
 // A chunk of U iterations.  Full: every iteration can rebuild its candidate list and serve overflow rows.
 // Lean: rebuild opportunities only every lean_U iterations; pairs that need more wait for a full chunk.
 // lean_U == 0: the full chunk WITHOUT k_assoc_dense - a rebuild opportunity in every iteration with the full graph's
@@ -618,15 +582,6 @@ void launch_chunk(cvo_ctx* c, const LaunchGeom& g, int U, bool lean, int lean_U,
     }
     return;
   }
-#ifdef CVO_WITH_RESIDENT
-  if (g.res_nb > 0 && !dense) {  // the lean iterations between two rebuild opportunities in ONE launch
-    for (int u = 0; u < U; u += lean_U) {
-      launch_rebuild(c, g);
-      launch_resident(c, g, std::min(lean_U, U - u));
-    }
-    return;
-  }
-#endif
   for (int u = 0; u < U; u++) {
     if (u % lean_U == 0) launch_rebuild(c, g);
     const bool last = (u % lean_U == lean_U - 1) || u == U - 1;
@@ -843,7 +798,6 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.gate = (int*)(base + S->L.gate);
     D.gate_flow = (int*)(base + S->L.gate_flow);
     D.done = (int*)(base + S->L.done);
-    D.rsync = (ResidentSync*)(base + S->L.rsync);
 
     PairState& st = ctx->h_states[p];
     std::memset(&st, 0, sizeof(st));
@@ -896,34 +850,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.general = dp.use_col || dp.use_sem || dp.use_geotype || dp.mode == 2;
   S->geom.instr = dp.kernel_clock || dp.phase_ticks;
   S->geom.verify = dp.verify_lists != 0;
-  // XCD-resident lean iterations (k_resident): calls with FEW pairs in flight (an iteration is a chain of latencies
-  // there; large batches are throughput-bound and keep the two-kernel iteration, whose launches fill the chip at a
-  // higher occupancy than blocks that wait for each other can).  The align loop only, not under the kernel clock or the
-  // list self-check (they hook into the two-kernel iteration), every pair with one coefficient slice per row block
-  // (clouds above 4096 points).  All blocks of a launch must be co-resident and the launches of the G sub-batch streams
-  // run side by side: row blocks per pair = what keeps the total at or below 1.5 blocks of 256 threads per CU (the
-  // kernel is built for 2).
-  S->geom.res_nb = 0;
   S->geom.horizon_cap = std::max(1, dp.lean_U);
-  // OFF by default (option RESIDENT=1): measured on MI355X it does not beat the two launches it replaces - DESIGN.md
-  // section 3, ROUND_LOG.md round 3 have the numbers (an L2-local hop is 260 ns, a reduce + broadcast among the blocks of
-  // a pair 1.5 - 2 us: what a launch boundary plus its cold prologue cost).  Kept because it is bit-identical, bounded
-  // and the harness for any further in-launch experiment; tests/test_gpu_parity.py runs it.
-#ifdef CVO_WITH_RESIDENT
-  if (mode == 0 && ctx_opt_on(ctx, "RESIDENT") && !ctx->resident_off && !dp.kernel_clock && !S->geom.verify && S->geom.csplit == 1 &&
-      dp.lean_U <= 255 &&  // (the launch packs its iteration count into eight bits)
-      (n_pairs <= 16 || ctx_opt(ctx, "RESIDENT_BLOCKS"))) {
-    const int per_group = (n_pairs + S->G - 1) / S->G, ppx = (per_group + 7) / 8;
-    int nb = std::max(1, 48 / (S->G * ppx) - 1);
-    if (const char* e = ctx_opt(ctx, "RESIDENT_BLOCKS")) nb = std::max(1, atoi(e));
-    nb = std::min(std::min(nb, S->d.nblk_assoc), 4094);
-    // (never more than the chip holds at 2 blocks per CU, whatever the option says: a launch that is not fully resident
-    // would wait for its own queued blocks until the time-out)
-    while (nb > 1 && (long)S->G * ppx * (nb + 1) > 64) nb--;
-    if ((long)S->G * ppx * (nb + 1) <= 64) S->geom.res_nb = nb;
-  }
-#endif
-  ctx->last_resident_nb = S->geom.res_nb;
   ctx->last_xorder = sources[0]->h_order;
   ctx->last_groups = S->G;
   ctx->last_pairs = n_pairs;
@@ -1061,10 +988,8 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
   }
   bool ok = (pooled || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess) &&
             hipMalloc(&c->d_params, sizeof(DevParams)) == hipSuccess &&
-            hipMalloc(&c->d_teams, sizeof(ResidentTeams) * cvo_ctx::MAX_GROUPS) == hipSuccess &&
-            // (cleared on the context's own stream: a synchronous hipMemset would run on the NULL stream, whose hardware
-            // queue is then the first one this process creates - see the note on the sub-batch streams below)
-            hipMemsetAsync(c->d_teams, 0, sizeof(ResidentTeams) * cvo_ctx::MAX_GROUPS, c->stream) == hipSuccess &&
+            // (nothing here may run on the NULL stream - a synchronous hipMemset, say: its hardware queue would then be the
+            // first one this process creates - see the note on the sub-batch streams below)
             hipEventCreate(&c->ev_start) == hipSuccess &&
             hipEventCreate(&c->ev_stop) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -1120,7 +1045,6 @@ void cvo_ctx_destroy(cvo_ctx* c) {
   drop_graphs(c);
   free_workspace(c);
   if (c->d_params) (void)hipFree(c->d_params);
-  if (c->d_teams) (void)hipFree(c->d_teams);
   if (c->d_kd_jobs) (void)hipFree(c->d_kd_jobs);
   for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++) {
     for (int i = 0; i < 2; i++)
@@ -1156,11 +1080,6 @@ int cvo_ctx_set_option(cvo_ctx* ctx, const char* name, const char* value) {
   bool known = false;
   for (const char* k : kOptionNames) known = known || std::strcmp(k, name) == 0;
   if (!known) return fail(ctx, CVO_E_INVALID, std::string("cvo_ctx_set_option: unknown option ") + name);
-#ifndef CVO_WITH_RESIDENT
-  if ((std::strcmp(name, "RESIDENT") == 0 || std::strcmp(name, "RESIDENT_BLOCKS") == 0) && value && atoi(value) != 0)
-    return fail(ctx, CVO_E_UNSUPPORTED, "this library was built without the XCD-resident iteration (k_resident): build "
-                                        "libcvo_hip_resident.so (unified_cvo_amd/build.py, -DCVO_WITH_RESIDENT)");
-#endif
   if (value)
     ctx->opt[name] = value;
   else
@@ -1704,7 +1623,6 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
 
   if (max_iter > 0) {
     const int lean_U = std::max(1, std::min(dp.lean_U, U));
-    bool resident_broken = false;
     const int lean_U2 = std::max(0, std::min(dp.lean_U2, U));
     // graphs: 0 full (rebuild opportunity + k_assoc_dense in every iteration), 1 lean, 2 short lean, 3 full without the
     // dense kernel, 4 calm; 5 / 6 / 7 = lean / short lean / calm WITH the dense kernel (pairs with overflow rows, or in
@@ -1730,7 +1648,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       key.idx16 = S.geom.idx16 ? 1 : 0;
       key.general = (S.geom.general ? 1 : 0) | (S.geom.csplit_heavy << 1);
       key.U = Uc * 256 + lean_period(v, Uc) + (v == 3 ? 128 : 0);
-      key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0) | (geom[g].res_nb << 2) | (v << 24);
+      key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0) | (v << 24);
       key.arena = geom[g].arena.base;
       key.stride256 = geom[g].arena.stride256;
       key.Npad = geom[g].arena.Npad;
@@ -1815,22 +1733,13 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
           // the most demanding unfinished pair of the group decides the level (2 = full, 1 = short lean, 0 = lean,
           // -1 = calm), any of them that needs k_assoc_dense gets it (want_level / want_encode, cvo_kernels.h)
           int want = -1;
-          bool dense = false, timed_out = false;
+          bool dense = false;
           for (int q = 0; q < ng; q++)
             if (hs[q] == 0) {
               const int w = hs[ng + q];
-              timed_out = timed_out || w == 3;
               dense = dense || w == 4 || w >= 8;
-              want = std::max(want, w == 4 || w == 3 ? 2 : (w >= 8 ? w - 9 : w));
+              want = std::max(want, w == 4 ? 2 : (w >= 8 ? w - 9 : w));
             }
-          if (timed_out) {  // a resident launch timed out: its pairs are served by the two-kernel graphs from now on
-            want = 2;
-            if (!resident_broken)
-              fprintf(stderr, "[cvo] warning: a resident launch timed out (blocks of a pair not co-resident); this context "
-                              "continues with the two-kernel iteration\n");
-            resident_broken = true;
-            for (int q = 0; q < G; q++) geom[q].res_nb = 0;  // (graphs are keyed on it: the next ones are captured anew)
-          }
           if (want == 1 && lean_U2 <= 0) want = 2;
           if (!allow_lean)
             graph_next[g] = 0;
@@ -1851,7 +1760,6 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
       }
     }
     ctx->last_chunks = ch;
-    if (resident_broken) ctx->resident_off = true;
     if (ctx_opt(ctx, "VERBOSE")) fprintf(stderr, "[cvo] host loop: %.2f ms in hipGraphLaunch, %.2f ms waiting for the device\n", t_launch, t_wait);
     ctx->last_lean_launches = n_lean_launch;
     ctx->last_full_launches = n_full_launch;
@@ -2332,23 +2240,6 @@ int cvo_debug_scalar_math(cvo_ctx* ctx, int op, int n, const double* in, double*
   if (e != hipSuccess) rc = fail(ctx, CVO_E_HIP, std::string("cvo_debug_scalar_math: ") + hipGetErrorString(e));
   cleanup();
   return rc;
-}
-
-// CVO_PHASE_TICKS=1: the resident kernel's per-phase tick sums (g_res_ticks, 100 MHz) since the last call of this
-// function; out[16].  Also reports how many blocks per pair the last call's resident launches used (*blocks_per_pair).
-int cvo_debug_resident_ticks(cvo_ctx* ctx, unsigned long long* out, int* blocks_per_pair) {
-  if (!ctx || !out) return CVO_E_INVALID;
-#ifdef CVO_WITH_RESIDENT
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipDeviceSynchronize());
-  HIP_TRY(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_res_ticks), sizeof(unsigned long long) * 16));
-  unsigned long long zero[16] = {};
-  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_res_ticks), zero, sizeof zero));
-#else
-  for (int q = 0; q < 16; q++) out[q] = 0ull;  // (a library built without k_resident: no resident launch ever ran)
-#endif
-  if (blocks_per_pair) *blocks_per_pair = ctx->last_resident_nb;
-  return CVO_OK;
 }
 
 int cvo_debug_cloud_order(const cvo_cloud* c, int* out) {

@@ -1,0 +1,139 @@
+// cvo_wave.h -- wave-wide primitives of the gfx950 kernels: DPP / permlane reductions, the XCD-aware pair -> block mapping, address-space qualified loads and the coherent (sc1) accessors.
+// Part of the kernel set of cvo_kernels.h (which states the whole iteration); compiled only as part of cvo_hip.hip.
+#pragma once
+#include "cvo_device.h"
+
+namespace cvo_dev {
+
+// Wave-wide reductions on the DPP cross-lane paths (no LDS traffic, unlike ds_bpermute shuffles): a butterfly
+// inside every row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row results
+// through scalar registers.  Every lane takes part and every lane gets the result; the order of the
+// additions is fixed.
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = dpp_i32<CTRL>(__double2loint(v)), hi = dpp_i32<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// own + partner across rows of 16 lanes (lane ^ 16, lane ^ 32) on gfx950's v_permlane16_swap / v_permlane32_swap:
+// with both operands = v the two results are {own, partner} in an order that depends on the lane's half - the sum
+// does not (IEEE addition commutes), so this is bit for bit `v + __shfl_xor(v, 16 / 32)` without the two
+// ds_bpermute round trips through the LDS (scripts/ubench/permlane_swap.hip prints what the instructions return).
+__device__ __forceinline__ double xor16_sum(double v) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double xor32_sum(double v) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double lane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+  const unsigned lo = (unsigned)dpp_i32<CTRL>((int)(unsigned)v), hi = (unsigned)dpp_i32<CTRL>((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long lane_u64(unsigned long long v, int l) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l) << 32) |
+         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_f64<DPP_XOR1>(v);
+  v += dpp_f64<DPP_XOR2>(v);
+  v += dpp_f64<DPP_HALF_MIRROR>(v);
+  v += dpp_f64<DPP_MIRROR>(v);
+  return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {  // (the caller's sum fits 32 bits)
+  v += (unsigned)dpp_i32<DPP_XOR1>((int)v);
+  v += (unsigned)dpp_i32<DPP_XOR2>((int)v);
+  v += (unsigned)dpp_i32<DPP_HALF_MIRROR>((int)v);
+  v += (unsigned)dpp_i32<DPP_MIRROR>((int)v);
+  return (unsigned)(__builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) +
+                    __builtin_amdgcn_readlane((int)v, 32) + __builtin_amdgcn_readlane((int)v, 48));
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = max(v, (unsigned)dpp_i32<DPP_XOR1>((int)v));
+  v = max(v, (unsigned)dpp_i32<DPP_XOR2>((int)v));
+  v = max(v, (unsigned)dpp_i32<DPP_HALF_MIRROR>((int)v));
+  v = max(v, (unsigned)dpp_i32<DPP_MIRROR>((int)v));
+  return max(max((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 16)),
+             max((unsigned)__builtin_amdgcn_readlane((int)v, 32), (unsigned)__builtin_amdgcn_readlane((int)v, 48)));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o));
+  return v;
+}
+
+// XCD-aware placement of the row-block kernels (k_list, k_assoc, k_coeff): the dispatcher is observed to place
+// workgroup b on XCD b % 8, so a 1-D grid is decoded as pair = (b / 8 / nblk) * 8 + b % 8, row block = (b / 8) % nblk:
+// all blocks of a pair run on one XCD and its lists, targets and ELL rows stay in that XCD's 4 MB L2 across
+// kernels and iterations (with the default mapping every XCD touches every pair: ~8x the L2 footprint).  Purely a
+// speed choice: nothing depends on where a block actually runs.  Grid = nblk * round_up(n_pairs, 8).
+struct PairBlock {
+  int pair, bx;
+};
+__device__ __forceinline__ bool pair_block(int nblk, int n_pairs, PairBlock& pb) {
+  const int b = (int)blockIdx.x;
+  const int slot = b >> 3;
+  const int grp = slot / nblk;
+  pb.pair = grp * 8 + (b & 7);
+  pb.bx = slot - grp * nblk;
+  return pb.pair < n_pairs;
+}
+
+// Values exchanged between the blocks of one launch (k_coeff's partials -> its last block): on this multi-die part the L2 of an XCD is not
+// coherent with the others inside a kernel, and agent-scope fences write back / invalidate whole caches.  Relaxed
+// agent-scope atomics carry the coherence bits on the instruction itself, which is all a handful of partial
+// sums needs.  COH = false: plain accesses (the producer is an earlier kernel).
+// Address-space qualified views: pointers read out of a PairDesc are generic ("flat") to the compiler.  A flat load
+// counts against vmcnt AND lgkmcnt and the compiler waits for both counters to reach zero before it uses one: a loop
+// that prefetches (k_assoc's candidates, k_coeff's entries) or a tail that has several groups of loads in flight then
+// serialises on every use.  Re-qualified as global, the same loads are global_load with exact vmcnt(n) waits.
+#define CVO_GLOBAL __attribute__((address_space(1)))
+#define CVO_CONST __attribute__((address_space(4)))
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // plain vector: loadable from any address space
+// (float4 is a class type: its copy constructor only takes generic references)
+__device__ __forceinline__ float4 ldg_f4(const CVO_GLOBAL f32x4* p) {
+  const f32x4 v = *p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+// ... and only its xyz: a 16-byte load whose fourth register is dead gets that register handed to the next load the loop
+// issues, which then has to wait for this one (k_assoc's candidate prefetch was serialised that way)
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ float4 ldg_xyz(const CVO_GLOBAL f32x4* p) {
+  const f32x3 v = *reinterpret_cast<const CVO_GLOBAL f32x3*>(p);
+  return make_float4(v.x, v.y, v.z, 0.f);
+}
+template <typename T>
+__device__ __forceinline__ const CVO_GLOBAL T* as_global(const T* p) {
+  return (const CVO_GLOBAL T*)p;
+}
+template <bool COH, typename T>
+__device__ __forceinline__ T ld_g(const CVO_GLOBAL T* p) {
+  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <bool COH, typename T>
+__device__ __forceinline__ void st_x(T* p, T v) {
+  if (COH)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    *p = v;
+}
+template <bool COH, typename T>
+__device__ __forceinline__ T ld_x(const T* p) {
+  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+
+}  // namespace cvo_dev
