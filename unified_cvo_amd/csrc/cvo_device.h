@@ -62,6 +62,10 @@ struct DevParams {
   int keep_columns;  // write ell_j (the column of every ELL entry): exports, traces, the self-check and the single
                      // evaluations need it, the optimiser loop itself never reads it (4 of 20 bytes per nonzero)
   int fast_div_cd;  // 2^-20 <= |c|, |d| <= 2^20: the per-row float divisions by c and d may take their hoisted form (fdiv_hoisted)
+  int row_max_cap;  // rows with more candidates than this leave the thread-per-row kernel for k_assoc_dense (a wave per row,
+                    // long lists) even though a cached list would hold them: the host lowers it when few pairs are in flight
+                    // (an iteration is then a chain of latencies and a wave runs as long as its longest row); only with long
+                    // lists, ASSOC_CAP16 = off.  No result depends on it (every row joins k_assoc's reduction at its position)
   int long_lists;  // overflow rows keep a cached sorted candidate list of up to LONG_CAP entries (PairDesc::long_j)
   unsigned long long call_serial;  // process-wide serial of this align call: generation tag of the cached long lists
   int debug_no_motion_bound;  // CVO_DEBUG_NO_MOTION_BOUND (tests only): the update pretends no target ever moves, so
@@ -123,6 +127,8 @@ struct PairState {
   unsigned clk_last_assoc, clk_n[2];
   float last_used, last_rate;  // list reuse: share of the motion allowance used since the build / used per iteration (statistics)
   int K_last;  // num_neighbors of the last EXECUTED iteration: the row stride upstream wrote its A matrix with (0: none ran)
+  float temp_coef;  // 1 / (2.0 * ell * ell) narrowed to float (CvoGPU.cu:1060) for the CURRENT ell: the same for every row
+                    // unless is_using_range_ell; evaluated by the update when ell changes instead of by every row of k_coeff
   unsigned long long clk_sum[2];
   // ---- everything above is the "hot" prefix k_update stages through LDS ----
   float sq[IND_CAP], eq[IND_CAP];
@@ -148,10 +154,38 @@ struct PairState {
 // the pair was evaluated with (so that the coefficient pass neither gathers the target again nor repeats the
 // transform: one streaming 16-byte load per nonzero).  The column index j lives in a parallel array (ell_j) that only
 // the exports and the self-check read.
+#ifdef CVO_ELL8
+// Experiment build (scripts/exp_time.py ell8): the 8-byte entry {value, the target's SORTED position}; k_coeff gathers the
+// initial target again and repeats transform_point_R_T (same function, same operands: same floats).  Half the bytes
+// k_assoc leaves behind and k_coeff streams, against a dependent gather + 9 FMAs per nonzero in the coefficient loop.
+struct EllEntry {
+  float a;
+  int p;
+};
+static_assert(sizeof(EllEntry) == 8, "EllEntry");
+constexpr bool ELL8 = true;
+#else
 struct EllEntry {
   float a, yx, yy, yz;
 };
 static_assert(sizeof(EllEntry) == 16, "EllEntry");
+constexpr bool ELL8 = false;
+#endif
+// p: the target's sorted position (what a cached list entry is)
+__device__ __forceinline__ EllEntry make_ell(float a, float yx, float yy, float yz, int p) {
+#ifdef CVO_ELL8
+  return EllEntry{a, p};
+#else
+  return EllEntry{a, yx, yy, yz};
+#endif
+}
+
+// What k_assoc_dense leaves per overflow row for the thread of k_assoc that owns the row's position.
+struct RowRes {
+  float o[3], v[3];  // sum_j a_ij (x_i x y_j), sum_j a_ij (y_j - x_i): float, accumulated in ascending j (CvoGPU.cu:779-780)
+  double asum;       // sum_j a_ij (mode 1: A_sum)
+};
+static_assert(sizeof(RowRes) == 32, "RowRes");
 
 // The row arrays of the per-iteration kernels open every pair's workspace, at offsets that depend only on the
 // launch-wide padded row count: a block computes their addresses from kernel arguments (arena of the launch's
@@ -169,7 +203,6 @@ __host__ __device__ inline size_t row_off_ell(int Np) { return (size_t)160 * Np;
 struct PairDesc {
   // ---- read by the per-iteration kernels (k_assoc, k_coeff): kept together at the front ----
   int N, M, nblk_assoc, nblk_coeff;  // nblk_coeff = nblk_assoc * csplit partials of the coefficient phase
-  int dense_blocks;                  // blocks of k_assoc_dense for this pair (dense_blocks_for: the launch's grid x)
   // k_list orders the rows of every 256-row window by candidate count; POSITION = index in that order
   int* cand_cnt;   // [N] candidates of the row at each position
   void* cand_j;    // [ASSOC_CAP][N] cached candidate lists by position, u16 or i32: the targets' SORTED positions, in
@@ -181,8 +214,9 @@ struct PairDesc {
   EllEntry* ell;              // ELL kernel matrix [K_max][N] by POSITION: value + transformed target, ascending ORIGINAL j in a row
   int* ell_j;                 // [K_max][N]: the column (ORIGINAL j) of every entry
   unsigned* nnz_row;          // nonzeros[N], by position
-  double* flow_part;          // [nblk_assoc + DENSE_BLOCKS_MAX][8]: omega(3), v(3), sum a, pad (row blocks, then k_assoc_dense)
-  unsigned long long* cnt_part;  // [nblk_assoc + DENSE_BLOCKS_MAX][4]: nnz, max, candidates, overflow rows
+  RowRes* rowres;             // [N] by position: results of the rows k_assoc_dense evaluated, picked up by k_assoc
+  double* flow_part;          // [nblk_assoc][8]: omega(3), v(3), sum a, pad - one partial per row block of k_assoc
+  unsigned long long* cnt_part;  // [nblk_assoc][4]: nnz, max, candidates, overflow rows
   double* coef_part;          // [nblk_assoc * COEFF_SPLIT_MAX][4]: B C D E
   int* done;        // [1] k_coeff: blocks that stored their partials (monotonic; the last one runs the update)
   int csplit, csplit_heavy;  // k_coeff: blocks per row block; block q of a row block takes the ELL slots s = q (mod csplit).
@@ -236,7 +270,7 @@ struct PairDesc {
   int* status_host;  // the same two words in pinned HOST memory: the device writes them when they change (posted
   int* want_host;    // writes), the host reads them after a chunk's event - no copy kernel between two chunks
   int* gate;        // [1] blocks of k_list that finished the current rebuild (the last one validates the list)
-  int* gate_flow;   // [1] blocks of k_assoc / k_assoc_dense that stored their flow partial (the last one reduces them)
+  int* gate_flow;   // [1] blocks of k_assoc that stored their flow partial (the last one reduces them)
 };
 
 constexpr int COEFF_SPLIT_MAX = 32;

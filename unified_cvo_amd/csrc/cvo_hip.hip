@@ -72,7 +72,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, done, cand_cnt, rowperm, iorig, long_j, long_stamp, xp4, ip, cand_j, ell, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, done, cand_cnt, rowperm, iorig, long_j, long_stamp, xp4, ip, cand_j, rowres, ell, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -100,7 +100,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static const char* const kOptionNames[] = {
     "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
     "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
-    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS"};
+    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS", "ROW_MAX"};
 
 struct cvo_ctx {
   int device = 0;
@@ -248,8 +248,9 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, bool long_lis
   L.iorig = take(sizeof(int) * (size_t)N);
   L.long_stamp = take(sizeof(unsigned long long) * (size_t)N);
   L.long_j = long_lists ? take(sizeof(unsigned short) * (size_t)N * LONG_CAP) : 0;
-  L.flow_part = take(sizeof(double) * 8 * (size_t)(nba + DENSE_BLOCKS_MAX));
-  L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)(nba + DENSE_BLOCKS_MAX));
+  L.rowres = take(sizeof(RowRes) * (size_t)N);
+  L.flow_part = take(sizeof(double) * 8 * (size_t)nba);
+  L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)nba);
   L.coef_part = take(sizeof(double) * 4 * (size_t)nbc * COEFF_SPLIT_MAX);
   L.trace = take(sizeof(cvo_trace_t) * (size_t)std::max(trace_capacity, 0));
   L.total = off;
@@ -554,9 +555,10 @@ void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags, bool den
   const PairDesc* descs = c->d_descs + g.p0;
   const int* st = c->d_status + 2 * g.p0;  // the sub-batch's status words (see setup_batch)
   const bool lean_dense = lean && dense;
+  // rows beyond their cached lists first (a wave per row; per-row results), then every row's reduction in k_assoc
+  if (!lean || dense) launch_dense(g.stream, g.general, g.N, g.n_pairs, g.dense_blocks, descs, c->d_params, st);
   launch_assoc(g.stream, g.idx16, g.general, g.instr, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena,
                (lean ? 1 : 0) | (lean_dense ? 4 : 0));
-  if (!lean || dense) launch_dense(g.stream, g.general, g.N, g.n_pairs, g.dense_blocks, descs, c->d_params, st);
   if (g.verify) launch_verify(g.stream, g.general, g.N, g.n_pairs, descs, c->d_params, st, (lean ? 1 : 0) | (lean_dense ? 4 : 0));
   launch_coeff(g.stream, g.instr, g.nba, (lean && !dense) ? g.csplit : g.csplit_heavy, g.n_pairs, descs, c->d_params,
                c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0) | (lean_dense ? 32 : 0));
@@ -688,6 +690,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   dp.T = S->T;
   dp.groups_per_block = S->gpb;
   dp.long_lists = S->long_lists ? 1 : 0;
+  dp.row_max_cap = ASSOC_CAP16;
+  if (const char* e = ctx_opt(ctx, "ROW_MAX")) dp.row_max_cap = std::max(1, std::min(atoi(e), (int)ASSOC_CAP16));
   {
     static std::atomic<unsigned long long> g_call_serial{1};  // never repeats inside a process: see PairDesc::long_stamp
     dp.call_serial = g_call_serial.fetch_add(1);
@@ -731,7 +735,6 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.nslices = S->d.Mpad / (64 * S->T);
     D.rbw = (int)align_up((size_t)(S->d.Mpad / (64 * S->T) + 31) / 32, 4);
     D.nblk_assoc = S->d.nblk_assoc;
-    D.dense_blocks = dense_blocks_for(N, n_pairs);
     // coefficient phase: small clouds get several blocks per row block (see coeff_rows); a function of the pair's own
     // size only, so that a pair is reduced in the same order whether it is solved alone or inside a batch
     D.csplit = coeff_split(X->n);
@@ -779,6 +782,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     D.ell = (EllEntry*)(base + S->L.ell);
     D.ell_j = (int*)(base + S->L.ell_j);
     D.nnz_row = (unsigned*)(base + S->L.nnz_row);
+    D.rowres = (RowRes*)(base + S->L.rowres);
     D.flow_part = (double*)(base + S->L.flow_part);
     D.cnt_part = (unsigned long long*)(base + S->L.cnt_part);
     D.coef_part = (double*)(base + S->L.coef_part);

@@ -8,7 +8,7 @@ namespace cvo_dev {
 
 // thrust::reduce of omega_gpu / v_gpu (CvoGPU.cu:824-825) from the association block partials, Eigen's
 // normalize() and the matrices of compute_step_size_xi: once per pair and iteration, by one wave of the block of
-// the association launch that stores its partial last (k_assoc in the lean graph, k_assoc_dense in the full one).
+// k_assoc that stores its partial last.
 // Lane l owns component (l & 7) of blocks l>>3, l>>3 + 8, ... (independent loads, all in flight), the eight
 // groups meet through DPP / ds_swizzle; the order of the additions is fixed.  k_coeff reads the 42 floats with
 // scalar loads in its first burst (they used to be reduced again by every one of its blocks: ~3 us of
@@ -151,7 +151,7 @@ __device__ __forceinline__ double block_reduce_lds(BlockRedShared<NC>& S, const 
 struct AssocShared {
   union {
     BlockRedShared<7> red;                   // after the row loop
-    float4 stage[ELL_STAGE][ASSOC_THREADS];  // during it: the rows' first ELL entries, one column per thread
+    EllEntry stage[ELL_STAGE][ASSOC_THREADS];  // during it: the rows' first ELL entries, one column per thread
   };
   unsigned long long cnt[ASSOC_THREADS / 64][4];
 };
@@ -175,6 +175,9 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
     if (!overflowed) {
       const int i = head.ip;
       const float4 x = head.x;
+      // (Round 5 cached den = 2 l^2 and its refined reciprocal per row, 16 bytes next to the row head, rewritten only when
+      // ell decays: 35 VALU instructions per row and iteration less - and the 64-pair step 3 % SLOWER, 60.9 against 59.1 ms
+      // in scripts/exp_time.py: these kernels pay for bytes, not for arithmetic.  The constants are recomputed.)
       const RowData r = make_row(P, x, iv.ell);
       const FeatDen F = make_feat_den(P);
       const V3 pxe{x.x, x.y, x.z};
@@ -214,13 +217,26 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
         const unsigned ns = min(A.nnz, (unsigned)ELL_STAGE);
         EllEntry* dst = D->ell + pos;
         for (unsigned q = 0; q < ns; q++) {
-          const float4 e4 = A.stage[q * ASSOC_THREADS];  // (own LDS column: no barrier)
-          const f32x4 ev = {e4.x, e4.y, e4.z, e4.w};
+          const EllEntry e4 = A.stage[q * ASSOC_THREADS];  // (own LDS column: no barrier)
+#ifdef CVO_ELL8
+          const f32x2 ev = {e4.a, __int_as_float(e4.p)};
+          asm volatile("flat_store_dwordx2 %0, %1 sc1" ::"v"(dst), "v"(ev) : "memory");
+#else
+          const f32x4 ev = {e4.a, e4.yx, e4.yy, e4.yz};
           asm volatile("flat_store_dwordx4 %0, %1 sc1" ::"v"(dst), "v"(ev) : "memory");
+#endif
           dst += N;
         }
       }
       if (INSTR) tt2 = __builtin_readcyclecounter();
+    } else {
+      // a row beyond its list: k_assoc_dense, which ran before this kernel, evaluated it (a wave per row) and left its
+      // nonzero count and float flow sums; they join the block's reduction at the row's own position
+      const RowRes rr = D->rowres[pos];
+      A.o0 = rr.o[0]; A.o1 = rr.o[1]; A.o2 = rr.o[2];
+      A.v0 = rr.v[0]; A.v1 = rr.v[1]; A.v2 = rr.v[2];
+      A.asum = rr.asum;
+      A.nnz = D->nnz_row[pos];
     }
   }
   if (INSTR && P.phase_ticks && threadIdx.x == 0) {
@@ -340,9 +356,9 @@ __global__ __launch_bounds__(ASSOC_THREADS, GENERAL ? 1 : CVO_ASSOC_WAVES) void 
   // acknowledgement and an atomic round trip (~2 us of a ~7 us wave life; with thousands of waves queued behind them
   // that wait was throughput, not just latency).  A barrier only counts the waves that are still alive.
   if (threadIdx.x >= 64) return;
-  // lean graph, or a pair without overflow rows in the full one (k_assoc_dense then has nothing to add and leaves at
-  // once): nothing else adds to the flow, the twist of the iteration can be finished here
-  if ((n_ovf_v == 0 || ((lean & 3) && !(lean & 4))) && P.mode == 0) {  // (bit 1: the timing replay includes it)
+  // every row of the pair has been reduced (rows beyond their lists were evaluated by k_assoc_dense before this launch):
+  // the block that stores its partial last finishes the twist of the iteration
+  if (P.mode == 0) {
     const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && (lean & 3) == 1, st, 0);
     const bool last = flow_gate(D, nblk, nblk);
     if (last && threadIdx.x == 0 && clk0) D->st->clk_last_assoc = pair_clock_ticks(clk0);  // added up by the update

@@ -81,9 +81,6 @@ __device__ __forceinline__ int build_long_list(const PairDesc* __restrict__ D, c
   return cnt;
 }
 
-// flow partials k_assoc_dense leaves for a pair with n_ovf overflow rows (4 waves per block, one row per wave at a time)
-__device__ __forceinline__ int dense_parts(int dense_blocks, int n_ovf) { return min(dense_blocks, (n_ovf + 3) >> 2); }
-
 template <bool GENERAL, int DENSE_WAVES>
 __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
                                                      const int* __restrict__ status) {
@@ -95,20 +92,12 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
   const int K = st->K;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n_ovf = st->n_ovf;
-  if (n_ovf == 0 && P.mode == 0) return;  // nothing to add: k_assoc has finished the twist, the update skips these slots
+  if (n_ovf == 0) return;   // no row of this pair is beyond its cached list
   if (st->rebuild) return;  // (lean graphs with this kernel: the pair waits for its rebuild opportunity, see k_assoc)
-  // one row per wave is the most there is to do: blocks beyond that leave no partial and stay out of the gate (the last
-  // block's reduction and the update read nblk_assoc + dense_parts() slots - with the whole grid's 1024 that tail alone
-  // was most of a launch that serves a few dozen rows)
-  const int n_parts = P.mode == 0 ? dense_parts((int)gridDim.x, n_ovf) : (int)gridDim.x;
-  if ((int)blockIdx.x >= n_parts) return;
   const bool all_dense = st->all_dense != 0;
   __shared__ float2 s_hits[DENSE_WAVES][128][6];  // per wave: the hits of one step, compacted ({flow term, value} per component)
   __shared__ unsigned s_keys[DENSE_WAVES][LONG_CAP];  // per wave: the long list being built (sort keys)
-  double red[7] = {0, 0, 0, 0, 0, 0, 0};
-  unsigned long long nnz_sum = 0;
-  unsigned nnz_max = 0;
-  if (n_ovf > 0) {
+  {
     const Pose pose = load_pose(st);
     const FeatDen F = make_feat_den(P);
     const bool long_lists = !all_dense && P.long_lists != 0 && D->long_j != nullptr;
@@ -150,7 +139,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
         float a[2] = {0.f, 0.f};
         float4 yt[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
         bool ok[2] = {false, false};
-        int col[2] = {0, 0};
+        int col[2] = {0, 0}, psort[2] = {0, 0};
 #pragma unroll
         for (int h = 0; h < 2; h++) {
           const int c = j0 + 64 * h + lane;
@@ -158,10 +147,12 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
             if (listed) {  // list entries are sorted positions: coordinates and features from the spatially ordered arrays
               const int p = fresh ? (int)(s_keys[wave][c] & 0xffffu) : (int)lj[c];
               col[h] = p;
+              psort[h] = p;
               ok[h] = eval_pair<GENERAL>(P, D, F, pose, i, r, p, D->ys4[p], a[h], yt[h]) && (a[h] > P.sp_thres);
             } else {
               col[h] = c;
-              ok[h] = eval_pair<GENERAL>(P, D, F, pose, i, r, GENERAL ? D->yinv[c] : 0, D->y4[c], a[h], yt[h]) && (a[h] > P.sp_thres);
+              psort[h] = (GENERAL || ELL8) ? D->yinv[c] : 0;
+              ok[h] = eval_pair<GENERAL>(P, D, F, pose, i, r, psort[h], D->y4[c], a[h], yt[h]) && (a[h] > P.sp_thres);
             }
           }
         }
@@ -173,7 +164,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
           const unsigned rank = nnz + below;
           const bool keep = ok[h] && rank < (unsigned)K;  // `if (num_inds == num_neighbors) break;`
           if (keep) {
-            D->ell[(size_t)rank * N + r_sorted] = EllEntry{a[h], yt[h].x, yt[h].y, yt[h].z};
+            D->ell[(size_t)rank * N + r_sorted] = make_ell(a[h], yt[h].x, yt[h].y, yt[h].z, psort[h]);
             if (P.keep_columns) D->ell_j[(size_t)rank * N + r_sorted] = listed ? D->yorder[col[h]] : col[h];
             // flow terms of this lane's pair (CvoGPU.cu:767-769)
             const V3 pye{yt[h].x, yt[h].y, yt[h].z};
@@ -214,52 +205,16 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
       }
       const float o0 = __shfl(acc, 0), o1 = __shfl(acc, 1), o2 = __shfl(acc, 2);
       const float v0 = __shfl(acc, 3), v1 = __shfl(acc, 4), v2 = __shfl(acc, 5);
+      // The row's result - nonzero count and its float flow sums, as compute_flow_gpu_no_eigen leaves them before the
+      // division by c / d (CvoGPU.cu:779-787) - for the thread of k_assoc that owns the position: k_assoc runs AFTER
+      // this kernel and reduces every row of the pair, whoever evaluated it, in one fixed order (no partial of this
+      // kernel's own: a pair's sums do not depend on this launch's grid, i.e. on how many pairs are in flight).
       if (lane == 0) {
         D->nnz_row[r_sorted] = nnz;
-        red[0] += (double)(o0 / P.c);
-        red[1] += (double)(o1 / P.c);
-        red[2] += (double)(o2 / P.c);
-        red[3] += (double)(v0 / P.d);
-        red[4] += (double)(v1 / P.d);
-        red[5] += (double)(v2 / P.d);
-        red[6] += asum;
-        nnz_sum += nnz;
-        nnz_max = max(nnz_max, nnz);
+        D->rowres[r_sorted] = RowRes{{o0, o1, o2}, {v0, v1, v2}, asum};
       }
     }
   }
-  // block partials are always written (zeros when there was nothing to do): k_coeff / k_update sum them
-  __shared__ double s_red[DENSE_WAVES][8];
-  __shared__ unsigned long long s_cnt[DENSE_WAVES][2];
-  if (lane == 0) {
-#pragma unroll
-    for (int c = 0; c < 7; c++) s_red[wave][c] = red[c];
-    s_cnt[wave][0] = nnz_sum;
-    s_cnt[wave][1] = nnz_max;
-  }
-  __syncthreads();
-  const size_t slot = (size_t)D->nblk_assoc + blockIdx.x;
-  if (threadIdx.x < 7) {
-    const int c = threadIdx.x;
-    double t = s_red[0][c];
-#pragma unroll
-    for (int w = 1; w < DENSE_WAVES; w++) t += s_red[w][c];
-    st_x<true>(D->flow_part + slot * 8 + c, t);
-  } else if (threadIdx.x == 8) {
-    unsigned long long* cp = D->cnt_part + slot * 4;
-    unsigned long long c0 = 0, c1 = 0;
-#pragma unroll
-    for (int w = 0; w < DENSE_WAVES; w++) {
-      c0 += s_cnt[w][0];
-      c1 = max(c1, s_cnt[w][1]);
-    }
-    cp[0] = c0;
-    cp[1] = c1;
-    cp[2] = 0;
-    cp[3] = 0;
-  }
-  // full graph: the twist of the iteration from the partials of k_assoc (an earlier launch) and of this kernel
-  if (P.mode == 0) flow_gate(D, n_parts, D->nblk_assoc + n_parts);
 }
 
 }  // namespace cvo_dev

@@ -59,8 +59,8 @@ struct CoeffRowHead {
 // COH: the block partial is read by another block of the same launch.
 template <bool COH>
 __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* __restrict__ D, const float ell,
-                                           CoeffShared& S, const XiMats& Mu, const CoeffRowHead& h, const int bx,
-                                           const int q, const int nsplit) {
+                                           const float coef_ell, CoeffShared& S, const XiMats& Mu, const CoeffRowHead& h, const int bx,
+                                           const int q, const int nsplit, const Pose& pose) {
   const int N = D->N;
   const int i = bx * ASSOC_THREADS + threadIdx.x;
   double Bi = 0, Ci = 0, Di = 0, Ei = 0;
@@ -70,13 +70,33 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
   const unsigned nnz = h.nnz;
   if ((unsigned)q < nnz) {
     const float4 x = h.x;
-    float temp_ell = ell;
+    // 1 / (2.0 * ell * ell), CvoGPU.cu:1060: the same for every row (PairState::temp_coef, evaluated by the update when
+    // ell changes) unless the range factor is on (CvoGPU.cu:1035-1037)
+    float temp_coef = coef_ell;
     if (P.use_range_ell) {
       const float d2_sqrt = sqrtf(dot3_dev(x.x, x.y, x.z, x.x, x.y, x.z));
-      temp_ell = compute_range_ell(temp_ell, d2_sqrt);
+      temp_coef = coef_of_ell(compute_range_ell(ell, d2_sqrt));
     }
-    const double cden = 2.0 * temp_ell * temp_ell;
-    const float temp_coef = (float)div_by(1.0, cden, rcp_refined(cden));  // 1 / (2.0 * ell * ell), CvoGPU.cu:1060
+#ifdef CVO_ELL8
+    // 8-byte entries: the initial target is gathered again by its sorted position and transformed with the iteration's
+    // pose - two loads deep: entry s + 2 nsplit and target s + nsplit are in flight while entry s is evaluated
+    const CVO_GLOBAL f32x4* ysrc = (const CVO_GLOBAL f32x4*)D->ys4;
+    const CVO_GLOBAL f32x2* ep = (const CVO_GLOBAL f32x2*)D->ell + i;
+    auto ld_e = [](const CVO_GLOBAL f32x2* p) { const f32x2 v = *p; return EllEntry{v.x, __float_as_int(v.y)}; };
+    EllEntry e_n = h.e_n;
+    float4 y_n = ldg_xyz(ysrc + e_n.p);
+    EllEntry e_nn = e_n;
+    if ((unsigned)q + nsplit < nnz) e_nn = ld_e(ep + (size_t)(q + nsplit) * N);
+    for (unsigned s = (unsigned)q; s < nnz; s += (unsigned)nsplit) {
+      const EllEntry e = e_n;
+      const float4 y0 = y_n;
+      e_n = e_nn;
+      if (s + nsplit < nnz) y_n = ldg_xyz(ysrc + e_n.p);
+      if (s + 2 * nsplit < nnz) e_nn = ld_e(ep + (size_t)(s + 2 * nsplit) * N);
+      const V3 yy = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
+      coeff_entry(Mu, x, temp_coef, yy, e.a, Bi, Ci, Di, Ei);
+    }
+#else
     EllEntry e_n = h.e_n;
     for (unsigned s = (unsigned)q; s < nnz; s += (unsigned)nsplit) {
       const EllEntry e = e_n;
@@ -84,6 +104,7 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
       // (the transformed target k_assoc evaluated the pair with: transform_point of the same operands, stored)
       coeff_entry(Mu, x, temp_coef, V3{e.yx, e.yy, e.yz}, e.a, Bi, Ci, Di, Ei);
     }
+#endif
   }
   const double red[4] = {Bi, Ci, Di, Ei};
   const double tot = block_reduce_lds<4>(S.red, red);
@@ -118,7 +139,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     const int pos = pb.bx * ASSOC_THREADS + threadIdx.x;  // < Npad; values of rows >= N are never used
     head.nnz = reinterpret_cast<const unsigned*>(wb + row_off_nnz(Npad))[pos];
     head.x = reinterpret_cast<const float4*>(wb + row_off_xp4(Npad))[pos];
-    head.e_n = EllEntry{0.f, 0.f, 0.f, 0.f};
+    head.e_n = make_ell(0.f, 0.f, 0.f, 0.f, 0);
     if (cq == 0) head.e_n = reinterpret_cast<const EllEntry*>(wb + row_off_ell(Npad))[pos];
   }
   const int csplit_light = D->csplit, csplit_heavy = D->csplit_heavy;
@@ -146,10 +167,10 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     const float4* a2 = D->xp4;
     const EllEntry* a3 = D->ell;
     const int a4 = D->M;
-    const float e = st_in->ell;
+    const float e = st_in->ell, tc = st_in->temp_coef;
     const int k_line = st_in->K;  // (rides in the 16-byte load of status / rebuild / n_ovf: pinned so that none of its
                                   // registers is dead and reused inside the burst, see k_assoc)
-    asm volatile("" ::"s"(n), "s"(nb), "s"(ep), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e), "s"(csplit_light),
+    asm volatile("" ::"s"(n), "s"(nb), "s"(ep), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e), "s"(tc), "s"(csplit_light),
                  "s"(csplit_heavy), "s"(status_v), "s"(rebuild_v), "s"(ovf), "s"(k_line), "s"(max_nnz_prev), "s"(P.mode), "s"(P.sp_thres), "s"(P.use_range_ell),
                  "s"(Mu.omega[0]), "s"(Mu.m2.m[0][0]), "s"(Mu.m4.m[2][2]), "s"(Mu.v[2]));
     // (nothing computed from these values - the slice count below is the first - may be scheduled into the middle of
@@ -162,9 +183,13 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   // (as many slices as keep a thread's share of the longest row at ~32 entries: every slice is four more partials for the
   // update to fetch, 128 per round trip)
   // ... and at least ~128 blocks per pair while rows are long
+  // (the pair's OWN row blocks, not the launch's: in a batch of ragged clouds the launch is sized by the largest one, and
+  // the split - hence the order in which a row's terms are summed - must not depend on the company a pair is solved in)
   int csplit = csplit_light;
-  if (ovf > 0 && max_nnz_prev > 48u && (!(flags & 1) || (flags & 32)))
-    while (csplit < csplit_heavy && ((unsigned)(csplit * 32) < max_nnz_prev || nblk * csplit < 128)) csplit <<= 1;
+  if (ovf > 0 && max_nnz_prev > 48u && (!(flags & 1) || (flags & 32))) {
+    const int nblk_own = (D->N + ASSOC_THREADS - 1) / ASSOC_THREADS;
+    while (csplit < csplit_heavy && ((unsigned)(csplit * 32) < max_nnz_prev || nblk_own * csplit < 128)) csplit <<= 1;
+  }
   if (cq >= csplit) return;
   const bool replay = (flags & 8) != 0;  // cvo_debug_time_kernels: same work, nothing written back
   if (!replay && status_v != 0) return;
@@ -198,7 +223,12 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     twist[3 + c] = Mu.v[c];
   }
   const unsigned long long tt1 = INSTR ? __builtin_readcyclecounter() : 0ull;
-  coeff_rows<true>(P, D, st_in->ell, S.c, Mu, head, pb.bx, cq, csplit);
+#ifdef CVO_ELL8
+  const Pose pose = load_pose(st_in);
+#else
+  const Pose pose{};
+#endif
+  coeff_rows<true>(P, D, st_in->ell, st_in->temp_coef, S.c, Mu, head, pb.bx, cq, csplit, pose);
   const unsigned long long tt2 = INSTR ? __builtin_readcyclecounter() : 0ull;
   if (threadIdx.x >= 64) return;  // the counter and (in one block of the pair) the update are the first wave's, see k_assoc
   // the scalar state, for whichever block turns out to be the last one: in flight while the counter round trip runs
@@ -210,9 +240,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && !replay, st, 1);
   UpdDesc upd = load_upd_desc(D);
   upd.nblk_coeff = nblk * csplit;
-  const int n_flow_upd = (((flags & 1) && !(flags & 32)) || ovf == 0) ? D->nblk_assoc : D->nblk_assoc + dense_parts(D->dense_blocks, ovf);  // (see k_assoc_dense)
-  // (how many flow partials the update will sum: known now - left to the compiler, the two descriptor words behind it are
-  // requested after the counter's round trip, one more dependent wait on the pair's serial tail)
+  const int n_flow_upd = D->nblk_assoc;  // (requested now, not after the counter's round trip on the pair's serial tail)
   asm volatile("" ::"s"(n_flow_upd));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partial stores before the counter, see flow_gate
   __syncthreads();

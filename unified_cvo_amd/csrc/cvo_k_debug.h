@@ -47,9 +47,14 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
         const EllEntry e = D->ell[(size_t)rank * N + pos];
         if (D->ell_j[(size_t)rank * N + pos] != j)
           err = 2;
+#ifdef CVO_ELL8
+        else if (__float_as_uint(e.a) != __float_as_uint(a) || D->yorder[e.p] != j)
+          err = 3;
+#else
         else if (__float_as_uint(e.a) != __float_as_uint(a) || __float_as_uint(e.yx) != __float_as_uint(yt.x) ||
                  __float_as_uint(e.yy) != __float_as_uint(yt.y) || __float_as_uint(e.yz) != __float_as_uint(yt.z))
           err = 3;
+#endif
       }
       nnz += (unsigned)__builtin_popcountll(__ballot(keep));
     }

@@ -24,6 +24,11 @@ __device__ __forceinline__ RowData make_row(const DevParams& P, const float4 x, 
   const double den = 2.0 * l * l;
   return RowData{x.x, x.y, x.z, l, thr, den, rcp_refined(den)};
 }
+// 1 / (2.0 * ell * ell) narrowed to float (compute_step_size_poly_coeff, CvoGPU.cu:1060), the division in its hoisted form
+__device__ __forceinline__ float coef_of_ell(float ell) {
+  const double cden = 2.0 * ell * ell;
+  return (float)div_by(1.0, cden, rcp_refined(cden));
+}
 // The colour and semantic kernels' exponent denominators (2.0 * c_ell^2, 2.0 * s_ell^2: the same for every pair of a
 // call) with their refined reciprocals; evaluated once per thread, outside the row loops.
 struct FeatDen {
@@ -167,7 +172,7 @@ struct RowAcc {
   double asum = 0;
   unsigned nnz = 0;
   EllEntry* slot = nullptr;  // where the row's next nonzero goes: D->ell + nnz * N + pos, advanced by N per nonzero
-  float4* stage = nullptr;   // this thread's column of the block's LDS staging area (AssocShared::stage)
+  EllEntry* stage = nullptr;  // this thread's column of the block's LDS staging area (AssocShared::stage)
 };
 // ELL entries a row parks in LDS before they are stored (see assoc_phase).  Six: 24.6 KB of LDS per block; 4 / 5 / 6 / 7 / 8
 // slots measured 63.6 / 63.3 / 62.9 / 63.8 / 64.9 ms per step (the early iterations have ~8 nonzeros per row, the
@@ -188,12 +193,9 @@ __device__ __forceinline__ void visit_pair_yt(const DevParams& P, const PairDesc
     // The row's first ELL_STAGE nonzeros are parked in the thread's own LDS column and leave after the loop as
     // write-through stores (assoc_phase); only rows longer than that store from inside the loop.
     if (A.nnz < (unsigned)ELL_STAGE)
-      A.stage[A.nnz * ASSOC_THREADS] = make_float4(a, yt.x, yt.y, yt.z);
+      A.stage[A.nnz * ASSOC_THREADS] = make_ell(a, yt.x, yt.y, yt.z, j);
     else
-      *A.slot = EllEntry{a, yt.x, yt.y, yt.z};
-#ifdef CVO_EXP_DOUBLE_ELL
-    if (A.nnz < 64u) reinterpret_cast<EllEntry*>(D->ell_j)[(size_t)A.nnz * N + pos] = EllEntry{a, yt.x, yt.y, yt.z};
-#endif
+      *A.slot = make_ell(a, yt.x, yt.y, yt.z, j);
     if (P.keep_columns) D->ell_j[(size_t)A.nnz * N + pos] = D->yorder[j];  // (list entries are sorted positions)
     A.slot += N;
     A.nnz++;
@@ -206,7 +208,7 @@ __device__ __forceinline__ void visit_pair_yt(const DevParams& P, const PairDesc
     A.v0 = __builtin_fmaf(dx, a, A.v0);
     A.v1 = __builtin_fmaf(dy, a, A.v1);
     A.v2 = __builtin_fmaf(dz, a, A.v2);
-    A.asum += (double)a;
+    if (P.mode != 0) A.asum += (double)a;  // A_sum (SparseKernelMat.cu:62-68): only the single evaluations read it
   }
 }
 

@@ -183,6 +183,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
   CVO_UPD_STAMP(2);
   if (tid == 0) {
     int done = 0;
+    if (INIT) st->temp_coef = coef_of_ell(st->ell);
     if (twist) {  // k_coeff: every block derived the same normalised twist
       for (int c = 0; c < 3; c++) {
         st->omega[c] = twist[c];
@@ -283,6 +284,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
               float e = ell_used * P.ell_decay_rate;
               if (e < P.ell_min) e = P.ell_min;
               st->ell = e;
+              st->temp_coef = coef_of_ell(e);  // (k_coeff's per-row constant, see PairState)
             }
             st->K = min(P.K_max, (int)((double)max_nnz * 1.2));  // CvoGPU.cu:1529
             st->k = k + 1;
@@ -420,6 +422,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         // cloud: k_assoc_dense runs in every iteration, its long lists cost what their candidates cost), rows of more
         // than 24 candidates join them - a wave per row, 64 candidates per step - instead of holding 63 neighbours back.
         st->row_max = (!INIT && P.long_lists && !c_dense && 16 * c_ovf > D.N) ? 24 : ASSOC_CAP16;
+        if (P.long_lists && P.row_max_cap > 0) st->row_max = min(st->row_max, P.row_max_cap);
         int want_full = 2;
         float s = 0.f;
         // rows beyond every list fall back to the literal scan over all targets (k_assoc_dense): fine for a few
@@ -536,11 +539,7 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
   }
   const DevParams P = *Pp;
   __shared__ UpdateShared U;
-  update_body<INIT, false>(load_upd_desc(D), P, flags,
-                           ((flags & 1) && !(flags & 32)) ? D->nblk_assoc
-                                                          : D->nblk_assoc + (P.mode == 0 ? dense_parts(D->dense_blocks, D->st->n_ovf) : D->dense_blocks),
-                           U, nullptr,
-                           nullptr);
+  update_body<INIT, false>(load_upd_desc(D), P, flags, D->nblk_assoc, U, nullptr, nullptr);
 }
 
 }  // namespace cvo_dev

@@ -102,6 +102,7 @@ __device__ __forceinline__ bool pair_block(int nblk, int n_pairs, PairBlock& pb)
 #define CVO_GLOBAL __attribute__((address_space(1)))
 #define CVO_CONST __attribute__((address_space(4)))
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // plain vector: loadable from any address space
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 // (float4 is a class type: its copy constructor only takes generic references)
 __device__ __forceinline__ float4 ldg_f4(const CVO_GLOBAL f32x4* p) {
   const f32x4 v = *p;
