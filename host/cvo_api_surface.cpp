@@ -7,6 +7,9 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <utility>
+#include <vector>
+
 #include "cvo/CvoGPU.hpp"
 
 int main(int argc, char* argv[]) {
@@ -52,6 +55,19 @@ int main(int argc, char* argv[]) {
               cvo_align.function_angle(ps.data(), (int)ps.size(), pt.data(), (int)pt.size(), init, ell, true),
               cvo_align.function_angle(source, target, init, ell, false, true),
               cvo_align.function_angle(ps.data(), (int)ps.size(), pt.data(), (int)pt.size(), init, ell, false));
+  {  // align_stream: five submissions of the pair through two in-flight slots, two of them cut short
+    std::vector<const cvo::CvoPointCloud*> cs{&source}, ct{&target};
+    auto rs = cvo_align.upload_clouds(cs), rt = cvo_align.upload_clouds(ct);
+    const std::vector<std::pair<int, int>> pairs(5, {0, 0});
+    const std::vector<cvo::Mat4f> inits(5, init);
+    const std::vector<int> limits{0, 7, 0, 7, 0};
+    std::vector<cvo::Mat4f> Ts;
+    const std::vector<int> rets = cvo_align.align_stream(*rs, *rt, pairs, inits, Ts, 2, &limits);
+    bool ok = rets.size() == 5;
+    for (int k = 0; ok && k < 5; k += 2) ok = rets[k] == r_soa && std::memcmp(Ts[k].data(), T_soa.data(), sizeof(float) * 16) == 0;
+    ok = ok && std::memcmp(Ts[1].data(), Ts[3].data(), sizeof(float) * 16) == 0 && std::memcmp(Ts[1].data(), T_soa.data(), sizeof(float) * 16) != 0;
+    std::printf("stream_equals_align %d\n", (int)ok);
+  }
   std::printf("inner_product_cpu %.9g %.9g\n", cvo_align.inner_product_cpu(source, target, init, ell),
               cvo_align.inner_product_cpu(source, target, T_soa.inverse_rigid(), ell));
   std::printf("function_angle_cpu %.9g %.9g\n", cvo_align.function_angle(source, target, init, ell, true, false),

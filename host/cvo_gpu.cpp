@@ -1,5 +1,6 @@
 // cvo::CvoGPU over the C-ABI (see include/UnifiedCvo/cvo/CvoGPU.hpp).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -302,6 +303,54 @@ std::vector<int> CvoGPU::align_batch(const ResidentClouds& sources, const Reside
     rets[i] = infos[i].ret;
   }
   if (seconds) *seconds = infos[0].seconds;
+  return rets;
+}
+
+std::vector<int> CvoGPU::align_stream(const ResidentClouds& sources, const ResidentClouds& targets,
+                                      const std::vector<std::pair<int, int>>& pairs, const std::vector<Mat4f>& inits,
+                                      std::vector<Mat4f>& transforms, int slots, const std::vector<int>* max_iterations,
+                                      double* seconds) const {
+  std::lock_guard<std::mutex> lk(call_mutex);
+  const int n = (int)pairs.size();
+  if ((int)inits.size() != n || (max_iterations && (int)max_iterations->size() != n)) throw std::runtime_error("align_stream: size mismatch");
+  transforms.resize(n);
+  std::vector<int> rets(n, 0);
+  if (n == 0) return rets;
+  int n_max = 0, n_min = 1 << 30, m_max = 0;
+  for (const auto& pr : pairs) {
+    if (pr.first < 0 || pr.first >= sources.size() || pr.second < 0 || pr.second >= targets.size())
+      throw std::runtime_error("align_stream: pair index out of range");
+    const int ns = cvo_cloud_size(sources.handles[pr.first]), nt = cvo_cloud_size(targets.handles[pr.second]);
+    n_max = std::max(n_max, ns);
+    n_min = std::min(n_min, ns);
+    m_max = std::max(m_max, nt);
+  }
+  cvo_batch_queue* q = nullptr;
+  check(ctx, cvo_batch_open(ctx, &params, std::max(1, std::min(slots, n)), n_max, m_max, n_min, nullptr, &q), "cvo_batch_open");
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<cvo_batch_result_t> buf((size_t)n);
+  int got = 0, rc = CVO_OK;
+  for (int k = 0; k < n && rc == CVO_OK; k++) {
+    rc = cvo_batch_submit(q, sources.handles[pairs[k].first], targets.handles[pairs[k].second], inits[k].data(),
+                          max_iterations ? (*max_iterations)[k] : 0, nullptr);
+    int m = 0;
+    if (rc == CVO_OK && (k & 15) == 15) rc = cvo_batch_poll(q, 0, n - got, buf.data() + got, &m);  // keep the device fed while submitting
+    got += m;
+  }
+  while (rc == CVO_OK && got < n) {
+    int m = 0;
+    rc = cvo_batch_poll(q, 2, n - got, buf.data() + got, &m);
+    got += m;
+    if (rc == CVO_OK && m == 0 && cvo_batch_pending(q) == 0) break;
+  }
+  cvo_batch_close(q);
+  check(ctx, rc, "cvo_batch_submit / cvo_batch_poll");
+  if (got != n) throw std::runtime_error("align_stream: the queue delivered fewer results than pairs were submitted");
+  for (int k = 0; k < n; k++) {  // (delivered in submission order: buf[k].ticket == k)
+    std::copy(buf[k].transform, buf[k].transform + 16, transforms[k].data());
+    rets[k] = buf[k].info.ret;
+  }
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return rets;
 }
 

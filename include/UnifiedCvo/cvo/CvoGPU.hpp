@@ -7,6 +7,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "cvo/Association.hpp"
@@ -67,6 +68,16 @@ class CvoGPU {
   std::unique_ptr<ResidentClouds> upload_clouds(const std::vector<const CvoPointCloud*>& clouds, int host_threads = 0) const;
   std::vector<int> align_batch(const ResidentClouds& sources, const ResidentClouds& targets, const std::vector<Mat4f>& inits,
                                std::vector<Mat4f>& transforms, double* seconds = nullptr) const;
+  // New: a STREAM of resident pairs through `slots` in-flight slots (cvo_batch_open / _submit / _poll, include/cvo_hip.h):
+  // a pair that finishes hands its slice of the workspace to the next one at the next chunk boundary, so the GPU stays
+  // full however different the pairs' iteration counts are - upstream's own use is a frame stream with warm starts
+  // (main_cvo_gpu_align_raw_image.cpp:100-170).  pairs[k] = {index into sources, index into targets}; max_iterations[k]
+  // (optional) = that pair's own iteration limit.  Transforms / return values in submission order, every pose
+  // bit-identical to a solo align().
+  std::vector<int> align_stream(const ResidentClouds& sources, const ResidentClouds& targets,
+                                const std::vector<std::pair<int, int>>& pairs, const std::vector<Mat4f>& inits,
+                                std::vector<Mat4f>& transforms, int slots = 128, const std::vector<int>* max_iterations = nullptr,
+                                double* seconds = nullptr) const;
   // cvo_ctx_advice of this object's context ("" = nothing to report; see include/cvo_hip.h, hardware queues)
   std::string advice() const;
 

@@ -207,6 +207,43 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
  * round trip). */
 int cvo_batch_poses_to_device(cvo_ctx* ctx, void* dst_device, int n_pairs);
 
+/* ---- batch queue (new, not in the reference): a STREAM of frame pairs through a fixed number of in-flight slots --------
+ * cvo_align_batch takes a fixed set of pairs.  The reference's real use is a frame stream (one align() per frame, warm
+ * starts, very different iteration counts: main_cvo_gpu_align_raw_image.cpp:100-170): here a pair that finishes hands its
+ * slice of the workspace to the next submitted pair at the next chunk boundary, so `slots` pairs stay in flight however
+ * long each of them runs.  Every pose is bit-identical to a solo cvo_align of the same pair.
+ *   cvo_batch_open    sizes the workspace for `slots` pairs of up to max_source_points x max_target_points
+ *                     (min_source_points: the smallest source cloud that will be submitted, 0 = same as max - small
+ *                     clouds split their coefficient pass over more blocks and the launches must provide for it).
+ *                     opts: only max_iterations is honoured.  While a queue is open the context's other align /
+ *                     evaluation calls are refused.
+ *   cvo_batch_submit  queues one pair (the clouds must stay alive until its result has been delivered); *ticket = its
+ *                     number in submission order, from 0.  max_iterations > 0: this pair's own iteration limit (a warm
+ *                     start that needs a few hundred iterations among cold starts that need thousands), at most the
+ *                     queue's.
+ *   cvo_batch_poll    drives the queue and delivers finished pairs IN SUBMISSION ORDER (a result is held back until
+ *                     every earlier ticket has been delivered).  wait = 0: make progress, do not wait for results;
+ *                     1: until at least one result can be delivered (or nothing is pending); 2: until everything
+ *                     submitted so far has finished (or `capacity` results are ready).
+ *   cvo_batch_pending submitted pairs not yet delivered.  cvo_batch_close waits for the device and releases the queue
+ *                     (undelivered results are dropped). */
+typedef struct cvo_batch_queue cvo_batch_queue;
+typedef struct cvo_batch_result_t {
+  long long ticket;
+  float transform[16]; /* column-major 4x4, as out_T of cvo_align */
+  cvo_align_info_t info; /* info.seconds: wall time from the pair's placement into a slot to its retirement */
+} cvo_batch_result_t;
+int cvo_batch_open(cvo_ctx* ctx, const cvo_params_t* params, int slots, int max_source_points, int max_target_points,
+                   int min_source_points, const cvo_align_opts_t* opts, cvo_batch_queue** out);
+int cvo_batch_submit(cvo_batch_queue* q, const cvo_cloud* source, const cvo_cloud* target, const float init_T[16],
+                     int max_iterations, long long* ticket);
+int cvo_batch_poll(cvo_batch_queue* q, int wait, int capacity, cvo_batch_result_t* results, int* n_results);
+int cvo_batch_pending(const cvo_batch_queue* q);
+/* chunks launched (all sub-batches), how many of them were full graphs, slots filled so far (statistics) */
+int cvo_batch_stats(const cvo_batch_queue* q, unsigned long long* chunks, unsigned long long* full_chunks,
+                    unsigned long long* refills);
+void cvo_batch_close(cvo_batch_queue* q);
+
 /* ---- the Association align() exports (CvoGPU.cu:1552-1556 -> gpu_association_to_cpu, CvoGPU_impl.cu:366-427) -------
  * What `align(..., Association*)` returns when params.is_exporting_association is set: the kernel matrix of the LAST
  * EXECUTED iteration of the loop (pose before that iteration's update, that iteration's ell and num_neighbors), of

@@ -143,6 +143,7 @@ def test_api_surface_driver(tmp_path):
                                    str(ell), "2.5"], text=True)
     rows = {l.split()[0]: l.split()[1:] for l in out.strip().splitlines()}
     assert rows["ret"] == ["0", "0"] and rows["aos_equals_soa"] == ["1"]
+    assert rows["stream_equals_align"] == ["1"]   # CvoGPU::align_stream (batch queue): poses bit-identical to align()
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

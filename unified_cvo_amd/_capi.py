@@ -124,6 +124,14 @@ class cvo_align_opts_t(C.Structure):
     ]
 
 
+class cvo_batch_result_t(C.Structure):
+    _fields_ = [
+        ("ticket", C.c_longlong),
+        ("transform", C.c_float * 16),
+        ("info", cvo_align_info_t),
+    ]
+
+
 # every symbol include/cvo_hip.h declares (tests/test_capi_symbols.py checks the two lists agree)
 EXPORTED = [
     "cvo_params_default", "cvo_ctx_create", "cvo_ctx_destroy", "cvo_last_error", "cvo_ctx_stream",
@@ -134,6 +142,7 @@ EXPORTED = [
     "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_row_classes", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
     "cvo_align_association", "cvo_debug_scalar_math", "cvo_debug_verified_rows", "cvo_debug_device_memory", "cvo_cloud_upload_many",
     "cvo_ctx_set_option", "cvo_ctx_advice", "cvo_debug_cloud_order",
+    "cvo_batch_open", "cvo_batch_submit", "cvo_batch_poll", "cvo_batch_pending", "cvo_batch_stats", "cvo_batch_close",
 ]
 
 _libs = {}
@@ -178,6 +187,13 @@ def lib(path=None):
     L.cvo_align_batch.argtypes = [vp, C.POINTER(cvo_params_t), ip, C.POINTER(vp), C.POINTER(vp), fp, fp,
                                   C.POINTER(cvo_align_info_t), C.POINTER(cvo_align_opts_t)]
     L.cvo_batch_poses_to_device.argtypes = [vp, vp, ip]
+    L.cvo_batch_open.argtypes = [vp, C.POINTER(cvo_params_t), ip, ip, ip, ip, C.POINTER(cvo_align_opts_t), C.POINTER(vp)]
+    L.cvo_batch_submit.argtypes = [vp, vp, vp, fp, ip, C.POINTER(C.c_longlong)]
+    L.cvo_batch_poll.argtypes = [vp, ip, ip, C.POINTER(cvo_batch_result_t), C.POINTER(C.c_int)]
+    L.cvo_batch_pending.argtypes = [vp]
+    L.cvo_batch_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    L.cvo_batch_close.argtypes = [vp]
+    L.cvo_batch_close.restype = None
     L.cvo_inner_product.argtypes = [vp, C.POINTER(cvo_params_t), vp, vp, fp, C.c_float, fp]
     L.cvo_function_angle.argtypes = [vp, C.POINTER(cvo_params_t), vp, vp, fp, C.c_float, ip, fp]
     L.cvo_association.argtypes = [vp, C.POINTER(cvo_params_t), vp, vp, fp, C.c_float, C.POINTER(C.c_int),

@@ -263,6 +263,60 @@ class AlignResult:
         self.trace = trace
 
 
+class BatchQueue:
+    """cvo_batch_open / _submit / _poll / _close: a stream of frame pairs through a fixed number of in-flight slots."""
+
+    def __init__(self, gpu, slots, max_source_points, max_target_points, min_source_points=0, max_iterations=0):
+        self.gpu = gpu
+        self.slots = slots
+        o = _capi.cvo_align_opts_t()
+        o.max_iterations = max_iterations
+        p = gpu.params.to_ctypes()
+        h = C.c_void_p()
+        gpu._check(gpu.L.cvo_batch_open(gpu.ctx, C.byref(p), slots, max_source_points, max_target_points, min_source_points,
+                                        C.byref(o), C.byref(h)))
+        self.handle = h
+        self._keep = {}
+
+    def submit(self, source, target, init, max_iterations=0):
+        src, tgt = self.gpu._dev(source), self.gpu._dev(target)
+        t = C.c_longlong()
+        Tm = _mat_to_c(init)
+        self.gpu._check(self.gpu.L.cvo_batch_submit(self.handle, src.handle, tgt.handle, _fptr(Tm), max_iterations, C.byref(t)))
+        self._keep[t.value] = (src, tgt)  # the clouds must outlive the solve
+        return t.value
+
+    def poll(self, wait=1, capacity=None):
+        """Finished pairs in submission order as (ticket, AlignResult); wait: 0 = just make progress, 1 = until one is
+        ready, 2 = until everything submitted has finished."""
+        cap = capacity or max(self.pending(), 1)
+        buf = (_capi.cvo_batch_result_t * cap)()
+        n = C.c_int()
+        self.gpu._check(self.gpu.L.cvo_batch_poll(self.handle, wait, cap, buf, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            r = buf[i]
+            T = np.array(list(r.transform), np.float32).reshape(4, 4).T.copy()
+            res = AlignResult(r.info.ret, T, r.info)
+            res.ticket = int(r.ticket)
+            self._keep.pop(res.ticket, None)
+            out.append(res)
+        return out
+
+    def pending(self):
+        return int(self.gpu.L.cvo_batch_pending(self.handle))
+
+    def stats(self):
+        a, b, c = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+        self.gpu._check(self.gpu.L.cvo_batch_stats(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return {"chunks": a.value, "full_chunks": b.value, "refills": c.value}
+
+    def close(self):
+        if self.handle:
+            self.gpu.L.cvo_batch_close(self.handle)
+            self.handle = None
+
+
 class CvoGPU:
     """cvo::CvoGPU(yaml) over the HIP backend."""
 
@@ -417,6 +471,27 @@ class CvoGPU:
             res.append(AlignResult(infos[i].ret, out[16 * i:16 * i + 16].reshape(4, 4).T.copy(), infos[i], trace))
         self._keepalive = keep
         return res
+
+    def open_queue(self, slots, max_source_points, max_target_points, min_source_points=0, max_iterations=0):
+        """A batch queue (cvo_batch_open): `slots` pairs in flight, finished pairs hand their slot to the next submitted
+        one at a chunk boundary, results in submission order."""
+        return BatchQueue(self, slots, max_source_points, max_target_points, min_source_points, max_iterations)
+
+    def align_stream(self, sources, targets, inits, slots=64, max_iterations=0, limits=None):
+        """All pairs through a batch queue of `slots` in-flight slots; returns their AlignResults in submission order
+        (limits: per-pair iteration limits)."""
+        src = [self._dev(s) for s in sources]
+        tgt = [self._dev(t) for t in targets]
+        q = self.open_queue(slots, max(s.n for s in src), max(t.n for t in tgt), min(s.n for s in src), max_iterations)
+        try:
+            for k, (s, t, T) in enumerate(zip(src, tgt, inits)):
+                q.submit(s, t, T, limits[k] if limits else 0)
+            out = []
+            while q.pending():
+                out.extend(q.poll(wait=2))
+            return out
+        finally:
+            q.close()
 
     def align_association(self, n_source, pair=0, capacity=None):
         """The Association `align()` exports under is_exporting_association (CvoGPU.cu:1552-1556): CSR of the kernel

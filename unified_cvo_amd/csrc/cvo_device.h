@@ -67,7 +67,6 @@ struct DevParams {
                     // (an iteration is then a chain of latencies and a wave runs as long as its longest row); only with long
                     // lists, ASSOC_CAP16 = off.  No result depends on it (every row joins k_assoc's reduction at its position)
   int long_lists;  // overflow rows keep a cached sorted candidate list of up to LONG_CAP entries (PairDesc::long_j)
-  unsigned long long call_serial;  // process-wide serial of this align call: generation tag of the cached long lists
   int debug_no_motion_bound;  // CVO_DEBUG_NO_MOTION_BOUND (tests only): the update pretends no target ever moves, so
                               // lists outlive their validity - what CVO_VERIFY_LISTS exists to catch
 };
@@ -260,9 +259,12 @@ struct PairDesc {
                                  // its last block, coherent stores / loads)
   // Long lists: the candidates of an overflow row (more than ASSOC_CAP, at most LONG_CAP), as the targets' sorted
   // positions in ascending ORIGINAL index, [overflow index q][LONG_CAP]; built and consumed by k_assoc_dense, valid while
-  // long_stamp[q] == (call_serial << 24 | n_builds).  Null when positions do not fit 16 bits or CVO_NO_LONG_LISTS is set.
+  // long_stamp[q] == (call_serial << 24 | n_builds), call_serial = a process-wide serial of the align call (of the
+  // submission, in a batch queue) this occupant of the workspace slot came with.  Null when positions do not fit 16 bits or CVO_NO_LONG_LISTS is set.
   unsigned short* long_j;
   unsigned long long* long_stamp;  // [N]
+  unsigned long long call_serial;
+  int max_iter;  // this pair's loop bound: DevParams::max_iter, or the smaller bound its submission to a batch queue came with
   PairState* st;
   cvo_trace_t* trace;
   int* status_out;  // mirror of st->status: the kernels' own early-exit word (device memory)

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -145,6 +146,7 @@ struct cvo_ctx {
   int last_N = 0, last_M = 0, last_Kmax = 0;
   DevParams last_params{};
   int last_gx = 0, last_gy = 0, last_csplit = 1;
+  bool queue_open = false;  // a cvo_batch_queue owns the workspace: the other align / evaluation calls are refused meanwhile
   double clock_ms_per_tick = 0.0;  // s_memrealtime, calibrated on first use (cvo_debug_kernel_clock)
   unsigned last_stride256 = 0;
   int last_Npad = 0;
@@ -601,134 +603,25 @@ struct BatchSetup {
   LaunchGeom geom;
 };
 
-// Builds descriptors + initial states for a batch and uploads them.
-int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo_cloud* const* sources,
-                const cvo_cloud* const* targets, const float* init_T, const cvo_align_opts_t* opts, int mode,
-                float mode_ell, BatchSetup* S, DevParams* dp_out, const float* kernel_inv_and_cull = nullptr) {
-  if (!ctx) return CVO_E_INVALID;
-  if (!params || n_pairs <= 0 || !sources || !targets) return fail(ctx, CVO_E_INVALID, "null argument");
-  if (params->is_using_kdtree)
-    return fail(ctx, CVO_E_UNSUPPORTED, "is_using_kdtree=1 is out of scope (SURVEY.md section 2, row 11)");
-  if (params->nearest_neighbors_max <= 0) return fail(ctx, CVO_E_INVALID, "nearest_neighbors_max must be > 0");
-  if (params->indicator_window_size + 1 >= IND_CAP || params->indicator_window_size < 0)
-    return fail(ctx, CVO_E_INVALID, "indicator_window_size out of range");
-  if (mode == 0 && opts && opts->override_state) {
-    // the ELL holds nearest_neighbors_max slots per row and the kernels write slot nnz while nnz < K
-    if (opts->K0 < 1 || opts->K0 > params->nearest_neighbors_max)
-      return fail(ctx, CVO_E_INVALID, "cvo_align_opts_t.K0 must lie in [1, nearest_neighbors_max]");
-    if (!(opts->ell0 > 0.f) || !std::isfinite(opts->ell0))
-      return fail(ctx, CVO_E_INVALID, "cvo_align_opts_t.ell0 must be finite and > 0");
-  }
-  int N = 0, M = 0;
-  for (int p = 0; p < n_pairs; p++) {
-    if (!sources[p] || !targets[p]) return fail(ctx, CVO_E_INVALID, "null cloud");
-    if (sources[p]->ctx != ctx || targets[p]->ctx != ctx)
-      return fail(ctx, CVO_E_INVALID, "cloud belongs to another context");
-    if (sources[p]->n <= 0 || targets[p]->n <= 0) return fail(ctx, CVO_E_INVALID, "empty cloud in batch");
-    N = std::max(N, sources[p]->n);
-    M = std::max(M, targets[p]->n);
-  }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be attributed to this one
-  {  // attribute arrays the kernels of this call read but a cloud was uploaded without: zeros, as upstream has them
-    const bool nf = params->is_using_intensity != 0, nl = params->is_using_semantics != 0,
-               ng = params->is_using_geometric_type != 0 && mode != 2;
-    if (nf || nl || ng)
-      for (int p = 0; p < n_pairs; p++) {
-        int rc0 = ensure_attributes(ctx, sources[p], nf, nl, ng);
-        if (rc0 == CVO_OK) rc0 = ensure_attributes(ctx, targets[p], nf, nl, ng);
-        if (rc0 != CVO_OK) return rc0;
-      }
-  }
+// Sizes of a batch queue (cvo_batch_open): the slots of the workspace are laid out for clouds of up to n_max / m_max points
+// and the launches for source clouds of at least n_min (the coefficient split of a pair follows from its own size).
+struct QueueDims {
+  int n_max, m_max, n_min;
+};
+
+// Descriptor + initial state of the pair that occupies slot p of the workspace (host copies; the caller uploads them).
+void fill_pair(cvo_ctx* ctx, const BatchSetup* S, const cvo_params_t* params, const cvo_align_opts_t* opts, int mode, float mode_ell,
+               int n_slots, int p, const cvo_cloud* X, const cvo_cloud* Y, const float* Tm, unsigned long long serial, int max_iter) {
   const int trace_cap = (opts && opts->trace) ? opts->trace_capacity : 0;
   const int Kmax = params->nearest_neighbors_max;
-  S->N = N;
-  S->M = M;
-  // k_list packs a row's candidate count next to an 8-bit row number; the candidate bitmap of a pair takes
-  // N * M / 8 bytes (DESIGN.md "Data layout"), every pair of a batch sized by the batch maxima
-  if (M >= (1 << 23)) return fail(ctx, CVO_E_INVALID, "target clouds are limited to 8388607 points");
-  // (the update reduces an iteration's nonzero count in 32 bits: rows x nearest_neighbors_max must fit)
-  if ((unsigned long long)N * (unsigned long long)std::max(params->nearest_neighbors_max, 1) >= (1ull << 32))
-    return fail(ctx, CVO_E_INVALID, "source rows x nearest_neighbors_max must stay below 2^32");
-  // overflow rows keep sorted candidate lists of their own (PairDesc::long_j) when sorted positions fit 16 bits
-  S->long_lists = mode == 0 && M <= 65535 && ctx_opt(ctx, "NO_LONG_LISTS") == nullptr;
-  S->L = make_layout(N, M, Kmax, trace_cap, S->long_lists, &S->d);
   {
-    size_t free_b = 0, total_b = 0;
-    const size_t need = S->L.total * (size_t)n_pairs;
-    if (need > ctx->arena_bytes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b + ctx->arena_bytes) {
-      char msg[320];
-      snprintf(msg, sizeof msg,
-               "workspace of %d pair(s) of %d x %d points needs %.1f GiB (candidate bitmap N*M/8 = %.1f GiB per pair, ELL "
-               "%.1f GiB per pair) but %.1f GiB of device memory are free: split the batch or the clouds",
-               n_pairs, N, M, need / 1073741824.0, (double)N * S->d.Mpad / 8.0 / 1073741824.0,
-               (double)S->d.Npad * Kmax * 20.0 / 1073741824.0, (free_b + ctx->arena_bytes) / 1073741824.0);
-      return fail(ctx, CVO_E_NOMEM, msg);
-    }
-  }
-  int rc = ensure_workspace(ctx, n_pairs, S->L.total);
-  if (rc != CVO_OK) return rc;
-  // sub-batches on separate streams (see cvo_ctx): the scan geometry is chosen for one group's launch
-  S->G = n_pairs >= 32 ? 4 : (n_pairs >= 8 ? 2 : 1);
-  if (const char* e = ctx_opt(ctx, "STREAMS")) S->G = std::max(1, std::min(atoi(e), (int)cvo_ctx::MAX_GROUPS));
-  S->G = std::min(S->G, n_pairs);
-  if ((n_pairs + S->G - 1) / S->G > 4095 || S->d.nblk_assoc > 16383)
-    return fail(ctx, CVO_E_INVALID, "batch too large for one call: at most 4095 pairs per stream and 2097024 source points per cloud");
-  choose_scan_config(ctx, (n_pairs + S->G - 1) / S->G, S->d.NG, S->d.Mpad, &S->T, &S->gpb);
-
-  DevParams dp = make_dev_params(ctx, *params);
-  dp.mode = mode;
-  if (mode == 2) {  // non-isotropic kernel: 9 floats of the inverse (row-major) + the squared cull radius
-    for (int q = 0; q < 9; q++) dp.kinv[q] = kernel_inv_and_cull[q];
-    dp.d2_cull = kernel_inv_and_cull[9];
-    dp.s_ell_sq = params->s_ell * params->s_ell;
-    dp.use_geotype = 0;  // CvoGPU.cu:1950-1951
-    // that kernel's prologue keeps s_ell^2 in float (CvoGPU.cu:236, 252)
-    if (params->is_using_semantics)
-      dp.d2_s_thres = (float)(-2.0 * dp.s_ell_sq * (double)std::log(params->sp_thres / (params->s_sigma * params->s_sigma)));
-  }
-  dp.T = S->T;
-  dp.groups_per_block = S->gpb;
-  dp.long_lists = S->long_lists ? 1 : 0;
-  dp.row_max_cap = ASSOC_CAP16;
-  if (const char* e = ctx_opt(ctx, "ROW_MAX")) dp.row_max_cap = std::max(1, std::min(atoi(e), (int)ASSOC_CAP16));
-  {
-    static std::atomic<unsigned long long> g_call_serial{1};  // never repeats inside a process: see PairDesc::long_stamp
-    dp.call_serial = g_call_serial.fetch_add(1);
-  }
-  dp.lean_U = 8;
-  if (const char* e = ctx_opt(ctx, "LEAN_U")) dp.lean_U = std::max(1, atoi(e));
-  // Calm pairs (see PairState::want_full).  In the end game the pose jitters around its optimum: the motion PER ITERATION
-  // stays at ~10 % of a list's allowance while the allowance used SINCE THE BUILD stays below 5 % for hundreds of
-  // iterations (CVO_VERBOSE=2 prints both), so a linear "outlives the next 64 iterations" test never fires.  Four
-  // iterations of linear margin it is: 62.3 -> 61.4 ms per headline step, single pairs -1.5 ... -2.5 %, no additional waits.
-  dp.calm_U = 4;
-  if (const char* e = ctx_opt(ctx, "CALM_U")) dp.calm_U = std::max(0, atoi(e));
-  dp.lean_U2 = 2;
-  if (const char* e = ctx_opt(ctx, "LEAN_U2")) dp.lean_U2 = std::max(0, atoi(e));  // 0 = no short lean graph
-  if (dp.lean_U2 >= dp.lean_U) dp.lean_U2 = 0;
-  dp.shrink_align = n_pairs >= 8 ? 63 : 0;
-  if (const char* e = ctx_opt(ctx, "SHRINK_ALIGN")) dp.shrink_align = std::max(0, atoi(e));
-  if (opts && opts->max_iterations > 0) dp.max_iter = std::min(dp.max_iter, opts->max_iterations);
-  if (opts && opts->kernel_clock) dp.kernel_clock = 1;
-  dp.trace_capacity = trace_cap;
-  // the columns of the ELL entries (ell_j) are only written when somebody can ask for them afterwards
-  dp.keep_columns = (mode != 0 || trace_cap > 0 || dp.verify_lists || params->is_exporting_association ||
-                     ctx_opt(ctx, "KEEP_COLUMNS")) ? 1 : 0;
-  dp.trace_dense = opts ? opts->trace_dense : 0;
-  dp.trace_every = opts ? opts->trace_every : 0;
-  *dp_out = dp;
-
-  ctx->h_descs.resize(n_pairs);
-  ctx->h_states.resize(n_pairs);
-  for (int p = 0; p < n_pairs; p++) {
-    const cvo_cloud* X = sources[p];
-    const cvo_cloud* Y = targets[p];
     char* base = ctx->arena + S->L.total * (size_t)p;
     PairDesc& D = ctx->h_descs[p];
     std::memset(&D, 0, sizeof(D));
     D.N = X->n;
     D.M = Y->n;
+    D.call_serial = serial;
+    D.max_iter = max_iter;
     // paddings are derived from the batch maxima so every pair shares one launch geometry
     D.Mpad = S->d.Mpad;
     D.nchunks = S->d.nchunks;
@@ -792,8 +685,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
       // status / requested-graph mirrors the host polls: every sub-batch owns ONE contiguous block [status[n_g] | want[n_g]]
       // at 2 * p0(g), fetched with one copy per chunk (two copies per chunk and stream were two 5 us blits)
       int g = 0;
-      while (g + 1 < S->G && (int)((long)n_pairs * (g + 1) / S->G) <= p) g++;
-      const int p0 = (int)((long)n_pairs * g / S->G), p1 = (int)((long)n_pairs * (g + 1) / S->G);
+      while (g + 1 < S->G && (int)((long)n_slots * (g + 1) / S->G) <= p) g++;
+      const int p0 = (int)((long)n_slots * g / S->G), p1 = (int)((long)n_slots * (g + 1) / S->G);
       D.status_out = ctx->d_status + 2 * p0 + (p - p0);
       D.want_out = ctx->d_status + 2 * p0 + (p1 - p0) + (p - p0);
       D.status_host = ctx->h_status[0] + 2 * p0 + (p - p0);
@@ -805,14 +698,13 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
 
     PairState& st = ctx->h_states[p];
     std::memset(&st, 0, sizeof(st));
-    const float* Tm = init_T + 16 * (size_t)p;
     for (int i = 0; i < 3; i++) {
       for (int j = 0; j < 3; j++) st.R[3 * i + j] = Tm[4 * j + i];  // CvoGPU.cu:1363-1364
       st.T[i] = Tm[12 + i];
     }
     st.ell = mode == 0 ? params->ell_init : mode_ell;  // CvoState.cu:30
     st.K = Kmax;                                        // CvoGPU.cu:1385
-    if (mode == 0 && opts && opts->override_state) {  // (validated above)
+    if (mode == 0 && opts && opts->override_state) {  // (validated by the caller)
       st.ell = opts->ell0;
       st.K = opts->K0;
     }
@@ -820,14 +712,153 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     // (the pair's counters - gate, gate_flow, done, tile_count - are zeroed by k_update<INIT>; the slice bits of a row
     // are cleared by k_prep before every build, the first one included: five memsets per pair used to cost 10 us each call)
   }
+}
+
+unsigned long long next_call_serial() {
+  static std::atomic<unsigned long long> g_call_serial{1};  // never repeats inside a process: see PairDesc::long_stamp
+  return g_call_serial.fetch_add(1);
+}
+
+// Builds descriptors + initial states for a batch and uploads them.  qd != nullptr: plans the workspace of a batch queue
+// (cvo_batch_open) for n_pairs SLOTS without occupants - every slot starts out finished, cvo_batch_submit fills them.
+int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo_cloud* const* sources,
+                const cvo_cloud* const* targets, const float* init_T, const cvo_align_opts_t* opts, int mode,
+                float mode_ell, BatchSetup* S, DevParams* dp_out, const float* kernel_inv_and_cull = nullptr,
+                const QueueDims* qd = nullptr) {
+  if (!ctx) return CVO_E_INVALID;
+  if (ctx->queue_open && !qd) return fail(ctx, CVO_E_INVALID, "a batch queue is open on this context (cvo_batch_close it first)");
+  if (!params || n_pairs <= 0 || (!qd && (!sources || !targets))) return fail(ctx, CVO_E_INVALID, "null argument");
+  if (params->is_using_kdtree)
+    return fail(ctx, CVO_E_UNSUPPORTED, "is_using_kdtree=1 is out of scope (SURVEY.md section 2, row 11)");
+  if (params->nearest_neighbors_max <= 0) return fail(ctx, CVO_E_INVALID, "nearest_neighbors_max must be > 0");
+  if (params->indicator_window_size + 1 >= IND_CAP || params->indicator_window_size < 0)
+    return fail(ctx, CVO_E_INVALID, "indicator_window_size out of range");
+  if (mode == 0 && opts && opts->override_state) {
+    // the ELL holds nearest_neighbors_max slots per row and the kernels write slot nnz while nnz < K
+    if (opts->K0 < 1 || opts->K0 > params->nearest_neighbors_max)
+      return fail(ctx, CVO_E_INVALID, "cvo_align_opts_t.K0 must lie in [1, nearest_neighbors_max]");
+    if (!(opts->ell0 > 0.f) || !std::isfinite(opts->ell0))
+      return fail(ctx, CVO_E_INVALID, "cvo_align_opts_t.ell0 must be finite and > 0");
+  }
+  int N = qd ? qd->n_max : 0, M = qd ? qd->m_max : 0;
+  if (qd && (qd->n_max <= 0 || qd->m_max <= 0 || qd->n_min <= 0 || qd->n_min > qd->n_max))
+    return fail(ctx, CVO_E_INVALID, "cvo_batch_open: bad cloud sizes");
+  for (int p = 0; p < n_pairs && !qd; p++) {
+    if (!sources[p] || !targets[p]) return fail(ctx, CVO_E_INVALID, "null cloud");
+    if (sources[p]->ctx != ctx || targets[p]->ctx != ctx)
+      return fail(ctx, CVO_E_INVALID, "cloud belongs to another context");
+    if (sources[p]->n <= 0 || targets[p]->n <= 0) return fail(ctx, CVO_E_INVALID, "empty cloud in batch");
+    N = std::max(N, sources[p]->n);
+    M = std::max(M, targets[p]->n);
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be attributed to this one
+  {  // attribute arrays the kernels of this call read but a cloud was uploaded without: zeros, as upstream has them
+    const bool nf = params->is_using_intensity != 0, nl = params->is_using_semantics != 0,
+               ng = params->is_using_geometric_type != 0 && mode != 2;
+    if ((nf || nl || ng) && !qd)
+      for (int p = 0; p < n_pairs; p++) {
+        int rc0 = ensure_attributes(ctx, sources[p], nf, nl, ng);
+        if (rc0 == CVO_OK) rc0 = ensure_attributes(ctx, targets[p], nf, nl, ng);
+        if (rc0 != CVO_OK) return rc0;
+      }
+  }
+  const int trace_cap = (opts && opts->trace) ? opts->trace_capacity : 0;
+  const int Kmax = params->nearest_neighbors_max;
+  S->N = N;
+  S->M = M;
+  // k_list packs a row's candidate count next to an 8-bit row number; the candidate bitmap of a pair takes
+  // N * M / 8 bytes (DESIGN.md "Data layout"), every pair of a batch sized by the batch maxima
+  if (M >= (1 << 23)) return fail(ctx, CVO_E_INVALID, "target clouds are limited to 8388607 points");
+  // (the update reduces an iteration's nonzero count in 32 bits: rows x nearest_neighbors_max must fit)
+  if ((unsigned long long)N * (unsigned long long)std::max(params->nearest_neighbors_max, 1) >= (1ull << 32))
+    return fail(ctx, CVO_E_INVALID, "source rows x nearest_neighbors_max must stay below 2^32");
+  // overflow rows keep sorted candidate lists of their own (PairDesc::long_j) when sorted positions fit 16 bits
+  S->long_lists = mode == 0 && M <= 65535 && ctx_opt(ctx, "NO_LONG_LISTS") == nullptr;
+  S->L = make_layout(N, M, Kmax, trace_cap, S->long_lists, &S->d);
+  {
+    size_t free_b = 0, total_b = 0;
+    const size_t need = S->L.total * (size_t)n_pairs;
+    if (need > ctx->arena_bytes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b + ctx->arena_bytes) {
+      char msg[320];
+      snprintf(msg, sizeof msg,
+               "workspace of %d pair(s) of %d x %d points needs %.1f GiB (candidate bitmap N*M/8 = %.1f GiB per pair, ELL "
+               "%.1f GiB per pair) but %.1f GiB of device memory are free: split the batch or the clouds",
+               n_pairs, N, M, need / 1073741824.0, (double)N * S->d.Mpad / 8.0 / 1073741824.0,
+               (double)S->d.Npad * Kmax * 20.0 / 1073741824.0, (free_b + ctx->arena_bytes) / 1073741824.0);
+      return fail(ctx, CVO_E_NOMEM, msg);
+    }
+  }
+  int rc = ensure_workspace(ctx, n_pairs, S->L.total);
+  if (rc != CVO_OK) return rc;
+  // sub-batches on separate streams (see cvo_ctx): the scan geometry is chosen for one group's launch
+  S->G = n_pairs >= 32 ? 4 : (n_pairs >= 8 ? 2 : 1);
+  if (const char* e = ctx_opt(ctx, "STREAMS")) S->G = std::max(1, std::min(atoi(e), (int)cvo_ctx::MAX_GROUPS));
+  S->G = std::min(S->G, n_pairs);
+  if ((n_pairs + S->G - 1) / S->G > 4095 || S->d.nblk_assoc > 16383)
+    return fail(ctx, CVO_E_INVALID, "batch too large for one call: at most 4095 pairs per stream and 2097024 source points per cloud");
+  choose_scan_config(ctx, (n_pairs + S->G - 1) / S->G, S->d.NG, S->d.Mpad, &S->T, &S->gpb);
+
+  DevParams dp = make_dev_params(ctx, *params);
+  dp.mode = mode;
+  if (mode == 2) {  // non-isotropic kernel: 9 floats of the inverse (row-major) + the squared cull radius
+    for (int q = 0; q < 9; q++) dp.kinv[q] = kernel_inv_and_cull[q];
+    dp.d2_cull = kernel_inv_and_cull[9];
+    dp.s_ell_sq = params->s_ell * params->s_ell;
+    dp.use_geotype = 0;  // CvoGPU.cu:1950-1951
+    // that kernel's prologue keeps s_ell^2 in float (CvoGPU.cu:236, 252)
+    if (params->is_using_semantics)
+      dp.d2_s_thres = (float)(-2.0 * dp.s_ell_sq * (double)std::log(params->sp_thres / (params->s_sigma * params->s_sigma)));
+  }
+  dp.T = S->T;
+  dp.groups_per_block = S->gpb;
+  dp.long_lists = S->long_lists ? 1 : 0;
+  dp.row_max_cap = ASSOC_CAP16;
+  if (const char* e = ctx_opt(ctx, "ROW_MAX")) dp.row_max_cap = std::max(1, std::min(atoi(e), (int)ASSOC_CAP16));
+  dp.lean_U = 8;
+  if (const char* e = ctx_opt(ctx, "LEAN_U")) dp.lean_U = std::max(1, atoi(e));
+  // Calm pairs (see PairState::want_full).  In the end game the pose jitters around its optimum: the motion PER ITERATION
+  // stays at ~10 % of a list's allowance while the allowance used SINCE THE BUILD stays below 5 % for hundreds of
+  // iterations (CVO_VERBOSE=2 prints both), so a linear "outlives the next 64 iterations" test never fires.  Four
+  // iterations of linear margin it is: 62.3 -> 61.4 ms per headline step, single pairs -1.5 ... -2.5 %, no additional waits.
+  dp.calm_U = 4;
+  if (const char* e = ctx_opt(ctx, "CALM_U")) dp.calm_U = std::max(0, atoi(e));
+  dp.lean_U2 = 2;
+  if (const char* e = ctx_opt(ctx, "LEAN_U2")) dp.lean_U2 = std::max(0, atoi(e));  // 0 = no short lean graph
+  if (dp.lean_U2 >= dp.lean_U) dp.lean_U2 = 0;
+  dp.shrink_align = n_pairs >= 8 ? 63 : 0;
+  if (const char* e = ctx_opt(ctx, "SHRINK_ALIGN")) dp.shrink_align = std::max(0, atoi(e));
+  if (opts && opts->max_iterations > 0) dp.max_iter = std::min(dp.max_iter, opts->max_iterations);
+  if (opts && opts->kernel_clock) dp.kernel_clock = 1;
+  dp.trace_capacity = trace_cap;
+  // the columns of the ELL entries (ell_j) are only written when somebody can ask for them afterwards
+  dp.keep_columns = (mode != 0 || trace_cap > 0 || dp.verify_lists || params->is_exporting_association ||
+                     ctx_opt(ctx, "KEEP_COLUMNS")) ? 1 : 0;
+  dp.trace_dense = opts ? opts->trace_dense : 0;
+  dp.trace_every = opts ? opts->trace_every : 0;
+  *dp_out = dp;
+
+  ctx->h_descs.resize(n_pairs);
+  ctx->h_states.resize(n_pairs);
+  if (!qd) {
+    const unsigned long long serial = next_call_serial();
+    for (int p = 0; p < n_pairs; p++)
+      fill_pair(ctx, S, params, opts, mode, mode_ell, n_pairs, p, sources[p], targets[p], init_T + 16 * (size_t)p, serial, dp.max_iter);
+  } else {  // empty slots: finished pairs, which every kernel skips
+    for (int p = 0; p < n_pairs; p++) {
+      std::memset(&ctx->h_descs[p], 0, sizeof(PairDesc));
+      std::memset(&ctx->h_states[p], 0, sizeof(PairState));
+      ctx->h_states[p].status = 1;
+    }
+  }
   // the blocks of k_assoc beyond a smaller pair's N still write their (zero) partials, but the
   // partial arrays of pairs whose N is smaller than the batch maximum are fully covered by nblk.
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_descs, ctx->h_descs.data(), sizeof(PairDesc) * (size_t)n_pairs,
                               hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_states, ctx->h_states.data(), sizeof(PairState) * (size_t)n_pairs,
                               hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int) * 2 * (size_t)ctx->cap_pairs, ctx->stream));
-  std::memset(ctx->h_status[0], 0, sizeof(int) * 2 * (size_t)ctx->cap_pairs);  // (no call is in flight on this context)
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, qd ? 1 : 0, sizeof(int) * 2 * (size_t)ctx->cap_pairs, ctx->stream));  // (queue: any non-zero word = finished)
+  std::memset(ctx->h_status[0], qd ? 1 : 0, sizeof(int) * 2 * (size_t)ctx->cap_pairs);  // (no call is in flight on this context)
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_params, &dp, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
   S->gx = (S->d.Mpad / (64 * S->T) + 3) / 4;
   S->gy = ((int)align_up((size_t)S->d.NG, 64) + S->gpb - 1) / S->gpb;
@@ -843,10 +874,10 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.arena.base = ctx->arena;
   S->geom.arena.stride256 = (unsigned)(S->L.total >> 8);
   S->geom.arena.Npad = S->d.Npad;
-  S->geom.csplit = 1;
-  for (int p = 0; p < n_pairs; p++) S->geom.csplit = std::max(S->geom.csplit, coeff_split(sources[p]->n));
-  S->geom.csplit_heavy = 1;
-  for (int p = 0; p < n_pairs; p++) S->geom.csplit_heavy = std::max(S->geom.csplit_heavy, coeff_split_heavy(sources[p]->n));
+  S->geom.csplit = qd ? coeff_split(qd->n_min) : 1;
+  for (int p = 0; p < n_pairs && !qd; p++) S->geom.csplit = std::max(S->geom.csplit, coeff_split(sources[p]->n));
+  S->geom.csplit_heavy = qd ? coeff_split_heavy(qd->n_min) : 1;
+  for (int p = 0; p < n_pairs && !qd; p++) S->geom.csplit_heavy = std::max(S->geom.csplit_heavy, coeff_split_heavy(sources[p]->n));
   S->geom.nbc = S->d.nblk_coeff;
   S->geom.npb = S->d.Mpad / PREP_THREADS + (S->d.NGpad * ROWS_PER_GROUP + PREP_THREADS - 1) / PREP_THREADS;
   S->geom.idx16 = M < 65536;
@@ -855,7 +886,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.instr = dp.kernel_clock || dp.phase_ticks;
   S->geom.verify = dp.verify_lists != 0;
   S->geom.horizon_cap = std::max(1, dp.lean_U);
-  ctx->last_xorder = sources[0]->h_order;
+  if (!qd) ctx->last_xorder = sources[0]->h_order;
   ctx->last_groups = S->G;
   ctx->last_pairs = n_pairs;
   ctx->last_N = N;
@@ -1573,6 +1604,76 @@ void cvo_cloud_free(cvo_cloud* c) {
   delete c;
 }
 
+// ---- the chunk graphs of a sub-batch (shared by cvo_align_batch and the batch queue) ----------------------------
+// graphs: 0 full (rebuild opportunity + k_assoc_dense in every iteration), 1 lean, 2 short lean, 3 full without the
+// dense kernel, 4 calm; 5 / 6 / 7 = lean / short lean / calm WITH the dense kernel (pairs with overflow rows, or in
+// the dense regime, whose lists live long enough)
+namespace {
+struct LoopCfg {
+  int U, U_late, lean_U, lean_U2;
+  int v_instr;  // 8 when the instrumented kernels run (they have their own cached graphs)
+};
+inline int graph_lean_base(int v) { return v >= 5 ? (v == 7 ? 4 : v - 4) : v; }
+inline int graph_lean_period(const LoopCfg& c, int v, int Uc) {
+  const int b = graph_lean_base(v);
+  return b == 4 ? Uc : (b == 3 ? 0 : (b == 2 ? c.lean_U2 : c.lean_U));
+}
+inline int graph_slot(const LoopCfg& c, int v, int Uc) { return v + c.v_instr + (Uc == c.U ? 0 : (Uc == c.U_late && c.U_late != c.U ? 16 : 32)); }
+
+int ensure_graph(cvo_ctx* ctx, const BatchSetup& S, const LaunchGeom* geom, int G, const LoopCfg& cfg, int g, int v, int Uc) {
+  const int vi = graph_slot(cfg, v, Uc);
+  GraphKey key;
+  key.n_pairs = geom[g].n_pairs;
+  key.p0 = geom[g].p0;
+  key.T = S.T;
+  key.gx = S.gx;
+  key.gy = S.gy;
+  key.nba = S.d.nblk_assoc;
+  key.nbc = S.d.nblk_coeff * 64 + S.geom.csplit;
+  key.npb = S.geom.npb + (S.geom.dense_blocks << 20);  // (npb < 2^20: Mpad / 256 + rows / 256)
+  key.idx16 = S.geom.idx16 ? 1 : 0;
+  key.general = (S.geom.general ? 1 : 0) | (S.geom.csplit_heavy << 1);
+  key.U = Uc * 256 + graph_lean_period(cfg, v, Uc) + (v == 3 ? 128 : 0);
+  key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0) | (v << 24);
+  key.arena = geom[g].arena.base;
+  key.stride256 = geom[g].arena.stride256;
+  key.Npad = geom[g].arena.Npad;
+  if (ctx->graph_exec[g][vi] && ctx->graph_key[g][vi] == key) return CVO_OK;
+  if (ctx->graph_exec[g][vi]) {
+    (void)hipGraphExecDestroy(ctx->graph_exec[g][vi]);
+    ctx->graph_exec[g][vi] = nullptr;
+  }
+  hipGraph_t gr = nullptr;
+  HIP_TRY(ctx, hipStreamBeginCapture(geom[g].stream, hipStreamCaptureModeThreadLocal));
+  launch_chunk(ctx, geom[g], Uc, v != 0, graph_lean_period(cfg, v, Uc), v >= 5);
+  // (the capture is always ended, whatever the launches reported: a stream left in capture mode would poison
+  // every later call on this context)
+  const hipError_t e_launch = hipGetLastError();
+  hipError_t e = hipStreamEndCapture(geom[g].stream, &gr);
+  if (e == hipSuccess && e_launch != hipSuccess) e = e_launch;
+  if (e == hipSuccess) e = hipGraphInstantiate(&ctx->graph_exec[g][vi], gr, nullptr, nullptr, 0);
+  if (gr) (void)hipGraphDestroy(gr);
+  if (e != hipSuccess) {
+    ctx->graph_exec[g][vi] = nullptr;
+    for (int q = 0; q < G; q++) (void)hipStreamSynchronize(geom[q].stream);  // other groups may be in flight
+    return fail(ctx, CVO_E_HIP, std::string("graph capture / instantiate: ") + hipGetErrorString(e));
+  }
+  ctx->graph_key[g][vi] = key;
+  return CVO_OK;
+}
+
+// Which graph a sub-batch runs next: `want` = the level its most demanding unfinished pair asked for (2 = a rebuild
+// opportunity in every iteration, 1 = short lean, 0 = lean, -1 = calm), `dense` = one of them needs k_assoc_dense.
+inline int choose_graph(int want, bool dense, bool allow_lean, bool start_nodense, bool allow_calm, int lean_U2) {
+  if (want == 1 && lean_U2 <= 0) want = 2;
+  if (!allow_lean) return 0;
+  if (want >= 2) return dense ? 0 : (start_nodense ? 3 : 0);
+  if (want == 1) return dense ? 6 : 2;
+  if (want == 0 || !allow_calm) return dense ? 5 : 1;
+  return dense ? 7 : 4;
+}
+}  // namespace
+
 int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo_cloud* const* sources,
                     const cvo_cloud* const* targets, const float* init_T, float* out_T, cvo_align_info_t* infos,
                     const cvo_align_opts_t* opts) {
@@ -1628,57 +1729,10 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
   if (max_iter > 0) {
     const int lean_U = std::max(1, std::min(dp.lean_U, U));
     const int lean_U2 = std::max(0, std::min(dp.lean_U2, U));
-    // graphs: 0 full (rebuild opportunity + k_assoc_dense in every iteration), 1 lean, 2 short lean, 3 full without the
-    // dense kernel, 4 calm; 5 / 6 / 7 = lean / short lean / calm WITH the dense kernel (pairs with overflow rows, or in
-    // the dense regime, whose lists live long enough)
-    auto lean_base = [](int v) { return v >= 5 ? (v == 7 ? 4 : v - 4) : v; };
-    auto lean_period = [&](int v, int Uc) {
-      const int b = lean_base(v);
-      return b == 4 ? Uc : (b == 3 ? 0 : (b == 2 ? lean_U2 : lean_U));
-    };
-    const int v_instr = S.geom.instr ? 8 : 0;  // the instrumented kernels have their own cached graphs
-    auto graph_index = [&](int v, int Uc) { return v + v_instr + (Uc == U ? 0 : (Uc == U_late && U_late != U ? 16 : 32)); };
-    auto get_graph = [&](int g, int v, int Uc) -> int {
-      const int vi = graph_index(v, Uc);
-      GraphKey key;
-      key.n_pairs = geom[g].n_pairs;
-      key.p0 = geom[g].p0;
-      key.T = S.T;
-      key.gx = S.gx;
-      key.gy = S.gy;
-      key.nba = S.d.nblk_assoc;
-      key.nbc = S.d.nblk_coeff * 64 + S.geom.csplit;
-      key.npb = S.geom.npb + (S.geom.dense_blocks << 20);  // (npb < 2^20: Mpad / 256 + rows / 256)
-      key.idx16 = S.geom.idx16 ? 1 : 0;
-      key.general = (S.geom.general ? 1 : 0) | (S.geom.csplit_heavy << 1);
-      key.U = Uc * 256 + lean_period(v, Uc) + (v == 3 ? 128 : 0);
-      key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0) | (v << 24);
-      key.arena = geom[g].arena.base;
-      key.stride256 = geom[g].arena.stride256;
-      key.Npad = geom[g].arena.Npad;
-      if (ctx->graph_exec[g][vi] && ctx->graph_key[g][vi] == key) return CVO_OK;
-      if (ctx->graph_exec[g][vi]) {
-        (void)hipGraphExecDestroy(ctx->graph_exec[g][vi]);
-        ctx->graph_exec[g][vi] = nullptr;
-      }
-      hipGraph_t gr = nullptr;
-      HIP_TRY(ctx, hipStreamBeginCapture(geom[g].stream, hipStreamCaptureModeThreadLocal));
-      launch_chunk(ctx, geom[g], Uc, v != 0, lean_period(v, Uc), v >= 5);
-      // (the capture is always ended, whatever the launches reported: a stream left in capture mode would poison
-      // every later call on this context)
-      const hipError_t e_launch = hipGetLastError();
-      hipError_t e = hipStreamEndCapture(geom[g].stream, &gr);
-      if (e == hipSuccess && e_launch != hipSuccess) e = e_launch;
-      if (e == hipSuccess) e = hipGraphInstantiate(&ctx->graph_exec[g][vi], gr, nullptr, nullptr, 0);
-      if (gr) (void)hipGraphDestroy(gr);
-      if (e != hipSuccess) {
-        ctx->graph_exec[g][vi] = nullptr;
-        for (int q = 0; q < G; q++) (void)hipStreamSynchronize(geom[q].stream);  // other groups may be in flight
-        return fail(ctx, CVO_E_HIP, std::string("graph capture / instantiate: ") + hipGetErrorString(e));
-      }
-      ctx->graph_key[g][vi] = key;
-      return CVO_OK;
-    };
+    const LoopCfg cfg{U, U_late, lean_U, lean_U2, S.geom.instr ? 8 : 0};
+    auto lean_period = [&](int v, int Uc) { return graph_lean_period(cfg, v, Uc); };
+    auto graph_index = [&](int v, int Uc) { return graph_slot(cfg, v, Uc); };
+    auto get_graph = [&](int g, int v, int Uc) -> int { return ensure_graph(ctx, S, geom, G, cfg, g, v, Uc); };
     // Chunks are enqueued until every pair has finished.  A pair advances one iteration per slot unless it is
     // waiting in a lean chunk for a rebuild / dense kernel, so the bound below is only a safety net.
     const int n_chunks = (max_iter + U_first - 1) / U_first;
@@ -1744,17 +1798,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
               dense = dense || w == 4 || w >= 8;
               want = std::max(want, w == 4 ? 2 : (w >= 8 ? w - 9 : w));
             }
-          if (want == 1 && lean_U2 <= 0) want = 2;
-          if (!allow_lean)
-            graph_next[g] = 0;
-          else if (want >= 2)
-            graph_next[g] = dense ? 0 : (start_nodense ? 3 : 0);
-          else if (want == 1)
-            graph_next[g] = dense ? 6 : 2;
-          else if (want == 0 || !allow_calm)
-            graph_next[g] = dense ? 5 : 1;
-          else
-            graph_next[g] = dense ? 7 : 4;
+          graph_next[g] = choose_graph(want, dense, allow_lean, start_nodense, allow_calm, lean_U2);
           if (ctx_opt(ctx, "VERBOSE") && atoi(ctx_opt(ctx, "VERBOSE")) >= 2 && ch < 12) {
             int nw = 0;
             for (int q = 0; q < ng; q++) nw += hs[ng + q] != 0;
@@ -1835,6 +1879,346 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     }
   }
   return CVO_OK;
+}
+
+// ---- batch queue (new, not in the reference): a STREAM of frame pairs through a fixed number of in-flight slots --------
+// The reference's real use is a frame stream with warm starts and very different iteration counts
+// (main_cvo_gpu_align_raw_image.cpp:100-170, one align() per frame).  cvo_align_batch takes a fixed set, and a sub-batch
+// runs at the pace of its most demanding pair until its last pair ends.  Here a pair that finishes hands its slice of
+// the workspace to the next queued pair at the next chunk boundary: the slot's result is read out, descriptor and
+// initial state of the newcomer are copied in and k_update<INIT> runs for that slot, all in stream order behind the
+// chunk in flight - the sub-batch's graphs never change (their kernel arguments are the slots, not the occupants).
+// Results are delivered in submission order.
+struct cvo_batch_queue {
+  cvo_ctx* ctx = nullptr;
+  cvo_params_t params{};
+  cvo_align_opts_t opts{};
+  BatchSetup S{};
+  DevParams dp{};
+  LoopCfg cfg{};
+  int slots = 0, G = 1;
+  bool allow_lean = true, start_nodense = false, allow_calm = true;
+  LaunchGeom geom[cvo_ctx::MAX_GROUPS];
+  struct Job {
+    long long ticket;
+    const cvo_cloud* X;
+    const cvo_cloud* Y;
+    float T[16];
+    int max_iter;
+  };
+  std::deque<Job> waiting;
+  struct Slot {
+    long long ticket = -1;  // occupant (-1 = free)
+    int start_chunk = 0;    // first chunk of the group whose status words belong to this occupant
+    std::chrono::steady_clock::time_point t0;
+  };
+  std::vector<Slot> slot;
+  struct Readout {  // a finished pair whose state is on its way to h_out[slot]
+    long long ticket;
+    int slot, ready_chunk;  // complete once the group's chunk `ready_chunk` has been waited for
+    double seconds;
+  };
+  std::vector<Readout> readouts[cvo_ctx::MAX_GROUPS];
+  std::map<long long, cvo_batch_result_t> done;
+  long long next_ticket = 0, next_deliver = 0;
+  int launched[cvo_ctx::MAX_GROUPS] = {}, inspected[cvo_ctx::MAX_GROUPS] = {}, graph_next[cvo_ctx::MAX_GROUPS] = {};
+  int running[cvo_ctx::MAX_GROUPS] = {};  // occupied slots per group
+  char* pinned = nullptr;                 // [slots] x (PairState out | PairDesc stage | PairState stage)
+  PairState* h_out = nullptr;
+  PairDesc* h_desc_stage = nullptr;
+  PairState* h_state_stage = nullptr;
+  unsigned long long n_chunks = 0, n_full_chunks = 0, n_refills = 0;
+};
+
+namespace {
+
+int queue_group_of(const cvo_batch_queue* q, int p) {
+  int g = 0;
+  while (g + 1 < q->G && (int)((long)q->slots * (g + 1) / q->G) <= p) g++;
+  return g;
+}
+
+// Places `job` into free slot p: descriptor + initial state + k_update<INIT>, in stream order on the slot's sub-batch stream.
+int queue_fill(cvo_batch_queue* q, int p, const cvo_batch_queue::Job& job) {
+  cvo_ctx* ctx = q->ctx;
+  const int g = queue_group_of(q, p);
+  fill_pair(ctx, &q->S, &q->params, &q->opts, 0, 0.f, q->slots, p, job.X, job.Y, job.T, next_call_serial(), job.max_iter);
+  q->h_desc_stage[p] = ctx->h_descs[p];
+  q->h_state_stage[p] = ctx->h_states[p];
+  hipStream_t st = q->geom[g].stream;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_descs + p, q->h_desc_stage + p, sizeof(PairDesc), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_states + p, q->h_state_stage + p, sizeof(PairState), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_update<true>, dim3(1), dim3(64), 0, st, ctx->d_descs + p, ctx->d_params, ctx->d_status, 0);
+  HIP_TRY(ctx, hipGetLastError());
+  q->slot[p].ticket = job.ticket;
+  q->slot[p].start_chunk = q->launched[g];
+  q->slot[p].t0 = std::chrono::steady_clock::now();
+  q->running[g]++;
+  q->graph_next[g] = q->start_nodense ? 3 : 0;  // a newcomer moves fast: a rebuild opportunity in every iteration
+  q->n_refills++;
+  return CVO_OK;
+}
+
+// One step of sub-batch g: wait for its older chunk in flight (if two are) and act on what it reports - collect
+// read-outs, retire finished pairs, refill their slots - then enqueue the next chunk.  block = false: returns without
+// waiting when the older chunk has not finished yet.
+int queue_step(cvo_batch_queue* q, int g, bool block, bool* progressed) {
+  cvo_ctx* ctx = q->ctx;
+  const int p0 = q->geom[g].p0, ng = q->geom[g].n_pairs;
+  hipStream_t st = q->geom[g].stream;
+  // ---- inspect
+  const bool idle_tail = q->running[g] == 0 && q->launched[g] > q->inspected[g];  // nothing left to launch for: drain what is in flight
+  if (q->launched[g] - q->inspected[g] >= 2 || idle_tail) {
+    const int c = q->inspected[g];
+    hipEvent_t ev = ctx->ev_chk[c & 1][g];
+    if (!block) {
+      const hipError_t e = hipEventQuery(ev);
+      if (e == hipErrorNotReady) return CVO_OK;
+      if (e != hipSuccess) return fail(ctx, CVO_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+    } else {
+      HIP_TRY(ctx, hipEventSynchronize(ev));
+    }
+    q->inspected[g] = c + 1;
+    *progressed = true;
+    // read-outs enqueued before chunk c was launched are complete
+    auto& ro = q->readouts[g];
+    for (size_t k = 0; k < ro.size();) {
+      if (ro[k].ready_chunk <= c) {
+        const PairState& ps = q->h_out[ro[k].slot];
+        cvo_batch_result_t r{};
+        r.ticket = ro[k].ticket;
+        std::memcpy(r.transform, ps.out_T, sizeof(float) * 16);
+        r.info.iterations = ps.status ? ps.iterations : ps.k;
+        r.info.ret = ps.ret;
+        r.info.final_ell = ps.ell;
+        r.info.final_num_neighbors = ps.K;
+        r.info.seconds = ro[k].seconds;
+        q->done[r.ticket] = r;
+        ro[k] = ro.back();
+        ro.pop_back();
+      } else {
+        k++;
+      }
+    }
+    // finished pairs: their state is read out behind everything enqueued so far; the slot goes to the next waiting pair
+    const volatile int* hs = ctx->h_status[0] + 2 * p0;  // [status[ng] | want[ng]]
+    int want = -1;
+    bool dense = false;
+    for (int k = 0; k < ng; k++) {
+      cvo_batch_queue::Slot& sl = q->slot[p0 + k];
+      if (sl.ticket < 0 || c < sl.start_chunk) {
+        if (sl.ticket >= 0) want = 2;  // (placed, not yet reported: still asks for the full graph)
+        continue;
+      }
+      if (hs[k] != 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(q->h_out + p0 + k, ctx->d_states + p0 + k, offsetof(PairState, sq), hipMemcpyDeviceToHost, st));
+        q->readouts[g].push_back({sl.ticket, p0 + k, q->launched[g],
+                                  std::chrono::duration<double>(std::chrono::steady_clock::now() - sl.t0).count()});
+        sl.ticket = -1;
+        q->running[g]--;
+      } else {
+        const int w = hs[ng + k];
+        dense = dense || w == 4 || w >= 8;
+        want = std::max(want, w == 4 ? 2 : (w >= 8 ? w - 9 : w));
+      }
+    }
+    q->graph_next[g] = choose_graph(want, dense, q->allow_lean, q->start_nodense, q->allow_calm, q->cfg.lean_U2);
+    // Admission.  A newcomer moves fast: its lists last an iteration or two, so its sub-batch runs the full graph (six
+    // launches per iteration, three of which find nothing to do for the settled pairs) until it has calmed down.  Free
+    // slots are therefore refilled in cohorts: at once while the sub-batch runs a fast graph anyway or stands empty,
+    // otherwise when a quarter of its slots have come free.
+    if (!q->waiting.empty() && q->running[g] < ng) {
+      const int v = q->graph_next[g];
+      const bool fast = v == 0 || v == 3 || v == 2 || v == 6;
+      if (fast || q->running[g] == 0 || 4 * (ng - q->running[g]) >= ng)
+        for (int k = 0; k < ng && !q->waiting.empty(); k++)
+          if (q->slot[p0 + k].ticket < 0) {
+            const cvo_batch_queue::Job job = q->waiting.front();
+            q->waiting.pop_front();
+            const int rc = queue_fill(q, p0 + k, job);
+            if (rc != CVO_OK) return rc;
+          }
+    }
+  }
+  // ---- launch
+  if (q->running[g] > 0 && q->launched[g] - q->inspected[g] < 2) {
+    const int v = q->graph_next[g];
+    const bool fast = v == 0 || v == 3 || v == 2 || v == 6;
+    const int Uc = fast ? q->cfg.U : q->cfg.U_late;
+    int rc = ensure_graph(ctx, q->S, q->geom, q->G, q->cfg, g, v, Uc);
+    if (rc != CVO_OK) return rc;
+    HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[g][graph_slot(q->cfg, v, Uc)], st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_chk[q->launched[g] & 1][g], st));
+    q->launched[g]++;
+    q->n_chunks++;
+    if (v == 0 || v == 3) q->n_full_chunks++;
+    *progressed = true;
+  } else if (q->running[g] == 0 && !q->readouts[g].empty() && q->launched[g] == q->inspected[g]) {
+    // read-outs behind the last chunk of a group that has gone idle: an event of their own
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_chk[q->launched[g] & 1][g], st));
+    q->launched[g]++;
+    *progressed = true;
+  }
+  return CVO_OK;
+}
+
+int queue_pending(const cvo_batch_queue* q) { return (int)(q->next_ticket - q->next_deliver); }
+
+}  // namespace
+
+int cvo_batch_open(cvo_ctx* ctx, const cvo_params_t* params, int slots, int max_source_points, int max_target_points,
+                   int min_source_points, const cvo_align_opts_t* opts, cvo_batch_queue** out) {
+  if (!ctx || !out) return CVO_E_INVALID;
+  *out = nullptr;
+  if (!params || slots <= 0) return fail(ctx, CVO_E_INVALID, "cvo_batch_open: bad argument");
+  if (ctx->queue_open) return fail(ctx, CVO_E_INVALID, "cvo_batch_open: this context already has an open batch queue");
+  if (opts && (opts->trace || opts->override_state))
+    return fail(ctx, CVO_E_UNSUPPORTED, "cvo_batch_open: traces and state overrides are per-call features of cvo_align_ex / cvo_align_batch");
+  cvo_batch_queue* q = new cvo_batch_queue();
+  q->ctx = ctx;
+  q->params = *params;
+  if (opts) q->opts.max_iterations = opts->max_iterations;
+  q->slots = slots;
+  const QueueDims qd{max_source_points, max_target_points, min_source_points > 0 ? min_source_points : max_source_points};
+  int rc = setup_batch(ctx, params, slots, nullptr, nullptr, nullptr, &q->opts, 0, 0.f, &q->S, &q->dp, nullptr, &qd);
+  if (rc != CVO_OK) {
+    delete q;
+    return rc;
+  }
+  q->G = q->S.G;
+  for (int g = 0; g < q->G; g++) {
+    const int p0 = (int)((long)slots * g / q->G), p1 = (int)((long)slots * (g + 1) / q->G);
+    q->geom[g] = q->S.geom;
+    q->geom[g].group = g;
+    q->geom[g].p0 = p0;
+    q->geom[g].n_pairs = p1 - p0;
+    q->geom[g].arena.base = q->S.geom.arena.base + q->S.L.total * (size_t)p0;
+    q->geom[g].stream = ctx->gstream[g];
+  }
+  const int U = 16;
+  q->cfg = LoopCfg{U, 2 * U, std::max(1, std::min(q->dp.lean_U, U)), std::max(0, std::min(q->dp.lean_U2, U)), q->S.geom.instr ? 8 : 0};
+  q->allow_lean = ctx_opt(ctx, "NO_LEAN") == nullptr;
+  q->start_nodense = q->allow_lean && q->S.N > 4096 && ctx_opt(ctx, "NO_NODENSE") == nullptr;
+  q->allow_calm = q->dp.calm_U > 0;
+  q->slot.assign((size_t)slots, cvo_batch_queue::Slot());
+  const size_t per = align_up(sizeof(PairState), 256) * 2 + align_up(sizeof(PairDesc), 256);
+  hipError_t e = hipHostMalloc(&q->pinned, per * (size_t)slots, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    delete q;
+    return fail(ctx, CVO_E_NOMEM, std::string("cvo_batch_open: hipHostMalloc: ") + hipGetErrorString(e));
+  }
+  q->h_out = (PairState*)q->pinned;
+  q->h_state_stage = (PairState*)(q->pinned + align_up(sizeof(PairState), 256) * (size_t)slots);
+  q->h_desc_stage = (PairDesc*)(q->pinned + align_up(sizeof(PairState), 256) * 2 * (size_t)slots);
+  // the set-up copies went to group 0's stream: the other sub-batch streams start behind them
+  e = hipEventRecord(ctx->ev_fork, ctx->stream);
+  for (int g = 1; g < q->G && e == hipSuccess; g++) e = hipStreamWaitEvent(q->geom[g].stream, ctx->ev_fork, 0);
+  if (e != hipSuccess) {
+    (void)hipHostFree(q->pinned);
+    delete q;
+    return fail(ctx, CVO_E_HIP, std::string("cvo_batch_open: ") + hipGetErrorString(e));
+  }
+  ctx->queue_open = true;
+  *out = q;
+  return CVO_OK;
+}
+
+int cvo_batch_submit(cvo_batch_queue* q, const cvo_cloud* source, const cvo_cloud* target, const float init_T[16],
+                     int max_iterations, long long* ticket) {
+  if (!q) return CVO_E_INVALID;
+  cvo_ctx* ctx = q->ctx;
+  if (!source || !target || !init_T) return fail(ctx, CVO_E_INVALID, "cvo_batch_submit: null argument");
+  if (source->ctx != ctx || target->ctx != ctx) return fail(ctx, CVO_E_INVALID, "cloud belongs to another context");
+  if (source->n <= 0 || target->n <= 0) return fail(ctx, CVO_E_INVALID, "cvo_batch_submit: empty cloud");
+  if (source->n > q->S.N || target->n > q->S.M || coeff_split(source->n) > q->S.geom.csplit)
+    return fail(ctx, CVO_E_INVALID, "cvo_batch_submit: cloud outside the sizes the queue was opened for");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    const bool nf = q->params.is_using_intensity != 0, nl = q->params.is_using_semantics != 0, ng = q->params.is_using_geometric_type != 0;
+    if (nf || nl || ng) {
+      int rc0 = ensure_attributes(ctx, source, nf, nl, ng);
+      if (rc0 == CVO_OK) rc0 = ensure_attributes(ctx, target, nf, nl, ng);
+      if (rc0 != CVO_OK) return rc0;
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (a zero slab is filled on the context's stream; the sub-batch streams read it)
+    }
+  }
+  cvo_batch_queue::Job job;
+  job.ticket = q->next_ticket++;
+  job.X = source;
+  job.Y = target;
+  std::memcpy(job.T, init_T, sizeof(float) * 16);
+  job.max_iter = max_iterations > 0 ? std::min(max_iterations, q->dp.max_iter) : q->dp.max_iter;
+  if (ticket) *ticket = job.ticket;
+  // a free slot, in the sub-batch with the fewest occupants (newcomers of one sub-batch share their fast first iterations)
+  int best = -1, best_run = 1 << 30;
+  if (q->waiting.empty())
+    for (int g = 0; g < q->G; g++) {
+      if (q->running[g] >= q->geom[g].n_pairs || q->running[g] >= best_run) continue;
+      for (int k = 0; k < q->geom[g].n_pairs; k++)
+        if (q->slot[q->geom[g].p0 + k].ticket < 0) {
+          // (its previous occupant's read-out may still be in flight: stream order protects it)
+          best = q->geom[g].p0 + k;
+          best_run = q->running[g];
+          break;
+        }
+    }
+  if (best >= 0) return queue_fill(q, best, job);
+  q->waiting.push_back(job);
+  return CVO_OK;
+}
+
+int cvo_batch_poll(cvo_batch_queue* q, int wait, int capacity, cvo_batch_result_t* results, int* n_results) {
+  if (!q || !n_results || (capacity > 0 && !results)) return CVO_E_INVALID;
+  cvo_ctx* ctx = q->ctx;
+  *n_results = 0;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  auto deliverable = [&] { return q->done.count(q->next_deliver) != 0; };
+  for (;;) {
+    bool progressed = false;
+    // (every sub-batch is stepped without blocking first; only when none of them moved does the call wait for one)
+    for (int g = 0; g < q->G; g++) {
+      const int rc = queue_step(q, g, false, &progressed);
+      if (rc != CVO_OK) return rc;
+    }
+    if (wait == 0) break;
+    if (wait == 1 && (deliverable() || queue_pending(q) == 0)) break;
+    if (wait >= 2 && ((int)q->done.size() == queue_pending(q) || (capacity > 0 && (int)q->done.size() >= capacity && deliverable()))) break;
+    if (!progressed) {
+      int gw = -1;  // the sub-batch with the most chunks in flight
+      for (int g = 0; g < q->G; g++)
+        if (q->launched[g] > q->inspected[g] && (gw < 0 || q->launched[g] - q->inspected[g] > q->launched[gw] - q->inspected[gw])) gw = g;
+      if (gw < 0) break;  // nothing in flight and nothing to launch
+      const int rc = queue_step(q, gw, true, &progressed);
+      if (rc != CVO_OK) return rc;
+    }
+  }
+  while (*n_results < capacity && deliverable()) {
+    results[*n_results] = q->done[q->next_deliver];
+    q->done.erase(q->next_deliver);
+    q->next_deliver++;
+    (*n_results)++;
+  }
+  return CVO_OK;
+}
+
+int cvo_batch_pending(const cvo_batch_queue* q) { return q ? queue_pending(q) : 0; }
+
+int cvo_batch_stats(const cvo_batch_queue* q, unsigned long long* chunks, unsigned long long* full_chunks, unsigned long long* refills) {
+  if (!q) return CVO_E_INVALID;
+  if (chunks) *chunks = q->n_chunks;
+  if (full_chunks) *full_chunks = q->n_full_chunks;
+  if (refills) *refills = q->n_refills;
+  return CVO_OK;
+}
+
+void cvo_batch_close(cvo_batch_queue* q) {
+  if (!q) return;
+  cvo_ctx* ctx = q->ctx;
+  (void)hipSetDevice(ctx->device);
+  for (int g = 0; g < q->G; g++) (void)hipStreamSynchronize(q->geom[g].stream);
+  if (q->pinned) (void)hipHostFree(q->pinned);
+  ctx->queue_open = false;
+  delete q;
 }
 
 int cvo_align_ex(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source, const cvo_cloud* target,

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
     const Pose pose = load_pose(st);
     const FeatDen F = make_feat_den(P);
     const bool long_lists = !all_dense && P.long_lists != 0 && D->long_j != nullptr;
-    const unsigned long long gen = (P.call_serial << 24) | (unsigned long long)((unsigned)st->n_builds & 0xffffffu);
+    const unsigned long long gen = (D->call_serial << 24) | (unsigned long long)((unsigned)st->n_builds & 0xffffffu);
     for (int q = blockIdx.x * DENSE_WAVES + wave; q < n_ovf; q += (int)gridDim.x * DENSE_WAVES) {
       // a position of k_list's ordering (all per-row outputs are stored by position); dense regime: every row
       const int r_sorted = all_dense ? q : D->ovf_rows[q];

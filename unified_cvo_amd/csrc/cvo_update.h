@@ -30,7 +30,7 @@ struct UpdDesc {
   int* want_out;
   int* status_host;
   int* want_host;
-  int nblk_coeff, N, M;
+  int nblk_coeff, N, M, max_iter;
   float ymax;
   double sqrt_nm;
 };
@@ -48,6 +48,7 @@ __device__ __forceinline__ UpdDesc load_upd_desc(const PairDesc* __restrict__ D)
   u.nblk_coeff = D->nblk_coeff;
   u.N = D->N;
   u.M = D->M;
+  u.max_iter = D->max_iter;
   u.ymax = D->ymax;
   u.sqrt_nm = D->sqrt_nm;
   asm volatile("" ::"s"(u.st), "s"(u.coef_part), "s"(u.flow_part), "s"(u.cnt_part), "s"(u.trace), "s"(u.status_out),
@@ -288,7 +289,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
             }
             st->K = min(P.K_max, (int)((double)max_nnz * 1.2));  // CvoGPU.cu:1529
             st->k = k + 1;
-            if (k + 1 >= P.max_iter) {
+            if (k + 1 >= D.max_iter) {
               done = 1;
               st->iterations = k + 1;
             }
@@ -532,6 +533,8 @@ __global__ __launch_bounds__(64) void k_update(const PairDesc* __restrict__ desc
   const PairDesc* __restrict__ D = descs + blockIdx.x;
   if (!INIT && (flags & 1) && (D->st->rebuild || (D->st->n_ovf > 0 && !(flags & 32)))) return;  // lean graph: the pair is waiting (k_assoc)
   if (INIT && threadIdx.x == 0) {  // the pair's cross-block counters start at zero
+    *D->status_out = 0;   // (a slot of a batch queue: the words of its previous occupant say "finished")
+    *D->status_host = 0;
     *D->gate = 0;
     *D->gate_flow = 0;
     *D->done = 0;
