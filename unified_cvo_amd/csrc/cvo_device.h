@@ -271,6 +271,8 @@ struct PairDesc {
   int* want_out;    // mirror of st->want_full
   int* status_host;  // the same two words in pinned HOST memory: the device writes them when they change (posted
   int* want_host;    // writes), the host reads them after a chunk's event - no copy kernel between two chunks
+  double* asum_host;  // pinned HOST memory: the sum of the kernel values of a single evaluation (inner_product_gpu), written by
+                      // the block of k_assoc that finishes last - no k_update launch, no copy back
   int* gate;        // [1] blocks of k_list that finished the current rebuild (the last one validates the list)
   int* gate_flow;   // [1] blocks of k_assoc that stored their flow partial (the last one reduces them)
 };

@@ -121,6 +121,12 @@ struct cvo_ctx {
   PairState* d_states = nullptr;
   int* d_status = nullptr;
   DevParams* d_params = nullptr;
+  // descriptors, states, status words and the parameter block live in ONE device allocation with a pinned staging copy
+  // of the same layout: a call uploads its control state with one copy (four copies cost every cvo_align ~10 us and
+  // an inner product a third of its time)
+  char* d_ctl = nullptr;
+  char* h_ctl = nullptr;
+  size_t ctl_bytes = 0, ctl_off_status = 0, ctl_off_descs = 0, ctl_off_states = 0;
   int cap_pairs = 0;
   std::vector<PairDesc> h_descs;
   std::vector<PairState> h_states;
@@ -137,7 +143,7 @@ struct cvo_ctx {
   // graph cache (one per group)
   // [group][0 = full chunk, 1 = lean chunk, 2 = short lean chunk, 3 = full chunk without k_assoc_dense, 4 = calm chunk (lean, one rebuild opportunity); + 5 for the instrumented kernels (CVO_KERNEL_CLOCK /
   // CVO_PHASE_TICKS), cached side by side so that a caller can time single steps of a loop without re-capturing]
-  static constexpr int GRAPH_VARIANTS = 48;  // 8 graphs (see cvo_align_batch) x instrumented or not x 3 chunk lengths
+  static constexpr int GRAPH_VARIANTS = 49;  // 8 graphs (see cvo_align_batch) x instrumented or not x 3 chunk lengths + the inner-product chain
   hipGraphExec_t graph_exec[MAX_GROUPS][GRAPH_VARIANTS] = {};
   GraphKey graph_key[MAX_GROUPS][GRAPH_VARIANTS] = {};
   int last_chunks = 0, last_lean_launches = 0, last_full_launches = 0;
@@ -269,12 +275,13 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, bool long_lis
 
 void free_workspace(cvo_ctx* c) {
   if (c->arena) (void)hipFree(c->arena);
-  if (c->d_descs) (void)hipFree(c->d_descs);
-  if (c->d_states) (void)hipFree(c->d_states);
-  if (c->d_status) (void)hipFree(c->d_status);
+  if (c->d_ctl) (void)hipFree(c->d_ctl);
+  if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   for (int i = 0; i < 2; i++)
     if (c->h_status[i]) (void)hipHostFree(c->h_status[i]);
   c->arena = nullptr;
+  c->d_ctl = c->h_ctl = nullptr;
+  c->d_params = nullptr;
   c->d_descs = nullptr;
   c->d_states = nullptr;
   c->d_status = nullptr;
@@ -294,18 +301,27 @@ void drop_graphs(cvo_ctx* c) {
 
 int ensure_workspace(cvo_ctx* c, int n_pairs, size_t bytes_per_pair) {
   if (n_pairs > c->cap_pairs) {
-    if (c->d_descs) (void)hipFree(c->d_descs);
-    if (c->d_states) (void)hipFree(c->d_states);
-    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->d_ctl) (void)hipFree(c->d_ctl);
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     for (int i = 0; i < 2; i++)
       if (c->h_status[i]) (void)hipHostFree(c->h_status[i]);
+    c->d_ctl = c->h_ctl = nullptr;
+    c->d_params = nullptr;
     c->d_descs = nullptr;
     c->d_states = nullptr;
     c->d_status = nullptr;
-    HIP_TRY(c, hipMalloc(&c->d_descs, sizeof(PairDesc) * (size_t)n_pairs));
-    HIP_TRY(c, hipMalloc(&c->d_states, sizeof(PairState) * (size_t)n_pairs));
-    // [0, n): st->status mirrors, [n, 2n): st->want_full mirrors
-    HIP_TRY(c, hipMalloc(&c->d_status, sizeof(int) * 2 * (size_t)n_pairs));
+    c->cap_pairs = 0;
+    // control block: [DevParams | status words: per sub-batch status[n_g], want[n_g] | PairDesc[n] | PairState[n]]
+    c->ctl_off_status = align_up(sizeof(DevParams), 256);
+    c->ctl_off_descs = align_up(c->ctl_off_status + sizeof(int) * 2 * (size_t)n_pairs, 256);
+    c->ctl_off_states = align_up(c->ctl_off_descs + sizeof(PairDesc) * (size_t)n_pairs, 256);
+    c->ctl_bytes = align_up(c->ctl_off_states + sizeof(PairState) * (size_t)n_pairs, 256);
+    HIP_TRY(c, hipMalloc(&c->d_ctl, c->ctl_bytes));
+    HIP_TRY(c, hipHostMalloc(&c->h_ctl, c->ctl_bytes, hipHostMallocDefault));
+    c->d_params = (DevParams*)c->d_ctl;
+    c->d_status = (int*)(c->d_ctl + c->ctl_off_status);
+    c->d_descs = (PairDesc*)(c->d_ctl + c->ctl_off_descs);
+    c->d_states = (PairState*)(c->d_ctl + c->ctl_off_states);
     for (int i = 0; i < 2; i++)  // fine-grained: what the device writes there needs no cache maintenance to be seen
       HIP_TRY(c, hipHostMalloc(&c->h_status[i], sizeof(int) * 2 * (size_t)n_pairs, hipHostMallocMapped | hipHostMallocCoherent));
     c->cap_pairs = n_pairs;
@@ -692,6 +708,7 @@ void fill_pair(cvo_ctx* ctx, const BatchSetup* S, const cvo_params_t* params, co
       D.status_host = ctx->h_status[0] + 2 * p0 + (p - p0);
       D.want_host = ctx->h_status[0] + 2 * p0 + (p1 - p0) + (p - p0);
     }
+    D.asum_host = reinterpret_cast<double*>(ctx->h_status[1]) + p;  // (2 ints per pair = one double)
     D.gate = (int*)(base + S->L.gate);
     D.gate_flow = (int*)(base + S->L.gate_flow);
     D.done = (int*)(base + S->L.done);
@@ -774,7 +791,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   if ((unsigned long long)N * (unsigned long long)std::max(params->nearest_neighbors_max, 1) >= (1ull << 32))
     return fail(ctx, CVO_E_INVALID, "source rows x nearest_neighbors_max must stay below 2^32");
   // overflow rows keep sorted candidate lists of their own (PairDesc::long_j) when sorted positions fit 16 bits
-  S->long_lists = mode == 0 && M <= 65535 && ctx_opt(ctx, "NO_LONG_LISTS") == nullptr;
+  S->long_lists = M <= 65535 && ctx_opt(ctx, "NO_LONG_LISTS") == nullptr;
   S->L = make_layout(N, M, Kmax, trace_cap, S->long_lists, &S->d);
   {
     size_t free_b = 0, total_b = 0;
@@ -853,13 +870,23 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   }
   // the blocks of k_assoc beyond a smaller pair's N still write their (zero) partials, but the
   // partial arrays of pairs whose N is smaller than the batch maximum are fully covered by nblk.
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_descs, ctx->h_descs.data(), sizeof(PairDesc) * (size_t)n_pairs,
-                              hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_states, ctx->h_states.data(), sizeof(PairState) * (size_t)n_pairs,
-                              hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, qd ? 1 : 0, sizeof(int) * 2 * (size_t)ctx->cap_pairs, ctx->stream));  // (queue: any non-zero word = finished)
-  std::memset(ctx->h_status[0], qd ? 1 : 0, sizeof(int) * 2 * (size_t)ctx->cap_pairs);  // (no call is in flight on this context)
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_params, &dp, sizeof(DevParams), hipMemcpyHostToDevice, ctx->stream));
+  // one copy from the pinned staging block (no call is in flight on this context: every call ends synchronised)
+  std::memcpy(ctx->h_ctl, &dp, sizeof(DevParams));
+  std::memset(ctx->h_ctl + ctx->ctl_off_status, qd ? 1 : 0, sizeof(int) * 2 * (size_t)ctx->cap_pairs);  // (queue: any non-zero word = finished)
+  std::memcpy(ctx->h_ctl + ctx->ctl_off_descs, ctx->h_descs.data(), sizeof(PairDesc) * (size_t)n_pairs);
+  std::memcpy(ctx->h_ctl + ctx->ctl_off_states, ctx->h_states.data(), sizeof(PairState) * (size_t)n_pairs);
+  std::memset(ctx->h_status[0], qd ? 1 : 0, sizeof(int) * 2 * (size_t)ctx->cap_pairs);
+  {
+    // (descriptors and states of at most n_pairs <= cap_pairs slots are used; the block is laid out for cap_pairs)
+    const size_t upto = ctx->ctl_off_states + sizeof(PairState) * (size_t)n_pairs;
+    if ((size_t)n_pairs * 2 >= (size_t)ctx->cap_pairs) {
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctl, ctx->h_ctl, upto, hipMemcpyHostToDevice, ctx->stream));
+    } else {  // a small call on a context sized for a large batch: skip the unused descriptors in between
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctl, ctx->h_ctl, ctx->ctl_off_descs + sizeof(PairDesc) * (size_t)n_pairs, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctl + ctx->ctl_off_states, ctx->h_ctl + ctx->ctl_off_states, sizeof(PairState) * (size_t)n_pairs,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
   S->gx = (S->d.Mpad / (64 * S->T) + 3) / 4;
   S->gy = ((int)align_up((size_t)S->d.NG, 64) + S->gpb - 1) / S->gpb;
   S->geom.n_pairs = n_pairs;
@@ -917,6 +944,61 @@ int run_single_eval(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_states.data(), ctx->d_states, sizeof(PairState), hipMemcpyDeviceToHost,
                               ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CVO_OK;
+}
+
+// inner_product_gpu for n (<= 8) pairs in ONE chain: INIT, the rebuild trio, [k_assoc_dense], k_assoc whose last block
+// posts A_sum to pinned host memory - one upload, one graph launch, one synchronisation.  The three inner products of the
+// exact function_angle (CvoGPU.cu:1835-1837) are such a batch.  Every value is what the one-pair path returns.
+int run_inner_products(cvo_ctx* ctx, const cvo_params_t* params, int n, const cvo_cloud* const* src, const cvo_cloud* const* tgt,
+                       const float* Tms, float ell, double* out) {
+  BatchSetup S;
+  DevParams dp;
+  int rc = setup_batch(ctx, params, n, src, tgt, Tms, nullptr, 1, ell, &S, &dp);
+  if (rc != CVO_OK) return rc;
+  if (S.G != 1) return fail(ctx, CVO_E_INVALID, "run_inner_products: too many pairs for one chain");
+  const LaunchGeom& g = S.geom;
+  constexpr int VI = cvo_ctx::GRAPH_VARIANTS - 1;
+  GraphKey key;
+  key.n_pairs = n;
+  key.T = S.T;
+  key.gx = S.gx;
+  key.gy = S.gy;
+  key.nba = S.d.nblk_assoc;
+  key.npb = g.npb + (g.dense_blocks << 20);
+  key.idx16 = g.idx16 ? 1 : 0;
+  key.general = g.general ? 1 : 0;
+  key.flags = (g.instr ? 1 : 0) | (99 << 24);
+  key.arena = g.arena.base;
+  key.stride256 = g.arena.stride256;
+  key.Npad = g.arena.Npad;
+  if (!(ctx->graph_exec[0][VI] && ctx->graph_key[0][VI] == key)) {
+    if (ctx->graph_exec[0][VI]) (void)hipGraphExecDestroy(ctx->graph_exec[0][VI]);
+    ctx->graph_exec[0][VI] = nullptr;
+    hipGraph_t gr = nullptr;
+    HIP_TRY(ctx, hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+    launch_init(ctx, g);
+    launch_rebuild(ctx, g);
+    launch_dense(g.stream, g.general, g.N, g.n_pairs, g.dense_blocks, ctx->d_descs, ctx->d_params, ctx->d_status);
+    launch_assoc(g.stream, g.idx16, g.general, g.instr, g.nba, g.n_pairs, ctx->d_descs, ctx->d_params, ctx->d_states, g.arena, 8);
+    const hipError_t e_launch = hipGetLastError();
+    hipError_t e = hipStreamEndCapture(g.stream, &gr);
+    if (e == hipSuccess && e_launch != hipSuccess) e = e_launch;
+    if (e == hipSuccess) e = hipGraphInstantiate(&ctx->graph_exec[0][VI], gr, nullptr, nullptr, 0);
+    if (gr) (void)hipGraphDestroy(gr);
+    if (e != hipSuccess) {
+      ctx->graph_exec[0][VI] = nullptr;
+      return fail(ctx, CVO_E_HIP, std::string("inner product graph: ") + hipGetErrorString(e));
+    }
+    ctx->graph_key[0][VI] = key;
+  }
+  HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec[0][VI], g.stream));
+  HIP_TRY(ctx, hipStreamSynchronize(g.stream));
+  const volatile double* res = reinterpret_cast<const volatile double*>(ctx->h_status[1]);
+  for (int p = 0; p < n; p++) {
+    out[p] = res[p];
+    ctx->h_states[p].asum = res[p];
+  }
   return CVO_OK;
 }
 
@@ -1022,7 +1104,6 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
     }
   }
   bool ok = (pooled || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess) &&
-            hipMalloc(&c->d_params, sizeof(DevParams)) == hipSuccess &&
             // (nothing here may run on the NULL stream - a synchronous hipMemset, say: its hardware queue would then be the
             // first one this process creates - see the note on the sub-batch streams below)
             hipEventCreate(&c->ev_start) == hipSuccess &&
@@ -1079,7 +1160,6 @@ void cvo_ctx_destroy(cvo_ctx* c) {
     if (c->gstream[g]) (void)hipStreamSynchronize(c->gstream[g]);
   drop_graphs(c);
   free_workspace(c);
-  if (c->d_params) (void)hipFree(c->d_params);
   if (c->d_kd_jobs) (void)hipFree(c->d_kd_jobs);
   for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++) {
     for (int i = 0; i < 2; i++)
@@ -2261,10 +2341,12 @@ int cvo_inner_product(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud*
     *out = 0.f;
     return CVO_OK;
   }
-  BatchSetup S;
-  int rc = run_single_eval(ctx, params, source, target, T, ell, &S);
+  const cvo_cloud* src[1] = {source};
+  const cvo_cloud* tgt[1] = {target};
+  double v = 0;
+  const int rc = run_inner_products(ctx, params, 1, src, tgt, T, ell, &v);
   if (rc != CVO_OK) return rc;
-  *out = (float)ctx->h_states[0].asum;
+  *out = (float)v;
   return CVO_OK;
 }
 
@@ -2279,19 +2361,26 @@ int cvo_function_angle(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud
   }
   const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   float fxfz = 0, fx_norm = 0, fz_norm = 0;
-  int rc = cvo_inner_product(ctx, params, source, target, T, ell, &fxfz);
-  if (rc != CVO_OK) return rc;
   if (is_approximate) {
+    const int rc = cvo_inner_product(ctx, params, source, target, T, ell, &fxfz);
+    if (rc != CVO_OK) return rc;
     fx_norm = (float)std::sqrt((double)source->n);
     fz_norm = (float)std::sqrt((double)target->n);
   } else {
-    float a = 0, b = 0;
-    rc = cvo_inner_product(ctx, params, source, source, identity, ell, &a);
+    // the three inner products of CvoGPU.cu:1829-1837 - <fx, fz>, <fx, fx>, <fz, fz> - as one three-pair batch: one chain
+    // of launches instead of three (each value is what its own call returns: a pair's sums do not depend on its company)
+    const cvo_cloud* src[3] = {source, source, target};
+    const cvo_cloud* tgt[3] = {target, source, target};
+    float Ts[48];
+    std::memcpy(Ts, T, sizeof(float) * 16);
+    std::memcpy(Ts + 16, identity, sizeof(float) * 16);
+    std::memcpy(Ts + 32, identity, sizeof(float) * 16);
+    double v[3] = {0, 0, 0};
+    const int rc = run_inner_products(ctx, params, 3, src, tgt, Ts, ell, v);
     if (rc != CVO_OK) return rc;
-    rc = cvo_inner_product(ctx, params, target, target, identity, ell, &b);
-    if (rc != CVO_OK) return rc;
-    fx_norm = std::sqrt(a);
-    fz_norm = std::sqrt(b);
+    fxfz = (float)v[0];
+    fx_norm = std::sqrt((float)v[1]);
+    fz_norm = std::sqrt((float)v[2]);
   }
   *out = fxfz / (fx_norm * fz_norm);
   return CVO_OK;

@@ -78,6 +78,34 @@ __device__ __forceinline__ bool flow_gate(const PairDesc* __restrict__ D, int nb
   return s_flow_last != 0;
 }
 
+// A_sum of a single evaluation (SparseKernelMat.cu:62-68; inner_product_gpu, CvoGPU.cu:1719-1778): the block of k_assoc
+// that stores its partial last adds the row blocks' sums of kernel values - in the order k_update's reduction uses (lane l
+// of sixteen takes blocks l, l + 16, ...; a four-step butterfly), so the value is the one that path returns - and posts
+// it to pinned host memory: the chain of an inner product ends with k_assoc.  Every thread of the first wave calls this.
+__device__ __forceinline__ void asum_gate(const PairDesc* __restrict__ D, int nblk) {
+  __shared__ int s_asum_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (see flow_gate)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int done = __hip_atomic_fetch_add(D->gate_flow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_asum_last = (done == nblk - 1) ? 1 : 0;
+    if (done == nblk - 1) __hip_atomic_store(D->gate_flow, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_asum_last) return;
+  double s = 0;
+  if (threadIdx.x < 16)
+    for (int b = (int)threadIdx.x; b < nblk; b += 16) s += ld_x<true>(D->flow_part + (size_t)b * 8 + 6);
+  s += dpp_f64<DPP_XOR1>(s);
+  s += dpp_f64<DPP_XOR2>(s);
+  s += dpp_f64<DPP_HALF_MIRROR>(s);
+  s += dpp_f64<DPP_MIRROR>(s);
+  if (threadIdx.x == 0) {
+    D->st->asum = s;
+    *D->asum_host = s;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Association phase: ordered association + flow, one thread per (sorted) source row, over the cached
 // candidate list.
@@ -362,6 +390,8 @@ __global__ __launch_bounds__(ASSOC_THREADS, GENERAL ? 1 : CVO_ASSOC_WAVES) void 
     const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && (lean & 3) == 1, st, 0);
     const bool last = flow_gate(D, nblk, nblk);
     if (last && threadIdx.x == 0 && clk0) D->st->clk_last_assoc = pair_clock_ticks(clk0);  // added up by the update
+  } else if (lean & 8) {  // single evaluation that only wants A_sum (inner_product_gpu)
+    asum_gate(D, nblk);
   }
   if (INSTR && P.phase_ticks && threadIdx.x == 0) {
     g_phase_ticks[0][blockIdx.x & 8191][0] = tt0;

@@ -23,6 +23,47 @@ constexpr int LIST_THREADS = 256;
 #endif
 constexpr int LIST_RB = CVO_LIST_RB;  // candidates ranked per sweep of a row's list in k_list (2 / 4 / 8 / 16: 59.7 / 59.5 / 59.1 / 59.5 ms per step)
 
+// A row's candidates in ascending ORIGINAL target index, 16-bit positions: NN keys (original index << 16 | sorted position)
+// in REGISTERS - every index below is a compile-time constant once the loops are unrolled -, sorted by a bitonic network of
+// v_min_u32 / v_max_u32 pairs (NN = 8 / 16 / 32 / 64: 24 / 80 / 240 / 672 compare-exchanges) and written to their
+// slots.  The rank sort this replaces cost cnt^2 compares and cnt^2 / LIST_RB LDS reads per row plus a second dependent
+// gather (position -> index -> position) per candidate: the longest row of a wave decided k_list's time, and k_list a
+// fifth of the first iterations of a batch.  The keys of a row are distinct: any correct sort leaves the same list.
+template <int NN>
+__device__ __forceinline__ void sort_network(unsigned (&v)[NN]) {
+#pragma unroll
+  for (int k = 2; k <= NN; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < NN; i++) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned a = v[i], b = v[l];
+          const unsigned lo = min(a, b), hi = max(a, b);
+          const bool asc = (i & k) == 0;
+          v[i] = asc ? lo : hi;
+          v[l] = asc ? hi : lo;
+        }
+      }
+    }
+  }
+}
+template <int NN>
+__device__ __forceinline__ void sort_and_store_list(const unsigned short* list, const int cnt, const int* __restrict__ yorder,
+                                                    unsigned short* __restrict__ out, const int N, const int pos) {
+  unsigned v[NN];
+#pragma unroll
+  for (int k = 0; k < NN; k++) {  // all gathers of the row are in flight together
+    const unsigned p = list[k];   // (slots >= cnt hold leftovers of earlier rows: valid LDS, masked below)
+    v[k] = k < cnt ? (((unsigned)yorder[k < cnt ? p : 0u] << 16) | p) : 0xffffffffu;
+  }
+  sort_network<NN>(v);
+#pragma unroll
+  for (int k = 0; k < NN; k++)
+    if (k < cnt) out[(size_t)k * N + pos] = (unsigned short)(v[k] & 0xffffu);
+}
+
 template <typename IdxT, int ASSOC_CAP>
 __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restrict__ descs,
                                                         const DevParams* __restrict__ Pp,
@@ -111,6 +152,7 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
   const int rr = w0row + (s_row[tid] & 0xff);
   const int cnt_all = s_row[tid] >> 8;
   IdxT* list = s_list + tid * ASSOC_STRIDE;
+  int cnt = 0;  // candidates this thread lists (0: a pad position, or a row for k_assoc_dense)
   if (rr < N) {  // real rows occupy the positions below N
     const int* yorder = D->yorder;
     D->cand_cnt[pos] = cnt_all;
@@ -129,7 +171,29 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
       // which k_assoc_dense's waves accumulate their rows never depends on the arrival order of atomics.
     } else {
       const unsigned* rb = D->rowbits + (size_t)rr * rbw;
-      int cnt = 0;  // sorted-space positions of the candidates (the mask words come from L1/L2 this time)
+      // sorted-space positions of the candidates (the mask words come from L1/L2 this time)
+      // The slices the row has candidates in (its rowbits) and their mask words: up to WQ words are requested together and
+      // decoded when they have arrived - one round trip per batch instead of one per slice on every thread's serial chain
+      // (a row of the slab touches 1-4 slices, a clustered one a dozen).
+      constexpr int WQ = 8;  // (T = 1, 2, 4 or 8 words per slice: a slice's words always fit the rest of a batch)
+      int ch_q[WQ];
+      int nq = 0;
+      auto flush = [&]() {
+        unsigned long long mq[WQ];
+#pragma unroll
+        for (int u = 0; u < WQ; u++) mq[u] = u < nq ? D->masks[((size_t)(ch_q[u] / T) * N + rr) * T + (ch_q[u] % T)] : 0ull;
+#pragma unroll
+        for (int u = 0; u < WQ; u++) {
+          unsigned long long m = mq[u];  // (0 beyond nq)
+          const int chunk = ch_q[u];
+          while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            list[cnt++] = (IdxT)(chunk * 64 + b);
+          }
+        }
+        nq = 0;
+      };
       for (int w0 = 0; w0 < rbw; w0 += 4) {
         const uint4 bits4 = *reinterpret_cast<const uint4*>(rb + w0);
         if ((bits4.x | bits4.y | bits4.z | bits4.w) == 0) continue;
@@ -140,20 +204,41 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
           while (f) {
             const int sl = (w0 + q) * 32 + __builtin_ctz(f);
             f &= f - 1;
-            const unsigned long long* mw = D->masks + ((size_t)sl * N + rr) * T;
+            if (nq + T > WQ) flush();
             for (int t = 0; t < T; t++) {
-              unsigned long long m = mw[t];
-              const int chunk = sl * T + t;
-              while (m) {
-                const int b = __builtin_ctzll(m);
-                m &= m - 1;
-                list[cnt++] = (IdxT)(chunk * 64 + b);
-              }
+#pragma unroll
+              for (int u = 0; u < WQ; u++)
+                if (u == nq) ch_q[u] = sl * T + t;  // (no run-time index into a register array)
+              nq++;
             }
           }
         }
       }
-      // original indices: independent gathers, four in flight
+      if (nq > 0) flush();
+    }
+  }
+  if constexpr (sizeof(IdxT) == 2) {
+    // ---- ascending original j (the order of the reference's first-K truncation and float accumulation), the list entry
+    // being the target's sorted position: a sorting network in registers, sized by the longest row of the wave (uniform)
+    const unsigned wmax = wave_max_u32((unsigned)cnt);
+    const int* __restrict__ yorder = D->yorder;
+    unsigned short* __restrict__ out = reinterpret_cast<unsigned short*>(D->cand_j);
+    const unsigned short* l16 = reinterpret_cast<const unsigned short*>(list);
+    if (wmax == 0u) {
+    } else if (wmax <= 8u) {
+      sort_and_store_list<8>(l16, cnt, yorder, out, N, pos);
+    } else if (wmax <= 16u) {
+      sort_and_store_list<16>(l16, cnt, yorder, out, N, pos);
+    } else if (wmax <= 32u) {
+      sort_and_store_list<32>(l16, cnt, yorder, out, N, pos);
+    } else {
+      sort_and_store_list<64>(l16, cnt, yorder, out, N, pos);
+    }
+  } else if (cnt > 0) {
+    {
+      {
+        const int* yorder = D->yorder;
+      // 32-bit positions (M >= 65536): rank sort.  Original indices first: independent gathers, LIST_RB in flight
       for (int k0 = 0; k0 < cnt; k0 += LIST_RB) {
         int jj[LIST_RB];
 #pragma unroll
@@ -190,6 +275,7 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
 #pragma unroll
         for (int u = 0; u < LIST_RB; u++)
           if (k0 + u < cnt) out[(size_t)rank[u] * N + pos] = (IdxT)entry[u];
+      }
       }
     }
   }
