@@ -21,11 +21,11 @@ import time
 
 import numpy as np
 
-# Per-pair kernel durations inside the timed loop (roofline.avg_launch_ms) come from the instrumented instantiation of the
-# per-iteration kernels (cvo_align_opts_t.kernel_clock); it costs ~3 % of a step, so only the LAST timed step runs it -
-# the other steps run the production kernels.  CVO_KERNEL_CLOCK=0 in the environment switches the instrumented step off
-# (the variable itself is cleared: set, it would instrument every call).
-CLOCK_LAST_STEP = os.environ.pop("CVO_KERNEL_CLOCK", "1") != "0"
+# Per-pair kernel durations inside the loop (roofline.avg_launch_ms) come from the instrumented instantiation of the
+# per-iteration kernels (cvo_align_opts_t.kernel_clock, ~3 % slower): ONE EXTRA step AFTER the timed region runs it - every
+# timed step runs the production kernels.  CVO_KERNEL_CLOCK=0 in the environment switches the instrumented step off (the
+# variable itself is cleared: set, it would instrument every call).
+CLOCK_EXTRA_STEP = os.environ.pop("CVO_KERNEL_CLOCK", "1") != "0"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=0, help="0 = one whole align() on the CPU (about 3 s)")
     ap.add_argument("--no-single-pair", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the PCIe-inclusive pipeline leg")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the early-phase, 20k, colour / semantic batch and batch-queue legs (they run after the timed region)")
     args = ap.parse_args()
 
     import torch
@@ -166,17 +168,18 @@ def main():
     # middle of a step costs ~35 ms of pure interpreter time.  Collect now and park what exists.
     gc.collect()
     gc.freeze()
-    if CLOCK_LAST_STEP:
-        step(clocked=True)  # untimed, in front of the warm-up: captures the graphs of the instrumented kernels
     for _ in range(args.warmup):
         step()
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        res, poses, stat = step(clocked=CLOCK_LAST_STEP and k == args.steps - 1)
+        res, poses, stat = step()
     fence()
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, dev)
+    if CLOCK_EXTRA_STEP:  # outside the timed region: the instrumented kernels (device clock per launch)
+        step(clocked=True)
+        step(clocked=True)
     iters = [r.iterations for r in res]
     loop_s = res[0].seconds
 
@@ -193,7 +196,7 @@ def main():
         # cached candidate lists) and k_coeff (pass 2: K4+K5, plus the scalar update in its last block); k_scan only
         # runs when a pair's candidate list has expired.  k_coeff holds the largest share of GPU time.
         tiles, rpt, tpt = gpu.debug_scan_stats()        # over the last measured step (all pairs, all list builds)
-        # Durations of the two per-iteration kernels INSIDE the timed loop (last measured step): every block reports its
+        # Durations of the two per-iteration kernels inside the loop (the instrumented step after the timed region): every block reports its
         # entry on the device's constant-rate counter, the block that finishes a pair's work closes the interval
         # (CVO_KERNEL_CLOCK, rate calibrated against HIP events) - first block in to last block out, per pair and launch,
         # i.e. what rocprofv3 --kernel-trace --stats averages for the same launches.  The launches sit inside hipGraphs,
@@ -223,6 +226,8 @@ def main():
         # were measured on, and is only reported while that hash matches the library that runs here (else null).
         traffic, traffic_note = {}, "profiles/kernel_traffic.json missing"
         valu_insts_per_step = None
+        valu_f64_per_step = None
+        trace_avg_us = {}
         tpath = os.path.join(ROOT, "profiles", "kernel_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -237,24 +242,35 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch", {})
                     traffic_note = tj.get("source", "")
                     valu_insts_per_step = tj.get("valu_wave_insts_per_step")
+                    valu_f64_per_step = tj.get("valu_f64_wave_insts_per_step")
+                    trace_avg_us = tj.get("trace_avg_launch_us", {})
             except Exception as e:  # noqa: BLE001
                 traffic_note = f"unreadable: {e}"
         if not traffic:
             log(f"[bench] roofline.traffic = null ({traffic_note})")
 
         def kernel_entry(name, ms, share, alone_ms=None):
-            gbs = bytes_pass / (ms * 1e-3) / 1e9
+            # `achieved` is priced with the LONGER of the two in-loop durations we have for the kernel: the device clock of
+            # this run (first block in -> last block out) and, while its kernel-source hash matches, the average of the
+            # rocprofv3 kernel trace of the same command (profiles/<round>/bench_kernel_stats.csv; it includes dispatch and
+            # end-of-kernel release, ~1 us more per launch)
+            tr = trace_avg_us.get(name.split("::")[-1])
+            priced = max(ms, tr * 1e-3) if tr else ms
+            gbs = bytes_pass / (priced * 1e-3) / 1e9
             e = {"kernel": name, "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6),
-                 "avg_launch_ms": round(ms, 5), "launches_per_iteration_and_subbatch": share,
+                 "avg_launch_ms": round(priced, 5), "device_clock_avg_launch_ms": round(ms, 5),
+                 "rocprof_trace_avg_launch_ms": round(tr * 1e-3, 5) if tr else None,
+                 "launches_per_iteration_and_subbatch": share,
                  "traffic": traffic.get(name.split("::")[-1])}
             if alone_ms is not None:
                 e["alone_on_gpu_launch_ms"] = round(alone_ms, 5)
             return e
 
-        # the dominant kernel is whichever of the two per-iteration kernels measures longer inside the loop
+        # the dominant kernel: the one the rocprofv3 trace has longer (when the committed trace belongs to these kernel
+        # sources), else the one this run's device clock has longer
         ent_coeff = kernel_entry("cvo_dev::k_coeff", coeff_ms, 1.0, coeff_alone_ms)
         ent_assoc = kernel_entry("cvo_dev::k_assoc", assoc_ms, 1.0, assoc_alone_ms)
-        dom, other = (ent_coeff, ent_assoc) if coeff_ms >= assoc_ms else (ent_assoc, ent_coeff)
+        dom, other = (ent_coeff, ent_assoc) if ent_coeff["avg_launch_ms"] >= ent_assoc["avg_launch_ms"] else (ent_assoc, ent_coeff)
         # memory-side traffic of a whole step from the PMC bytes per launch: every iteration of every sub-batch launches
         # both kernels once (rebuild kernels: 2 % of the iterations, not counted)
         step_traffic_gbs = None
@@ -265,10 +281,19 @@ def main():
             "kernel": dom["kernel"], "bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_note,
             "algorithmic_bytes_per_launch": bytes_pass, "avg_launch_ms": dom["avg_launch_ms"],
+            "device_clock_avg_launch_ms": dom["device_clock_avg_launch_ms"],
+            "rocprof_trace_avg_launch_ms": dom["rocprof_trace_avg_launch_ms"],
             "alone_on_gpu_launch_ms": dom["alone_on_gpu_launch_ms"], "launches_clocked": int(clocked),
-            "avg_launch_source": ("device clock, every launch of the LAST timed step (instrumented instantiation of the "
-                                  "kernels, ~3 % slower; the other timed steps run the production kernels)" if clocked
+            "avg_launch_source": (("the longer of: device clock over every launch of one instrumented step run AFTER the timed "
+                                   "region (first block in -> last block out; all timed steps run the production kernels), and "
+                                   "the rocprofv3 --kernel-trace average of the same command committed under profiles/ "
+                                   "(kernel-source hash checked)") if clocked
                                   else "HIP events around replayed launches, alone on the GPU"),
+            # what binds, as measured (profiles/r5/ell8_experiment.txt): the 64-pair step is four chains of dependent launches
+            # whose kernels wait on memory - 16 extra bytes per row cost 3 % although they saved 35 VALU instructions per row,
+            # halving the ELL stream gains 3 % only at 128 pairs in flight.  "hbm" is the closer of the two roofs this field
+            # can name; the honest description is "memory-side latency and bytes, far from either roof".
+            "binds": "memory-side latency and bytes per dependent launch (measured: profiles/r5/ell8_experiment.txt), not VALU issue",
             "pairs_per_launch": ppl, "sub_batches": n_groups, "timed_at_iteration": mid_iters,
             "step_traffic_gbs": step_traffic_gbs,
             "other_kernels": [other, kernel_entry("cvo_dev::k_scan", scan_ms, round(builds / max(iters_total, 1), 5))],
@@ -281,7 +306,11 @@ def main():
             # almost all of the 2 N M algorithmic pair tests: `executed_fraction_of_pair_tests` is the share really run.
             "valu": {"valu_issue_utilisation": (round(valu_insts_per_step * 4.0 / (N_SIMD * SHADER_CLOCK_HZ * (elapsed / args.steps)), 4)
                                                 if valu_insts_per_step else None),
-                     "valu_wave_insts_per_step": valu_insts_per_step,
+                     # ... with FP64 instructions (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64) counted at their half rate: 8 cycles
+                     "valu_issue_utilisation_fp64_weighted": (
+                         round((valu_insts_per_step + valu_f64_per_step) * 4.0 / (N_SIMD * SHADER_CLOCK_HZ * (elapsed / args.steps)), 4)
+                         if valu_insts_per_step and valu_f64_per_step else None),
+                     "valu_wave_insts_per_step": valu_insts_per_step, "valu_f64_wave_insts_per_step": valu_f64_per_step,
                      "simds": N_SIMD, "clock_hz": SHADER_CLOCK_HZ,
                      "algorithmic_pair_tests_per_s": pair_rate,
                      "executed_fraction_of_pair_tests": round(executed_frac, 6),
@@ -404,6 +433,112 @@ def main():
                 da.free()
                 db.free()
                 gq.close()
+        # ---- the first 256 iterations of the headline batch (a third of the step: rows have ~13 candidates there, ~3 later)
+        early_phase = None
+        extra = world == 1 and args.max_iterations <= 0 and not args.no_extra_legs
+        if extra:
+            gpu.align_batch(src, tgt, inits, max_iterations=256)
+            t_e = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                gpu.align_batch(src, tgt, inits, max_iterations=256)
+                t_e.append(time.perf_counter() - t1)
+            early_phase = {"iterations": 256, "ms": round(min(t_e) * 1e3, 3), "share_of_step": round(min(t_e) / (elapsed / args.steps), 3)}
+            log(f"[bench] first 256 iterations of the batch: {min(t_e)*1e3:.2f} ms ({100*min(t_e)/(elapsed/args.steps):.0f}% of a step)")
+
+        def timed_batch(g, s_, t_, i_, reps=2, **kw3):
+            g.align_batch(s_, t_, i_, **kw3)
+            best_t, best_r = None, None
+            for _ in range(reps):
+                t1 = time.perf_counter()
+                r_ = g.align_batch(s_, t_, i_, **kw3)
+                dt_ = time.perf_counter() - t1
+                if best_t is None or dt_ < best_t:
+                    best_t, best_r = dt_, r_
+            return best_t, best_r
+
+        # ---- north_star: "synthetic N = 5k-20k clouds": the 20k x 20k shape, one pair in flight and a 16-pair batch
+        shapes_20k = None
+        if extra:
+            p20 = [cases.config2(n=20000, pair_id=p) for p in range(16)]
+            g20 = CvoGPU(params=P, device=local_rank)
+            c20 = g20.upload_many([q[1] for q in p20] + [q[2] for q in p20], threads=n_threads)
+            g20.align(c20[0], c20[16], p20[0][3], max_iterations=50)
+            r1 = min((g20.align(c20[0], c20[16], p20[0][3]) for _ in range(2)), key=lambda r_: r_.seconds)
+            tb, rb = timed_batch(g20, c20[:16], c20[16:], [q[3] for q in p20])
+            shapes_20k = {"single_pair": {"iterations": r1.iterations, "align_ms": round(r1.seconds * 1e3, 3),
+                                          "ms_per_iter": round(r1.seconds * 1e3 / max(r1.iterations, 1), 6)},
+                          "batch_of_16": {"ms": round(tb * 1e3, 3), "align_per_s": round(16 / tb, 2),
+                                          "iterations": int(np.mean([r_.iterations for r_ in rb])),
+                                          "equals_single_pair": bool(np.array_equal(rb[0].transform, r1.transform))}}
+            log(f"[bench] 20k x 20k: one pair {r1.seconds*1e3:.1f} ms ({r1.seconds*1e6/max(r1.iterations,1):.1f} us/iteration), "
+                f"16-pair batch {tb*1e3:.1f} ms = {16/tb:.1f} align/s")
+            for h in c20:
+                h.free()
+            g20.close()
+
+        # ---- colour / semantic batches: 64 x config 3 and 64 x config 4 (BASELINE.json configs[2], [3] as batches), align/s,
+        # one sample of each checked against the CPU oracle
+        def feature_batch(builder, label):
+            prs = [builder(n=10000, pair_id=p) for p in range(B)]
+            gf = CvoGPU(params=prs[0][0], device=local_rank)
+            cl = gf.upload_many([q[1] for q in prs] + [q[2] for q in prs], threads=n_threads)
+            tb, rb = timed_batch(gf, cl[:B], cl[B:], [q[3] for q in prs])
+            its = [r_.iterations for r_ in rb]
+            ent = {"pairs": B, "ms": round(tb * 1e3, 3), "align_per_s": round(B / tb, 2), "mean_iterations": float(np.mean(its)),
+                   "us_per_pair_iteration": round(tb * 1e6 / max(sum(its), 1), 4)}
+            if not args.no_cpu_baseline:
+                from oracle import pyoracle as po
+                po.set_num_threads(n_threads)
+                o_ = po.align(po.params_from(prs[0][0]), po.Cloud.from_pointcloud(prs[0][1]), po.Cloud.from_pointcloud(prs[0][2]),
+                              prs[0][3], max_iterations=300)
+                g_ = gf.align(cl[0], cl[B], prs[0][3], max_iterations=300)
+                ent["sample_parity_max_abs_at_300_iterations"] = float(np.max(np.abs(g_.transform - o_["transform"])))
+                ent["sample_iterations"] = [int(g_.iterations), int(o_["iterations"])]
+            log(f"[bench] batch of {B} x {label}: {tb*1e3:.1f} ms = {B/tb:.1f} align/s ({np.mean(its):.0f} iterations each)")
+            for h in cl:
+                h.free()
+            gf.close()
+            return ent
+
+        batch_colour = feature_batch(cases.config3, "config 3 (10k x 10k + colour)") if extra else None
+        batch_semantic = feature_batch(cases.config4, "config 4 (10k x 10k + colour + one-hot semantics, warm start)") if extra else None
+
+        # ---- batch queue (cvo_batch_open / _submit / _poll): the 8-GPU headline's whole work list - 512 pairs - on ONE GPU
+        # through 128 in-flight slots, and a mixed queue (three pairs in four stop after 300 iterations, like warm-started
+        # tracking frames, the fourth runs its 2000) against the cost-weighted ideal of uniform fixed batches
+        batch_queue = None
+        if extra:
+            def run_queue(slots, limits):
+                q_ = gpu.open_queue(slots, n, n)
+                t1 = time.perf_counter()
+                for k_, lim_ in enumerate(limits):
+                    q_.submit(src[k_ % B], tgt[k_ % B], inits[k_ % B], lim_)
+                got = []
+                while q_.pending():
+                    got.extend(q_.poll(wait=2))
+                dt_ = time.perf_counter() - t1
+                st_ = q_.stats()
+                q_.close()
+                return dt_, got, st_
+            run_queue(128, [0] * 128)  # graphs of the queue's sub-batch geometry
+            tq, gq_, sq_ = run_queue(128, [0] * 512)
+            same = all(np.array_equal(r_.transform, res[k_ % B].transform) and r_.iterations == res[k_ % B].iterations for k_, r_ in enumerate(gq_))
+            t300, _ = timed_batch(gpu, src, tgt, inits, max_iterations=300)
+            limits = [0 if k_ % 4 == 0 else 300 for k_ in range(256)]
+            tm, gm_, sm_ = run_queue(128, limits)
+            ideal = (64 * (elapsed / args.steps) + 192 * t300) / B     # uniform batches of 64 of either kind, back to back
+            batch_queue = {"uniform_512_pairs_128_slots": {"ms": round(tq * 1e3, 2), "align_per_s": round(512 / tq, 1),
+                                                           "bit_identical_to_fixed_batch": bool(same), **sq_},
+                           "mixed_256_pairs_128_slots": {"ms": round(tm * 1e3, 2), "short_iterations": 300, "long_iterations": int(mean_iters),
+                                                         "ideal_ms_uniform_batches_of_64": round(ideal * 1e3, 2),
+                                                         "fraction_of_cost_weighted_ideal": round(ideal / tm, 3),
+                                                         "fraction_of_iteration_weighted_ideal": round(
+                                                             (sum(r_.iterations for r_ in gm_) / tm) / (B * mean_iters / (elapsed / args.steps)), 3),
+                                                         **sm_}}
+            log(f"[bench] batch queue: 512 pairs through 128 slots {tq*1e3:.1f} ms = {512/tq:.1f} align/s (poses "
+                f"{'identical' if same else 'DIFFERENT'}); mixed 300 / {mean_iters:.0f}-iteration queue {tm*1e3:.1f} ms = "
+                f"{ideal/tm:.2f} of the cost-weighted ideal")
         upload_ms_per_cloud = t_h2d * 1e3 / max(2 * len(host_clouds), 1)
         # PCIe-inclusive, as a frame pipeline runs it: while the GPU solves batch k the host threads order and upload
         # batch k + 1 (cvo_cloud_upload_many on its own streams); every step pays for fresh inputs, the timed region
@@ -444,7 +579,7 @@ def main():
         out = {
             "metric": "frame-pair align()/sec, 10k x 10k geometric clouds", "value": value, "unit": "align/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "ms_per_iter": ms_per_iter_pair, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_pair_iteration_amortised": ms_per_iter_pair, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[4] shape: {B} independent {n}x{n} xyz-only frame pairs per GPU "
                                    f"(seeds 1000+p / 2000+p), cvo_geometric_params_gpu.yaml, identity init, "
@@ -453,14 +588,14 @@ def main():
                        "parallelism": (f"pairs sharded {B}/GPU over {world} GPU(s); one RCCL all-gather of poses per step "
                                        f"(process group of {world} rank(s))" if use_dist else
                                        f"{B} pairs on 1 GPU; NO collective ran (the one-rank process group failed to initialise)"),
-                       "timed_steps": (f"{args.steps} steps; the LAST one runs the instrumented instantiation of the per-iteration "
-                                       "kernels (device clock per launch, ~3 % slower), the others the production kernels"
-                                       if CLOCK_LAST_STEP else f"{args.steps} steps, production kernels"),
+                       "timed_steps": f"{args.steps} steps, production kernels (the instrumented step behind roofline.avg_launch_ms runs after the timed region)",
                        "host_threads_per_rank": n_threads,
                        "hardware_queues": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES") or _getenv_c("GPU_MAX_HW_QUEUES"),
                                            "advice": gpu.advice()}},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "single_pair": single_pair,
             "overlap_queries": overlap_queries, "pcie_inclusive": pcie_inclusive,
+            "early_phase": early_phase, "shapes_20k": shapes_20k, "batch_colour": batch_colour, "batch_semantic": batch_semantic,
+            "batch_queue": batch_queue,
         }
         h2d_rate = (2 * n * 16 * 1.0) * B / max(t_h2d, 1e-9) / 1e9
         log(f"[bench] inputs: generated in {t_gen:.2f}s, uploaded in {t_h2d:.3f}s ({h2d_rate:.2f} GB/s incl. host-side k-d ordering on {n_threads} threads); "

@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-rnd = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r4"
+rnd = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r5"
 src = os.path.join(ROOT, "gpurun_out", rnd + "_prof") + "/"
 dst = os.path.join(ROOT, "profiles", rnd) + "/"
 KT = os.path.join(ROOT, "profiles", "kernel_traffic.json")
@@ -31,7 +31,20 @@ if "--traffic" in sys.argv:
     # every launch (early-exit launches included)
     valu_total = int(sum(v["SQ_INSTS_VALU"]["launches"] * v["SQ_INSTS_VALU"]["avg_per_launch"] for k, v in raw.items()
                          if "SQ_INSTS_VALU" in v and "k_hold" not in k))
-    kt = {"points": 10000, "pairs": 16, "valu_wave_insts_per_step": valu_total,
+    # FP64 VALU instructions (half rate: 8 cycles per wave instruction)
+    f64_total = int(sum(v[c]["launches"] * v[c]["avg_per_launch"] for k, v in raw.items() if "k_hold" not in k
+                        for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64") if c in v))
+    # per-kernel averages of the rocprofv3 kernel trace of the bench command (production kernels of the timed steps)
+    trace = {}
+    if os.path.exists(src + "bench_kernel_stats.csv"):
+        for row in csv.DictReader(open(src + "bench_kernel_stats.csv")):
+            nm = row["Name"]
+            for key, pat in (("k_assoc", "cvo_dev::k_assoc<"), ("k_coeff", "cvo_dev::k_coeff<false>"), ("k_scan", "cvo_dev::k_scan<"),
+                             ("k_list", "cvo_dev::k_list<"), ("k_prep", "cvo_dev::k_prep")):
+                if pat in nm and key not in trace and "true>" not in nm.split("(")[0][-8:]:
+                    trace[key] = round(float(row["AverageNs"]) / 1e3, 3)
+    kt = {"points": 10000, "pairs": 16, "valu_wave_insts_per_step": valu_total, "valu_f64_wave_insts_per_step": f64_total or None,
+          "trace_avg_launch_us": trace,
           "valu_wave_insts_per_launch": {k.replace("cvo_dev::", "").split("<")[0]: int(v["SQ_INSTS_VALU"]["avg_per_launch"])
                                          for k, v in raw.items() if "SQ_INSTS_VALU" in v and "k_hold" not in k},
           "hbm_bytes_per_launch": {"k_coeff": hbm("cvo_dev::k_coeff"), "k_assoc": hbm("cvo_dev::k_assoc<"), "k_scan": hbm("cvo_dev::k_scan<")},

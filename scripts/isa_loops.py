@@ -20,8 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from unified_cvo_amd import build as B  # noqa: E402
 
-DEFAULT = ["k_assoc<unsigned short, 64, false, false>", "k_coeff<false>", "k_list<unsigned short, 64>", "k_scan<2>",
-           "k_prep", "k_assoc<unsigned short, 64, true, false>"]
+DEFAULT = ["k_assoc<unsigned short, 64, 0, false>", "k_coeff<false>", "k_list<unsigned short, 64>", "k_scan<2>",
+           "k_prep", "k_assoc<unsigned short, 64, 2, false>", "k_assoc<unsigned short, 64, 3, false>"]
 
 
 def classify(m):

@@ -463,6 +463,35 @@ def test_lean_graph_waits_do_not_change_results(monkeypatch):
     assert np.array_equal(a.transform, c.transform)
 
 
+def test_one_hot_semantics_equal_the_general_kernel_bit_for_bit():
+    """Config 4's class rows are exact one-hot rows: the upload finds that out and the association kernels compare 4-byte
+    class ids (squared class distance 0 or exactly 2, the semantic kernel one of two constants: FEAT_HOT) instead of
+    streaming two 80-byte rows per surviving pair (CvoGPU.cu:563-569).  Same bits as the general kernel (NO_ONEHOT), in
+    the loop, in the inner product and in the exported matrix; a soft row anywhere sends the call down the general path."""
+    P, a, b, init = cases.config4(n=4000)
+    gpu = CvoGPU(params=P)
+    da, db = gpu.upload(a), gpu.upload(b)
+    hot = gpu.align(da, db, init, max_iterations=120)
+    ip_hot = gpu.inner_product_gpu(da, db, init, 0.25)
+    A_hot = gpu.compute_association_gpu(da, db, init, 0.25)
+    gpu.set_option("NO_ONEHOT", "1")
+    gen = gpu.align(da, db, init, max_iterations=120)
+    assert hot.iterations == gen.iterations == 120 and np.array_equal(hot.transform, gen.transform)
+    assert (hot.final_ell, hot.final_num_neighbors) == (gen.final_ell, gen.final_num_neighbors)
+    assert ip_hot == gpu.inner_product_gpu(da, db, init, 0.25)
+    A_gen = gpu.compute_association_gpu(da, db, init, 0.25)
+    assert all(np.array_equal(x, y) for x, y in zip(A_hot, A_gen)) and len(A_hot[1]) > 1000
+    gpu.set_option("NO_ONEHOT", None)
+    # one soft row in the target: no class ids for that cloud, the general kernel runs by itself
+    lab = np.array(b.labels(), np.float32).copy()
+    lab[7] = 0.0
+    lab[7, :2] = 0.5
+    b2 = type(b).from_arrays(np.array(b.positions()), np.array(b.features()), lab, np.array(b.geometric_types()).reshape(-1, 2))
+    soft = gpu.align(da, gpu.upload(b2), init, max_iterations=120)
+    assert soft.iterations == 120 and not np.array_equal(soft.transform, hot.transform)
+    assert cases.max_abs_diff(soft.transform, hot.transform) < 1e-3
+
+
 def test_context_options_are_validated():
     gpu = CvoGPU(params=CvoParams())
     gpu.set_option("CVO_VERBOSE", None)      # with or without the prefix; None clears

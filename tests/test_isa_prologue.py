@@ -44,8 +44,10 @@ def _scalar_rounds_before_first_exit(lines, span):
     return loads, waits
 
 
-@pytest.mark.parametrize("kernel,max_waits", [("k_assoc<unsigned short, 64, false, false>", 1),
-                                              ("k_assoc<unsigned short, 64, true, false>", 1),
+@pytest.mark.parametrize("kernel,max_waits", [("k_assoc<unsigned short, 64, 0, false>", 1),   # FEAT_GEO
+                                              ("k_assoc<unsigned short, 64, 1, false>", 1),   # FEAT_ALL
+                                              ("k_assoc<unsigned short, 64, 2, false>", 1),   # FEAT_COL
+                                              ("k_assoc<unsigned short, 64, 3, false>", 1),   # FEAT_HOT
                                               # k_coeff sits at the SGPR limit (the 42 floats of the twist matrices live in
                                               # scalar registers through its row loop): the compiler pulls parameter loads of
                                               # the update into the burst and spills them to a VGPR, a wait each time.  Measured
@@ -62,6 +64,7 @@ def test_prologue_is_one_burst_of_scalar_loads(device_code, kernel, max_waits):
 
 def test_no_scratch_in_the_per_iteration_kernels(device_code):
     lines, ks = device_code
-    for kernel in ("k_assoc<unsigned short, 64, false, false>", "k_coeff<false>", "k_assoc_dense<false, 4>"):
+    for kernel in ("k_assoc<unsigned short, 64, 0, false>", "k_assoc<unsigned short, 64, 2, false>",
+                   "k_assoc<unsigned short, 64, 3, false>", "k_coeff<false>", "k_assoc_dense<0, 4>"):
         a, b = ks[kernel]
         assert not any(re.search(r"\bscratch_(load|store)", lines[i]) for i in range(a, b + 1)), kernel

@@ -227,6 +227,8 @@ struct PairDesc {
   const float4* ylabel;
   const float2* xgeo;
   const float2* ygeo;
+  const int* xlid;  // class ids of one-hot clouds, spatial order (FEAT_HOT launches only: every cloud of the call has them)
+  const int* ylid;
   // ---- rebuild kernels, update, exports ----
   int Mpad, nchunks, nslices, rbw;  // rbw: 32-bit words of slice bits per row
   int NG;     // row groups of ROWS_PER_GROUP sorted rows

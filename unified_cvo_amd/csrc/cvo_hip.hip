@@ -59,6 +59,8 @@ struct cvo_cloud {
   float4* feat = nullptr;   // 2 float4 per point      } in SPATIAL order (position r = point order[r]): the kernels
   float4* label = nullptr;  // 5 float4 per point      } index them by sorted position, like the coordinates they
   float2* geo = nullptr;    //                         } gather per candidate
+  int* lid = nullptr;       // class id per point, spatial order: only when EVERY label row is an exact one-hot (a single
+                            // 1.0f, the rest 0.0f) - the semantic kernel then needs 4 bytes per candidate, not 80
   // Attributes the caller did not supply are zeros (what the reference leaves in the default-constructed CvoPoint).
   // They are not uploaded: a zeroed slab is allocated the first time a call needs them (colour / semantic /
   // geometric-type kernels on a cloud without those arrays), see ensure_attributes.
@@ -101,7 +103,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static const char* const kOptionNames[] = {
     "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
     "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
-    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS", "ROW_MAX"};
+    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS", "ROW_MAX", "NO_ONEHOT"};
 
 struct cvo_ctx {
   int device = 0;
@@ -158,6 +160,7 @@ struct cvo_ctx {
   int last_Npad = 0;
   std::vector<int> last_xorder;  // pair 0's source order: sorted row -> original row
   int last_groups = 1;           // sub-batches (streams) of the last call
+  int last_feat = 0;             // FEAT_* of the last call's association kernels
   PairLayout last_layout{};
 };
 
@@ -482,31 +485,36 @@ struct ArenaArg {
 };
 
 // instr: the instantiation with time stamps (CVO_KERNEL_CLOCK / CVO_PHASE_TICKS); the production kernels have none
-template <typename IdxT, int CAP, bool GENERAL>
+template <typename IdxT, int CAP, int FEAT>
 void launch_assoc_t(hipStream_t s, bool instr, dim3 grid, const PairDesc* descs, const DevParams* dp, const PairState* st,
                     const ArenaArg& A, int packed) {
   const dim3 blk(ASSOC_THREADS);
   if (instr)
-    hipLaunchKernelGGL((k_assoc<IdxT, CAP, GENERAL, true>), grid, blk, 0, s, descs, dp, st, A.base, packed, A.stride256, A.Npad);
+    hipLaunchKernelGGL((k_assoc<IdxT, CAP, FEAT, true>), grid, blk, 0, s, descs, dp, st, A.base, packed, A.stride256, A.Npad);
   else
-    hipLaunchKernelGGL((k_assoc<IdxT, CAP, GENERAL, false>), grid, blk, 0, s, descs, dp, st, A.base, packed, A.stride256, A.Npad);
+    hipLaunchKernelGGL((k_assoc<IdxT, CAP, FEAT, false>), grid, blk, 0, s, descs, dp, st, A.base, packed, A.stride256, A.Npad);
 }
 
-void launch_assoc(hipStream_t s, bool idx16, bool general, bool instr, int nblk, int n_pairs, const PairDesc* descs,
+// feat: FEAT_GEO / FEAT_ALL / FEAT_COL / FEAT_HOT (cvo_pair_math.h), chosen per call by call_feat()
+void launch_assoc(hipStream_t s, bool idx16, int feat, bool instr, int nblk, int n_pairs, const PairDesc* descs,
                   const DevParams* dp, const PairState* st, const ArenaArg& A, int lean) {
   const dim3 grid = row_grid(nblk, n_pairs);
   const int packed = (lean & 0xf) | (nblk << 4) | (int)((unsigned)n_pairs << 20);  // (ensure_workspace bounds both)
-  if (idx16) {
-    if (general)
-      launch_assoc_t<unsigned short, ASSOC_CAP16, true>(s, instr, grid, descs, dp, st, A, packed);
-    else
-      launch_assoc_t<unsigned short, ASSOC_CAP16, false>(s, instr, grid, descs, dp, st, A, packed);
-  } else {
-    if (general)
-      launch_assoc_t<int, ASSOC_CAP32, true>(s, instr, grid, descs, dp, st, A, packed);
-    else
-      launch_assoc_t<int, ASSOC_CAP32, false>(s, instr, grid, descs, dp, st, A, packed);
+#define CVO_ASSOC_CASE(F)                                                                              \
+  case F:                                                                                              \
+    if (idx16)                                                                                         \
+      launch_assoc_t<unsigned short, ASSOC_CAP16, F>(s, instr, grid, descs, dp, st, A, packed);        \
+    else                                                                                               \
+      launch_assoc_t<int, ASSOC_CAP32, F>(s, instr, grid, descs, dp, st, A, packed);                   \
+    break;
+  switch (feat) {
+    CVO_ASSOC_CASE(FEAT_GEO)
+    CVO_ASSOC_CASE(FEAT_COL)
+    CVO_ASSOC_CASE(FEAT_HOT)
+    default:
+      CVO_ASSOC_CASE(FEAT_ALL)
   }
+#undef CVO_ASSOC_CASE
 }
 
 void launch_coeff(hipStream_t s, bool instr, int nblk, int split, int n_pairs, const PairDesc* descs, const DevParams* dp,
@@ -521,22 +529,33 @@ void launch_coeff(hipStream_t s, bool instr, int nblk, int split, int n_pairs, c
 }
 
 // CVO_VERIFY_LISTS: literal re-derivation of every row after the association of an iteration (k_verify)
-void launch_verify(hipStream_t s, bool general, int N, int n_pairs, const PairDesc* descs, const DevParams* dp, const int* st,
+void launch_verify(hipStream_t s, int feat, int N, int n_pairs, const PairDesc* descs, const DevParams* dp, const int* st,
                    int lean) {
   const dim3 grid((unsigned)std::min((N + 3) / 4, 2048), (unsigned)n_pairs);
-  if (general)
-    hipLaunchKernelGGL(k_verify<true>, grid, dim3(256), 0, s, descs, dp, st, lean);
+  // (the self-check always takes the general form of the semantic kernel: one-hot rows through the row arithmetic)
+  if (feat != FEAT_GEO)
+    hipLaunchKernelGGL(k_verify<FEAT_ALL>, grid, dim3(256), 0, s, descs, dp, st, lean);
   else
-    hipLaunchKernelGGL(k_verify<false>, grid, dim3(256), 0, s, descs, dp, st, lean);
+    hipLaunchKernelGGL(k_verify<FEAT_GEO>, grid, dim3(256), 0, s, descs, dp, st, lean);
 }
 
-void launch_dense(hipStream_t s, bool general, int N, int n_pairs, int dense_blocks, const PairDesc* descs, const DevParams* dp,
+void launch_dense(hipStream_t s, int feat, int N, int n_pairs, int dense_blocks, const PairDesc* descs, const DevParams* dp,
                   const int* st) {
   const dim3 grid(dense_blocks, n_pairs);
-  if (general)
-    hipLaunchKernelGGL((k_assoc_dense<true, 4>), grid, dim3(256), 0, s, descs, dp, st);  // (dense_waves_for)
-  else
-    hipLaunchKernelGGL((k_assoc_dense<false, 4>), grid, dim3(256), 0, s, descs, dp, st);
+  switch (feat) {  // (4 waves per block: dense_waves_for)
+    case FEAT_GEO: hipLaunchKernelGGL((k_assoc_dense<FEAT_GEO, 4>), grid, dim3(256), 0, s, descs, dp, st); break;
+    case FEAT_COL: hipLaunchKernelGGL((k_assoc_dense<FEAT_COL, 4>), grid, dim3(256), 0, s, descs, dp, st); break;
+    case FEAT_HOT: hipLaunchKernelGGL((k_assoc_dense<FEAT_HOT, 4>), grid, dim3(256), 0, s, descs, dp, st); break;
+    default: hipLaunchKernelGGL((k_assoc_dense<FEAT_ALL, 4>), grid, dim3(256), 0, s, descs, dp, st); break;
+  }
+}
+
+// which instantiation of the association kernels a call needs (FEAT_*, cvo_pair_math.h)
+inline int call_feat(const DevParams& dp, bool all_one_hot) {
+  if (dp.mode == 2) return FEAT_ALL;
+  if (!(dp.use_col || dp.use_sem || dp.use_geotype)) return FEAT_GEO;
+  if (!dp.use_sem) return FEAT_COL;
+  return all_one_hot ? FEAT_HOT : FEAT_ALL;
 }
 
 struct LaunchGeom {
@@ -545,7 +564,8 @@ struct LaunchGeom {
   int dense_blocks = DENSE_BLOCKS_MIN;  // k_assoc_dense grid x = PairDesc::dense_blocks of every pair of the launch
   int group = 0;        // sub-batch index (its stream)
   int horizon_cap = 1 << 20;  // the lean graph's period (DevParams::lean_U)
-  bool idx16, general, instr, verify;
+  bool idx16, instr, verify;
+  int feat = FEAT_GEO;  // which instantiation of the association kernels the call needs (call_feat)
   hipStream_t stream;
   ArenaArg arena;  // of pair p0
 };
@@ -574,10 +594,10 @@ void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags, bool den
   const int* st = c->d_status + 2 * g.p0;  // the sub-batch's status words (see setup_batch)
   const bool lean_dense = lean && dense;
   // rows beyond their cached lists first (a wave per row; per-row results), then every row's reduction in k_assoc
-  if (!lean || dense) launch_dense(g.stream, g.general, g.N, g.n_pairs, g.dense_blocks, descs, c->d_params, st);
-  launch_assoc(g.stream, g.idx16, g.general, g.instr, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena,
+  if (!lean || dense) launch_dense(g.stream, g.feat, g.N, g.n_pairs, g.dense_blocks, descs, c->d_params, st);
+  launch_assoc(g.stream, g.idx16, g.feat, g.instr, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena,
                (lean ? 1 : 0) | (lean_dense ? 4 : 0));
-  if (g.verify) launch_verify(g.stream, g.general, g.N, g.n_pairs, descs, c->d_params, st, (lean ? 1 : 0) | (lean_dense ? 4 : 0));
+  if (g.verify) launch_verify(g.stream, g.feat, g.N, g.n_pairs, descs, c->d_params, st, (lean ? 1 : 0) | (lean_dense ? 4 : 0));
   launch_coeff(g.stream, g.instr, g.nba, (lean && !dense) ? g.csplit : g.csplit_heavy, g.n_pairs, descs, c->d_params,
                c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0) | (lean_dense ? 32 : 0));
 }
@@ -667,6 +687,8 @@ void fill_pair(cvo_ctx* ctx, const BatchSetup* S, const cvo_params_t* params, co
     D.yfeat = Y->feat;
     D.ylabel = Y->label;
     D.ygeo = Y->geo;
+    D.xlid = X->lid;
+    D.ylid = Y->lid;
     D.yorder = Y->order;
     D.yinv = Y->inv;
     D.ycull = (float4*)(base + S->L.ycull);
@@ -909,12 +931,18 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.npb = S->d.Mpad / PREP_THREADS + (S->d.NGpad * ROWS_PER_GROUP + PREP_THREADS - 1) / PREP_THREADS;
   S->geom.idx16 = M < 65536;
   // (the non-isotropic kernel of mode 2 lives in the GENERAL instantiations only: single evaluations, never the loop)
-  S->geom.general = dp.use_col || dp.use_sem || dp.use_geotype || dp.mode == 2;
+  {
+    // every cloud of the call with exact one-hot class rows (ids made at upload): the semantic kernel by class id
+    bool all_hot = !qd && ctx_opt(ctx, "NO_ONEHOT") == nullptr;
+    for (int p = 0; p < n_pairs && all_hot; p++) all_hot = sources[p]->lid != nullptr && targets[p]->lid != nullptr;
+    S->geom.feat = call_feat(dp, all_hot);
+  }
   S->geom.instr = dp.kernel_clock || dp.phase_ticks;
   S->geom.verify = dp.verify_lists != 0;
   S->geom.horizon_cap = std::max(1, dp.lean_U);
   if (!qd) ctx->last_xorder = sources[0]->h_order;
   ctx->last_groups = S->G;
+  ctx->last_feat = S->geom.feat;
   ctx->last_pairs = n_pairs;
   ctx->last_N = N;
   ctx->last_M = M;
@@ -967,7 +995,7 @@ int run_inner_products(cvo_ctx* ctx, const cvo_params_t* params, int n, const cv
   key.nba = S.d.nblk_assoc;
   key.npb = g.npb + (g.dense_blocks << 20);
   key.idx16 = g.idx16 ? 1 : 0;
-  key.general = g.general ? 1 : 0;
+  key.general = g.feat;
   key.flags = (g.instr ? 1 : 0) | (99 << 24);
   key.arena = g.arena.base;
   key.stride256 = g.arena.stride256;
@@ -979,8 +1007,8 @@ int run_inner_products(cvo_ctx* ctx, const cvo_params_t* params, int n, const cv
     HIP_TRY(ctx, hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
     launch_init(ctx, g);
     launch_rebuild(ctx, g);
-    launch_dense(g.stream, g.general, g.N, g.n_pairs, g.dense_blocks, ctx->d_descs, ctx->d_params, ctx->d_status);
-    launch_assoc(g.stream, g.idx16, g.general, g.instr, g.nba, g.n_pairs, ctx->d_descs, ctx->d_params, ctx->d_states, g.arena, 8);
+    launch_dense(g.stream, g.feat, g.N, g.n_pairs, g.dense_blocks, ctx->d_descs, ctx->d_params, ctx->d_status);
+    launch_assoc(g.stream, g.idx16, g.feat, g.instr, g.nba, g.n_pairs, ctx->d_descs, ctx->d_params, ctx->d_states, g.arena, 8);
     const hipError_t e_launch = hipGetLastError();
     hipError_t e = hipStreamEndCapture(g.stream, &gr);
     if (e == hipSuccess && e_launch != hipSuccess) e = e_launch;
@@ -1323,6 +1351,28 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
   const char* ord = ctx_opt(ctx, "ORDER");
   const bool device_order = n >= 8 && n <= KD_MAX_POINTS && finite && ctx_opt(ctx, "NO_SORT") == nullptr &&
                             !(ord && (std::strcmp(ord, "host") == 0 || std::strcmp(ord, "virtual") == 0));
+  // one-hot class rows?  (exactly: the fast path replaces arithmetic on the rows by two constants)
+  std::vector<int> lid_host;
+  if (h.label && n > 0 && ctx_opt(ctx, "NO_ONEHOT") == nullptr) {
+    lid_host.resize((size_t)n);
+    bool onehot = true;
+    for (int i = 0; i < n && onehot; i++) {
+      const float* l = reinterpret_cast<const float*>(h.label + (size_t)i * h.label_stride);
+      int hot = -1, ones = 0;
+      for (int c = 0; c < NC; c++) {
+        if (l[c] == 1.0f) {
+          hot = c;
+          ones++;
+        } else if (!(l[c] == 0.0f)) {
+          ones = 2;  // (neither 0 nor 1: a soft distribution)
+        }
+      }
+      onehot = ones == 1;
+      lid_host[i] = hot;
+    }
+    if (!onehot) lid_host.clear();
+  }
+  const bool has_lid = !lid_host.empty();
   size_t off = 0;
   auto take = [&](size_t bytes) {
     const size_t o = off;
@@ -1333,11 +1383,12 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
   // the kernel writes the spatially ordered ones; host ordering: everything is staged in its final form)
   const size_t o_x4 = take(sizeof(float4) * nn);
   const size_t o_rawf = device_order && h.feat ? take(sizeof(float) * FD * nn) : 0, o_rawl = device_order && h.label ? take(sizeof(float) * NC * nn) : 0,
-               o_rawg = device_order && h.geo ? take(sizeof(float) * 2 * nn) : 0;
+               o_rawg = device_order && h.geo ? take(sizeof(float) * 2 * nn) : 0,
+               o_rawlid = device_order && has_lid ? take(sizeof(int) * nn) : 0;
   const size_t up_bytes_device = off;
   const size_t o_xs4 = take(sizeof(float4) * nn), o_order = take(sizeof(int) * nn), o_inv = take(sizeof(int) * nn);
   const size_t o_feat = h.feat ? take(sizeof(float4) * 2 * nn) : 0, o_label = h.label ? take(sizeof(float4) * 5 * nn) : 0,
-               o_geo = h.geo ? take(sizeof(float2) * nn) : 0;
+               o_geo = h.geo ? take(sizeof(float2) * nn) : 0, o_lid = has_lid ? take(sizeof(int) * nn) : 0;
   int NP = KD_THREADS;
   while (NP < n) NP *= 2;
   const size_t o_segpos = device_order ? take(sizeof(unsigned short) * (size_t)NP) : 0,
@@ -1379,6 +1430,7 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
       float* g = reinterpret_cast<float*>(&stage[o_rawg]);
       for (int i = 0; i < n; i++) std::memcpy(&g[2 * (size_t)i], h.geo + (size_t)i * h.geo_stride, sizeof(float) * 2);
     }
+    if (has_lid) std::memcpy(&stage[o_rawlid], lid_host.data(), sizeof(int) * (size_t)n);
   } else {
     std::vector<int> order;
     spatial_order(x4, n, order, ctx_opt(ctx, "NO_SORT") != nullptr, ord && std::strcmp(ord, "virtual") == 0);
@@ -1395,6 +1447,10 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
     if (h.geo) {
       float* g2 = reinterpret_cast<float*>(&stage[o_geo]);
       for (int r = 0; r < n; r++) std::memcpy(&g2[2 * (size_t)r], h.geo + (size_t)order[r] * h.geo_stride, sizeof(float) * 2);
+    }
+    if (has_lid) {
+      int* li = reinterpret_cast<int*>(&stage[o_lid]);
+      for (int r = 0; r < n; r++) li[r] = lid_host[(size_t)order[r]];
     }
     float* xs = reinterpret_cast<float*>(&stage[o_xs4]);
     for (int r = 0; r < n; r++) std::memcpy(&xs[4 * (size_t)r], &x4[4 * (size_t)order[r]], 16);
@@ -1418,6 +1474,7 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
   c->feat = h.feat ? (float4*)(c->slab + o_feat) : nullptr;
   c->label = h.label ? (float4*)(c->slab + o_label) : nullptr;
   c->geo = h.geo ? (float2*)(c->slab + o_geo) : nullptr;
+  c->lid = has_lid ? (int*)(c->slab + o_lid) : nullptr;
   if (n > 0) {
     e = hipMemcpyAsync(c->slab, stage.data(), up_bytes, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) {
@@ -1443,6 +1500,8 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
     J.label = c->label;
     J.raw_geo = h.geo ? (const float*)(c->slab + o_rawg) : nullptr;
     J.geo = c->geo;
+    J.raw_lid = has_lid ? (const int*)(c->slab + o_rawlid) : nullptr;
+    J.lid = c->lid;
     c->h_order.assign((size_t)n, 0);
   }
   return CVO_OK;
@@ -1643,6 +1702,7 @@ int cvo_cloud_transformed(cvo_ctx* ctx, const cvo_cloud* in, const float pose12[
   c->feat = (float4*)rebase(in->feat);
   c->label = (float4*)rebase(in->label);
   c->geo = (float2*)rebase(in->geo);
+  c->lid = (int*)rebase(in->lid);
   c->order = (int*)rebase(in->order);
   c->inv = (int*)rebase(in->inv);
   Pose12 P;
@@ -1712,7 +1772,7 @@ int ensure_graph(cvo_ctx* ctx, const BatchSetup& S, const LaunchGeom* geom, int 
   key.nbc = S.d.nblk_coeff * 64 + S.geom.csplit;
   key.npb = S.geom.npb + (S.geom.dense_blocks << 20);  // (npb < 2^20: Mpad / 256 + rows / 256)
   key.idx16 = S.geom.idx16 ? 1 : 0;
-  key.general = (S.geom.general ? 1 : 0) | (S.geom.csplit_heavy << 1);
+  key.general = S.geom.feat | (S.geom.csplit_heavy << 2);
   key.U = Uc * 256 + graph_lean_period(cfg, v, Uc) + (v == 3 ? 128 : 0);
   key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0) | (v << 24);
   key.arena = geom[g].arena.base;
@@ -2757,7 +2817,7 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
   const int n_pairs = ctx->last_pairs, G = ctx->last_groups;
   const bool idx16 = ctx->last_M < 65536;
   const DevParams& dp = ctx->last_params;
-  const bool general = dp.use_col || dp.use_sem || dp.use_geotype || dp.mode == 2;
+  const int general = ctx->last_feat;
   const bool instr = dp.kernel_clock || dp.phase_ticks;
   const int nba = (ctx->last_N + ASSOC_THREADS - 1) / ASSOC_THREADS;
   float out[2] = {0.f, 0.f};

@@ -184,7 +184,7 @@ struct AssocShared {
   unsigned long long cnt[ASSOC_THREADS / 64][4];
 };
 
-template <typename IdxT, int ASSOC_CAP, bool GENERAL, bool INSTR>
+template <typename IdxT, int ASSOC_CAP, int FEAT, bool INSTR>
 __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* __restrict__ D, const IterView& iv,
                                             AssocShared& S, const int bx, const AssocRowHead& head) {
   const int N = D->N;
@@ -192,7 +192,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
   const int K = iv.K;
   RowAcc A;
   A.slot = D->ell + pos;
-  A.stage = &S.stage[0][threadIdx.x];
+  A.stage = (CVO_LDS ell_vec_t*)&S.stage[0][threadIdx.x];
   unsigned overflowed = 0;
   unsigned long long tt1 = 0, tt2 = 0;
   if (pos < N) {
@@ -206,7 +206,8 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
       // (Round 5 cached den = 2 l^2 and its refined reciprocal per row, 16 bytes next to the row head, rewritten only when
       // ell decays: 35 VALU instructions per row and iteration less - and the 64-pair step 3 % SLOWER, 60.9 against 59.1 ms
       // in scripts/exp_time.py: these kernels pay for bytes, not for arithmetic.  The constants are recomputed.)
-      const RowData r = make_row(P, x, iv.ell);
+      RowData r = make_row(P, x, iv.ell);
+      if (FEAT == FEAT_HOT) r.lid = D->xlid[i];
       const FeatDen F = make_feat_den(P);
       const V3 pxe{x.x, x.y, x.z};
       const Pose& pose = iv.pose;
@@ -231,7 +232,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
         // iteration, +5 % for the 64-pair batch: most waves hold rows of one to three candidates, where the exp already
         // runs once or twice per wave either way, and the second loop and its LDS traffic are pure overhead.)
         const V3 ytv = transform_point(pose.Ri, pose.Ti, ycur.x, ycur.y, ycur.z);
-        visit_pair_yt<GENERAL>(P, D, F, i, pos, N, r, pxe, j, make_float4(ytv.x, ytv.y, ytv.z, 0.f), A);
+        visit_pair_yt<FEAT>(P, D, F, i, pos, N, r, pxe, j, make_float4(ytv.x, ytv.y, ytv.z, 0.f), A);
       }
       D->nnz_row[pos] = A.nnz;
       {
@@ -245,12 +246,10 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
         const unsigned ns = min(A.nnz, (unsigned)ELL_STAGE);
         EllEntry* dst = D->ell + pos;
         for (unsigned q = 0; q < ns; q++) {
-          const EllEntry e4 = A.stage[q * ASSOC_THREADS];  // (own LDS column: no barrier)
+          const ell_vec_t ev = A.stage[q * ASSOC_THREADS];  // (own LDS column: no barrier)
 #ifdef CVO_ELL8
-          const f32x2 ev = {e4.a, __int_as_float(e4.p)};
           asm volatile("flat_store_dwordx2 %0, %1 sc1" ::"v"(dst), "v"(ev) : "memory");
 #else
-          const f32x4 ev = {e4.a, e4.yx, e4.yy, e4.yz};
           asm volatile("flat_store_dwordx4 %0, %1 sc1" ::"v"(dst), "v"(ev) : "memory");
 #endif
           dst += N;
@@ -328,8 +327,8 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
 
 // INSTR = true is the instrumented instantiation (CVO_KERNEL_CLOCK / CVO_PHASE_TICKS); the production one carries no
 // time stamps at all.
-template <typename IdxT, int ASSOC_CAP, bool GENERAL, bool INSTR>
-__global__ __launch_bounds__(ASSOC_THREADS, GENERAL ? 1 : CVO_ASSOC_WAVES) void k_assoc(const PairDesc* __restrict__ descs,
+template <typename IdxT, int ASSOC_CAP, int FEAT, bool INSTR>
+__global__ __launch_bounds__(ASSOC_THREADS, FEAT != FEAT_GEO ? 1 : CVO_ASSOC_WAVES) void k_assoc(const PairDesc* __restrict__ descs,
                                                           const DevParams* __restrict__ Pp,
                                                           const PairState* __restrict__ states,
                                                           const char* __restrict__ arena, int lean_nblk_pairs,
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, GENERAL ? 1 : CVO_ASSOC_WAVES) void 
   {
     const char* wb = arena + (size_t)pb.pair * ((size_t)stride256 << 8);
     const int pos = pb.bx * ASSOC_THREADS + threadIdx.x;  // < Npad; values of rows >= N are never used
-    head.ip = GENERAL ? reinterpret_cast<const int*>(wb + row_off_ip(Npad))[pos] : 0;  // (only the feature lookups need it)
+    head.ip = FEAT != FEAT_GEO ? reinterpret_cast<const int*>(wb + row_off_ip(Npad))[pos] : 0;  // (only the feature lookups need it)
     head.j1 = (int)reinterpret_cast<const IdxT*>(wb + row_off_cand_j(Npad))[pos];
     head.x = reinterpret_cast<const float4*>(wb + row_off_xp4(Npad))[pos];
     head.cnt = __float_as_int(head.x.w);  // (k_list packs the row's candidate count next to its coordinates)
@@ -378,7 +377,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, GENERAL ? 1 : CVO_ASSOC_WAVES) void 
   if ((lean & 1) && (rebuild_v || (n_ovf_v > 0 && !(lean & 4)))) return;  // (bit 2: k_assoc_dense follows in this graph)
   pair_clock_begin(INSTR && P.kernel_clock && (lean & 3) == 1 && pb.bx == 0, const_cast<PairState*>(st), 0);
   __shared__ AssocShared S;
-  assoc_phase<IdxT, ASSOC_CAP, GENERAL, INSTR>(P, D, load_iter_view(st), S, pb.bx, head);
+  assoc_phase<IdxT, ASSOC_CAP, FEAT, INSTR>(P, D, load_iter_view(st), S, pb.bx, head);
   // Everything from here on - the block's partial is on its way, the last-block counter, possibly the twist - is the
   // first wave's business.  The other waves retire now instead of sitting on their registers through a store
   // acknowledgement and an atomic round trip (~2 us of a ~7 us wave life; with thousands of waves queued behind them

@@ -81,7 +81,7 @@ __device__ __forceinline__ int build_long_list(const PairDesc* __restrict__ D, c
   return cnt;
 }
 
-template <bool GENERAL, int DENSE_WAVES>
+template <int FEAT, int DENSE_WAVES>
 __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
                                                      const int* __restrict__ status) {
   if (status[blockIdx.y] != 0) return;
@@ -107,7 +107,8 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
       const int r_sorted = all_dense ? q : D->ovf_rows[q];
       const int i = D->ip[r_sorted];
       const float4 x = D->xp4[r_sorted];
-      const RowData r = make_row(P, x, st->ell);
+      RowData r = make_row(P, x, st->ell);
+      if (FEAT == FEAT_HOT) r.lid = D->xlid[i];
       const V3 pxe{x.x, x.y, x.z};
       // where this row's candidates come from: its long list (built now if it is not the current one) or all targets
       int n_cand = M;
@@ -148,11 +149,11 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
               const int p = fresh ? (int)(s_keys[wave][c] & 0xffffu) : (int)lj[c];
               col[h] = p;
               psort[h] = p;
-              ok[h] = eval_pair<GENERAL>(P, D, F, pose, i, r, p, D->ys4[p], a[h], yt[h]) && (a[h] > P.sp_thres);
+              ok[h] = eval_pair<FEAT>(P, D, F, pose, i, r, p, D->ys4[p], a[h], yt[h]) && (a[h] > P.sp_thres);
             } else {
               col[h] = c;
-              psort[h] = (GENERAL || ELL8) ? D->yinv[c] : 0;
-              ok[h] = eval_pair<GENERAL>(P, D, F, pose, i, r, psort[h], D->y4[c], a[h], yt[h]) && (a[h] > P.sp_thres);
+              psort[h] = (FEAT != FEAT_GEO || ELL8) ? D->yinv[c] : 0;
+              ok[h] = eval_pair<FEAT>(P, D, F, pose, i, r, psort[h], D->y4[c], a[h], yt[h]) && (a[h] > P.sp_thres);
             }
           }
         }

@@ -40,6 +40,8 @@ struct KdJob {
   float4* label;             // out: n x NC_PAD
   const float* raw_geo;      // n x 2
   float2* geo;
+  const int* raw_lid;        // n class ids (one-hot clouds), original order, or null
+  int* lid;                  // out: the ids in spatial order
 };
 
 __device__ __forceinline__ unsigned kd_ordered(float v) {
@@ -203,6 +205,8 @@ __global__ __launch_bounds__(KD_THREADS) void k_kd_order(const KdJob* __restrict
       const float* src = J.raw_label + (size_t)(kd_key[r] & 0xffffull) * NC + 4 * h;
       J.label[q] = make_float4(src[0], src[1], src[2], h < 4 ? src[3] : 0.f);
     }
+  if (J.raw_lid)
+    for (int r = tid; r < n; r += KD_THREADS) J.lid[r] = J.raw_lid[kd_key[r] & 0xffffull];
   if (J.raw_geo)
     for (int r = tid; r < n; r += KD_THREADS) {
       const float* src = J.raw_geo + (size_t)(kd_key[r] & 0xffffull) * 2;

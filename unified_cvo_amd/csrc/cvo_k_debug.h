@@ -15,7 +15,7 @@ namespace cvo_dev {
 // The first mismatch of a pair is latched in its state (sticky) and turns the call's return code into CVO_E_VERIFY.
 // Independent of the oracle and of the clouds' size: the tests run it at 10k x 10k over the fast-moving first iterations.
 // ------------------------------------------------------------------------------------------
-template <bool GENERAL>
+template <int FEAT>
 __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
                                                 const int* __restrict__ status, int lean) {
   if (status[blockIdx.y] != 0) return;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
       float a = 0.f;
       float4 yt;
       bool ok = false;
-      if (j < M) ok = eval_pair<GENERAL>(P, D, F, pose, i, r, GENERAL ? D->yinv[j] : 0, D->y4[j], a, yt) && (a > P.sp_thres);
+      if (j < M) ok = eval_pair<FEAT>(P, D, F, pose, i, r, FEAT != FEAT_GEO ? D->yinv[j] : 0, D->y4[j], a, yt) && (a > P.sp_thres);
       const unsigned long long m = __ballot(ok);
       const unsigned rank = nnz + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
       const bool keep = ok && rank < (unsigned)K;

@@ -10,6 +10,7 @@ namespace cvo_dev {
 // ------------------------------------------------------------------------------------------
 struct RowData {
   float x, y, z, l, d2_thres;
+  int lid = 0;  // FEAT_HOT: the row's class (PairDesc::xlid), set by the caller that knows the row's feature index
   // denominator of the geometric kernel's exponent, 2.0 * l * l (CvoGPU.cu:552), and its refined reciprocal: the part of
   // the per-pair IEEE division that depends on the row only (rcp_refined / div_by, cvo_device.h)
   double den, rcp;
@@ -22,7 +23,7 @@ __device__ __forceinline__ RowData make_row(const DevParams& P, const float4 x, 
   if (P.use_geo) thr = (float)(-2.0 * l * l * (double)P.log_geo);
   if (P.mode == 2) thr = P.d2_cull;  // non-isotropic kernel: no cut-off of its own, this one only steers the scan
   const double den = 2.0 * l * l;
-  return RowData{x.x, x.y, x.z, l, thr, den, rcp_refined(den)};
+  return RowData{x.x, x.y, x.z, l, thr, 0, den, rcp_refined(den)};
 }
 // 1 / (2.0 * ell * ell) narrowed to float (compute_step_size_poly_coeff, CvoGPU.cu:1060), the division in its hoisted form
 __device__ __forceinline__ float coef_of_ell(float ell) {
@@ -33,6 +34,8 @@ __device__ __forceinline__ float coef_of_ell(float ell) {
 // call) with their refined reciprocals; evaluated once per thread, outside the row loops.
 struct FeatDen {
   double c_den, c_rcp, s_den, s_rcp;
+  float sk_same, sk_diff;  // FEAT_HOT: the semantic kernel for a squared class distance of 0 / of 2
+  bool same_ok, diff_ok;   // ... and whether that distance passes the cut-off d2_s_thres at all
   ExpConsts ek;  // (rides along: every evaluation of a pair needs it)
 };
 __device__ __forceinline__ FeatDen make_feat_den(const DevParams& P) {
@@ -42,6 +45,14 @@ __device__ __forceinline__ FeatDen make_feat_den(const DevParams& P) {
   f.s_den = P.mode == 2 ? 2.0 * P.s_ell_sq : 2.0 * P.s_ell * P.s_ell;
   f.s_rcp = rcp_refined(f.s_den);
   f.ek = make_exp_consts();
+  {  // (the general branch of eval_pair_yt, word for word, on the only two distances one-hot rows can have)
+    const float ss = P.s_sigma * P.s_sigma;
+    const float r0 = 0.f, r2 = 2.f;
+    f.same_ok = r0 < P.d2_s_thres;
+    f.diff_ok = r2 < P.d2_s_thres;
+    f.sk_same = (float)((double)ss * exp_ocml<true>(div_by((double)(-r0), f.s_den, f.s_rcp), f.ek));
+    f.sk_diff = (float)((double)ss * exp_ocml<true>(div_by((double)(-r2), f.s_den, f.s_rcp), f.ek));
+  }
   return f;
 }
 struct Pose {  // the transform applied to the target cloud this iteration (update_tf, CvoGPU.cu:94-112)
@@ -73,14 +84,22 @@ __device__ __forceinline__ IterView load_iter_view(const PairState* st) {
   return v;
 }
 
-// GENERAL = false is the geometry-only specialisation (no colour / semantic / geometric-type code at all:
-// 1/3 fewer VGPRs, one more wave per SIMD for the latency-bound association kernel).
+// FEAT selects what the instantiation carries (the host picks per call, launch_assoc):
+//   FEAT_GEO  geometry only - no colour / semantic / geometric-type code at all: 1/3 fewer VGPRs, more waves per SIMD for the
+//             latency-bound association kernel;
+//   FEAT_COL  + colour and geometric types, no semantic code (config 3);
+//   FEAT_HOT  + ONE-HOT semantics: every cloud of the call has exact one-hot class rows (checked at upload), so the 19-term
+//             squared distance of CvoGPU.cu:563-569 is 0 (same class) or exactly 2 (different) and the semantic kernel one of
+//             two constants - a 4-byte class id per candidate instead of two 80-byte rows (config 4);
+//   FEAT_ALL  everything: soft class distributions, the non-isotropic kernel of mode 2.
+constexpr int FEAT_GEO = 0, FEAT_ALL = 1, FEAT_COL = 2, FEAT_HOT = 3;
 // i / j index the FEATURE arrays (colour, class distributions, geometric types), which clouds keep in spatial order:
 // i = the row's sorted position, j = the target's sorted position.
 // The pair arithmetic for an already transformed target yt (everything of CvoGPU.cu:528-573 but the transform).
-template <bool GENERAL>
+template <int FEAT>
 __device__ __forceinline__ bool eval_pair_yt(const DevParams& P, const PairDesc* __restrict__ D, const FeatDen& F, int i,
                                              const RowData& r, int j, const float4 yt, float& a_out) {
+  constexpr bool GENERAL = FEAT != FEAT_GEO, SEM_ROWS = FEAT == FEAT_ALL, SEM_HOT = FEAT == FEAT_HOT, MODE2 = FEAT == FEAT_ALL;
   float sk = 1, ck = 1, k = 1, geo_sim = 1;
   if (GENERAL && P.use_geotype) {  // compute_geometric_type_ip, CvoGPU.cu:203-215
     const float2 ga = D->xgeo[i], gb = D->ygeo[j];
@@ -90,7 +109,7 @@ __device__ __forceinline__ bool eval_pair_yt(const DevParams& P, const PairDesc*
     geo_sim = dab * dab / (n2a * n2b);
     if ((double)geo_sim < 0.01) return false;
   }
-  if (GENERAL && P.use_geo && P.mode == 2) {  // (the host launches the GENERAL instantiations for mode 2)
+  if (MODE2 && P.use_geo && P.mode == 2) {  // (the host launches the FEAT_ALL instantiations for mode 2)
     // mahananobis_distance (CvoGPU.cu:152-171): dist = a - b, (dist^T * kernel_inv) * dist; no cut-off (236-238, 279-284)
     const float d0 = r.x - yt.x, d1 = r.y - yt.y, d2v = r.z - yt.z;
     const float r0 = dot3_dev(d0, d1, d2v, P.kinv[0], P.kinv[3], P.kinv[6]);
@@ -120,7 +139,15 @@ __device__ __forceinline__ bool eval_pair_yt(const DevParams& P, const PairDesc*
     else
       return false;
   }
-  if (GENERAL && P.use_sem) {
+  if (SEM_HOT && P.use_sem) {
+    // one-hot rows: d2 is 0 or 2 exactly (FeatDen::sk_same / sk_diff are the general branch's own arithmetic on those two)
+    const bool same = D->ylid[j] == r.lid;
+    if (same ? F.same_ok : F.diff_ok)
+      sk = same ? F.sk_same : F.sk_diff;
+    else
+      return false;
+  }
+  if (SEM_ROWS && P.use_sem) {
     float res = 0;
 #pragma unroll
     for (int q = 0; q < NC_PAD / 4; q++) {
@@ -144,13 +171,13 @@ __device__ __forceinline__ bool eval_pair_yt(const DevParams& P, const PairDesc*
 // transform_point_R_T (CvoGPU_impl.cu:31-82) of the INITIAL target y0 = y4[j], recomputed where it is needed, then the
 // pair arithmetic.  (The gates of a pair - geometric type, distance, colour, semantics - only ever reject: the order in
 // which they are tested does not reach a result.)
-template <bool GENERAL>
+template <int FEAT>
 __device__ __forceinline__ bool eval_pair(const DevParams& P, const PairDesc* __restrict__ D, const FeatDen& F, const Pose& pose,
                                           int i, const RowData& r, int j, const float4 y0, float& a_out, float4& yt_out) {
   const V3 ytv = transform_point(pose.Ri, pose.Ti, y0.x, y0.y, y0.z);
   const float4 yt = make_float4(ytv.x, ytv.y, ytv.z, 0.f);
   yt_out = yt;
-  return eval_pair_yt<GENERAL>(P, D, F, i, r, j, yt, a_out);
+  return eval_pair_yt<FEAT>(P, D, F, i, r, j, yt, a_out);
 }
 // ------------------------------------------------------------------------------------------
 // k_assoc: ordered association + flow, one thread per (sorted) source row.
@@ -172,7 +199,9 @@ struct RowAcc {
   double asum = 0;
   unsigned nnz = 0;
   EllEntry* slot = nullptr;  // where the row's next nonzero goes: D->ell + nnz * N + pos, advanced by N per nonzero
-  EllEntry* stage = nullptr;  // this thread's column of the block's LDS staging area (AssocShared::stage)
+  // this thread's column of the block's LDS staging area (AssocShared::stage), as an LDS-qualified pointer (a generic one
+  // made hipcc 7.2 emit an illegal V_CMP against src_shared_base in one instantiation of k_assoc)
+  CVO_LDS ell_vec_t* stage = nullptr;
 };
 // ELL entries a row parks in LDS before they are stored (see assoc_phase).  Six: 24.6 KB of LDS per block; 4 / 5 / 6 / 7 / 8
 // slots measured 63.6 / 63.3 / 62.9 / 63.8 / 64.9 ms per step (the early iterations have ~8 nonzeros per row, the
@@ -184,16 +213,16 @@ constexpr int ELL_STAGE = CVO_ELL_STAGE_SLOTS;
 
 // One pair (i, j) that passed the geometric cut-off, with its transformed target: the rest of CvoGPU.cu:528-589 (kernel
 // values, a > sp_thres, ELL store) + the flow terms of 758-782.
-template <bool GENERAL>
+template <int FEAT>
 __device__ __forceinline__ void visit_pair_yt(const DevParams& P, const PairDesc* __restrict__ D, const FeatDen& F, int i, int pos,
                                               int N, const RowData& r, const V3& pxe, int j, const float4 yt, RowAcc& A) {
   float a;
-  if (!eval_pair_yt<GENERAL>(P, D, F, i, r, j, yt, a)) return;
+  if (!eval_pair_yt<FEAT>(P, D, F, i, r, j, yt, a)) return;
   if (a > P.sp_thres) {
     // The row's first ELL_STAGE nonzeros are parked in the thread's own LDS column and leave after the loop as
     // write-through stores (assoc_phase); only rows longer than that store from inside the loop.
     if (A.nnz < (unsigned)ELL_STAGE)
-      A.stage[A.nnz * ASSOC_THREADS] = make_ell(a, yt.x, yt.y, yt.z, j);
+      A.stage[A.nnz * ASSOC_THREADS] = ell_to_vec(make_ell(a, yt.x, yt.y, yt.z, j));
     else
       *A.slot = make_ell(a, yt.x, yt.y, yt.z, j);
     if (P.keep_columns) D->ell_j[(size_t)A.nnz * N + pos] = D->yorder[j];  // (list entries are sorted positions)

@@ -103,6 +103,15 @@ __device__ __forceinline__ bool pair_block(int nblk, int n_pairs, PairBlock& pb)
 #define CVO_CONST __attribute__((address_space(4)))
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // plain vector: loadable from any address space
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define CVO_LDS __attribute__((address_space(3)))
+// an ELL entry as a plain vector (storable through address-space qualified pointers, which class types are not)
+#ifdef CVO_ELL8
+typedef f32x2 ell_vec_t;
+__device__ __forceinline__ ell_vec_t ell_to_vec(const EllEntry& e) { return ell_vec_t{e.a, __int_as_float(e.p)}; }
+#else
+typedef f32x4 ell_vec_t;
+__device__ __forceinline__ ell_vec_t ell_to_vec(const EllEntry& e) { return ell_vec_t{e.a, e.yx, e.yy, e.yz}; }
+#endif
 // (float4 is a class type: its copy constructor only takes generic references)
 __device__ __forceinline__ float4 ldg_f4(const CVO_GLOBAL f32x4* p) {
   const f32x4 v = *p;
