@@ -213,14 +213,15 @@ struct PairDesc {
   EllEntry* ell;              // ELL kernel matrix [K_max][N] by POSITION: value + transformed target, ascending ORIGINAL j in a row
   int* ell_j;                 // [K_max][N]: the column (ORIGINAL j) of every entry
   unsigned* nnz_row;          // nonzeros[N], by position
+  double* rowcoef;            // [N x csplit][4] by position and slice: (B, C, D, E) of the rows k_coeff_dense evaluated - summed
+                              // slot by slot in the order a thread of k_coeff would have - picked up by k_coeff
   RowRes* rowres;             // [N] by position: results of the rows k_assoc_dense evaluated, picked up by k_assoc
   double* flow_part;          // [nblk_assoc][8]: omega(3), v(3), sum a, pad - one partial per row block of k_assoc
   unsigned long long* cnt_part;  // [nblk_assoc][4]: nnz, max, candidates, overflow rows
   double* coef_part;          // [nblk_assoc * COEFF_SPLIT_MAX][4]: B C D E
   int* done;        // [1] k_coeff: blocks that stored their partials (monotonic; the last one runs the update)
-  int csplit, csplit_heavy;  // k_coeff: blocks per row block; block q of a row block takes the ELL slots s = q (mod csplit).
-                             // csplit_heavy >= csplit: while the pair has overflow rows (rows of hundreds of nonzeros; only
-                             // the full graph runs such a pair) - a function of the pair's own state, so that batch == solo
+  int csplit;                // k_coeff: blocks per row block; block q of a row block takes the ELL slots s = q (mod csplit).
+                             // (small clouds; a function of the pair's own size, so that batch == solo)
   const float4* xfeat;
   const float4* yfeat;
   const float4* xlabel;

@@ -75,7 +75,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, done, cand_cnt, rowperm, iorig, long_j, long_stamp, xp4, ip, cand_j, rowres, ell, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, done, cand_cnt, rowperm, iorig, long_j, long_stamp, xp4, ip, cand_j, rowres, rowcoef, ell, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -260,6 +260,8 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, bool long_lis
   L.long_stamp = take(sizeof(unsigned long long) * (size_t)N);
   L.long_j = long_lists ? take(sizeof(unsigned short) * (size_t)N * LONG_CAP) : 0;
   L.rowres = take(sizeof(RowRes) * (size_t)N);
+  // (rows x the pair's own coefficient split, coeff_split(): one slice above 4096 points, at most 32768 / rows below)
+  L.rowcoef = take(sizeof(double) * 4 * (size_t)std::max(N, 32768));
   L.flow_part = take(sizeof(double) * 8 * (size_t)nba);
   L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)nba);
   L.coef_part = take(sizeof(double) * 4 * (size_t)nbc * COEFF_SPLIT_MAX);
@@ -341,15 +343,6 @@ int ensure_workspace(cvo_ctx* c, int n_pairs, size_t bytes_per_pair) {
     drop_graphs(c);
   }
   return CVO_OK;
-}
-
-int coeff_split(int n);
-// blocks per row block while a pair has overflow rows (PairDesc::csplit_heavy): ~1000 blocks per pair
-int coeff_split_heavy(int n) {
-  const int nba = (n + ASSOC_THREADS - 1) / ASSOC_THREADS;
-  int s = coeff_split(n);
-  while (s < COEFF_SPLIT_MAX && nba * (2 * s) <= 1024) s *= 2;
-  return s;
 }
 
 int coeff_split(int n) {
@@ -560,7 +553,6 @@ inline int call_feat(const DevParams& dp, bool all_one_hot) {
 
 struct LaunchGeom {
   int n_pairs, p0, T, gx, gy, nba, nbc, npb, N, csplit;
-  int csplit_heavy = 1;  // k_coeff grid of the graph with the dense kernel (the only one that runs pairs with overflow rows)
   int dense_blocks = DENSE_BLOCKS_MIN;  // k_assoc_dense grid x = PairDesc::dense_blocks of every pair of the launch
   int group = 0;        // sub-batch index (its stream)
   int horizon_cap = 1 << 20;  // the lean graph's period (DevParams::lean_U)
@@ -598,8 +590,11 @@ void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags, bool den
   launch_assoc(g.stream, g.idx16, g.feat, g.instr, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena,
                (lean ? 1 : 0) | (lean_dense ? 4 : 0));
   if (g.verify) launch_verify(g.stream, g.feat, g.N, g.n_pairs, descs, c->d_params, st, (lean ? 1 : 0) | (lean_dense ? 4 : 0));
-  launch_coeff(g.stream, g.instr, g.nba, (lean && !dense) ? g.csplit : g.csplit_heavy, g.n_pairs, descs, c->d_params,
-               c->d_states + g.p0, g.arena, flags | (lean ? 1 : 0) | (lean_dense ? 32 : 0));
+  // ... their coefficient sums likewise (k_coeff_dense leaves per-row sums, k_coeff picks them up)
+  if (!lean || dense)
+    hipLaunchKernelGGL((k_coeff_dense<4>), dim3(g.dense_blocks, g.n_pairs), dim3(256), 0, g.stream, descs, c->d_params, st);
+  launch_coeff(g.stream, g.instr, g.nba, g.csplit, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena,
+               flags | (lean ? 1 : 0) | (lean_dense ? 32 : 0) | (g.idx16 ? 0 : 64));
 }
 
 // A chunk of U iterations.  Full: every iteration can rebuild its candidate list and serve overflow rows.
@@ -667,7 +662,6 @@ void fill_pair(cvo_ctx* ctx, const BatchSetup* S, const cvo_params_t* params, co
     // coefficient phase: small clouds get several blocks per row block (see coeff_rows); a function of the pair's own
     // size only, so that a pair is reduced in the same order whether it is solved alone or inside a batch
     D.csplit = coeff_split(X->n);
-    D.csplit_heavy = coeff_split_heavy(X->n);
     D.nblk_coeff = S->d.nblk_assoc * D.csplit;
     D.NG = (X->n + ROWS_PER_GROUP - 1) / ROWS_PER_GROUP;
     D.NGpad = S->d.NGpad;
@@ -714,6 +708,7 @@ void fill_pair(cvo_ctx* ctx, const BatchSetup* S, const cvo_params_t* params, co
     D.ell_j = (int*)(base + S->L.ell_j);
     D.nnz_row = (unsigned*)(base + S->L.nnz_row);
     D.rowres = (RowRes*)(base + S->L.rowres);
+    D.rowcoef = (double*)(base + S->L.rowcoef);
     D.flow_part = (double*)(base + S->L.flow_part);
     D.cnt_part = (unsigned long long*)(base + S->L.cnt_part);
     D.coef_part = (double*)(base + S->L.coef_part);
@@ -925,8 +920,6 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->geom.arena.Npad = S->d.Npad;
   S->geom.csplit = qd ? coeff_split(qd->n_min) : 1;
   for (int p = 0; p < n_pairs && !qd; p++) S->geom.csplit = std::max(S->geom.csplit, coeff_split(sources[p]->n));
-  S->geom.csplit_heavy = qd ? coeff_split_heavy(qd->n_min) : 1;
-  for (int p = 0; p < n_pairs && !qd; p++) S->geom.csplit_heavy = std::max(S->geom.csplit_heavy, coeff_split_heavy(sources[p]->n));
   S->geom.nbc = S->d.nblk_coeff;
   S->geom.npb = S->d.Mpad / PREP_THREADS + (S->d.NGpad * ROWS_PER_GROUP + PREP_THREADS - 1) / PREP_THREADS;
   S->geom.idx16 = M < 65536;
@@ -1772,7 +1765,7 @@ int ensure_graph(cvo_ctx* ctx, const BatchSetup& S, const LaunchGeom* geom, int 
   key.nbc = S.d.nblk_coeff * 64 + S.geom.csplit;
   key.npb = S.geom.npb + (S.geom.dense_blocks << 20);  // (npb < 2^20: Mpad / 256 + rows / 256)
   key.idx16 = S.geom.idx16 ? 1 : 0;
-  key.general = S.geom.feat | (S.geom.csplit_heavy << 2);
+  key.general = S.geom.feat;
   key.U = Uc * 256 + graph_lean_period(cfg, v, Uc) + (v == 3 ? 128 : 0);
   key.flags = (S.geom.instr ? 1 : 0) | (S.geom.verify ? 2 : 0) | (v << 24);
   key.arena = geom[g].arena.base;

@@ -16,8 +16,8 @@ struct CoeffShared {
 
 // one nonzero (i, j): compute_step_size_xi for target j (CvoGPU.cu:974-986) + compute_step_size_poly_coeff
 // (CvoGPU.cu:1053-1078); yy is the transformed target
-__device__ __forceinline__ void coeff_entry(const XiMats& M, const float4 x, float temp_coef, const V3 yy, float A_ij,
-                                            double& Bi, double& Ci, double& Di, double& Ei) {
+// t[0..3]: what the nonzero adds to B_i, C_i, D_i, E_i (the `+=` right-hand sides of CvoGPU.cu:1068-1078)
+__device__ __forceinline__ void coeff_terms(const XiMats& M, const float4 x, float temp_coef, const V3 yy, float A_ij, double (&tq)[4]) {
   const V3 w{M.omega[0], M.omega[1], M.omega[2]};
   const V3 c = cross_dev(w, yy);
   const V3 xiz{c.x + M.v[0], c.y + M.v[1], c.z + M.v[2]};
@@ -39,19 +39,29 @@ __device__ __forceinline__ void coeff_entry(const XiMats& M, const float4 x, flo
       (float)(2.0 * temp_coef * (double)(xiz_dot_xi2z + dot3_dev(-xi3z.x, -xi3z.y, -xi3z.z, dfx, dfy, dfz)));
   const float epsil_ij =
       (-temp_coef) * (epsil_const + dot3_dev(2.0f * xi4z.x, 2.0f * xi4z.y, 2.0f * xi4z.z, dfx, dfy, dfz));
-  Bi += (double)(A_ij * beta_ij);
-  Ci += (double)A_ij * ((double)gamma_ij + (double)(beta_ij * beta_ij) / 2.0);
+  tq[0] = (double)(A_ij * beta_ij);
+  tq[1] = (double)A_ij * ((double)gamma_ij + (double)(beta_ij * beta_ij) / 2.0);
   // beta^3 / 6.0 (CvoGPU.cu:1072): the IEEE division with its constant half folded (rcp_refined / div_by, cvo_device.h)
-  Di += (double)A_ij * ((double)__builtin_fmaf(beta_ij, gamma_ij, delta_ij) +
-                        div_by((double)(beta_ij * beta_ij * beta_ij), 6.0, rcp_refined(6.0)));
-  Ei += (double)A_ij * ((double)__builtin_fmaf(beta_ij, delta_ij, epsil_ij) +
-                        1 / 2.0 * beta_ij * beta_ij * gamma_ij + 1 / 2.0 * gamma_ij * gamma_ij +
-                        1 / 24.0 * beta_ij * beta_ij * beta_ij * beta_ij);
+  tq[2] = (double)A_ij * ((double)__builtin_fmaf(beta_ij, gamma_ij, delta_ij) +
+                         div_by((double)(beta_ij * beta_ij * beta_ij), 6.0, rcp_refined(6.0)));
+  tq[3] = (double)A_ij * ((double)__builtin_fmaf(beta_ij, delta_ij, epsil_ij) +
+                         1 / 2.0 * beta_ij * beta_ij * gamma_ij + 1 / 2.0 * gamma_ij * gamma_ij +
+                         1 / 24.0 * beta_ij * beta_ij * beta_ij * beta_ij);
+}
+__device__ __forceinline__ void coeff_entry(const XiMats& M, const float4 x, float temp_coef, const V3 yy, float A_ij,
+                                            double& Bi, double& Ci, double& Di, double& Ei) {
+  double t[4];
+  coeff_terms(M, x, temp_coef, yy, A_ij, t);
+  Bi += t[0];
+  Ci += t[1];
+  Di += t[2];
+  Ei += t[3];
 }
 
 // Rows of this block, in two steps so that the first loads of the row loop (count -> first ELL entry -> its target:
 // three dependent round trips) are in flight while the twist is reduced.
 struct CoeffRowHead {
+  bool dense;  // the row is beyond its cached list: k_coeff_dense has left its sums (PairDesc::rowcoef)
   unsigned nnz;
   float4 x;
   EllEntry e_n;  // the row's first entry of this block's slice
@@ -68,7 +78,16 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
   // otherwise leave the chip to a handful of waves walking hundreds of entries each).  Software pipeline: the
   // next entry's index / value / target are in flight while the current one is evaluated.
   const unsigned nnz = h.nnz;
-  if ((unsigned)q < nnz) {
+  if (h.dense) {
+    // a row k_assoc_dense and k_coeff_dense evaluated (a wave per row): its sums, slice by slice in this kernel's own order
+    if (i < N) {
+      const double* rc = D->rowcoef + ((size_t)i * nsplit + q) * 4;
+      Bi = rc[0];
+      Ci = rc[1];
+      Di = rc[2];
+      Ei = rc[3];
+    }
+  } else if ((unsigned)q < nnz) {
     const float4 x = h.x;
     // 1 / (2.0 * ell * ell), CvoGPU.cu:1060: the same for every row (PairState::temp_coef, evaluated by the update when
     // ell changes) unless the range factor is on (CvoGPU.cu:1035-1037)
@@ -139,17 +158,18 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     const int pos = pb.bx * ASSOC_THREADS + threadIdx.x;  // < Npad; values of rows >= N are never used
     head.nnz = reinterpret_cast<const unsigned*>(wb + row_off_nnz(Npad))[pos];
     head.x = reinterpret_cast<const float4*>(wb + row_off_xp4(Npad))[pos];
+    head.dense = false;
     head.e_n = make_ell(0.f, 0.f, 0.f, 0.f, 0);
     if (cq == 0) head.e_n = reinterpret_cast<const EllEntry*>(wb + row_off_ell(Npad))[pos];
   }
-  const int csplit_light = D->csplit, csplit_heavy = D->csplit_heavy;
+  const int csplit = D->csplit;
   PairState* const st = states + pb.pair;  // == D->st, without the dependent pointer load
   // The state as this launch found it, through a read-only view so that the loads are scalar (only the block that
   // finishes last writes the state, after every block has read it); one burst together with what the row loop
   // needs first, see k_assoc.
   const PairState* __restrict__ st_in = states + pb.pair;
   const int status_v = st_in->status, rebuild_v = st_in->rebuild, ovf = st_in->n_ovf;
-  const unsigned max_nnz_prev = st_in->max_nnz;  // longest row of the iteration before (this one's is not reduced yet)
+  const int row_max_v = st_in->row_max;
   const DevParams P = *Pp;
   // the twist and its matrices (twist_finalize): wave-uniform scalar loads
   XiMats Mu;
@@ -170,26 +190,15 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     const float e = st_in->ell, tc = st_in->temp_coef;
     const int k_line = st_in->K;  // (rides in the 16-byte load of status / rebuild / n_ovf: pinned so that none of its
                                   // registers is dead and reused inside the burst, see k_assoc)
-    asm volatile("" ::"s"(n), "s"(nb), "s"(ep), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e), "s"(tc), "s"(csplit_light),
-                 "s"(csplit_heavy), "s"(status_v), "s"(rebuild_v), "s"(ovf), "s"(k_line), "s"(max_nnz_prev), "s"(P.mode), "s"(P.sp_thres), "s"(P.use_range_ell),
+    asm volatile("" ::"s"(n), "s"(nb), "s"(ep), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(e), "s"(tc), "s"(csplit),
+                 "s"(row_max_v), "s"(status_v), "s"(rebuild_v), "s"(ovf), "s"(k_line), "s"(P.mode), "s"(P.sp_thres), "s"(P.use_range_ell),
                  "s"(Mu.omega[0]), "s"(Mu.m2.m[0][0]), "s"(Mu.m4.m[2][2]), "s"(Mu.v[2]));
     // (nothing computed from these values - the slice count below is the first - may be scheduled into the middle of
     // the burst, where it would need a wait of its own: one more round trip)
     __builtin_amdgcn_sched_barrier(0);
   }
-  // rows with hundreds of nonzeros (a pair with overflow rows: clustered clouds, the K cap) are spread over more blocks -
-  // while its rows really are that long (the longest row of the iteration before: the pair's own state, like n_ovf)
-  // (both counts are requested in the burst above: a load that depends on the branch would be one more round trip)
-  // (as many slices as keep a thread's share of the longest row at ~32 entries: every slice is four more partials for the
-  // update to fetch, 128 per round trip)
-  // ... and at least ~128 blocks per pair while rows are long
-  // (the pair's OWN row blocks, not the launch's: in a batch of ragged clouds the launch is sized by the largest one, and
-  // the split - hence the order in which a row's terms are summed - must not depend on the company a pair is solved in)
-  int csplit = csplit_light;
-  if (ovf > 0 && max_nnz_prev > 48u && (!(flags & 1) || (flags & 32))) {
-    const int nblk_own = (D->N + ASSOC_THREADS - 1) / ASSOC_THREADS;
-    while (csplit < csplit_heavy && ((unsigned)(csplit * 32) < max_nnz_prev || nblk_own * csplit < 128)) csplit <<= 1;
-  }
+  // (rows beyond their cached lists - hundreds of nonzeros: clustered clouds, the K cap - are not walked here: k_coeff_dense,
+  // a wave per row, has left their sums in PairDesc::rowcoef; the split is the pair's own, whatever company it is solved in)
   if (cq >= csplit) return;
   const bool replay = (flags & 8) != 0;  // cvo_debug_time_kernels: same work, nothing written back
   if (!replay && status_v != 0) return;
@@ -216,6 +225,8 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   __shared__ int s_last;
   const int N_ = D->N, pos_ = pb.bx * ASSOC_THREADS + threadIdx.x;
   if (pos_ >= N_) head.nnz = 0;
+  // the row's class as k_list and k_assoc see it: more candidates than row_max (bit 6: 32-entry lists, M >= 65536)
+  head.dense = pos_ < N_ && ovf > 0 && __float_as_int(head.x.w) > min(row_max_v, (flags & 64) ? ASSOC_CAP32 : ASSOC_CAP16);
   if (cq > 0 && (unsigned)cq < head.nnz) head.e_n = D->ell[(size_t)cq * N_ + pos_];  // (small clouds only: later slices)
   float twist[6];
   for (int c = 0; c < 3; c++) {

@@ -1,0 +1,82 @@
+// cvo_k_coeff_dense.h -- k_coeff_dense: the coefficient pass of the rows beyond their cached lists, a wave per row.
+// Part of the kernel set of cvo_kernels.h (which states the whole iteration); compiled only as part of cvo_hip.hip.
+#pragma once
+#include "cvo_k_coeff.h"
+
+namespace cvo_dev {
+
+// ------------------------------------------------------------------------------------------
+// k_coeff_dense (graphs with the dense kernels, after k_assoc, before k_coeff).  The rows k_assoc_dense evaluated carry
+// hundreds of nonzeros (a clustered cloud, rows on the K cap): one thread walking such a row - compute_step_size_xi +
+// _poly_coeff per nonzero, CvoGPU.cu:953-1082 - was the longest kernel of a clustered pair's iteration, and spreading a
+// row's slots over more blocks while rows were long made the order of a row's sum depend on that choice.  Here a wave
+// owns the row: its 64 lanes evaluate 64 nonzeros' terms at a time, and the sums are then formed EXACTLY as a thread of
+// k_coeff forms them - slice q of the pair's own coefficient split adds the terms of slots q, q + csplit, ... one after
+// the other, in double - by one lane per (slice, component) reading the terms back from LDS.  The result goes to
+// PairDesc::rowcoef; k_coeff picks it up at the row's position.  Whether a row is evaluated here or by a thread of
+// k_coeff does not reach a bit of B, C, D, E: the row classes (PairState::row_max) are free to follow the launch.
+// ------------------------------------------------------------------------------------------
+template <int DENSE_WAVES>
+__global__ __launch_bounds__(64 * DENSE_WAVES) void k_coeff_dense(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
+                                                                  const int* __restrict__ status) {
+  if (status[blockIdx.y] != 0) return;
+  const PairDesc* __restrict__ D = descs + blockIdx.y;
+  const PairState* __restrict__ st = D->st;
+  const DevParams P = *Pp;
+  if (P.mode != 0) return;
+  const int n_ovf = st->n_ovf;
+  if (n_ovf == 0 || st->rebuild) return;  // (see k_assoc_dense)
+  const int N = D->N, csplit = D->csplit;
+  const bool all_dense = st->all_dense != 0;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  XiMats Mu;
+  {
+    float* mu = reinterpret_cast<float*>(&Mu);
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(XiMats) / sizeof(float)); q++) mu[q] = st->xi[q];
+  }
+  const float ell = st->ell, coef_ell = st->temp_coef;
+  __shared__ double s_terms[DENSE_WAVES][64][4];
+  for (int q = blockIdx.x * DENSE_WAVES + wave; q < n_ovf; q += (int)gridDim.x * DENSE_WAVES) {
+    const int pos = all_dense ? q : D->ovf_rows[q];
+    const unsigned nnz = D->nnz_row[pos];
+    const float4 x = D->xp4[pos];
+    float temp_coef = coef_ell;
+    if (P.use_range_ell) {  // CvoGPU.cu:1035-1037
+      const float d2_sqrt = sqrtf(dot3_dev(x.x, x.y, x.z, x.x, x.y, x.z));
+      temp_coef = coef_of_ell(compute_range_ell(ell, d2_sqrt));
+    }
+    // chains: (slice, component) = lane / 4, lane % 4, and a second one 16 slices further for splits above 16
+    double acc0 = 0, acc1 = 0;
+    const int qs0 = lane >> 2, qs1 = 16 + (lane >> 2), comp = lane & 3;
+    for (unsigned s0 = 0; s0 < nnz; s0 += 64u) {
+      const unsigned s = s0 + (unsigned)lane;
+      double t[4] = {0, 0, 0, 0};
+      if (s < nnz) {
+        const EllEntry e = D->ell[(size_t)s * N + pos];
+#ifdef CVO_ELL8
+        const f32x4 y0 = ((const CVO_GLOBAL f32x4*)D->ys4)[e.p];
+        const V3 yy = transform_point(st->Rinv, st->Tinv, y0.x, y0.y, y0.z);
+#else
+        const V3 yy{e.yx, e.yy, e.yz};
+#endif
+        coeff_terms(Mu, x, temp_coef, yy, e.a, t);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) s_terms[wave][lane][c] = t[c];
+      __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order)
+      const int n_here = (int)min(64u, nnz - s0);
+      // slot s belongs to slice s % csplit; s0 is a multiple of 64 and csplit divides 64: local index l, slice l % csplit
+      if (qs0 < csplit)
+        for (int l = qs0; l < n_here; l += csplit) acc0 += s_terms[wave][l][comp];
+      if (qs1 < csplit)
+        for (int l = qs1; l < n_here; l += csplit) acc1 += s_terms[wave][l][comp];
+      __builtin_amdgcn_wave_barrier();
+    }
+    double* rc = D->rowcoef + (size_t)pos * csplit * 4;
+    if (qs0 < csplit) rc[qs0 * 4 + comp] = acc0;
+    if (qs1 < csplit) rc[qs1 * 4 + comp] = acc1;
+  }
+}
+
+}  // namespace cvo_dev
