@@ -56,7 +56,7 @@ def available_cpus():
 
 
 def _getenv_c(name):
-    """The C environment (what HIP and the library's load-time hint see; os.environ is Python's start-up snapshot)."""
+    """The C environment (what HIP and cvo_process_hint_hw_queues see; os.environ is Python's start-up snapshot)."""
     import ctypes
     g = ctypes.CDLL(None).getenv
     g.restype = ctypes.c_char_p
@@ -93,8 +93,8 @@ def main():
     import torch.distributed as dist
     import cases
     from unified_cvo_amd import CvoGPU, sharding, _capi
-    # The hardware-queue contract lives in the library (include/cvo_hip.h, cvo_ctx_advice): loading it puts
-    # GPU_MAX_HW_QUEUES=8 into the environment unless the caller chose a value.  HIP reads the variable at the process's
+    # The hardware-queue contract lives in the library (include/cvo_hip.h, cvo_ctx_advice): _capi.lib() calls
+    # cvo_process_hint_hw_queues(), which puts GPU_MAX_HW_QUEUES=8 into the environment unless the caller chose a value.  HIP reads the variable at the process's
     # first HIP call, so the library is loaded HERE - after `import torch` (the process must end up with ONE HIP runtime:
     # torch's), before torch touches the GPU; the bench line reports what the context found (config.hardware_queues).
     _capi.lib()

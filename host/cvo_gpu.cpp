@@ -134,6 +134,9 @@ CvoGPU::CvoGPU(const std::string& f, int device) {
   read_CvoParams_yaml(f.c_str(), &params, &warnings);
   if (std::getenv("CVO_VERBOSE"))
     for (const std::string& w : warnings) std::fprintf(stderr, "[cvo] %s: %s\n", f.c_str(), w.c_str());
+  // (process-wide, explicit: GPU_MAX_HW_QUEUES=8 unless the host chose a value - include/cvo_hip.h, hardware queues; it takes
+  // effect if this is the process's first contact with HIP, otherwise cvo_ctx_advice says what to export)
+  cvo_process_hint_hw_queues();
   int rc = cvo_ctx_create(device, &ctx);
   if (rc != CVO_OK) throw std::runtime_error("cvo_ctx_create failed: no usable HIP device " + std::to_string(device));
 }

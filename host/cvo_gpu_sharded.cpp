@@ -57,6 +57,7 @@ struct CvoGPUSharded::Impl {
 
 CvoGPUSharded::CvoGPUSharded(const std::string& yaml, const std::vector<int>& devices_in) : impl(new Impl) {
   std::vector<int> devs = devices_in;
+  cvo_process_hint_hw_queues();  // (before this host's first HIP call: include/cvo_hip.h, hardware queues)
   if (devs.empty()) {
     int n = 0;
     hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount");

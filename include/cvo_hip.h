@@ -152,12 +152,19 @@ void cvo_ctx_destroy(cvo_ctx* ctx);
 const char* cvo_last_error(const cvo_ctx* ctx);
 /* Hardware queues.  A batch (cvo_align_batch, CvoGPUSharded) runs on four sub-batch HIP streams that must sit on four
  * different hardware queues; HIP deals streams onto GPU_MAX_HW_QUEUES queues (default 4, read once at the process's
- * first HIP call) and the upload stream, RCCL and the host application bring streams of their own.  The library
- * therefore puts GPU_MAX_HW_QUEUES=8 into the environment when it is LOADED, unless the variable is already set
- * (CVO_NO_HW_QUEUE_HINT=1 disables this).  If HIP was initialised earlier, or the variable says less than 8,
- * cvo_ctx_create leaves an advisory text here ("" = nothing to report) and prints it once per process on stderr
- * (CVO_QUIET=1 silences the print).  Nothing but speed depends on it. */
+ * first HIP call) and the upload stream, RCCL and the host application bring streams of their own.
+ * cvo_process_hint_hw_queues() puts GPU_MAX_HW_QUEUES=8 into the environment unless the variable is already set
+ * (CVO_NO_HW_QUEUE_HINT=1 disables it) and returns the value in force: a PROCESS-WIDE side effect, which is why it is
+ * an explicit call - make it before the process's first HIP call and before other threads read the environment
+ * (setenv is not thread-safe).  The Python wrapper and cvo::CvoGPU's constructor call it; CVO_HW_QUEUE_HINT_AT_LOAD=1
+ * makes the library do it when it is loaded.  If HIP was initialised earlier, or the variable says less than 8,
+ * cvo_ctx_create leaves an advisory text in cvo_ctx_advice() ("" = nothing to report) and prints it once per process
+ * on stderr (CVO_QUIET=1 silences the print).  Nothing but speed depends on it. */
+int cvo_process_hint_hw_queues(void);
 const char* cvo_ctx_advice(const cvo_ctx* ctx);
+/* Destroys the HIP streams pooled from destroyed contexts (they are kept across contexts so that a later context finds
+ * its sub-batch streams on the hardware queues the first one was given).  Optional, e.g. before unloading the library. */
+void cvo_shutdown(void);
 /* Tuning / diagnostic switches of a context (none changes a result; the list is in unified_cvo_amd/csrc/cvo_hip.hip,
  * kOptionNames, and DESIGN.md).  A context reads CVO_<NAME> from the environment ONCE, in cvo_ctx_create; afterwards
  * only this call changes them (value NULL = unset), so no library call depends on the process environment while it

@@ -1,7 +1,7 @@
 """The headline workload (64 resident 10k x 10k geometric pairs, 2000 iterations) on the C++ host of the multi-GPU mode
 (host/cvo_align_sharded --bench: cvo::CvoGPUSharded, RCCL communicator alive) next to cvo_align_batch through the
-Python binding, and what the hardware-queue contract is worth: the same C++ run with the library's load-time
-GPU_MAX_HW_QUEUES hint switched off.  GPU box; usage: python scripts/cpp_host_bench.py > profiles/r4/cpp_host_bench.txt"""
+Python binding, and what the hardware-queue contract is worth: the same C++ run with the
+GPU_MAX_HW_QUEUES hint (cvo_process_hint_hw_queues) switched off.  GPU box; usage: python scripts/cpp_host_bench.py > profiles/r4/cpp_host_bench.txt"""
 import os
 import subprocess
 import sys
@@ -26,7 +26,7 @@ for p, (_, src, tgt, _) in enumerate(pairs):
 shard = os.path.join(ROOT, "host", "cvo_align_sharded")
 yaml = os.path.join(cases.CONFIGS, "geometric_gpu.yaml")
 base = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "CVO_NO_HW_QUEUE_HINT")}
-for label, env in (("no environment variable set (the library's load-time hint)", base),
+for label, env in (("no environment variable set (the host calls cvo_process_hint_hw_queues() before its first HIP call)", base),
                    ("CVO_NO_HW_QUEUE_HINT=1 (HIP's default of 4 hardware queues)", dict(base, CVO_NO_HW_QUEUE_HINT="1")),
                    ("GPU_MAX_HW_QUEUES=8 exported by the caller", dict(base, GPU_MAX_HW_QUEUES="8"))):
     r = subprocess.run([shard, "--bench", "7", yaml, "0", "1"] + args, text=True, env=env, capture_output=True)

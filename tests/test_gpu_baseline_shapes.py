@@ -225,3 +225,28 @@ def test_clustered_scene_full_length(oracle):
     assert cases.max_abs_diff(g.transform, o["transform"]) <= TOL_POSE_CLAMPED
     final = np.linalg.inv(g.transform.astype(np.float64)).astype(np.float32)
     _ip_and_angles(gpu, oracle, P, src, tgt, (final,))
+
+
+def test_clustered_pairs_batch_equals_solo():
+    """Clustered scenes have thousands of rows beyond their cached lists (k_assoc_dense / k_coeff_dense, a wave per row).
+    Those kernels leave PER-ROW results that k_assoc / k_coeff reduce at the row's own position, so a pair's sums do not
+    depend on the dense kernels' grid - which follows the number of pairs in flight: a batch of three ragged scenes ==
+    three solo calls, bit for bit (round 4's per-block partials of the dense kernel did not guarantee this), and the
+    row-class limit ROW_MAX does not reach a bit either."""
+    pairs = [cases.scene(n=3000 + 700 * p, pair_id=p) for p in range(3)]
+    P = pairs[0][0]
+    gpu = CvoGPU(params=P)
+    src = [gpu.upload(p[1]) for p in pairs]
+    tgt = [gpu.upload(p[2]) for p in pairs]
+    solo = [gpu.align(s, t, p[3], max_iterations=220) for s, t, p in zip(src, tgt, pairs)]
+    assert gpu.debug_row_classes(0)[0] > 50      # (the scenes really have overflow rows)
+    batch = gpu.align_batch(src, tgt, [p[3] for p in pairs], max_iterations=220)
+    for a, b in zip(solo, batch):
+        assert a.iterations == b.iterations == 220 and np.array_equal(a.transform, b.transform)
+        assert (a.final_ell, a.final_num_neighbors) == (b.final_ell, b.final_num_neighbors)
+    g2 = CvoGPU(params=P)
+    g2.set_option("ROW_MAX", "10")
+    for k in range(3):
+        r = g2.align(g2.upload(pairs[k][1]), g2.upload(pairs[k][2]), pairs[k][3], max_iterations=220)
+        assert np.array_equal(r.transform, solo[k].transform)
+

@@ -635,3 +635,40 @@ def test_large_and_odd_clouds_are_ordered_on_the_host():
     bad = src[:100].copy()
     bad[17, 1] = np.nan
     assert np.array_equal(gpu.upload(CvoPointCloud.from_xyz(bad)).debug_order(), np.arange(100))
+
+
+@pytest.mark.gpu
+def test_operands_outside_the_hoisted_divisions_domain_are_refused():
+    """The row loops evaluate their IEEE divisions in a hoisted form that equals the plain one only while the
+    denominators 2 l^2, 2 c_ell^2, 2 s_ell^2 stay far from zero / infinity (cvo_device.h, rcp_refined): lengthscales
+    outside [1e-30, 1e15] and clouds with non-finite or astronomically large coordinates are rejected with CVO_E_INVALID
+    instead of silently leaving that domain."""
+    from unified_cvo_amd import CvoError
+    P, src, tgt, init = cases.config2(n=600)
+    gpu = CvoGPU(params=P)
+    da, db = gpu.upload(src), gpu.upload(tgt)
+    assert gpu.align(da, db, init, max_iterations=3).iterations == 3
+    for field, bad in (("ell_min", 1e-38), ("ell_init", 0.0), ("ell_init", float("inf")), ("ell_min", float("nan"))):
+        Pb = cases.load_params("geometric_gpu")
+        setattr(Pb, field, bad)
+        gb = CvoGPU(params=Pb)
+        with pytest.raises(CvoError):
+            gb.align(gb.upload(src), gb.upload(tgt), init, max_iterations=3)
+    with pytest.raises(CvoError):
+        gpu.inner_product_gpu(da, db, init, 1e-35)
+    xyz = np.array(src.positions(), np.float32).copy()
+    xyz[5, 2] = np.nan
+    with pytest.raises(CvoError):
+        gpu.align(gpu.upload(CvoPointCloud.from_xyz(xyz)), db, init, max_iterations=3)
+    xyz[5, 2] = 3e20
+    with pytest.raises(CvoError):
+        gpu.align(da, gpu.upload(CvoPointCloud.from_xyz(xyz)), init, max_iterations=3)
+    Pc = cases.load_params("intensity_gpu")
+    Pc.c_ell = 1e-36
+    P3, s3, t3, i3 = cases.config3(n=500)
+    g3 = CvoGPU(params=Pc)
+    with pytest.raises(CvoError):
+        g3.align(g3.upload(s3), g3.upload(t3), i3, max_iterations=3)
+    gpu.L.cvo_shutdown()   # (pooled streams of the destroyed contexts above: harmless to call at any time)
+    assert gpu.align(da, db, init, max_iterations=3).iterations == 3
+

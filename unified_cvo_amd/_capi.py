@@ -142,6 +142,7 @@ EXPORTED = [
     "cvo_debug_last_candidates", "cvo_debug_list_builds", "cvo_debug_row_classes", "cvo_debug_scan_stats", "cvo_debug_last_geometry", "cvo_version",
     "cvo_align_association", "cvo_debug_scalar_math", "cvo_debug_verified_rows", "cvo_debug_device_memory", "cvo_cloud_upload_many",
     "cvo_ctx_set_option", "cvo_ctx_advice", "cvo_debug_cloud_order",
+    "cvo_process_hint_hw_queues", "cvo_shutdown",
     "cvo_batch_open", "cvo_batch_submit", "cvo_batch_poll", "cvo_batch_pending", "cvo_batch_stats", "cvo_batch_close",
 ]
 
@@ -159,6 +160,9 @@ def lib(path=None):
             f"{path} is missing: build it with `python -m unified_cvo_amd.build` "
             "(there is no CPU fallback for the hot path)")
     L = C.CDLL(path)
+    # process-wide: GPU_MAX_HW_QUEUES=8 unless the caller chose a value (include/cvo_hip.h, hardware queues).  Here, right
+    # after the load: before this process's first HIP call if the library is loaded before anything touches the GPU
+    L.cvo_process_hint_hw_queues()
     vp, ip, fp = C.c_void_p, C.c_int, C.POINTER(C.c_float)
     L.cvo_version.restype = C.c_char_p
     L.cvo_params_default.argtypes = [C.POINTER(cvo_params_t)]

@@ -30,23 +30,36 @@ using namespace cvo_dev;
 // turns kernel by kernel: 0.37 s instead of 0.25 s per step measured under torchrun, where RCCL brings streams of its
 // own; see also the note in cvo_ctx_create).  HIP deals streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
 // reads that variable once, when the runtime initialises - i.e. at the process's first HIP call.  So:
-//   * when this library is LOADED (before any of its kernels is registered) it puts GPU_MAX_HW_QUEUES=8 into the
-//     environment unless the variable is already set or CVO_NO_HW_QUEUE_HINT is; a process whose first HIP call comes
-//     after that - any C++ host linking the library, any Python process that loads it before torch touches the GPU -
-//     needs nothing else;
+//   * cvo_process_hint_hw_queues() puts GPU_MAX_HW_QUEUES=8 into the environment unless the variable is already set or
+//     CVO_NO_HW_QUEUE_HINT is: an EXPLICIT call a host makes before its first HIP call and before it starts threads
+//     (unified_cvo_amd/_capi.py does right after loading the library, cvo::CvoGPU's constructor before its context);
+//     at load time only with CVO_HW_QUEUE_HINT_AT_LOAD=1;
 //   * cvo_ctx_create checks what the variable says NOW and, below 8, leaves an advisory text in cvo_ctx_advice() and
 //     prints it once per process (stderr) - the case of a host that initialised HIP first with the default, or
 //     that set a smaller value on purpose.
 namespace {
 bool g_hw_queue_hint_set = false;
-__attribute__((constructor(101))) void cvo_hw_queue_hint() {
+void hw_queue_hint() {
   if (std::getenv("CVO_NO_HW_QUEUE_HINT")) return;
   if (!std::getenv("GPU_MAX_HW_QUEUES")) {
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
     g_hw_queue_hint_set = true;
   }
 }
+// At LOAD time only on request (CVO_HW_QUEUE_HINT_AT_LOAD=1): a library constructor that edits the environment changes HIP's
+// queue allocation for the whole host process behind its back, and setenv is not safe against getenv in other threads.
+// The hint is an explicit call - cvo_process_hint_hw_queues() - that a host makes where it controls the ordering: before
+// its first HIP call, before it starts threads (the Python wrapper and the C++ veneer's CvoGPU constructor do).
+__attribute__((constructor(101))) void cvo_hw_queue_hint_at_load() {
+  if (std::getenv("CVO_HW_QUEUE_HINT_AT_LOAD")) hw_queue_hint();
+}
 }  // namespace
+
+extern "C" int cvo_process_hint_hw_queues(void) {
+  hw_queue_hint();
+  const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+  return q ? atoi(q) : 4;
+}
 
 struct cvo_cloud {
   cvo_ctx* ctx = nullptr;  // identity check only: never dereferenced after upload (the context may be gone)
@@ -767,6 +780,18 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   if (params->nearest_neighbors_max <= 0) return fail(ctx, CVO_E_INVALID, "nearest_neighbors_max must be > 0");
   if (params->indicator_window_size + 1 >= IND_CAP || params->indicator_window_size < 0)
     return fail(ctx, CVO_E_INVALID, "indicator_window_size out of range");
+  {
+    // The row loops evaluate their IEEE double divisions in a hoisted form (rcp_refined / div_by, cvo_device.h) that equals
+    // the plain division wherever v_div_scale / v_div_fixup would pass the operands through: denominators 2 l^2, 2 c_ell^2,
+    // 2 s_ell^2 far from zero, denormals and infinity.  Lengthscales outside [1e-30, 1e15] (and non-finite ones) are refused
+    // here instead of silently leaving that domain; coordinates are bounded the same way below.
+    auto ok_scale = [](float v) { return std::isfinite(v) && v >= 1e-30f && v <= 1e15f; };
+    const float ell0 = mode == 0 ? ((opts && opts->override_state) ? opts->ell0 : params->ell_init) : mode_ell;
+    if (!ok_scale(ell0) || (mode == 0 && !ok_scale(params->ell_min)))
+      return fail(ctx, CVO_E_INVALID, "lengthscale outside [1e-30, 1e15] (ell_init / ell_min / the ell of the call)");
+    if (params->is_using_intensity && !ok_scale(params->c_ell)) return fail(ctx, CVO_E_INVALID, "c_ell outside [1e-30, 1e15]");
+    if (params->is_using_semantics && !ok_scale(params->s_ell)) return fail(ctx, CVO_E_INVALID, "s_ell outside [1e-30, 1e15]");
+  }
   if (mode == 0 && opts && opts->override_state) {
     // the ELL holds nearest_neighbors_max slots per row and the kernels write slot nnz while nnz < K
     if (opts->K0 < 1 || opts->K0 > params->nearest_neighbors_max)
@@ -782,6 +807,8 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
     if (sources[p]->ctx != ctx || targets[p]->ctx != ctx)
       return fail(ctx, CVO_E_INVALID, "cloud belongs to another context");
     if (sources[p]->n <= 0 || targets[p]->n <= 0) return fail(ctx, CVO_E_INVALID, "empty cloud in batch");
+    if (!(sources[p]->rmax <= 1e15f) || !(targets[p]->rmax <= 1e15f))  // (NaN sticks in rmax, see upload_host_cloud)
+      return fail(ctx, CVO_E_INVALID, "cloud with non-finite or astronomically large coordinates (|p| > 1e15)");
     N = std::max(N, sources[p]->n);
     M = std::max(M, targets[p]->n);
   }
@@ -812,12 +839,22 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   S->L = make_layout(N, M, Kmax, trace_cap, S->long_lists, &S->d);
   {
     size_t free_b = 0, total_b = 0;
-    const size_t need = S->L.total * (size_t)n_pairs;
+    size_t need = S->L.total * (size_t)n_pairs;
+    const bool tight = need > ctx->arena_bytes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b + ctx->arena_bytes;
+    if (tight && S->long_lists) {
+      // the long lists of overflow rows (N x 2 KB per pair) are a speed feature: without them such rows are scanned
+      // literally.  Give them up before giving up the call.
+      S->long_lists = false;
+      S->L = make_layout(N, M, Kmax, trace_cap, false, &S->d);
+      need = S->L.total * (size_t)n_pairs;
+      if (ctx_opt(ctx, "VERBOSE")) fprintf(stderr, "[cvo] workspace: long lists dropped to fit device memory\n");
+    }
     if (need > ctx->arena_bytes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b + ctx->arena_bytes) {
       char msg[320];
       snprintf(msg, sizeof msg,
                "workspace of %d pair(s) of %d x %d points needs %.1f GiB (candidate bitmap N*M/8 = %.1f GiB per pair, ELL "
-               "%.1f GiB per pair) but %.1f GiB of device memory are free: split the batch or the clouds",
+               "%.1f GiB per pair; the long lists of overflow rows have already been dropped) but %.1f GiB of device memory are "
+               "free: split the batch or the clouds",
                n_pairs, N, M, need / 1073741824.0, (double)N * S->d.Mpad / 8.0 / 1073741824.0,
                (double)S->d.Npad * Kmax * 20.0 / 1073741824.0, (free_b + ctx->arena_bytes) / 1073741824.0);
       return fail(ctx, CVO_E_NOMEM, msg);
@@ -1140,7 +1177,7 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
                "RCCL / the host application adds; with fewer than 8 hardware queues streams share a queue and take turns "
                "(measured: 0.37 s instead of 0.25 s per 64-pair step under torchrun).  Export GPU_MAX_HW_QUEUES=8 before "
                "the process's first HIP call",
-               q ? q : "unset (HIP's default: 4)", q ? "" : ": the load-time hint of this library was switched off");
+               q ? q : "unset (HIP's default: 4)", q ? "" : ": cvo_process_hint_hw_queues() was not called before HIP initialised");
       c->advice = msg;
       static std::atomic<bool> said{false};
       if (!said.exchange(true) && !std::getenv("CVO_QUIET")) fprintf(stderr, "[cvo] advice: %s\n", msg);
@@ -1177,8 +1214,12 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
 void cvo_ctx_destroy(cvo_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  // every stream of the set must be idle before the workspace goes (work queued by a call that returned early on an
+  // error would otherwise run against freed memory) - and a set whose streams cannot be drained is not pooled
+  bool drained = true;
   for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++)
-    if (c->gstream[g]) (void)hipStreamSynchronize(c->gstream[g]);
+    if (c->gstream[g]) drained = (hipStreamSynchronize(c->gstream[g]) == hipSuccess) && drained;
+  if (c->upload_stream) drained = (hipStreamSynchronize(c->upload_stream) == hipSuccess) && drained;
   drop_graphs(c);
   free_workspace(c);
   if (c->d_kd_jobs) (void)hipFree(c->d_kd_jobs);
@@ -1190,9 +1231,8 @@ void cvo_ctx_destroy(cvo_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
-  if (c->upload_stream) (void)hipStreamSynchronize(c->upload_stream);
-  {  // a complete set goes back to the device's pool (see StreamSet); a partial one (failed creation) is destroyed
-    bool complete = c->upload_stream != nullptr;
+  {  // a complete, drained set goes back to the device's pool (see StreamSet); anything else is destroyed
+    bool complete = drained && c->upload_stream != nullptr;
     for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++) complete = complete && c->gstream[g] != nullptr;
     if (complete) {
       StreamSet ss;
@@ -1208,6 +1248,20 @@ void cvo_ctx_destroy(cvo_ctx* c) {
     }
   }
   delete c;
+}
+
+void cvo_shutdown(void) {
+  // the pooled stream sets of destroyed contexts (contexts still alive keep theirs)
+  std::lock_guard<std::mutex> lk(g_stream_pool_mutex);
+  for (auto& kv : g_stream_pool) {
+    (void)hipSetDevice(kv.first);
+    for (StreamSet& ss : kv.second) {
+      for (int g = 0; g < cvo_ctx::MAX_GROUPS; g++)
+        if (ss.g[g]) (void)hipStreamDestroy(ss.g[g]);
+      if (ss.upload) (void)hipStreamDestroy(ss.upload);
+    }
+    kv.second.clear();
+  }
 }
 
 int cvo_ctx_set_option(cvo_ctx* ctx, const char* name, const char* value) {
@@ -1401,7 +1455,7 @@ static int upload_host_cloud(cvo_ctx* ctx, const HostCloud& h, hipStream_t strea
     sy += py;
     sz += pz;
     const double r2 = px * px + py * py + pz * pz;
-    if (!(r2 <= r2max)) r2max = r2;  // NaN sticks: an unbounded cloud never reuses a candidate list
+    if (r2max == r2max && !(r2 <= r2max)) r2max = r2;  // a NaN sticks (an unbounded cloud is refused by the solvers)
   }
   c->rmax = (float)(std::sqrt(r2max) * 1.000001);
   if (n > 0) {
@@ -2263,6 +2317,8 @@ int cvo_batch_submit(cvo_batch_queue* q, const cvo_cloud* source, const cvo_clou
   if (!source || !target || !init_T) return fail(ctx, CVO_E_INVALID, "cvo_batch_submit: null argument");
   if (source->ctx != ctx || target->ctx != ctx) return fail(ctx, CVO_E_INVALID, "cloud belongs to another context");
   if (source->n <= 0 || target->n <= 0) return fail(ctx, CVO_E_INVALID, "cvo_batch_submit: empty cloud");
+  if (!(source->rmax <= 1e15f) || !(target->rmax <= 1e15f))
+    return fail(ctx, CVO_E_INVALID, "cloud with non-finite or astronomically large coordinates (|p| > 1e15)");
   if (source->n > q->S.N || target->n > q->S.M || coeff_split(source->n) > q->S.geom.csplit)
     return fail(ctx, CVO_E_INVALID, "cvo_batch_submit: cloud outside the sizes the queue was opened for");
   HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -154,7 +154,6 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
   IdxT* list = s_list + tid * ASSOC_STRIDE;
   int cnt = 0;  // candidates this thread lists (0: a pad position, or a row for k_assoc_dense)
   if (rr < N) {  // real rows occupy the positions below N
-    const int* yorder = D->yorder;
     D->cand_cnt[pos] = cnt_all;
     D->rowperm[pos] = rr;
     {  // the row's head for the per-iteration kernels: coordinates + its candidate count in one 16-byte record
