@@ -66,6 +66,9 @@ struct DevParams {
                     // long lists) even though a cached list would hold them: the host lowers it when few pairs are in flight
                     // (an iteration is then a chain of latencies and a wave runs as long as its longest row); only with long
                     // lists, ASSOC_CAP16 = off.  No result depends on it (every row joins k_assoc's reduction at its position)
+  int row_max_busy;  // ... and the limit while a sixteenth of the rows overflow anyway (k_assoc_dense runs in every iteration
+                     // then): 24 in a batch, 8 when at most four pairs are in flight (scripts/rowmax_probe.py: a clustered
+                     // 3000-point pair 42.8 -> 34.4 us per iteration, 10k 92.5 -> 85.5)
   int long_lists;  // overflow rows keep a cached sorted candidate list of up to LONG_CAP entries (PairDesc::long_j)
   int debug_no_motion_bound;  // CVO_DEBUG_NO_MOTION_BOUND (tests only): the update pretends no target ever moves, so
                               // lists outlive their validity - what CVO_VERIFY_LISTS exists to catch

@@ -885,6 +885,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   dp.groups_per_block = S->gpb;
   dp.long_lists = S->long_lists ? 1 : 0;
   dp.row_max_cap = ASSOC_CAP16;
+  dp.row_max_busy = n_pairs <= 4 ? 8 : 24;
   if (const char* e = ctx_opt(ctx, "ROW_MAX")) dp.row_max_cap = std::max(1, std::min(atoi(e), (int)ASSOC_CAP16));
   dp.lean_U = 8;
   if (const char* e = ctx_opt(ctx, "LEAN_U")) dp.lean_U = std::max(1, atoi(e));
