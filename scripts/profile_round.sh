@@ -48,6 +48,12 @@ timeout 600 python $R/scripts/perf_probe.py $O/perf_probe.json > $O/perf_probe.t
 # the clustered street scene (not a BASELINE config): us per iteration at 3000 / 10k points, and its kernels
 timeout 300 python $R/scripts/scene_probe.py 2>&1 | grep -v "chunk [0-9]" > $O/scene_probe.txt
 GRAFT_REPO_ROOT=$R timeout 300 bash $R/scripts/scene_profile.sh > /dev/null 2>&1; cp $R/gpurun_out/scene_prof/kernel_stats.csv $O/scene_kernel_stats.csv
+# round 5: the batch queue (512 pairs through 64 ... 192 slots, mixed queue), overlap queries, row-class limit, one rank's
+# host budget on two CPUs
+timeout 600 python $R/scripts/queue_probe.py $O/queue_probe.json > $O/queue_probe.txt 2>&1
+timeout 300 python $R/scripts/overlap_probe.py > $O/overlap_probe.txt 2>&1
+timeout 600 python $R/scripts/rowmax_probe.py > $O/rowmax_probe.txt 2>&1
+timeout 900 bash $R/scripts/rank_rehearsal.sh gpurun_out/${ROUND:-r5}_prof/rehearsal > $O/rank_rehearsal.txt 2>&1
 # run-to-run reproducibility under load
 timeout 900 python $R/scripts/stress_repeat.py ${STRESS_BATCH:-100} ${STRESS_SINGLE:-40} > $O/stress.txt 2>&1
 tail -3 $O/bench_n1.log
