@@ -76,3 +76,33 @@ def test_queue_rejects_what_it_was_not_sized_for():
     r = q.poll(wait=2)
     q.close()
     assert len(r) == 1 and _same(r[0], gpu.align(da, db, init))
+
+
+def test_queue_random_mix_equals_solo():
+    """A soak in miniature: 36 submissions of slab and clustered pairs of three sizes with random iteration limits through
+    six slots (two sub-batch streams would need eight: one stream, refills all the time), polled at random - every result,
+    in submission order, bit-identical to the same pair solved alone with the same limit."""
+    rng = np.random.default_rng(7)
+    kinds = [cases.config2(n=1800, pair_id=1), cases.config2(n=2600, pair_id=2), cases.scene(n=2200, pair_id=3)]
+    P = kinds[0][0]
+    gpu = CvoGPU(params=P)
+    dev = [(gpu.upload(k[1]), gpu.upload(k[2]), k[3]) for k in kinds]
+    jobs = [(int(rng.integers(0, 3)), int(rng.choice([15, 60, 140, 260]))) for _ in range(36)]
+    solo = {}
+    for kind, lim in sorted(set(jobs)):
+        s, t, T = dev[kind]
+        solo[(kind, lim)] = gpu.align(s, t, T, max_iterations=lim)
+    q = gpu.open_queue(6, 2600, 2600, min_source_points=1800, max_iterations=300)
+    got = []
+    for kind, lim in jobs:
+        s, t, T = dev[kind]
+        q.submit(s, t, T, lim)
+        if rng.random() < 0.5:
+            got.extend(q.poll(wait=int(rng.integers(0, 2))))
+    while q.pending():
+        got.extend(q.poll(wait=1))
+    q.close()
+    assert [r.ticket for r in got] == list(range(36))
+    for r, (kind, lim) in zip(got, jobs):
+        assert _same(r, solo[(kind, lim)]), (r.ticket, kind, lim)
+

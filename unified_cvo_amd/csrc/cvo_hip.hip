@@ -116,7 +116,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static const char* const kOptionNames[] = {
     "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
     "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
-    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS", "ROW_MAX", "NO_ONEHOT"};
+    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS", "ROW_MAX", "NO_ONEHOT", "QUEUE_U", "QUEUE_ADMIT"};
 
 struct cvo_ctx {
   int device = 0;
@@ -2218,7 +2218,9 @@ int queue_step(cvo_batch_queue* q, int g, bool block, bool* progressed) {
     if (!q->waiting.empty() && q->running[g] < ng) {
       const int v = q->graph_next[g];
       const bool fast = v == 0 || v == 3 || v == 2 || v == 6;
-      if (fast || q->running[g] == 0 || 4 * (ng - q->running[g]) >= ng)
+      int den = 4;  // (QUEUE_ADMIT: the share of free slots - 1 / den - at which a settled sub-batch takes newcomers)
+      if (const char* e = ctx_opt(ctx, "QUEUE_ADMIT")) den = std::max(1, atoi(e));
+      if (fast || q->running[g] == 0 || den * (ng - q->running[g]) >= ng)
         for (int k = 0; k < ng && !q->waiting.empty(); k++)
           if (q->slot[p0 + k].ticket < 0) {
             const cvo_batch_queue::Job job = q->waiting.front();
@@ -2283,7 +2285,11 @@ int cvo_batch_open(cvo_ctx* ctx, const cvo_params_t* params, int slots, int max_
     q->geom[g].arena.base = q->S.geom.arena.base + q->S.L.total * (size_t)p0;
     q->geom[g].stream = ctx->gstream[g];
   }
-  const int U = 16;
+  // Iterations per chunk: a finished pair idles until the chunk after next (the host learns of it one chunk behind), so a
+  // queue of short solves wants short chunks; a boundary costs a stream ~10 us.  QUEUE_U (default 16 for the fast graphs,
+  // twice that for the lean ones, as cvo_align_batch).
+  int U = 16;
+  if (const char* e = ctx_opt(ctx, "QUEUE_U")) U = std::max(2, std::min(atoi(e), 64));
   q->cfg = LoopCfg{U, 2 * U, std::max(1, std::min(q->dp.lean_U, U)), std::max(0, std::min(q->dp.lean_U2, U)), q->S.geom.instr ? 8 : 0};
   q->allow_lean = ctx_opt(ctx, "NO_LEAN") == nullptr;
   q->start_nodense = q->allow_lean && q->S.N > 4096 && ctx_opt(ctx, "NO_NODENSE") == nullptr;
