@@ -295,7 +295,8 @@ inline int dense_waves_for(int) { return 4; }
 inline int dense_blocks_for(int N, int pairs_in_launch) {
   const int waves_pair = 8192 / (pairs_in_launch < 1 ? 1 : pairs_in_launch);  // 1024 SIMDs x 8 wave slots
   int nb = waves_pair / dense_waves_for(N);
-  const int rows = (N + dense_waves_for(N) - 1) / dense_waves_for(N);          // one row per wave is the most there is to do
+  // one row per wave is the most there is to do - or, a small pair solved alone, one row per BLOCK (k_assoc_dense's wide rows)
+  const int rows = (pairs_in_launch <= 1 && N <= DENSE_BLOCKS_MAX) ? N : (N + dense_waves_for(N) - 1) / dense_waves_for(N);
   if (nb > rows) nb = rows;
   if (nb > DENSE_BLOCKS_MAX) nb = DENSE_BLOCKS_MAX;
   if (nb < DENSE_BLOCKS_MIN) nb = DENSE_BLOCKS_MIN;

@@ -546,7 +546,7 @@ void launch_verify(hipStream_t s, int feat, int N, int n_pairs, const PairDesc* 
 }
 
 void launch_dense(hipStream_t s, int feat, int N, int n_pairs, int dense_blocks, const PairDesc* descs, const DevParams* dp,
-                  const int* st) {
+                  const PairState* st) {
   const dim3 grid(dense_blocks, n_pairs);
   switch (feat) {  // (4 waves per block: dense_waves_for)
     case FEAT_GEO: hipLaunchKernelGGL((k_assoc_dense<FEAT_GEO, 4>), grid, dim3(256), 0, s, descs, dp, st); break;
@@ -599,13 +599,16 @@ void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags, bool den
   const int* st = c->d_status + 2 * g.p0;  // the sub-batch's status words (see setup_batch)
   const bool lean_dense = lean && dense;
   // rows beyond their cached lists first (a wave per row; per-row results), then every row's reduction in k_assoc
-  if (!lean || dense) launch_dense(g.stream, g.feat, g.N, g.n_pairs, g.dense_blocks, descs, c->d_params, st);
+  if (!lean || dense) launch_dense(g.stream, g.feat, g.N, g.n_pairs, g.dense_blocks, descs, c->d_params, c->d_states + g.p0);
   launch_assoc(g.stream, g.idx16, g.feat, g.instr, g.nba, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena,
                (lean ? 1 : 0) | (lean_dense ? 4 : 0));
   if (g.verify) launch_verify(g.stream, g.feat, g.N, g.n_pairs, descs, c->d_params, st, (lean ? 1 : 0) | (lean_dense ? 4 : 0));
   // ... their coefficient sums likewise (k_coeff_dense leaves per-row sums, k_coeff picks them up)
   if (!lean || dense)
-    hipLaunchKernelGGL((k_coeff_dense<4>), dim3(g.dense_blocks, g.n_pairs), dim3(256), 0, g.stream, descs, c->d_params, st);
+    // (7 waves per SIMD against k_assoc_dense's 4: twice the blocks, so that a lone pair's rows get a wave each - the kernel
+    // then lasts as long as its longest row, not as two)
+    hipLaunchKernelGGL((k_coeff_dense<4>), dim3(g.n_pairs <= 4 ? 2 * g.dense_blocks : g.dense_blocks, g.n_pairs), dim3(256), 0, g.stream, descs,
+                       c->d_params, c->d_states + g.p0);
   launch_coeff(g.stream, g.instr, g.nba, g.csplit, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena,
                flags | (lean ? 1 : 0) | (lean_dense ? 32 : 0) | (g.idx16 ? 0 : 64));
 }
@@ -1038,7 +1041,7 @@ int run_inner_products(cvo_ctx* ctx, const cvo_params_t* params, int n, const cv
     HIP_TRY(ctx, hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
     launch_init(ctx, g);
     launch_rebuild(ctx, g);
-    launch_dense(g.stream, g.feat, g.N, g.n_pairs, g.dense_blocks, ctx->d_descs, ctx->d_params, ctx->d_status);
+    launch_dense(g.stream, g.feat, g.N, g.n_pairs, g.dense_blocks, ctx->d_descs, ctx->d_params, ctx->d_states);
     launch_assoc(g.stream, g.idx16, g.feat, g.instr, g.nba, g.n_pairs, ctx->d_descs, ctx->d_params, ctx->d_states, g.arena, 8);
     const hipError_t e_launch = hipGetLastError();
     hipError_t e = hipStreamEndCapture(g.stream, &gr);

@@ -83,10 +83,10 @@ __device__ __forceinline__ int build_long_list(const PairDesc* __restrict__ D, c
 
 template <int FEAT, int DENSE_WAVES>
 __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
-                                                     const int* __restrict__ status) {
-  if (status[blockIdx.y] != 0) return;
+                                                     const PairState* __restrict__ states) {
+  const PairState* __restrict__ st = states + blockIdx.y;  // == D->st, as wave-uniform scalar loads (see k_coeff_dense)
+  if (st->status != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.y;
-  const PairState* st = D->st;
   const DevParams P = *Pp;
   const int N = D->N, M = D->M;
   const int K = st->K;
@@ -95,8 +95,28 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
   if (n_ovf == 0) return;   // no row of this pair is beyond its cached list
   if (st->rebuild) return;  // (lean graphs with this kernel: the pair waits for its rebuild opportunity, see k_assoc)
   const bool all_dense = st->all_dense != 0;
-  __shared__ float2 s_hits[DENSE_WAVES][128][6];  // per wave: the hits of one step, compacted ({flow term, value} per component)
-  __shared__ unsigned s_keys[DENSE_WAVES][LONG_CAP];  // per wave: the long list being built (sort keys)
+  static_assert(DENSE_WAVES == 4, "the wide-row phase splits a row over four waves");
+  // LDS, carved twice.  Narrow rows (a wave per row): s_keys - the long list being built, per wave - and s_hits - the hits
+  // of one step, compacted ({flow term, value} per component), per wave.  Wide rows (the block per row): wave 0's s_keys,
+  // then every wave's hits of its quarter of the row ({value, transformed target}, column) and two 128-slot replay blocks.
+  constexpr int WIDE_MIN = 256;   // candidates from which a row is worth the whole block
+  constexpr int WIDE_CAP = 304;   // candidates (hence hits) a wave's quarter of a wide row can have: rows of up to 1216
+  __shared__ __attribute__((aligned(16))) char s_raw[sizeof(unsigned) * DENSE_WAVES * LONG_CAP + sizeof(float2) * DENSE_WAVES * 128 * 6];
+  unsigned(*s_keys)[LONG_CAP] = reinterpret_cast<unsigned(*)[LONG_CAP]>(s_raw);
+  float2(*s_hits)[128][6] = reinterpret_cast<float2(*)[128][6]>(s_raw + sizeof(unsigned) * DENSE_WAVES * LONG_CAP);
+  float4(*w_hit)[WIDE_CAP] = reinterpret_cast<float4(*)[WIDE_CAP]>(s_raw + sizeof(unsigned) * LONG_CAP);
+  int(*w_col)[WIDE_CAP] = reinterpret_cast<int(*)[WIDE_CAP]>(s_raw + sizeof(unsigned) * LONG_CAP + sizeof(float4) * DENSE_WAVES * WIDE_CAP);
+  float2(*w_rep)[128][6] = reinterpret_cast<float2(*)[128][6]>(s_raw + sizeof(unsigned) * LONG_CAP + (sizeof(float4) + sizeof(int)) * DENSE_WAVES * WIDE_CAP);
+  int* s_wcnt = reinterpret_cast<int*>(s_raw + sizeof(unsigned) * LONG_CAP + (sizeof(float4) + sizeof(int)) * DENSE_WAVES * WIDE_CAP + 2 * sizeof(float2) * 128 * 6);
+  static_assert(sizeof(unsigned) * LONG_CAP + (sizeof(float4) + sizeof(int)) * DENSE_WAVES * (WIDE_CAP + 1) + 2 * sizeof(float2) * 128 * 6 <= sizeof(s_raw),
+                "wide-row buffers fit the narrow-row carve");
+  // WIDE rows.  With a block per overflow row to spare (a small pair solved alone: the demo pair's 523 rows all scan 1080
+  // targets, a wave at a time that is nine dependent steps and 19 of its 43 us per iteration) a row of more than WIDE_MIN
+  // candidates whose quarters fit the buffers - its long list, or, rows beyond every list and the dense regime, all targets
+  // of a small target cloud - is evaluated by the four waves of block q, a quarter each; see the second phase below.  With
+  // more rows than blocks the waves are better spent on a row each (the replay is a serial chain either way).
+  const bool wide_mode = n_ovf <= (int)gridDim.x;
+  auto wide_row = [&](int n_cand) { return wide_mode && n_cand > WIDE_MIN && n_cand <= DENSE_WAVES * WIDE_CAP; };
   {
     const Pose pose = load_pose(st);
     const FeatDen F = make_feat_den(P);
@@ -119,6 +139,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
         if (cnt <= LONG_CAP) {
           listed = true;
           n_cand = cnt;
+          if (wide_row(n_cand)) continue;  // the whole block's, below
           lj = D->long_j + (size_t)q * LONG_CAP;
           if (D->long_stamp[q] != gen) {
             n_cand = build_long_list(D, P.T, D->rowperm[r_sorted], s_keys[wave], lane);
@@ -129,6 +150,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
           }
         }
       }
+      if (!listed && wide_row(n_cand)) continue;
       unsigned nnz = 0;
       // Two chunks of 64 candidates per step: their (independent) evaluations overlap in the pipeline; if the first one
       // already fills the row, the second was evaluated for nothing.  Hits are compacted into LDS in ascending j
@@ -183,8 +205,23 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
           nstaged += nkeep;
         }
         __builtin_amdgcn_wave_barrier();  // (same wave wrote the slots: LDS operations of a wave complete in order)
+        // (sixteen hits per round trip to the LDS: the replay is one dependent chain per component, and with four reads in
+        // flight it - not the evaluation - was most of a long row's time; the double sum of the values only where somebody
+        // reads it: the single evaluations)
         const int c = lane < 6 ? lane : 0;
+        const bool want_asum = P.mode != 0;
         int k = 0;
+        for (; k + 16 <= nstaged; k += 16) {
+          float2 e[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) e[u] = s_hits[wave][k + u][c];
+#pragma unroll
+          for (int u = 0; u < 16; u++) acc = __builtin_fmaf(e[u].x, e[u].y, acc);
+          if (want_asum) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) asum += (double)e[u].y;
+          }
+        }
         for (; k + 4 <= nstaged; k += 4) {
           const float2 e0 = s_hits[wave][k][c], e1 = s_hits[wave][k + 1][c], e2 = s_hits[wave][k + 2][c],
                        e3 = s_hits[wave][k + 3][c];
@@ -192,15 +229,17 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
           acc = __builtin_fmaf(e1.x, e1.y, acc);
           acc = __builtin_fmaf(e2.x, e2.y, acc);
           acc = __builtin_fmaf(e3.x, e3.y, acc);
-          asum += (double)e0.y;
-          asum += (double)e1.y;
-          asum += (double)e2.y;
-          asum += (double)e3.y;
+          if (want_asum) {
+            asum += (double)e0.y;
+            asum += (double)e1.y;
+            asum += (double)e2.y;
+            asum += (double)e3.y;
+          }
         }
         for (; k < nstaged; k++) {
           const float2 e = s_hits[wave][k][c];
           acc = __builtin_fmaf(e.x, e.y, acc);
-          asum += (double)e.y;
+          if (want_asum) asum += (double)e.y;
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -212,6 +251,147 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
       // kernel's own: a pair's sums do not depend on this launch's grid, i.e. on how many pairs are in flight).
       if (lane == 0) {
         D->nnz_row[r_sorted] = nnz;
+        D->rowres[r_sorted] = RowRes{{o0, o1, o2}, {v0, v1, v2}, asum};
+      }
+    }
+    // ---- wide rows: block q evaluates row q.  Every wave evaluates a quarter of the row and compacts its hits in LDS; the
+    // quarters' hit counts give every hit its slot (first-K exact: slots >= K are dropped, whichever quarter they come from),
+    // the ELL entries leave in parallel, and the float flow sums are then replayed in ascending slot order by ONE wave - the
+    // order, hence every bit, is that of the lone wave's scan.
+    if (!wide_mode) return;
+    __syncthreads();  // (the carve changes: every wave has left its narrow rows)
+    const int q = (int)blockIdx.x;
+    if (q >= n_ovf) return;
+    const int r_sorted = all_dense ? q : D->ovf_rows[q];
+    const float4 x = D->xp4[r_sorted];
+    const int cnt = __float_as_int(x.w);
+    const bool listed = long_lists && cnt <= LONG_CAP;
+    const int n_cand = listed ? cnt : M;
+    if (!wide_row(n_cand)) return;  // (block-uniform)
+    const int i = D->ip[r_sorted];
+    RowData r = make_row(P, x, st->ell);
+    if (FEAT == FEAT_HOT) r.lid = D->xlid[i];
+    const V3 pxe{x.x, x.y, x.z};
+    const unsigned short* lj = D->long_j + (size_t)q * LONG_CAP;
+    bool fresh = false;
+    if (listed) {
+      fresh = D->long_stamp[q] != gen;  // (read by everybody BEFORE wave 0 may move it)
+      __syncthreads();
+      if (fresh) {
+        if (wave == 0) {
+          const int nb = build_long_list(D, P.T, D->rowperm[r_sorted], s_keys[0], lane);
+          unsigned short* out = D->long_j + (size_t)q * LONG_CAP;
+          for (int k = lane; k < nb; k += 64) out[k] = (unsigned short)(s_keys[0][k] & 0xffffu);
+          if (lane == 0) D->long_stamp[q] = gen;
+        }
+        __syncthreads();
+      }
+    }
+    // this wave's quarter: a multiple of 128 candidates, two chunks of 64 per step (independent evaluations in flight together)
+    const int per = ((n_cand + 128 * DENSE_WAVES - 1) / (128 * DENSE_WAVES)) * 128;
+    const int lo = wave * per, hi = min(n_cand, lo + per);
+    int nh = 0;
+    for (int c0 = lo; c0 < hi; c0 += 128) {
+      float a[2] = {0.f, 0.f};
+      float4 yt[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+      bool ok[2] = {false, false};
+      int col[2] = {0, 0};
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int c = c0 + 64 * h + lane;
+        if (c < hi) {
+          if (listed) {
+            col[h] = fresh ? (int)(s_keys[0][c] & 0xffffu) : (int)lj[c];
+            ok[h] = eval_pair<FEAT>(P, D, F, pose, i, r, col[h], D->ys4[col[h]], a[h], yt[h]) && (a[h] > P.sp_thres);
+          } else {
+            col[h] = c;
+            ok[h] = eval_pair<FEAT>(P, D, F, pose, i, r, (FEAT != FEAT_GEO) ? D->yinv[c] : 0, D->y4[c], a[h], yt[h]) && (a[h] > P.sp_thres);
+          }
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const unsigned long long m = __ballot(ok[h]);
+        const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (ok[h]) {
+          w_hit[wave][nh + below] = make_float4(a[h], yt[h].x, yt[h].y, yt[h].z);
+          w_col[wave][nh + below] = col[h];
+        }
+        nh += __builtin_popcountll(m);
+      }
+    }
+    if (lane == 0) s_wcnt[wave] = nh;
+    __syncthreads();
+    // slots: quarter v holds slots [kb[v], kb[v + 1]) of the row's first K hits
+    int kb[DENSE_WAVES + 1];
+    kb[0] = 0;
+#pragma unroll
+    for (int v = 0; v < DENSE_WAVES; v++) kb[v + 1] = min(K, kb[v] + s_wcnt[v]);
+    const int nnz = kb[DENSE_WAVES];
+    const int base = kb[wave], keep = kb[wave + 1] - kb[wave];
+    for (int idx = lane; idx < keep; idx += 64) {
+      const float4 h = w_hit[wave][idx];
+      const int col = w_col[wave][idx];
+      const int psort = listed ? col : ((FEAT != FEAT_GEO || ELL8) ? D->yinv[col] : 0);
+      D->ell[(size_t)(base + idx) * N + r_sorted] = make_ell(h.x, h.y, h.z, h.w, psort);
+      if (P.keep_columns) D->ell_j[(size_t)(base + idx) * N + r_sorted] = listed ? D->yorder[col] : col;
+    }
+    // ordered replay, 128 slots at a time: waves 2 and 3 lay the flow terms of block b + 1 out while wave 0 accumulates block b
+    // (CvoGPU.cu:767-780) - the replay is one dependent chain per component and the only serial part of a wide row
+    float acc = 0.f;
+    double asum = 0;
+    const bool want_asum = P.mode != 0;
+    auto fill = [&](int s0, float2(*buf)[6]) {
+      const int t = (int)threadIdx.x - 128;
+      const int sl = s0 + t;
+      if (t < 0 || sl >= nnz) return;
+      int v = 0;
+#pragma unroll
+      for (int u = 1; u < DENSE_WAVES; u++) v += (sl >= kb[u]) ? 1 : 0;
+      const float4 h = w_hit[v][sl - kb[v]];
+      const V3 pye{h.y, h.z, h.w};
+      const V3 cr = cross_dev(pxe, pye);
+      float2* slot = buf[t];
+      slot[0] = make_float2(cr.x, h.x);
+      slot[1] = make_float2(cr.y, h.x);
+      slot[2] = make_float2(cr.z, h.x);
+      slot[3] = make_float2(pye.x - pxe.x, h.x);
+      slot[4] = make_float2(pye.y - pxe.y, h.x);
+      slot[5] = make_float2(pye.z - pxe.z, h.x);
+    };
+    fill(0, w_rep[0]);
+    __syncthreads();
+    for (int s0 = 0, b = 0; s0 < nnz; s0 += 128, b ^= 1) {
+      if (s0 + 128 < nnz) fill(s0 + 128, w_rep[b ^ 1]);
+      if (wave == 0) {
+        const float2(*buf)[6] = w_rep[b];
+        const int n_here = min(128, nnz - s0);
+        const int c = lane < 6 ? lane : 0;
+        int k = 0;
+        for (; k + 16 <= n_here; k += 16) {
+          float2 e[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) e[u] = buf[k + u][c];
+#pragma unroll
+          for (int u = 0; u < 16; u++) acc = __builtin_fmaf(e[u].x, e[u].y, acc);
+          if (want_asum) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) asum += (double)e[u].y;
+          }
+        }
+        for (; k < n_here; k++) {
+          const float2 e = buf[k][c];
+          acc = __builtin_fmaf(e.x, e.y, acc);
+          if (want_asum) asum += (double)e.y;
+        }
+      }
+      __syncthreads();
+    }
+    if (wave == 0) {
+      const float o0 = __shfl(acc, 0), o1 = __shfl(acc, 1), o2 = __shfl(acc, 2);
+      const float v0 = __shfl(acc, 3), v1 = __shfl(acc, 4), v2 = __shfl(acc, 5);
+      if (lane == 0) {
+        D->nnz_row[r_sorted] = (unsigned)nnz;
         D->rowres[r_sorted] = RowRes{{o0, o1, o2}, {v0, v1, v2}, asum};
       }
     }

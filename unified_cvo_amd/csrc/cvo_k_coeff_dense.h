@@ -18,10 +18,12 @@ namespace cvo_dev {
 // ------------------------------------------------------------------------------------------
 template <int DENSE_WAVES>
 __global__ __launch_bounds__(64 * DENSE_WAVES) void k_coeff_dense(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
-                                                                  const int* __restrict__ status) {
-  if (status[blockIdx.y] != 0) return;
+                                                                  const PairState* __restrict__ states) {
+  // (the state through the kernel-argument array: wave-uniform SCALAR loads - through the descriptor's pointer the twist
+  // matrices alone were 42 VGPRs)
+  const PairState* __restrict__ st = states + blockIdx.y;  // == D->st
+  if (st->status != 0) return;
   const PairDesc* __restrict__ D = descs + blockIdx.y;
-  const PairState* __restrict__ st = D->st;
   const DevParams P = *Pp;
   if (P.mode != 0) return;
   const int n_ovf = st->n_ovf;
@@ -67,10 +69,21 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_coeff_dense(const PairDesc
       __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order)
       const int n_here = (int)min(64u, nnz - s0);
       // slot s belongs to slice s % csplit; s0 is a multiple of 64 and csplit divides 64: local index l, slice l % csplit
-      if (qs0 < csplit)
-        for (int l = qs0; l < n_here; l += csplit) acc0 += s_terms[wave][l][comp];
-      if (qs1 < csplit)
-        for (int l = qs1; l < n_here; l += csplit) acc1 += s_terms[wave][l][comp];
+      // (eight terms per round trip to the LDS: the sum is one dependent chain per (slice, component))
+      auto chain = [&](int qs, double acc) {
+        int l = qs;
+        for (; l + 7 * csplit < n_here; l += 8 * csplit) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) v[u] = s_terms[wave][l + u * csplit][comp];
+#pragma unroll
+          for (int u = 0; u < 8; u++) acc += v[u];
+        }
+        for (; l < n_here; l += csplit) acc += s_terms[wave][l][comp];
+        return acc;
+      };
+      if (qs0 < csplit) acc0 = chain(qs0, acc0);
+      if (qs1 < csplit) acc1 = chain(qs1, acc1);
       __builtin_amdgcn_wave_barrier();
     }
     double* rc = D->rowcoef + (size_t)pos * csplit * 4;
