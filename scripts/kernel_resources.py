@@ -18,7 +18,7 @@ cur, rows = None, {}
 for line in err.splitlines():
     m = re.search(r"Function Name: (\S+)", line)
     if m:
-        cur = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void ", "")
+        cur = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         rows[cur] = {}
         continue
     m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)

@@ -492,6 +492,55 @@ def test_one_hot_semantics_equal_the_general_kernel_bit_for_bit():
     assert cases.max_abs_diff(soft.transform, hot.transform) < 1e-3
 
 
+def test_overlap_kernel_equals_the_list_chain():
+    """inner_product_gpu / function_angle in one launch (k_overlap: 64-row blocks against the target tiles their bounding
+    spheres reach, the reference's per-pair arithmetic on what passes the cut-off) against the list chain the loop uses
+    (CVO_IP_CHAIN): the same values summed in another order - equal to a few ulp of the double sum, i.e. the same float
+    in all but exceptional cases.  Geometry only, colour, soft and one-hot semantics, ragged sizes, a tiny cloud, poses
+    away from the identity, a matrix that is no rotation; and rows beyond nearest_neighbors_max, where the first-K
+    truncation (CvoGPU.cu:585) sends the call down the chain by itself: then bit for bit."""
+    rng = np.random.default_rng(5)
+
+    def pose(angle, t):
+        c, s_ = np.cos(angle), np.sin(angle)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3] = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32)
+        T[:3, 3] = t
+        return T
+
+    work = [("geo 3000", cases.config2(n=3000), 0.3), ("geo ragged", cases.config2(n=1000, m=777), 0.25),
+            ("colour 2000", cases.config3(n=2000), None), ("semantic 2000", cases.config4(n=2000), None),
+            ("geo 10k", cases.config2(n=10000), None), ("geo tiny", cases.config2(n=5, m=3), 0.8)]
+    for name, (P, src, tgt, init), ell in work:
+        ell = P.ell_init if ell is None else ell
+        gpu = CvoGPU(params=P)
+        da, db = gpu.upload(src), gpu.upload(tgt)
+        skew = np.eye(4, dtype=np.float32)
+        skew[0, 0], skew[1, 2] = 1.3, 0.2  # (not a rotation: the cull may only trust its norm)
+        for T in (init, pose(0.05, (0.02, -0.01, 0.03)), pose(-0.4, (0.3, 0.1, -0.2)), skew):
+            fast = (gpu.inner_product_gpu(da, db, T, ell), gpu.function_angle(da, db, T, ell, True), gpu.function_angle(da, db, T, ell, False))
+            gpu.set_option("IP_CHAIN", "1")
+            chain = (gpu.inner_product_gpu(da, db, T, ell), gpu.function_angle(da, db, T, ell, True), gpu.function_angle(da, db, T, ell, False))
+            gpu.set_option("IP_CHAIN", None)
+            assert fast == pytest.approx(chain, rel=2e-7, abs=1e-30), (name, fast, chain)
+            assert fast == (gpu.inner_product_gpu(da, db, T, ell), gpu.function_angle(da, db, T, ell, True), gpu.function_angle(da, db, T, ell, False))
+        if name == "semantic 2000":  # class ids against class rows
+            hot = gpu.inner_product_gpu(da, db, init, ell)
+            gpu.set_option("NO_ONEHOT", "1")
+            assert hot == gpu.inner_product_gpu(da, db, init, ell)
+        gpu.close()
+    # rows that find more than K pairs: the sum is the chain's, bit for bit
+    P, src, tgt, init = cases.config2(n=2000)
+    P.nearest_neighbors_max = 6
+    gpu = CvoGPU(params=P)
+    da, db = gpu.upload(src), gpu.upload(tgt)
+    fast = gpu.inner_product_gpu(da, db, init, 0.5)
+    gpu.set_option("IP_CHAIN", "1")
+    assert fast == gpu.inner_product_gpu(da, db, init, 0.5) and fast > 0
+    A = gpu.compute_association_gpu(da, db, init, 0.5)
+    assert np.diff(A[0]).max() == 6  # (rows sit on the cap)
+
+
 def test_context_options_are_validated():
     gpu = CvoGPU(params=CvoParams())
     gpu.set_option("CVO_VERBOSE", None)      # with or without the prefix; None clears

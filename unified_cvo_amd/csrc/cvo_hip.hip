@@ -78,6 +78,8 @@ struct cvo_cloud {
   // They are not uploaded: a zeroed slab is allocated the first time a call needs them (colour / semantic /
   // geometric-type kernels on a cloud without those arrays), see ensure_attributes.
   mutable char* zero_slab = nullptr;
+  // bounding spheres of the 64-point tiles of xs4 (k_tile_spheres), made the first time k_overlap reads this cloud
+  mutable float4* tile4 = nullptr;
   int* order = nullptr;        // spatial (k-d) order: sorted position -> original index
   int* inv = nullptr;          // its inverse: original index -> sorted position
   std::vector<int> h_order;  // host copy (the ELL is stored by sorted row; exports map it back)
@@ -116,7 +118,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static const char* const kOptionNames[] = {
     "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
     "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
-    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS", "ROW_MAX", "NO_ONEHOT", "QUEUE_U", "QUEUE_ADMIT"};
+    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "IP_CHAIN", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS", "ROW_MAX", "NO_ONEHOT", "QUEUE_U", "QUEUE_ADMIT"};
 
 struct cvo_ctx {
   int device = 0;
@@ -145,6 +147,10 @@ struct cvo_ctx {
   int cap_pairs = 0;
   std::vector<PairDesc> h_descs;
   std::vector<PairState> h_states;
+  // k_overlap (one-launch inner products): row-tile partials + gate words of up to three jobs (device), results (pinned)
+  char* d_ov = nullptr;
+  int ov_tiles_cap = 0;
+  char* h_ov = nullptr;
   int* h_status[2] = {nullptr, nullptr};  // pinned; [0]: the live host mirror of the status / want words the device writes
                                           // (PairDesc::status_host / want_host), [1]: unused slot kept for the layout
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -293,6 +299,10 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, bool long_lis
 
 void free_workspace(cvo_ctx* c) {
   if (c->arena) (void)hipFree(c->arena);
+  if (c->d_ov) (void)hipFree(c->d_ov);
+  if (c->h_ov) (void)hipHostFree(c->h_ov);
+  c->d_ov = c->h_ov = nullptr;
+  c->ov_tiles_cap = 0;
   if (c->d_ctl) (void)hipFree(c->d_ctl);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   for (int i = 0; i < 2; i++)
@@ -771,10 +781,11 @@ unsigned long long next_call_serial() {
 
 // Builds descriptors + initial states for a batch and uploads them.  qd != nullptr: plans the workspace of a batch queue
 // (cvo_batch_open) for n_pairs SLOTS without occupants - every slot starts out finished, cvo_batch_submit fills them.
-int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo_cloud* const* sources,
-                const cvo_cloud* const* targets, const float* init_T, const cvo_align_opts_t* opts, int mode,
-                float mode_ell, BatchSetup* S, DevParams* dp_out, const float* kernel_inv_and_cull = nullptr,
-                const QueueDims* qd = nullptr) {
+// What every entry point checks before it touches the device: the arguments of the call, the parameter and coordinate
+// ranges the kernels' arithmetic is stated for, the attribute arrays the call's kernels will read.  N / M: the largest
+// source / target cloud of the call.
+int check_call(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo_cloud* const* sources, const cvo_cloud* const* targets,
+               const cvo_align_opts_t* opts, int mode, float mode_ell, const QueueDims* qd, int* N_out, int* M_out) {
   if (!ctx) return CVO_E_INVALID;
   if (ctx->queue_open && !qd) return fail(ctx, CVO_E_INVALID, "a batch queue is open on this context (cvo_batch_close it first)");
   if (!params || n_pairs <= 0 || (!qd && (!sources || !targets))) return fail(ctx, CVO_E_INVALID, "null argument");
@@ -826,6 +837,20 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
         if (rc0 == CVO_OK) rc0 = ensure_attributes(ctx, targets[p], nf, nl, ng);
         if (rc0 != CVO_OK) return rc0;
       }
+  }
+  *N_out = N;
+  *M_out = M;
+  return CVO_OK;
+}
+
+int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo_cloud* const* sources,
+                const cvo_cloud* const* targets, const float* init_T, const cvo_align_opts_t* opts, int mode,
+                float mode_ell, BatchSetup* S, DevParams* dp_out, const float* kernel_inv_and_cull = nullptr,
+                const QueueDims* qd = nullptr) {
+  int N = 0, M = 0;
+  {
+    const int rc0 = check_call(ctx, params, n_pairs, sources, targets, opts, mode, mode_ell, qd, &N, &M);
+    if (rc0 != CVO_OK) return rc0;
   }
   const int trace_cap = (opts && opts->trace) ? opts->trace_capacity : 0;
   const int Kmax = params->nearest_neighbors_max;
@@ -1012,8 +1037,137 @@ int run_single_eval(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* s
 // inner_product_gpu for n (<= 8) pairs in ONE chain: INIT, the rebuild trio, [k_assoc_dense], k_assoc whose last block
 // posts A_sum to pinned host memory - one upload, one graph launch, one synchronisation.  The three inner products of the
 // exact function_angle (CvoGPU.cu:1835-1837) are such a batch.  Every value is what the one-pair path returns.
+// The inner products of a call in one launch of k_overlap (cvo_k_overlap.h).  *void_out: some row found more than
+// nearest_neighbors_max pairs - its first-K truncation needs the hits in ascending original index, i.e. the list chain.
+struct OverlapArgs {
+  OverlapJob job[3];
+  DevParams P;
+};
+static_assert(sizeof(OverlapArgs) <= 4096, "k_overlap takes its jobs as kernel arguments");
+template <int FEAT>
+__global__ __launch_bounds__(64 * OV_WAVES) void k_overlap_entry(const OverlapArgs A) {
+  k_overlap<FEAT>(A.job[blockIdx.y], A.P);
+}
+
+int ensure_tiles(cvo_ctx* ctx, const cvo_cloud* c, hipStream_t s) {
+  if (c->tile4) return CVO_OK;
+  const int nt = (c->n + 63) / 64;
+  float4* t = nullptr;
+  HIP_TRY(ctx, hipMalloc(&t, sizeof(float4) * 2 * (size_t)nt));
+  hipLaunchKernelGGL(k_tile_spheres, dim3((nt + 3) / 4), dim3(256), 0, s, c->n, c->xs4, t);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    (void)hipFree(t);
+    return fail(ctx, CVO_E_HIP, std::string("k_tile_spheres: ") + hipGetErrorString(e));
+  }
+  c->tile4 = t;
+  return CVO_OK;
+}
+
+int run_overlap_kernel(cvo_ctx* ctx, const cvo_params_t* params, int n, const cvo_cloud* const* src, const cvo_cloud* const* tgt,
+                       const float* Tms, float ell, double* out, bool* void_out) {
+  int N = 0, M = 0;
+  int rc = check_call(ctx, params, n, src, tgt, nullptr, 1, ell, nullptr, &N, &M);
+  if (rc != CVO_OK) return rc;
+  if (n > 3) return fail(ctx, CVO_E_INVALID, "run_overlap_kernel: at most three pairs per launch");
+  hipStream_t stream = ctx->stream;
+  const int tiles_max = (N + 63) / 64;
+  if (!ctx->h_ov) HIP_TRY(ctx, hipHostMalloc(&ctx->h_ov, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  if (tiles_max > ctx->ov_tiles_cap) {
+    if (ctx->d_ov) (void)hipFree(ctx->d_ov);
+    ctx->d_ov = nullptr;
+    ctx->ov_tiles_cap = 0;
+    const size_t bytes = 256 + 3 * sizeof(double) * (size_t)tiles_max;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_ov, bytes));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_ov, 0, 256, stream));  // (the gate words; the kernel leaves them at zero)
+    ctx->ov_tiles_cap = tiles_max;
+  }
+  OverlapArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.P = make_dev_params(ctx, *params);
+  A.P.mode = 1;
+  bool all_hot = ctx_opt(ctx, "NO_ONEHOT") == nullptr;
+  for (int p = 0; p < n; p++) {
+    const cvo_cloud* X = src[p];
+    const cvo_cloud* Y = tgt[p];
+    if ((rc = ensure_tiles(ctx, X, stream)) != CVO_OK || (rc = ensure_tiles(ctx, Y, stream)) != CVO_OK) return rc;
+    all_hot = all_hot && X->lid != nullptr && Y->lid != nullptr;
+    OverlapJob& J = A.job[p];
+    J.D.N = X->n;
+    J.D.M = Y->n;
+    J.D.xs4 = X->xs4;
+    J.D.ys4 = Y->xs4;
+    J.D.xfeat = X->feat;
+    J.D.yfeat = Y->feat;
+    J.D.xlabel = X->label;
+    J.D.ylabel = Y->label;
+    J.D.xgeo = X->geo;
+    J.D.ygeo = Y->geo;
+    J.D.xlid = X->lid;
+    J.D.ylid = Y->lid;
+    J.xtile = X->tile4;
+    J.ytile = Y->tile4;
+    J.n_xtiles = (X->n + 63) / 64;
+    J.n_ytiles = (Y->n + 63) / 64;
+    const float* Tm = Tms + 16 * (size_t)p;
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) J.R[3 * i + j] = Tm[4 * j + i];  // CvoGPU.cu:1363-1364 (as fill_pair)
+      J.T[i] = Tm[12 + i];
+    }
+    {
+      // |R^T v| <= stretch |v|: 1 (+ rounding) for a rotation, the Frobenius norm for anything else a caller may pass
+      double dev = 0, fro = 0;
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+          double g = 0;
+          for (int k = 0; k < 3; k++) g += (double)J.R[3 * k + i] * (double)J.R[3 * k + j];
+          dev = std::max(dev, std::fabs(g - (i == j ? 1.0 : 0.0)));
+          fro += (double)J.R[3 * i + j] * (double)J.R[3 * i + j];
+        }
+      J.stretch = (dev <= 1e-4) ? 1.001f : (float)(std::sqrt(fro) * 1.001);
+      if (!std::isfinite(J.stretch)) J.stretch = __builtin_inff();  // (every tile is visited)
+    }
+    J.ell = ell;
+    J.K = params->nearest_neighbors_max;
+    J.part = reinterpret_cast<double*>(ctx->d_ov + 256) + (size_t)p * ctx->ov_tiles_cap;
+    J.gate = reinterpret_cast<int*>(ctx->d_ov) + 2 * p;
+    J.sum_host = reinterpret_cast<double*>(ctx->h_ov) + p;
+    J.over_host = reinterpret_cast<int*>(ctx->h_ov + 32) + p;
+  }
+  const int feat = call_feat(A.P, all_hot);
+  const dim3 grid(tiles_max, n), block(64 * OV_WAVES);
+  switch (feat) {
+    case FEAT_GEO: hipLaunchKernelGGL((k_overlap_entry<FEAT_GEO>), grid, block, 0, stream, A); break;
+    case FEAT_COL: hipLaunchKernelGGL((k_overlap_entry<FEAT_COL>), grid, block, 0, stream, A); break;
+    case FEAT_HOT: hipLaunchKernelGGL((k_overlap_entry<FEAT_HOT>), grid, block, 0, stream, A); break;
+    default: hipLaunchKernelGGL((k_overlap_entry<FEAT_ALL>), grid, block, 0, stream, A); break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) {
+    (void)hipMemset(ctx->d_ov, 0, 256);  // (a launch that died may have left the gate words behind)
+    return fail(ctx, CVO_E_HIP, std::string("k_overlap: ") + hipGetErrorString(e));
+  }
+  *void_out = false;
+  for (int p = 0; p < n; p++) {
+    out[p] = reinterpret_cast<const volatile double*>(ctx->h_ov)[p];
+    if (reinterpret_cast<const volatile int*>(ctx->h_ov + 32)[p] != 0) *void_out = true;
+  }
+  ctx->last_pairs = 0;  // (no workspace of the list chain belongs to this call: the debug getters have nothing to read)
+  return CVO_OK;
+}
+
 int run_inner_products(cvo_ctx* ctx, const cvo_params_t* params, int n, const cvo_cloud* const* src, const cvo_cloud* const* tgt,
                        const float* Tms, float ell, double* out) {
+  // One launch when the call has a geometric cut-off to cull by and nobody asked for the list chain (CVO_IP_CHAIN; the
+  // instrumented / verifying runs are the chain's); the chain when a row overflows K (first-K needs the original order).
+  if (ctx && params && params->is_using_geometry && !params->is_using_kdtree && n <= 3 && ctx_opt(ctx, "IP_CHAIN") == nullptr &&
+      ctx_opt(ctx, "VERIFY_LISTS") == nullptr && ctx_opt(ctx, "KERNEL_CLOCK") == nullptr && ctx_opt(ctx, "PHASE_TICKS") == nullptr) {
+    bool void_sum = false;
+    const int rc = run_overlap_kernel(ctx, params, n, src, tgt, Tms, ell, out, &void_sum);
+    if (rc != CVO_OK) return rc;
+    if (!void_sum) return CVO_OK;
+  }
   BatchSetup S;
   DevParams dp;
   int rc = setup_batch(ctx, params, n, src, tgt, Tms, nullptr, 1, ell, &S, &dp);
@@ -1792,6 +1946,7 @@ void cvo_cloud_free(cvo_cloud* c) {
   (void)hipSetDevice(c->device);
   if (c->slab) (void)hipFree(c->slab);
   if (c->zero_slab) (void)hipFree(c->zero_slab);
+  if (c->tile4) (void)hipFree(c->tile4);
   delete c;
 }
 
@@ -2451,6 +2606,12 @@ int cvo_batch_poses_to_device(cvo_ctx* ctx, void* dst_device, int n_pairs) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return CVO_OK;
 }
+
+#ifdef CVO_OV_STAMPS
+int cvo_debug_overlap_ticks(unsigned long long* out) {  // experiment builds only
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ov_ticks), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int cvo_inner_product(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source, const cvo_cloud* target,
                       const float T[16], float ell, float* out) {

@@ -58,6 +58,7 @@
 #include "cvo_k_assoc_dense.h"
 #include "cvo_update.h"
 #include "cvo_k_coeff.h"
+#include "cvo_k_overlap.h"
 #include "cvo_k_coeff_dense.h"
 #include "cvo_k_debug.h"
 #include "cvo_k_cloud.h"

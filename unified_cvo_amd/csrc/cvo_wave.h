@@ -68,6 +68,22 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   return max(max((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 16)),
              max((unsigned)__builtin_amdgcn_readlane((int)v, 32), (unsigned)__builtin_amdgcn_readlane((int)v, 48)));
 }
+// min / max of a float over the wave on the DPP paths (every lane gets the result; NaNs are dropped as fminf / fmaxf drop them)
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax_f32(float v) {
+  auto meet = [](float a, int ob) {
+    const float o = __builtin_bit_cast(float, ob);
+    return MAX ? fmaxf(a, o) : fminf(a, o);
+  };
+  v = meet(v, dpp_i32<DPP_XOR1>(__builtin_bit_cast(int, v)));
+  v = meet(v, dpp_i32<DPP_XOR2>(__builtin_bit_cast(int, v)));
+  v = meet(v, dpp_i32<DPP_HALF_MIRROR>(__builtin_bit_cast(int, v)));
+  v = meet(v, dpp_i32<DPP_MIRROR>(__builtin_bit_cast(int, v)));
+  const int iv = __builtin_bit_cast(int, v);
+  float m = meet(__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), __builtin_amdgcn_readlane(iv, 16));
+  m = meet(m, __builtin_amdgcn_readlane(iv, 32));
+  return meet(m, __builtin_amdgcn_readlane(iv, 48));
+}
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o));
