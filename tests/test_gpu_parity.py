@@ -529,6 +529,21 @@ def test_overlap_kernel_equals_the_list_chain():
             gpu.set_option("NO_ONEHOT", "1")
             assert hot == gpu.inner_product_gpu(da, db, init, ell)
         gpu.close()
+    # far from the origin, under a pose whose translation cancels the rotated coordinates (the cull's rounding slack is
+    # measured on the terms of Rinv y + Tinv, not on the result)
+    P, src, tgt, init = cases.config2(n=3000)
+    off = np.array([800.0, -300.0, 150.0], np.float32)
+    xs, ys = np.array(src.positions()) + off, np.array(tgt.positions()) + off
+    R = pose(0.05, (0, 0, 0))[:3, :3].astype(np.float64)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = R
+    T[:3, 3] = (off.astype(np.float64) - R @ off.astype(np.float64)).astype(np.float32)
+    gpu = CvoGPU(params=P)
+    da, db = gpu.upload(CvoPointCloud.from_xyz(xs)), gpu.upload(CvoPointCloud.from_xyz(ys))
+    fast = gpu.inner_product_gpu(da, db, T, 0.3)
+    gpu.set_option("IP_CHAIN", "1")
+    assert fast == pytest.approx(gpu.inner_product_gpu(da, db, T, 0.3), rel=2e-7) and fast > 0
+    gpu.close()
     # rows that find more than K pairs: the sum is the chain's, bit for bit
     P, src, tgt, init = cases.config2(n=2000)
     P.nearest_neighbors_max = 6

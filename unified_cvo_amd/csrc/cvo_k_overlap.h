@@ -194,8 +194,12 @@ __device__ __forceinline__ void k_overlap(const OverlapJob& Jr, const DevParams&
         const V3 c = transform_point(pose.Ri, pose.Ti, s.x, s.y, s.z);
         const float dx = c.x - xs.x, dy = c.y - xs.y, dz = c.z - xs.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
-        // (slack: the rounding of the transformed centre and of the transformed points, ~30 ulp of the coordinates' size)
-        const float slack = 4e-6f * (fabsf(c.x) + fabsf(c.y) + fabsf(c.z) + fabsf(xs.x) + fabsf(xs.y) + fabsf(xs.z));
+        // (slack: the rounding of the transformed centre and of the tile's transformed points - a few ulp of the TERMS of
+        // Rinv y + Tinv, which a translation that cancels the rotated coordinates leaves far larger than the result)
+        const float ym = fabsf(s.x) + fabsf(s.y) + fabsf(s.z) + s.w;
+        const float rm = fabsf(pose.Ri[0]) + fabsf(pose.Ri[1]) + fabsf(pose.Ri[2]) + fabsf(pose.Ri[3]) + fabsf(pose.Ri[4]) +
+                         fabsf(pose.Ri[5]) + fabsf(pose.Ri[6]) + fabsf(pose.Ri[7]) + fabsf(pose.Ri[8]);
+        const float slack = 4e-6f * (rm * ym + fabsf(pose.Ti[0]) + fabsf(pose.Ti[1]) + fabsf(pose.Ti[2]) + fabsf(xs.x) + fabsf(xs.y) + fabsf(xs.z));
         const float reach = (xs.w + r_cut_all + s.w * stretch) * 1.0001f + slack;
         // the box of the moved tile: |Rinv| h about the moved centre
         const float bx = fabsf(pose.Ri[0]) * h.x + fabsf(pose.Ri[1]) * h.y + fabsf(pose.Ri[2]) * h.z;
