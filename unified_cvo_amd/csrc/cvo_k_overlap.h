@@ -6,8 +6,8 @@
 // long at 5k x 5k.  Here a block takes 64 consecutive source rows of the spatial order (a compact blob), its OV_WAVES waves
 // share out the 64-target tiles of the spatially ordered target cloud whose bounding sphere - under the pose of the call -
 // comes within reach of the rows' sphere, and every lane runs its row against a tile's 64 transformed targets (broadcast
-// reads out of LDS): the reference's own distance expression as the filter.  What passes is QUEUED, and the
-// queue is evaluated 64 pairs at a time - eval_pair_yt, the reference's exact per-pair arithmetic, on full waves - with
+// reads out of LDS): the reference's own distance expression as the filter.  What passes is compacted per tile, and the
+// list is evaluated 64 pairs at a time - eval_pair_yt, the reference's exact per-pair arithmetic, on full waves - with
 // every row adding its own pairs in ascending position.  Row sums and counts meet in LDS, block partials in a last-block
 // gate; the sum lands in pinned host memory.
 //
@@ -25,6 +25,7 @@ namespace cvo_dev {
 #endif
 constexpr int OV_WAVES = CVO_OV_WAVES;  // waves per block of k_overlap = shares of a row tile's target tiles
 constexpr int OV_LIST_CAP = 1024;       // target tiles a block lists per round (65536 targets)
+constexpr int OV_QCAP = 1024;           // pairs a wave's compacted list holds: 16 rows x 64 targets
 
 struct OverlapJob {
   PairDesc D;              // N, M, xs4, ys4 and the attribute arrays in spatial order (nothing else is set)
@@ -119,63 +120,14 @@ __device__ __forceinline__ void k_overlap(const OverlapJob& Jr, const DevParams&
     s_rowd[lane][1] = r.rcp;
     s_rowlid[lane] = r.lid;
   }
-  // The wave's queue of pairs of the CURRENT tile that passed the cut-off: {row | slot of the target in the tile << 6};
-  // slots 0..63 are the batch evaluated next, 64..127 take what arrives while it fills.  (Queueing costs one LDS write and
-  // no wait; a queue that outlived its tile would have to carry the transformed targets along - a read-then-write round
-  // trip per queued pair, measured: three quarters of the slowest wave's time.)  A lane keeps the slots of ITS row's pairs
-  // as two 64-bit masks: after a batch every row adds its own values in ascending slot = ascending position.
-  __shared__ unsigned s_qm[OV_WAVES][128];
-  __shared__ float s_qa[OV_WAVES][64];
-  unsigned* const qm = &s_qm[wave][0];
+  // The pairs of the tile being scanned that passed the cut-off, compacted: {row | slot of the target in the tile << 6},
+  // row-major, a row's pairs in ascending slot - every lane knows where its row's run starts - and the values they
+  // evaluate to (-1: the pair was dropped), read back by the rows.  OV_QCAP entries: all a tile can have for 16 rows.
+  __shared__ unsigned short s_qm[OV_WAVES][OV_QCAP];
+  __shared__ float s_qa[OV_WAVES][OV_QCAP];
+  unsigned short* const qm = &s_qm[wave][0];
   float* const qa = &s_qa[wave][0];
-  int qn = 0;                            // pairs in the queue (wave-uniform)
-  unsigned long long mine_lo = 0, mine_hi = 0;
   const int row0 = (int)blockIdx.x * 64;
-  // evaluates slots 0 .. min(qn, 64) - 1 and moves the rest of the queue down
-  auto run_batch = [&](int tile) {
-    [[maybe_unused]] const unsigned long long tf = OV_T();
-    __builtin_amdgcn_wave_barrier();
-    const int nb = min(qn, 64);
-    if (lane < nb) {
-      const unsigned m = qm[lane];
-      const int rho = (int)(m & 63u), j = tile * 64 + (int)(m >> 6);
-      const f32x4 y = my_y[m >> 6];
-      const f32x4 rx = s_rowx[rho];
-      RowData rr;
-      rr.x = rx.x;
-      rr.y = rx.y;
-      rr.z = rx.z;
-      rr.l = 0.f;  // (not read by the pair arithmetic)
-      rr.d2_thres = rx.w;
-      rr.lid = FEAT == FEAT_HOT ? s_rowlid[rho] : 0;
-      rr.den = s_rowd[rho][0];
-      rr.rcp = s_rowd[rho][1];
-      float a;
-      const bool kept = eval_pair_yt<FEAT>(P, D, F, row0 + rho, rr, j, make_float4(y.x, y.y, y.z, 0.f), a) && a > P.sp_thres;
-      qa[lane] = kept ? a : -1.f;  // (kernel values are products of squares and exponentials: never negative)
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (unsigned long long m = mine_lo; m; m &= m - 1) {
-      const float v = qa[__builtin_ctzll(m)];
-      if (v >= 0.f) {
-        asum += (double)v;
-        cnt++;
-      }
-    }
-    // what arrived beyond slot 63 becomes the next batch
-    if (qn > 64) {
-      const unsigned m = qm[64 + lane];
-      __builtin_amdgcn_wave_barrier();
-      qm[lane] = m;
-    }
-    mine_lo = mine_hi;
-    mine_hi = 0;
-    qn = max(qn - 64, 0);
-#ifdef CVO_OV_STAMPS
-    ov_flush += OV_T() - tf;
-    ov_n_flush++;
-#endif
-  };
   [[maybe_unused]] const unsigned long long ov_t1 = OV_T();
   // The target tiles this block has to look at: those whose bounding sphere AND bounding box - moved by the pose - come
   // within reach of the rows'.  All waves test (a tile per thread), the survivors are listed in ascending tile order and
@@ -280,10 +232,13 @@ __device__ __forceinline__ void k_overlap(const OverlapJob& Jr, const DevParams&
       __builtin_amdgcn_wave_barrier();  // (the previous tile's slots have been read: LDS operations of a wave complete in order)
       my_y[lane] = f32x4{yt.x, yt.y, yt.z, 0.f};
       __builtin_amdgcn_wave_barrier();
-      // Lanes = rows; the tile's targets reach them as broadcast LDS reads, eight at a time, and leave a byte of hit bits
-      // per lane.  A pair that passes the cut-off is not
-      // evaluated at once - the whole wave would run the double exp for one or two lanes, at nearly every target of a near
-      // tile - but queued (see run_batch).
+      // Lanes = rows; the tile's targets reach them as broadcast LDS reads, eight at a time, and leave a bit per target in
+      // the lane's hit mask.  A pair that passes the cut-off is not evaluated at once - the whole wave would run the double
+      // exp for one or two lanes, at nearly every target of a near tile - and not queued one by one either (a ballot, a
+      // rank and a store per lane and target cost as much as the scan): after the tile every lane knows its row's count,
+      // a prefix sum over the wave gives every row its run in the compacted list, the runs are written, the list is
+      // evaluated 64 pairs at a time on full waves, and every row adds its own run in ascending position.
+      unsigned long long hits = 0;
       for (int k0 = 0; k0 < 64; k0 += 8) {
         unsigned bits = 0;
 #pragma unroll
@@ -296,25 +251,75 @@ __device__ __forceinline__ void k_overlap(const OverlapJob& Jr, const DevParams&
           const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));  // (eval_pair_yt's expression)
           bits |= (d2 < r.d2_thres) ? (1u << u) : 0u;
         }
-        if (!live) bits = 0;
-        // every lane with hits left queues its lowest one (a row's pairs enter in ascending position)
-        unsigned long long hm;
-        while ((hm = __ballot(bits != 0)) != 0ull) {
-          if (bits != 0) {
-            const int k = k0 + __builtin_ctz(bits);
-            bits &= bits - 1;
-            const int q = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
-            qm[q] = (unsigned)lane | ((unsigned)k << 6);
-            if (q < 64)
-              mine_lo |= 1ull << q;
-            else
-              mine_hi |= 1ull << (q - 64);
-          }
-          qn += __builtin_popcountll(hm);
-          if (qn >= 64) run_batch(cur);
-        }
+        hits |= (unsigned long long)bits << k0;
       }
-      if (qn > 0) run_batch(cur);  // (the queue does not outlive its tile)
+      if (!live) hits = 0;
+      if (__ballot(hits != 0) != 0ull) {
+        [[maybe_unused]] const unsigned long long tf = OV_T();
+        // runs: inclusive prefix of the counts inside every row of 16 lanes (DPP row_shr, zero fill), the four row totals
+        // through scalar registers
+        const int c = __builtin_popcountll(hits);
+        int inc = c;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+        const int t0 = __builtin_amdgcn_readlane(inc, 15), t1 = __builtin_amdgcn_readlane(inc, 31),
+                  t2 = __builtin_amdgcn_readlane(inc, 47), t3 = __builtin_amdgcn_readlane(inc, 63);
+        const int total = t0 + t1 + t2 + t3;
+        const int quarter = lane >> 4;
+        // all rows at once while the list holds them; a quarter of the rows (16 x 64 pairs at most) at a time otherwise
+        const int n_groups = total <= OV_QCAP ? 1 : 4;
+        for (int g = 0; g < n_groups; g++) {
+          const bool mine = n_groups == 1 || quarter == g;
+          const int before = n_groups == 1 ? (quarter > 0 ? t0 : 0) + (quarter > 1 ? t1 : 0) + (quarter > 2 ? t2 : 0) : 0;
+          const int base = before + inc - c;
+          const int n_here = n_groups == 1 ? total : (g == 0 ? t0 : g == 1 ? t1 : g == 2 ? t2 : t3);
+          if (mine) {
+            int q = base;
+            for (unsigned long long m = hits; m; m &= m - 1) qm[q++] = (unsigned short)(lane | (__builtin_ctzll(m) << 6));
+          }
+          __builtin_amdgcn_wave_barrier();
+          for (int b0 = 0; b0 < n_here; b0 += 64) {
+            const int q = b0 + lane;
+            if (q < n_here) {
+              const unsigned m = qm[q];
+              const int rho = (int)(m & 63u), k = (int)(m >> 6);
+              const f32x4 y = my_y[k];
+              const f32x4 rx = s_rowx[rho];
+              RowData rr;
+              rr.x = rx.x;
+              rr.y = rx.y;
+              rr.z = rx.z;
+              rr.l = 0.f;  // (not read by the pair arithmetic)
+              rr.d2_thres = rx.w;
+              rr.lid = FEAT == FEAT_HOT ? s_rowlid[rho] : 0;
+              rr.den = s_rowd[rho][0];
+              rr.rcp = s_rowd[rho][1];
+              float a;
+              const bool kept = eval_pair_yt<FEAT>(P, D, F, row0 + rho, rr, cur * 64 + k, make_float4(y.x, y.y, y.z, 0.f), a) && a > P.sp_thres;
+              qa[q] = kept ? a : -1.f;  // (kernel values are products of squares and exponentials: never negative)
+            }
+#ifdef CVO_OV_STAMPS
+            ov_n_flush++;
+#endif
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (mine) {
+            for (int q = base; q < base + c; q++) {
+              const float v = qa[q];
+              if (v >= 0.f) {
+                asum += (double)v;
+                cnt++;
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();  // (the list is the next group's, the next tile's)
+        }
+#ifdef CVO_OV_STAMPS
+        ov_flush += OV_T() - tf;
+#endif
+      }
 #ifdef CVO_OV_STAMPS
       ov_scan += OV_T() - ts - (ov_flush - fl0);
 #endif
