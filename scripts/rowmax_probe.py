@@ -14,7 +14,7 @@ work = [("scene10k", cases.scene, dict(n=10000), 600), ("scene3k", cases.scene, 
         ("config3", cases.config3, dict(n=10000), 1500), ("config4", cases.config4, dict(n=10000), 0)]
 for name, builder, kw, mi in work:
     P, a, b, init = builder(**kw)
-    g = CvoGPU(params=P)
+    g = CvoGPU(params=P, library=os.environ.get("CVO_LIB") or None)
     da, db = g.upload(a), g.upload(b)
     ref = None
     line = f"{name:9s}"

@@ -617,7 +617,7 @@ void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags, bool den
   if (!lean || dense)
     // (7 waves per SIMD against k_assoc_dense's 4: twice the blocks, so that a lone pair's rows get a wave each - the kernel
     // then lasts as long as its longest row, not as two)
-    hipLaunchKernelGGL((k_coeff_dense<4>), dim3(g.n_pairs <= 4 ? 2 * g.dense_blocks : g.dense_blocks, g.n_pairs), dim3(256), 0, g.stream, descs,
+    hipLaunchKernelGGL((k_coeff_dense<4>), dim3(g.n_pairs <= 4 ? std::min(2 * g.dense_blocks, (int)DENSE_BLOCKS_MAX) : g.dense_blocks, g.n_pairs), dim3(256), 0, g.stream, descs,
                        c->d_params, c->d_states + g.p0);
   launch_coeff(g.stream, g.instr, g.nba, g.csplit, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena,
                flags | (lean ? 1 : 0) | (lean_dense ? 32 : 0) | (g.idx16 ? 0 : 64));
@@ -1181,7 +1181,7 @@ int run_inner_products(cvo_ctx* ctx, const cvo_params_t* params, int n, const cv
   key.gx = S.gx;
   key.gy = S.gy;
   key.nba = S.d.nblk_assoc;
-  key.npb = g.npb + (g.dense_blocks << 20);
+  key.npb = (int)((unsigned)g.npb + ((unsigned)g.dense_blocks << 20));  // (dense_blocks <= 2048: twelve bits)
   key.idx16 = g.idx16 ? 1 : 0;
   key.general = g.feat;
   key.flags = (g.instr ? 1 : 0) | (99 << 24);
@@ -1976,7 +1976,7 @@ int ensure_graph(cvo_ctx* ctx, const BatchSetup& S, const LaunchGeom* geom, int 
   key.gy = S.gy;
   key.nba = S.d.nblk_assoc;
   key.nbc = S.d.nblk_coeff * 64 + S.geom.csplit;
-  key.npb = S.geom.npb + (S.geom.dense_blocks << 20);  // (npb < 2^20: Mpad / 256 + rows / 256)
+  key.npb = (int)((unsigned)S.geom.npb + ((unsigned)S.geom.dense_blocks << 20));  // (npb < 2^20: Mpad / 256 + rows / 256)
   key.idx16 = S.geom.idx16 ? 1 : 0;
   key.general = S.geom.feat;
   key.U = Uc * 256 + graph_lean_period(cfg, v, Uc) + (v == 3 ? 128 : 0);
