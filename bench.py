@@ -399,8 +399,10 @@ def main():
                     f"({best.seconds*1e6/max(best.iterations,1):.2f} us/iteration)")
         # ---- the other two entry points of the path: inner_product_gpu (CvoGPU.cu:1719-1778) and function_angle
         # (CvoGPU.cu:1814-1846; exact = three inner products) - the loop-closure / overlap queries of the reference drivers.
-        # One pass of the association over resident clouds, the candidate structure built from scratch in every call
-        # (k_prep, k_scan, k_list, k_assoc [+ k_assoc_dense], k_update); wall time per call, median of 9.
+        # One launch of k_overlap over resident clouds (64-row blocks against the target tiles their bounding volumes reach,
+        # no candidate structure; the list chain of the loop - k_prep, k_scan, k_list, k_assoc [+ k_assoc_dense] - when a
+        # row exceeds nearest_neighbors_max, and `list_chain_inner_product_gpu_ms` for comparison); wall time per call
+        # through the Python binding, median of 9.
         overlap_queries = []
         if world == 1 and args.max_iterations <= 0 and not args.no_single_pair:
             for name, builder, kw2, extra_bytes in (("config2 shape at 10k x 10k xyz", cases.config2, dict(n=10000), 0),
@@ -422,10 +424,13 @@ def main():
                 ip_ms = med(lambda: gq.inner_product_gpu(da, db, init_, Pc.ell_init))
                 fa_ms = med(lambda: gq.function_angle(da, db, init_, Pc.ell_init, True))
                 fe_ms = med(lambda: gq.function_angle(da, db, init_, Pc.ell_init, False))
+                gq.set_option("IP_CHAIN", "1")
+                chain_ms = med(lambda: gq.inner_product_gpu(da, db, init_, Pc.ell_init))
+                gq.set_option("IP_CHAIN", None)
                 one_pass = (12 + extra_bytes) * (a_.num_points() + b_.num_points())   # the loop's per-iteration bytes / 2
                 overlap_queries.append({"config": name, "inner_product_gpu_ms": round(ip_ms, 4),
                                         "function_angle_approximate_ms": round(fa_ms, 4), "function_angle_exact_ms": round(fe_ms, 4),
-                                        "algorithmic_bytes_one_pass": one_pass,
+                                        "list_chain_inner_product_gpu_ms": round(chain_ms, 4), "algorithmic_bytes_one_pass": one_pass,
                                         "achieved_gbs": round(one_pass / (ip_ms * 1e-3) / 1e9, 3),
                                         "frac_of_hbm_peak": round(one_pass / (ip_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)})
                 log(f"[bench] overlap queries, {name}: inner_product_gpu {ip_ms:.3f} ms, function_angle {fa_ms:.3f} (approximate) / "

@@ -265,7 +265,13 @@ void cvo_batch_close(cvo_batch_queue* q);
 int cvo_align_association(cvo_ctx* ctx, int pair, int* row_ptr, int* col, float* val, size_t capacity, size_t* nnz_out,
                           int* stride_written, int* stride_read);
 
-/* ---- inner_product_gpu / function_angle (CvoGPU.cu:1780-1873) ------------------------ */
+/* ---- inner_product_gpu / function_angle (CvoGPU.cu:1780-1873) ------------------------
+ * A_sum of fill_in_A_mat_gpu's matrix (first nearest_neighbors_max pairs of a row in ascending target index, a > sp_thres),
+ * accumulated in double.  With a geometric cut-off the evaluation is ONE kernel launch over the resident clouds (no candidate
+ * structure; up to three pairs - exact function_angle - in the same launch); a call in which a row finds more than
+ * nearest_neighbors_max pairs, a call without geometry, or a context with option "IP_CHAIN" set runs the loop's
+ * candidate-list chain instead.  Same pairs, same values; the two orders of summation agree in all but the last bits of
+ * the double sum. */
 int cvo_inner_product(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source,
                       const cvo_cloud* target, const float T[16], float ell, float* out);
 int cvo_function_angle(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud* source,
