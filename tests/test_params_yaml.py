@@ -97,3 +97,22 @@ def test_every_shipped_file_parses_like_pyyaml():
         for k in _YAML_KEYS:
             if k not in seen:
                 assert getattr(p, k) == getattr(d, k), (path, k)
+
+
+def test_c_struct_cache_follows_the_members():
+    """CvoParams.to_ctypes() hands out one cached cvo_params_t until a member changes (filling 52 fields per call was a
+    sixth of a one-launch inner product); copies, deep copies and pickles do not share it."""
+    import copy
+    import pickle
+    p = CvoParams()
+    a = p.to_ctypes()
+    assert a is p.to_ctypes()
+    p.ell_init = 0.7
+    b = p.to_ctypes()
+    assert b is not a and abs(b.ell_init - 0.7) < 1e-6 and abs(a.ell_init - 0.5) < 1e-6
+    p.warnings = ["x"]  # (not a member of the struct: the cache stays)
+    assert p.to_ctypes() is b
+    for q in (p.copy(), copy.deepcopy(p), pickle.loads(pickle.dumps(p))):
+        q.nearest_neighbors_max = 7
+        assert q.to_ctypes().nearest_neighbors_max == 7 and p.to_ctypes().nearest_neighbors_max == 512
+        assert abs(q.to_ctypes().ell_init - 0.7) < 1e-6
