@@ -1,5 +1,5 @@
 # PMC passes over one batched align (64 x 10k x 10k, 2000 iterations): instruction mix, SQ cycle breakdown, L2 / L1.
-# usage (GPU box): bash scripts/pmc_batch.sh OUTDIR   -> OUTDIR/pmc_batch.json
+# usage (GPU box): [PROBE_ITERS=64] [PROBE_PAIRS=64] bash scripts/pmc_batch.sh OUTDIR   -> OUTDIR/pmc_batch.json
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/${1:-gpurun_out/pmc}
@@ -15,7 +15,7 @@ NP = int(os.environ.get("PROBE_PAIRS", "64"))
 pairs = [cases.config2(n=10000, pair_id=p) for p in range(NP)]
 gpu = CvoGPU(params=P)
 both = gpu.upload_many([a[1] for a in pairs] + [a[2] for a in pairs])
-r = gpu.align_batch(both[:NP], both[NP:], [a[3] for a in pairs])
+r = gpu.align_batch(both[:NP], both[NP:], [a[3] for a in pairs], max_iterations=int(os.environ.get("PROBE_ITERS", "0")))
 print(r[0].iterations, r[0].seconds)
 PY
 i=0
