@@ -65,6 +65,6 @@ def test_prologue_is_one_burst_of_scalar_loads(device_code, kernel, max_waits):
 def test_no_scratch_in_the_per_iteration_kernels(device_code):
     lines, ks = device_code
     for kernel in ("k_assoc<unsigned short, 64, 0, false>", "k_assoc<unsigned short, 64, 2, false>",
-                   "k_assoc<unsigned short, 64, 3, false>", "k_coeff<false>", "k_assoc_dense<0, 4>"):
+                   "k_assoc<unsigned short, 64, 3, false>", "k_coeff<false>", "k_assoc_dense<0, 4, false>"):
         a, b = ks[kernel]
         assert not any(re.search(r"\bscratch_(load|store)", lines[i]) for i in range(a, b + 1)), kernel

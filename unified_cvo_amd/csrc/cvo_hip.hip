@@ -558,12 +558,22 @@ void launch_verify(hipStream_t s, int feat, int N, int n_pairs, const PairDesc* 
 void launch_dense(hipStream_t s, int feat, int N, int n_pairs, int dense_blocks, const PairDesc* descs, const DevParams* dp,
                   const PairState* st) {
   const dim3 grid(dense_blocks, n_pairs);
+  // a small pair solved alone has a block per overflow row (dense_blocks_for): the instantiation with the wide-row phase
+  const bool wide = n_pairs <= 1 && N <= DENSE_BLOCKS_MAX / 2;
+#define CVO_LAUNCH_DENSE(F)                                                                                  \
+  do {                                                                                                       \
+    if (wide)                                                                                                \
+      hipLaunchKernelGGL((k_assoc_dense<F, 4, true>), grid, dim3(256), 0, s, descs, dp, st);                 \
+    else                                                                                                     \
+      hipLaunchKernelGGL((k_assoc_dense<F, 4, false>), grid, dim3(256), 0, s, descs, dp, st);                \
+  } while (0)
   switch (feat) {  // (4 waves per block: dense_waves_for)
-    case FEAT_GEO: hipLaunchKernelGGL((k_assoc_dense<FEAT_GEO, 4>), grid, dim3(256), 0, s, descs, dp, st); break;
-    case FEAT_COL: hipLaunchKernelGGL((k_assoc_dense<FEAT_COL, 4>), grid, dim3(256), 0, s, descs, dp, st); break;
-    case FEAT_HOT: hipLaunchKernelGGL((k_assoc_dense<FEAT_HOT, 4>), grid, dim3(256), 0, s, descs, dp, st); break;
-    default: hipLaunchKernelGGL((k_assoc_dense<FEAT_ALL, 4>), grid, dim3(256), 0, s, descs, dp, st); break;
+    case FEAT_GEO: CVO_LAUNCH_DENSE(FEAT_GEO); break;
+    case FEAT_COL: CVO_LAUNCH_DENSE(FEAT_COL); break;
+    case FEAT_HOT: CVO_LAUNCH_DENSE(FEAT_HOT); break;
+    default: CVO_LAUNCH_DENSE(FEAT_ALL); break;
   }
+#undef CVO_LAUNCH_DENSE
 }
 
 // which instantiation of the association kernels a call needs (FEAT_*, cvo_pair_math.h)

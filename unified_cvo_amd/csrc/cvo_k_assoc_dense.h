@@ -81,8 +81,14 @@ __device__ __forceinline__ int build_long_list(const PairDesc* __restrict__ D, c
   return cnt;
 }
 
-template <int FEAT, int DENSE_WAVES>
-__global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
+#ifndef CVO_DENSE_WAVES_PER_SIMD
+#define CVO_DENSE_WAVES_PER_SIMD 6
+#endif
+// WIDE: the instantiation a small pair solved alone gets (a block per overflow row, see "wide rows" below); everybody else
+// runs the one without that phase - 24 KB of LDS per block instead of 40, six blocks per CU instead of four: the dense
+// kernels are most of a clustered BATCH's time, and there the waves in flight are throughput.
+template <int FEAT, int DENSE_WAVES, bool WIDE>
+__global__ __launch_bounds__(64 * DENSE_WAVES, (!WIDE && FEAT == FEAT_GEO) ? CVO_DENSE_WAVES_PER_SIMD : 1) void k_assoc_dense(const PairDesc* __restrict__ descs, const DevParams* __restrict__ Pp,
                                                      const PairState* __restrict__ states) {
   const PairState* __restrict__ st = states + blockIdx.y;  // == D->st, as wave-uniform scalar loads (see k_coeff_dense)
   if (st->status != 0) return;
@@ -96,26 +102,31 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
   if (st->rebuild) return;  // (lean graphs with this kernel: the pair waits for its rebuild opportunity, see k_assoc)
   const bool all_dense = st->all_dense != 0;
   static_assert(DENSE_WAVES == 4, "the wide-row phase splits a row over four waves");
-  // LDS, carved twice.  Narrow rows (a wave per row): s_keys - the long list being built, per wave - and s_hits - the hits
-  // of one step, compacted ({flow term, value} per component), per wave.  Wide rows (the block per row): wave 0's s_keys,
-  // then every wave's hits of its quarter of the row ({value, transformed target}, column) and two 128-slot replay blocks.
+  // LDS.  Narrow rows (a wave per row), a region per wave: the hits of one step, compacted ({flow term, value} per
+  // component) - and, before the row's first step, the sort keys of the long list being built (the list is written out and
+  // read back from memory like a list of an earlier iteration: the keys are dead when the first hit is stored).  Wide rows
+  // (the block per row, WIDE only) carve the same bytes again: wave 0's keys, then every wave's hits of its quarter of the
+  // row ({value, transformed target}, column) and two 128-slot replay blocks.
   constexpr int WIDE_MIN = 256;   // candidates from which a row is worth the whole block
   constexpr int WIDE_CAP = 304;   // candidates (hence hits) a wave's quarter of a wide row can have: rows of up to 1216
-  __shared__ __attribute__((aligned(16))) char s_raw[sizeof(unsigned) * DENSE_WAVES * LONG_CAP + sizeof(float2) * DENSE_WAVES * 128 * 6];
-  unsigned(*s_keys)[LONG_CAP] = reinterpret_cast<unsigned(*)[LONG_CAP]>(s_raw);
-  float2(*s_hits)[128][6] = reinterpret_cast<float2(*)[128][6]>(s_raw + sizeof(unsigned) * DENSE_WAVES * LONG_CAP);
+  constexpr size_t WAVE_REGION = sizeof(float2) * 128 * 6;  // 6 KB >= the 4 KB of keys
+  static_assert(WAVE_REGION >= sizeof(unsigned) * LONG_CAP, "a wave's keys fit its hit buffer");
+  constexpr size_t WIDE_BYTES = sizeof(unsigned) * LONG_CAP + (sizeof(float4) + sizeof(int)) * DENSE_WAVES * (WIDE_CAP + 1) + 2 * sizeof(float2) * 128 * 6;
+  constexpr size_t RAW_BYTES = WIDE && WIDE_BYTES > WAVE_REGION * DENSE_WAVES ? ((WIDE_BYTES + 255) / 256) * 256 : WAVE_REGION * DENSE_WAVES;
+  __shared__ __attribute__((aligned(16))) char s_raw[RAW_BYTES];
+  unsigned* const my_keys = reinterpret_cast<unsigned*>(s_raw + WAVE_REGION * wave);
+  float2(*const my_hits)[6] = reinterpret_cast<float2(*)[6]>(s_raw + WAVE_REGION * wave);
+  unsigned* const keys0 = reinterpret_cast<unsigned*>(s_raw);
   float4(*w_hit)[WIDE_CAP] = reinterpret_cast<float4(*)[WIDE_CAP]>(s_raw + sizeof(unsigned) * LONG_CAP);
   int(*w_col)[WIDE_CAP] = reinterpret_cast<int(*)[WIDE_CAP]>(s_raw + sizeof(unsigned) * LONG_CAP + sizeof(float4) * DENSE_WAVES * WIDE_CAP);
   float2(*w_rep)[128][6] = reinterpret_cast<float2(*)[128][6]>(s_raw + sizeof(unsigned) * LONG_CAP + (sizeof(float4) + sizeof(int)) * DENSE_WAVES * WIDE_CAP);
   int* s_wcnt = reinterpret_cast<int*>(s_raw + sizeof(unsigned) * LONG_CAP + (sizeof(float4) + sizeof(int)) * DENSE_WAVES * WIDE_CAP + 2 * sizeof(float2) * 128 * 6);
-  static_assert(sizeof(unsigned) * LONG_CAP + (sizeof(float4) + sizeof(int)) * DENSE_WAVES * (WIDE_CAP + 1) + 2 * sizeof(float2) * 128 * 6 <= sizeof(s_raw),
-                "wide-row buffers fit the narrow-row carve");
   // WIDE rows.  With a block per overflow row to spare (a small pair solved alone: the demo pair's 523 rows all scan 1080
   // targets, a wave at a time that is nine dependent steps and 19 of its 43 us per iteration) a row of more than WIDE_MIN
   // candidates whose quarters fit the buffers - its long list, or, rows beyond every list and the dense regime, all targets
   // of a small target cloud - is evaluated by the four waves of block q, a quarter each; see the second phase below.  With
   // more rows than blocks the waves are better spent on a row each (the replay is a serial chain either way).
-  const bool wide_mode = n_ovf <= (int)gridDim.x;
+  const bool wide_mode = WIDE && n_ovf <= (int)gridDim.x;
   auto wide_row = [&](int n_cand) { return wide_mode && n_cand > WIDE_MIN && n_cand <= DENSE_WAVES * WIDE_CAP; };
   {
     const Pose pose = load_pose(st);
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
       const V3 pxe{x.x, x.y, x.z};
       // where this row's candidates come from: its long list (built now if it is not the current one) or all targets
       int n_cand = M;
-      bool listed = false, fresh = false;
+      bool listed = false;
       const unsigned short* lj = nullptr;
       if (long_lists) {
         const int cnt = __float_as_int(x.w);  // (k_list keeps the row's candidate count next to its coordinates)
@@ -142,11 +153,14 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
           if (wide_row(n_cand)) continue;  // the whole block's, below
           lj = D->long_j + (size_t)q * LONG_CAP;
           if (D->long_stamp[q] != gen) {
-            n_cand = build_long_list(D, P.T, D->rowperm[r_sorted], s_keys[wave], lane);
-            fresh = true;
+            n_cand = build_long_list(D, P.T, D->rowperm[r_sorted], my_keys, lane);
             unsigned short* out = D->long_j + (size_t)q * LONG_CAP;
-            for (int k = lane; k < n_cand; k += 64) out[k] = (unsigned short)(s_keys[wave][k] & 0xffffu);
+            for (int k = lane; k < n_cand; k += 64) out[k] = (unsigned short)(my_keys[k] & 0xffffu);
             if (lane == 0) D->long_stamp[q] = gen;
+            // (the list is read back below by other lanes of this wave: the stores have reached the L2 first; no line of
+            // this row's list can sit in this CU's L1 - nobody read it in this launch)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
           }
         }
       }
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
           const int c = j0 + 64 * h + lane;
           if (c < n_cand) {
             if (listed) {  // list entries are sorted positions: coordinates and features from the spatially ordered arrays
-              const int p = fresh ? (int)(s_keys[wave][c] & 0xffffu) : (int)lj[c];
+              const int p = (int)lj[c];
               col[h] = p;
               psort[h] = p;
               ok[h] = eval_pair<FEAT>(P, D, F, pose, i, r, p, D->ys4[p], a[h], yt[h]) && (a[h] > P.sp_thres);
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
             // flow terms of this lane's pair (CvoGPU.cu:767-769)
             const V3 pye{yt[h].x, yt[h].y, yt[h].z};
             const V3 cr = cross_dev(pxe, pye);
-            float2* slot = s_hits[wave][nstaged + (int)below];
+            float2* slot = my_hits[nstaged + (int)below];
             slot[0] = make_float2(cr.x, a[h]);
             slot[1] = make_float2(cr.y, a[h]);
             slot[2] = make_float2(cr.z, a[h]);
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
         for (; k + 16 <= nstaged; k += 16) {
           float2 e[16];
 #pragma unroll
-          for (int u = 0; u < 16; u++) e[u] = s_hits[wave][k + u][c];
+          for (int u = 0; u < 16; u++) e[u] = my_hits[k + u][c];
 #pragma unroll
           for (int u = 0; u < 16; u++) acc = __builtin_fmaf(e[u].x, e[u].y, acc);
           if (want_asum) {
@@ -223,8 +237,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
           }
         }
         for (; k + 4 <= nstaged; k += 4) {
-          const float2 e0 = s_hits[wave][k][c], e1 = s_hits[wave][k + 1][c], e2 = s_hits[wave][k + 2][c],
-                       e3 = s_hits[wave][k + 3][c];
+          const float2 e0 = my_hits[k][c], e1 = my_hits[k + 1][c], e2 = my_hits[k + 2][c], e3 = my_hits[k + 3][c];
           acc = __builtin_fmaf(e0.x, e0.y, acc);
           acc = __builtin_fmaf(e1.x, e1.y, acc);
           acc = __builtin_fmaf(e2.x, e2.y, acc);
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
           }
         }
         for (; k < nstaged; k++) {
-          const float2 e = s_hits[wave][k][c];
+          const float2 e = my_hits[k][c];
           acc = __builtin_fmaf(e.x, e.y, acc);
           if (want_asum) asum += (double)e.y;
         }
@@ -279,9 +292,9 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
       __syncthreads();
       if (fresh) {
         if (wave == 0) {
-          const int nb = build_long_list(D, P.T, D->rowperm[r_sorted], s_keys[0], lane);
+          const int nb = build_long_list(D, P.T, D->rowperm[r_sorted], keys0, lane);
           unsigned short* out = D->long_j + (size_t)q * LONG_CAP;
-          for (int k = lane; k < nb; k += 64) out[k] = (unsigned short)(s_keys[0][k] & 0xffffu);
+          for (int k = lane; k < nb; k += 64) out[k] = (unsigned short)(keys0[k] & 0xffffu);
           if (lane == 0) D->long_stamp[q] = gen;
         }
         __syncthreads();
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_assoc_dense(const PairDesc
         const int c = c0 + 64 * h + lane;
         if (c < hi) {
           if (listed) {
-            col[h] = fresh ? (int)(s_keys[0][c] & 0xffffu) : (int)lj[c];
+            col[h] = fresh ? (int)(keys0[c] & 0xffffu) : (int)lj[c];
             ok[h] = eval_pair<FEAT>(P, D, F, pose, i, r, col[h], D->ys4[col[h]], a[h], yt[h]) && (a[h] > P.sp_thres);
           } else {
             col[h] = c;
