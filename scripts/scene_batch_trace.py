@@ -3,7 +3,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cases
 from unified_cvo_amd import CvoGPU
-NP = 16
+NP = int(os.environ.get("NP", "16"))
 pairs = [cases.scene(n=10000, pair_id=p) for p in range(NP)]
 gpu = CvoGPU(params=pairs[0][0])
 both = gpu.upload_many([a[1] for a in pairs] + [a[2] for a in pairs])

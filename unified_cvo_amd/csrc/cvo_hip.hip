@@ -118,7 +118,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static const char* const kOptionNames[] = {
     "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
     "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
-    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "IP_CHAIN", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS", "ROW_MAX", "NO_ONEHOT", "QUEUE_U", "QUEUE_ADMIT"};
+    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "IP_CHAIN", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS", "ROW_MAX", "ROW_MAX_BUSY", "NO_ONEHOT", "QUEUE_U", "QUEUE_ADMIT"};
 
 struct cvo_ctx {
   int device = 0;
@@ -923,8 +923,12 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   dp.groups_per_block = S->gpb;
   dp.long_lists = S->long_lists ? 1 : 0;
   dp.row_max_cap = ASSOC_CAP16;
-  dp.row_max_busy = n_pairs <= 4 ? 8 : 24;
+  // (clustered 10k scenes, scripts/scene_batch.py: 8 for a lone pair; 24 against 64 wins 9 % at 8 pairs in flight, nothing at
+  // 16, and LOSES 5 % at 32 and 10 % at 64 - a chip full of pairs wants its rows in the thread-per-row kernel, whose lanes
+  // are all rows, not in steps of 128 candidate slots per row)
+  dp.row_max_busy = n_pairs <= 4 ? 8 : (n_pairs <= 16 ? 24 : (int)ASSOC_CAP16);
   if (const char* e = ctx_opt(ctx, "ROW_MAX")) dp.row_max_cap = std::max(1, std::min(atoi(e), (int)ASSOC_CAP16));
+  if (const char* e = ctx_opt(ctx, "ROW_MAX_BUSY")) dp.row_max_busy = std::max(1, std::min(atoi(e), (int)ASSOC_CAP16));
   dp.lean_U = 8;
   if (const char* e = ctx_opt(ctx, "LEAN_U")) dp.lean_U = std::max(1, atoi(e));
   // Calm pairs (see PairState::want_full).  In the end game the pose jitters around its optimum: the motion PER ITERATION

@@ -421,7 +421,7 @@ __device__ __forceinline__ void update_body(const UpdDesc& D, const DevParams& P
         const bool dense_rows = c_ovf > 0 || c_dense != 0;
         // A wave of k_assoc runs as long as its longest row.  While a sixteenth of the rows overflow anyway (a clustered
         // cloud: k_assoc_dense runs in every iteration, its long lists cost what their candidates cost), rows of more
-        // than row_max_busy candidates (24 in a batch, 8 for a few pairs in flight) join them - a wave per row, 64 candidates
+        // than row_max_busy candidates (8 for a few pairs in flight, 24 up to 16 pairs, none beyond: a full chip keeps its rows here) join them - a wave per row, 64 candidates
         // per step - instead of holding 63 neighbours back.  (Free to follow the launch: no result depends on a row's class.)
         st->row_max = (!INIT && P.long_lists && !c_dense && 16 * c_ovf > D.N) ? P.row_max_busy : ASSOC_CAP16;
         if (P.long_lists && P.row_max_cap > 0) st->row_max = min(st->row_max, P.row_max_cap);
