@@ -61,7 +61,7 @@ if "--traffic" in sys.argv:
 os.makedirs(dst, exist_ok=True)
 for f in ("bench_kernel_stats.csv", "configs.json", "stress.txt", "cpp_host_bench.txt", "upload_probe.txt", "scale_probe.txt",
           "perf_probe.txt", "pmc_summary.txt", "scene_probe.txt", "scene_kernel_stats.csv", "queue_probe.txt", "queue_probe.json",
-          "overlap_probe.txt", "rowmax_probe.txt", "rank_rehearsal.txt", "perf_probe.json"):
+          "overlap_probe.txt", "rowmax_probe.txt", "rank_rehearsal.txt", "perf_probe.json", "scene_batch.txt", "soak.txt"):
     if os.path.exists(src + f):
         shutil.copy(src + f, dst + f)
 for f in ("bench_n1.json", "bench_under_rocprof.json", "bench_torchrun_n1.json"):
