@@ -1,15 +1,16 @@
 """The first iterations of the headline batch under list-reuse settings (options "NAME=value,NAME=value" per argument):
 ms for the first 64 / 256 iterations and the whole run, list builds, whether the poses stay the same.
-usage: early_sweep.py [SKIN_MAX=0.4 SKIN_MAX=0.4,SKIN=1.5 ...]"""
+usage: [SWEEP_CASE=config2|config3|config4|scene] [SWEEP_PAIRS=64] early_sweep.py [SKIN_MAX=0.4 SKIN_MAX=0.4,SKIN=1.5 ...]"""
 import os, sys, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import cases
 from unified_cvo_amd import CvoGPU
-P = cases.load_params("geometric_gpu")
-NP = 64
-pairs = [cases.config2(n=10000, pair_id=p) for p in range(NP)]
+NP = int(os.environ.get("SWEEP_PAIRS", "64"))
+builder = {"config2": cases.config2, "config3": cases.config3, "config4": cases.config4, "scene": cases.scene}[os.environ.get("SWEEP_CASE", "config2")]
+pairs = [builder(n=10000, pair_id=p) for p in range(NP)]
+P = pairs[0][0]
 gpu = CvoGPU(params=P)
 both = gpu.upload_many([a[1] for a in pairs] + [a[2] for a in pairs])
 inits = [a[3] for a in pairs]
