@@ -484,7 +484,7 @@ def main():
 
         # ---- colour / semantic batches: 64 x config 3 and 64 x config 4 (BASELINE.json configs[2], [3] as batches), align/s,
         # one sample of each checked against the CPU oracle
-        def feature_batch(builder, label):
+        def feature_batch(builder, label, sample_its=300):
             prs = [builder(n=10000, pair_id=p) for p in range(B)]
             gf = CvoGPU(params=prs[0][0], device=local_rank)
             cl = gf.upload_many([q[1] for q in prs] + [q[2] for q in prs], threads=n_threads)
@@ -496,9 +496,9 @@ def main():
                 from oracle import pyoracle as po
                 po.set_num_threads(n_threads)
                 o_ = po.align(po.params_from(prs[0][0]), po.Cloud.from_pointcloud(prs[0][1]), po.Cloud.from_pointcloud(prs[0][2]),
-                              prs[0][3], max_iterations=300)
-                g_ = gf.align(cl[0], cl[B], prs[0][3], max_iterations=300)
-                ent["sample_parity_max_abs_at_300_iterations"] = float(np.max(np.abs(g_.transform - o_["transform"])))
+                              prs[0][3], max_iterations=sample_its)
+                g_ = gf.align(cl[0], cl[B], prs[0][3], max_iterations=sample_its)
+                ent[f"sample_parity_max_abs_at_{sample_its}_iterations"] = float(np.max(np.abs(g_.transform - o_["transform"])))
                 ent["sample_iterations"] = [int(g_.iterations), int(o_["iterations"])]
             log(f"[bench] batch of {B} x {label}: {tb*1e3:.1f} ms = {B/tb:.1f} align/s ({np.mean(its):.0f} iterations each)")
             for h in cl:
@@ -508,6 +508,9 @@ def main():
 
         batch_colour = feature_batch(cases.config3, "config 3 (10k x 10k + colour)") if extra else None
         batch_semantic = feature_batch(cases.config4, "config 4 (10k x 10k + colour + one-hot semantics, warm start)") if extra else None
+        # ... and 64 clustered pairs (NOT a BASELINE shape: tests/synth.scene_pair - ground, facades, small dense objects, local
+        # density varying by more than 100x; 13 x the pair tests of the uniform slab, most of them in the wave-per-row kernels)
+        batch_clustered = feature_batch(cases.scene, "clustered street scene (10k x 10k xyz, not a BASELINE shape)", 100) if extra else None
 
         # ---- batch queue (cvo_batch_open / _submit / _poll): the 8-GPU headline's whole work list - 512 pairs - on ONE GPU
         # through 128 in-flight slots, and a mixed queue (three pairs in four stop after 300 iterations, like warm-started
@@ -599,7 +602,7 @@ def main():
                                            "advice": gpu.advice()}},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "single_pair": single_pair,
             "overlap_queries": overlap_queries, "pcie_inclusive": pcie_inclusive,
-            "early_phase": early_phase, "shapes_20k": shapes_20k, "batch_colour": batch_colour, "batch_semantic": batch_semantic,
+            "early_phase": early_phase, "shapes_20k": shapes_20k, "batch_colour": batch_colour, "batch_semantic": batch_semantic, "batch_clustered": batch_clustered,
             "batch_queue": batch_queue,
         }
         h2d_rate = (2 * n * 16 * 1.0) * B / max(t_h2d, 1e-9) / 1e9
