@@ -281,8 +281,31 @@ struct PairDesc {
                       // the block of k_assoc that finishes last - no k_update launch, no copy back
   int* gate;        // [1] blocks of k_list that finished the current rebuild (the last one validates the list)
   int* gate_flow;   // [1] blocks of k_assoc that stored their flow partial (the last one reduces them)
+  // Rows evaluated by the wave-per-row kernels keep their ELL entries ROW-major, a run of min(candidates, K) entries in the
+  // part of the ELL the thread-per-row kernels never touch (their rows hold at most 64 entries: slots >= 64 of the
+  // slot-major matrix, (K_max - 64) * N entries).  A 16-byte entry per 64-byte line - what a column walk of the slot-major
+  // matrix moves - made those kernels bandwidth-bound in a batch of clustered pairs (k_coeff_dense fetched 3.8x its bytes).
+  // The runs are laid out by k_list at every rebuild (no atomics in the loop: 8000 rows of a lone pair on one counter cost
+  // 80 us per iteration): dense_rel = the row's offset inside its 64-row word, word_base = the word's, word_base[words] = the
+  // total; all rows of the pair or none - the total has to fit, a slot-major row beyond slot 63 would write into the runs.
+  int* dense_rel;         // [N] by position (overflow rows only)
+  int* ovf_wsum;          // [words] entries the overflow rows of a 64-row word need
+  int* word_base;         // [words + 1]
+  int* dense_off;         // [N] by position: where k_assoc_dense put the row THIS iteration (entry index into the upper part),
+                          // -1 = slot-major; valid for rows whose nnz_row carries NNZ_DENSE_FLAG
 };
 
+// nnz_row[pos] of a row the wave-per-row kernels evaluated carries this flag (its entries may live row-major, dense_off)
+constexpr unsigned NNZ_DENSE_FLAG = 0x80000000u;
+__host__ __device__ inline unsigned nnz_count(unsigned v) { return v & ~NNZ_DENSE_FLAG; }
+constexpr int ELL_LOWER_SLOTS = 64;  // slots of the slot-major matrix the thread-per-row kernels can reach (ASSOC_CAP16)
+// index of entry `s` of the row at position `pos`: in its row-major run (off >= 0) or in the slot-major matrix
+__host__ __device__ inline size_t ell_index(int N, int s, int pos, int off) {
+  return off >= 0 ? (size_t)ELL_LOWER_SLOTS * (size_t)N + (size_t)off + (size_t)s : (size_t)s * (size_t)N + (size_t)pos;
+}
+__host__ __device__ inline size_t ell_upper_capacity(int N, int K_max) {
+  return K_max > ELL_LOWER_SLOTS ? (size_t)(K_max - ELL_LOWER_SLOTS) * (size_t)N : 0;
+}
 constexpr int COEFF_SPLIT_MAX = 32;
 constexpr int ROWS_PER_GROUP = 4;
 // k_assoc_dense blocks per pair (one overflow row per wave at a time; 4 waves per block).  A batch launches few per pair (its pairs fill the chip and

@@ -90,7 +90,7 @@ struct cvo_cloud {
 namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
-  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, done, cand_cnt, rowperm, iorig, long_j, long_stamp, xp4, ip, cand_j, rowres, rowcoef, ell, ell_j, nnz_row, flow_part, cnt_part,
+  size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, dense_off, dense_rel, ovf_wsum, word_base, done, cand_cnt, rowperm, iorig, long_j, long_stamp, xp4, ip, cand_j, rowres, rowcoef, ell, ell_j, nnz_row, flow_part, cnt_part,
       coef_part, trace, total;
 };
 
@@ -273,6 +273,10 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, bool long_lis
   L.ovf_bits = take(sizeof(unsigned long long) * (((size_t)N + 63) / 64 + 4));
   L.gate = take(sizeof(int));
   L.gate_flow = take(sizeof(int));
+  L.dense_off = take(sizeof(int) * (size_t)N);
+  L.dense_rel = take(sizeof(int) * (size_t)N);
+  L.ovf_wsum = take(sizeof(int) * (((size_t)N + 63) / 64 + 4));
+  L.word_base = take(sizeof(int) * (((size_t)N + 63) / 64 + 5));
   L.done = take(sizeof(int));
   L.rowperm = take(sizeof(int) * (size_t)N);
   L.iorig = take(sizeof(int) * (size_t)N);
@@ -764,6 +768,10 @@ void fill_pair(cvo_ctx* ctx, const BatchSetup* S, const cvo_params_t* params, co
     D.asum_host = reinterpret_cast<double*>(ctx->h_status[1]) + p;  // (2 ints per pair = one double)
     D.gate = (int*)(base + S->L.gate);
     D.gate_flow = (int*)(base + S->L.gate_flow);
+    D.dense_off = (int*)(base + S->L.dense_off);
+    D.dense_rel = (int*)(base + S->L.dense_rel);
+    D.ovf_wsum = (int*)(base + S->L.ovf_wsum);
+    D.word_base = (int*)(base + S->L.word_base);
     D.done = (int*)(base + S->L.done);
 
     PairState& st = ctx->h_states[p];
@@ -2680,25 +2688,62 @@ int cvo_function_angle(cvo_ctx* ctx, const cvo_params_t* params, const cvo_cloud
   return CVO_OK;
 }
 
+// Nonzero counts (by position) and the values of the last evaluation's matrix in slot-major form, [slot][position], whatever
+// the layout on the device: rows the wave-per-row kernels evaluated may keep their entries row-major (PairDesc::dense_off).
+static int fetch_ell_values(cvo_ctx* ctx, const PairDesc& D, std::vector<unsigned>& nzp, std::vector<float>& ap, unsigned* max_out) {
+  const int N = D.N;
+  nzp.assign(N, 0u);
+  HIP_TRY(ctx, hipMemcpy(nzp.data(), D.nnz_row, sizeof(unsigned) * (size_t)N, hipMemcpyDeviceToHost));
+  std::vector<char> dense(N, 0);
+  bool any_dense = false;
+  unsigned mx = 0;
+  for (int q = 0; q < N; q++) {
+    dense[q] = (nzp[q] & NNZ_DENSE_FLAG) ? 1 : 0;
+    any_dense = any_dense || dense[q];
+    nzp[q] = nnz_count(nzp[q]);
+    mx = std::max(mx, nzp[q]);
+  }
+  *max_out = mx;
+  ap.assign((size_t)mx * N, 0.f);
+  if (!mx) return CVO_OK;
+  std::vector<int> off;
+  bool any_run = false;
+  if (any_dense) {
+    off.resize(N);
+    HIP_TRY(ctx, hipMemcpy(off.data(), D.dense_off, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+    for (int q = 0; q < N; q++) any_run = any_run || (dense[q] && off[q] >= 0);
+  }
+  // the slot-major part up to the longest row; the whole matrix when some row lives in the row-major part
+  const size_t n_ent = any_run ? (size_t)N * (size_t)std::max(ctx->last_params.K_max, (int)mx) : (size_t)mx * N;
+  std::vector<EllEntry> ep(n_ent);
+  HIP_TRY(ctx, hipMemcpy(ep.data(), D.ell, sizeof(EllEntry) * n_ent, hipMemcpyDeviceToHost));
+  for (int q = 0; q < N; q++) {
+    const int o = (any_run && dense[q]) ? off[q] : -1;
+    for (unsigned sl = 0; sl < nzp[q]; sl++) {
+      const size_t e = ell_index(N, (int)sl, q, o);
+      if (e >= n_ent) return fail(ctx, CVO_E_HIP, "fetch_ell_values: corrupt row run");
+      ap[(size_t)sl * N + q] = ep[e].a;
+    }
+  }
+  return CVO_OK;
+}
+
 // The per-row outputs of the last evaluation, re-indexed from k_list's positions to SORTED rows.
 static int fetch_ell(cvo_ctx* ctx, int pair, std::vector<unsigned>& nz, std::vector<float>& a, std::vector<int>& j,
                      unsigned* max_out) {
   const PairDesc& D = ctx->h_descs[pair];
   const int N = D.N;
-  std::vector<unsigned> nzp(N);
+  std::vector<unsigned> nzp;
   std::vector<int> perm(N);
-  HIP_TRY(ctx, hipMemcpy(nzp.data(), D.nnz_row, sizeof(unsigned) * (size_t)N, hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(perm.data(), D.rowperm, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+  std::vector<float> ap;
   unsigned mx = 0;
-  for (int i = 0; i < N; i++) mx = std::max(mx, nzp[i]);
-  std::vector<float> ap((size_t)mx * N);
-  std::vector<int> jp((size_t)mx * N);
-  if (mx) {
-    std::vector<EllEntry> ep((size_t)mx * N);
-    HIP_TRY(ctx, hipMemcpy(ep.data(), D.ell, sizeof(EllEntry) * (size_t)mx * N, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(jp.data(), D.ell_j, sizeof(int) * (size_t)mx * N, hipMemcpyDeviceToHost));
-    for (size_t q = 0; q < ep.size(); q++) ap[q] = ep[q].a;
+  {
+    const int rc = fetch_ell_values(ctx, D, nzp, ap, &mx);
+    if (rc != CVO_OK) return rc;
   }
+  HIP_TRY(ctx, hipMemcpy(perm.data(), D.rowperm, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+  std::vector<int> jp((size_t)mx * N);
+  if (mx) HIP_TRY(ctx, hipMemcpy(jp.data(), D.ell_j, sizeof(int) * (size_t)mx * N, hipMemcpyDeviceToHost));
   nz.assign(N, 0);
   a.assign((size_t)mx * N, 0.f);
   j.assign((size_t)mx * N, -1);
@@ -2926,18 +2971,17 @@ int cvo_align_association(cvo_ctx* ctx, int pair, int* row_ptr, int* col, float*
   for (int i = 0; i <= N; i++) row_ptr[i] = 0;
   if (!executed || st.nnz == 0) return CVO_OK;  // `if (association_gpu.nonzero_sum == 0) return;`
   // the last iteration's matrix by position: count, original row index, entries (slot-major)
-  std::vector<unsigned> nzp(N);
+  std::vector<unsigned> nzp;
   std::vector<int> ip(N);
-  HIP_TRY(ctx, hipMemcpy(nzp.data(), D.nnz_row, sizeof(unsigned) * (size_t)N, hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(ip.data(), D.iorig, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+  std::vector<float> ea;  // values, [slot][position]
   unsigned mx = 0;
-  for (int q = 0; q < N; q++) mx = std::max(mx, nzp[q]);
-  std::vector<EllEntry> ep((size_t)mx * N);
-  std::vector<int> ej((size_t)mx * N);
-  if (mx) {
-    HIP_TRY(ctx, hipMemcpy(ep.data(), D.ell, sizeof(EllEntry) * (size_t)mx * N, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(ej.data(), D.ell_j, sizeof(int) * (size_t)mx * N, hipMemcpyDeviceToHost));
+  {
+    const int rc = fetch_ell_values(ctx, D, nzp, ea, &mx);
+    if (rc != CVO_OK) return rc;
   }
+  HIP_TRY(ctx, hipMemcpy(ip.data(), D.iorig, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+  std::vector<int> ej((size_t)mx * N);
+  if (mx) HIP_TRY(ctx, hipMemcpy(ej.data(), D.ell_j, sizeof(int) * (size_t)mx * N, hipMemcpyDeviceToHost));
   std::vector<int> pos_of(N, -1);  // original row -> position
   for (int q = 0; q < N; q++) {
     if (ip[q] < 0 || ip[q] >= N) return fail(ctx, CVO_E_HIP, "cvo_align_association: corrupt row index");
@@ -2954,7 +2998,7 @@ int cvo_align_association(cvo_ctx* ctx, int pair, int* row_ptr, int* col, float*
     const int q = pos_of[r];
     if (sidx < nzp[q]) {
       *j = ej[sidx * (size_t)N + q];
-      *a = ep[sidx * (size_t)N + q].a;
+      *a = ea[sidx * (size_t)N + q];
     } else {
       *j = -1;
       *a = 0.f;

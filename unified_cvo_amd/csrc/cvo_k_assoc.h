@@ -263,7 +263,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
       A.o0 = rr.o[0]; A.o1 = rr.o[1]; A.o2 = rr.o[2];
       A.v0 = rr.v[0]; A.v1 = rr.v[1]; A.v2 = rr.v[2];
       A.asum = rr.asum;
-      A.nnz = D->nnz_row[pos];
+      A.nnz = nnz_count(D->nnz_row[pos]);
     }
   }
   if (INSTR && P.phase_ticks && threadIdx.x == 0) {

@@ -82,7 +82,7 @@ __device__ __forceinline__ int build_long_list(const PairDesc* __restrict__ D, c
 }
 
 #ifndef CVO_DENSE_WAVES_PER_SIMD
-#define CVO_DENSE_WAVES_PER_SIMD 6
+#define CVO_DENSE_WAVES_PER_SIMD 5
 #endif
 // WIDE: the instantiation a small pair solved alone gets (a block per overflow row, see "wide rows" below); everybody else
 // runs the one without that phase - 24 KB of LDS per block instead of 40, six blocks per CU instead of four: the dense
@@ -133,6 +133,11 @@ __global__ __launch_bounds__(64 * DENSE_WAVES, (!WIDE && FEAT == FEAT_GEO) ? CVO
     const FeatDen F = make_feat_den(P);
     const bool long_lists = !all_dense && P.long_lists != 0 && D->long_j != nullptr;
     const unsigned long long gen = (D->call_serial << 24) | (unsigned long long)((unsigned)st->n_builds & 0xffffffu);
+    // The row's run in the row-major part of the ELL, laid out by k_list at the last rebuild (PairDesc::dense_rel /
+    // word_base).  All rows of the pair or none: the runs' total has to fit the part (the demo pair, all of its 523 rows on a
+    // cap of 256 of 256, stays slot-major); not in the dense regime, whose rows k_list does not list.
+    const bool use_runs = !all_dense && (size_t)D->word_base[(N + 63) >> 6] <= ell_upper_capacity(N, P.K_max);
+    auto run_of = [&](int pos) { return use_runs ? D->word_base[pos >> 6] + D->dense_rel[pos] : -1; };
     for (int q = blockIdx.x * DENSE_WAVES + wave; q < n_ovf; q += (int)gridDim.x * DENSE_WAVES) {
       // a position of k_list's ordering (all per-row outputs are stored by position); dense regime: every row
       const int r_sorted = all_dense ? q : D->ovf_rows[q];
@@ -165,6 +170,8 @@ __global__ __launch_bounds__(64 * DENSE_WAVES, (!WIDE && FEAT == FEAT_GEO) ? CVO
         }
       }
       if (!listed && wide_row(n_cand)) continue;
+      const int off = run_of(r_sorted);
+      if (lane == 0) D->dense_off[r_sorted] = off;  // (what the readers of this iteration's matrix go by)
       unsigned nnz = 0;
       // Two chunks of 64 candidates per step: their (independent) evaluations overlap in the pipeline; if the first one
       // already fills the row, the second was evaluated for nothing.  Hits are compacted into LDS in ascending j
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES, (!WIDE && FEAT == FEAT_GEO) ? CVO
           const unsigned rank = nnz + below;
           const bool keep = ok[h] && rank < (unsigned)K;  // `if (num_inds == num_neighbors) break;`
           if (keep) {
-            D->ell[(size_t)rank * N + r_sorted] = make_ell(a[h], yt[h].x, yt[h].y, yt[h].z, psort[h]);
+            D->ell[ell_index(N, (int)rank, r_sorted, off)] = make_ell(a[h], yt[h].x, yt[h].y, yt[h].z, psort[h]);
             if (P.keep_columns) D->ell_j[(size_t)rank * N + r_sorted] = listed ? D->yorder[col[h]] : col[h];
             // flow terms of this lane's pair (CvoGPU.cu:767-769)
             const V3 pye{yt[h].x, yt[h].y, yt[h].z};
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES, (!WIDE && FEAT == FEAT_GEO) ? CVO
       // this kernel and reduces every row of the pair, whoever evaluated it, in one fixed order (no partial of this
       // kernel's own: a pair's sums do not depend on this launch's grid, i.e. on how many pairs are in flight).
       if (lane == 0) {
-        D->nnz_row[r_sorted] = nnz;
+        D->nnz_row[r_sorted] = nnz | NNZ_DENSE_FLAG;
         D->rowres[r_sorted] = RowRes{{o0, o1, o2}, {v0, v1, v2}, asum};
       }
     }
@@ -300,6 +307,8 @@ __global__ __launch_bounds__(64 * DENSE_WAVES, (!WIDE && FEAT == FEAT_GEO) ? CVO
         __syncthreads();
       }
     }
+    const int off = run_of(r_sorted);
+    if (threadIdx.x == 0) D->dense_off[r_sorted] = off;
     // this wave's quarter: a multiple of 128 candidates, two chunks of 64 per step (independent evaluations in flight together)
     const int per = ((n_cand + 128 * DENSE_WAVES - 1) / (128 * DENSE_WAVES)) * 128;
     const int lo = wave * per, hi = min(n_cand, lo + per);
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES, (!WIDE && FEAT == FEAT_GEO) ? CVO
       const float4 h = w_hit[wave][idx];
       const int col = w_col[wave][idx];
       const int psort = listed ? col : ((FEAT != FEAT_GEO || ELL8) ? D->yinv[col] : 0);
-      D->ell[(size_t)(base + idx) * N + r_sorted] = make_ell(h.x, h.y, h.z, h.w, psort);
+      D->ell[ell_index(N, base + idx, r_sorted, off)] = make_ell(h.x, h.y, h.z, h.w, psort);
       if (P.keep_columns) D->ell_j[(size_t)(base + idx) * N + r_sorted] = listed ? D->yorder[col] : col;
     }
     // ordered replay, 128 slots at a time: waves 2 and 3 lay the flow terms of block b + 1 out while wave 0 accumulates block b
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES, (!WIDE && FEAT == FEAT_GEO) ? CVO
       const float o0 = __shfl(acc, 0), o1 = __shfl(acc, 1), o2 = __shfl(acc, 2);
       const float v0 = __shfl(acc, 3), v1 = __shfl(acc, 4), v2 = __shfl(acc, 5);
       if (lane == 0) {
-        D->nnz_row[r_sorted] = (unsigned)nnz;
+        D->nnz_row[r_sorted] = (unsigned)nnz | NNZ_DENSE_FLAG;
         D->rowres[r_sorted] = RowRes{{o0, o1, o2}, {v0, v1, v2}, asum};
       }
     }

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   {
     const char* wb = arena + (size_t)pb.pair * ((size_t)stride256 << 8);
     const int pos = pb.bx * ASSOC_THREADS + threadIdx.x;  // < Npad; values of rows >= N are never used
-    head.nnz = reinterpret_cast<const unsigned*>(wb + row_off_nnz(Npad))[pos];
+    head.nnz = nnz_count(reinterpret_cast<const unsigned*>(wb + row_off_nnz(Npad))[pos]);
     head.x = reinterpret_cast<const float4*>(wb + row_off_xp4(Npad))[pos];
     head.dense = false;
     head.e_n = make_ell(0.f, 0.f, 0.f, 0.f, 0);

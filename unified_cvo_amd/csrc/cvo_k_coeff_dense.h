@@ -41,7 +41,8 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_coeff_dense(const PairDesc
   __shared__ double s_terms[DENSE_WAVES][64][4];
   for (int q = blockIdx.x * DENSE_WAVES + wave; q < n_ovf; q += (int)gridDim.x * DENSE_WAVES) {
     const int pos = all_dense ? q : D->ovf_rows[q];
-    const unsigned nnz = D->nnz_row[pos];
+    const unsigned nnz = nnz_count(D->nnz_row[pos]);
+    const int off = D->dense_off[pos];  // the row's row-major run (k_assoc_dense), -1: slot-major
     const float4 x = D->xp4[pos];
     float temp_coef = coef_ell;
     if (P.use_range_ell) {  // CvoGPU.cu:1035-1037
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_coeff_dense(const PairDesc
       const unsigned s = s0 + (unsigned)lane;
       double t[4] = {0, 0, 0, 0};
       if (s < nnz) {
-        const EllEntry e = D->ell[(size_t)s * N + pos];
+        const EllEntry e = D->ell[ell_index(N, (int)s, pos, off)];
 #ifdef CVO_ELL8
         const f32x4 y0 = ((const CVO_GLOBAL f32x4*)D->ys4)[e.p];
         const V3 yy = transform_point(st->Rinv, st->Tinv, y0.x, y0.y, y0.z);

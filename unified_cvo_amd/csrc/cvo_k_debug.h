@@ -34,6 +34,8 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
     const RowData r = make_row(P, x, st->ell);
     unsigned nnz = 0;
     int err = 0;
+    const unsigned nnz_word = D->nnz_row[pos];  // (flagged: the wave-per-row kernels evaluated the row, its entries may lie row-major)
+    const int off = (nnz_word & NNZ_DENSE_FLAG) ? D->dense_off[pos] : -1;
     for (int j0 = 0; j0 < M && nnz < (unsigned)K; j0 += 64) {
       const int j = j0 + lane;
       float a = 0.f;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
       const unsigned rank = nnz + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
       const bool keep = ok && rank < (unsigned)K;
       if (keep) {
-        const EllEntry e = D->ell[(size_t)rank * N + pos];
+        const EllEntry e = D->ell[ell_index(N, (int)rank, pos, off)];
         if (D->ell_j[(size_t)rank * N + pos] != j)
           err = 2;
 #ifdef CVO_ELL8
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
       }
       nnz += (unsigned)__builtin_popcountll(__ballot(keep));
     }
-    if (D->nnz_row[pos] != nnz) err = 1;  // (also catches entries the list path has and the scan does not)
+    if (nnz_count(nnz_word) != nnz) err = 1;  // (also catches entries the list path has and the scan does not)
     if (__ballot(err != 0) != 0ull) {
       int e = err;
 #pragma unroll
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
       if (lane == 0 && atomicCAS(&st->verify_err, 0, 1) == 0) {
         st->verify_k = st->k;
         st->verify_pos = pos;
-        st->verify_what = (D->nnz_row[pos] != nnz) ? 1 : e;
+        st->verify_what = (nnz_count(nnz_word) != nnz) ? 1 : e;
       }
     }
     checked++;

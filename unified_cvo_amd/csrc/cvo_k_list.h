@@ -292,6 +292,13 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
     // statistic: candidate pairs the association evaluates per iteration while these lists live (one returnless atomic
     // per wave and rebuild instead of a wave reduction in every wave of every k_assoc launch)
     const unsigned wsum = wave_sum_u32(rr < N ? (unsigned)min(cnt_all, 0x3ffffff) : 0u);
+    {
+      // the row-major runs of the overflow rows (PairDesc::dense_rel): min(candidates, K_max) entries each, in position order
+      const int seg = ov ? min(cnt_all, Pp->K_max) : 0;
+      const int incl = wave_prefix_incl_i32(seg, tid & 63);
+      if (ov) D->dense_rel[pos] = incl - seg;
+      if ((tid & 63) == 63) st_x<true>(D->ovf_wsum + (pos >> 6), incl);
+    }
     if ((tid & 63) == 0) {
       st_x<true>(D->ovf_bits + (pos >> 6), m);
       if (m) atomicAdd(&D->st->n_ovf, __builtin_popcountll(m));
@@ -315,9 +322,14 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
     __shared__ int s_wave_cnt[LIST_THREADS / 64];
     const int nwords = (N + 63) >> 6;
     int base = 0;
+    long long run_base = 0;  // entries of the row-major runs so far (PairDesc::word_base)
+    __shared__ int s_wave_run[LIST_THREADS / 64];
     for (int w0 = 0; w0 < nwords; w0 += LIST_THREADS) {
       const int wi = w0 + tid;
       unsigned long long bits = wi < nwords ? ld_x<true>(D->ovf_bits + wi) : 0ull;
+      const int run = (wi < nwords && bits) ? ld_x<true>(D->ovf_wsum + wi) : 0;
+      const int run_incl = wave_prefix_incl_i32(run, tid & 63);
+      if ((tid & 63) == 63) s_wave_run[tid >> 6] = run_incl;
       const int mine = __builtin_popcountll(bits);
       // exclusive prefix of the popcounts over the chunk: inside the wave by a DPP-free shuffle scan, across waves via LDS
       int incl = mine;
@@ -329,11 +341,17 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
       if ((tid & 63) == 63) s_wave_cnt[tid >> 6] = incl;
       __syncthreads();
       int off = base + incl - mine, tot = 0;
+      long long rb = run_base + run_incl - run;
+      int run_tot = 0;
 #pragma unroll
       for (int w = 0; w < LIST_THREADS / 64; w++) {
         off += (w < (tid >> 6)) ? s_wave_cnt[w] : 0;
         tot += s_wave_cnt[w];
+        rb += (w < (tid >> 6)) ? s_wave_run[w] : 0;
+        run_tot += s_wave_run[w];
       }
+      if (wi < nwords) D->word_base[wi] = (int)(rb > 0x7fffffffll ? 0x7fffffffll : rb);
+      run_base += run_tot;
       while (bits) {
         const int b = __builtin_ctzll(bits);
         bits &= bits - 1;
@@ -342,6 +360,7 @@ __global__ __launch_bounds__(LIST_THREADS) void k_list(const PairDesc* __restric
       base += tot;
       __syncthreads();
     }
+    if (tid == 0) D->word_base[nwords] = (int)(run_base > 0x7fffffffll ? 0x7fffffffll : run_base);  // the total: all rows or none
   }
   if (tid == 0) {
     *D->gate = 0;

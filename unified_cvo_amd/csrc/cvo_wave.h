@@ -84,6 +84,17 @@ __device__ __forceinline__ float wave_minmax_f32(float v) {
   m = meet(m, __builtin_amdgcn_readlane(iv, 32));
   return meet(m, __builtin_amdgcn_readlane(iv, 48));
 }
+// inclusive prefix sum of an int over the wave, in lane order, on the DPP paths: row_shr 1 / 2 / 4 / 8 with zero fill inside
+// every row of 16 lanes, the three lower rows' totals through scalar registers
+__device__ __forceinline__ int wave_prefix_incl_i32(int v, int lane) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+  const int quarter = lane >> 4;
+  return v + (quarter > 0 ? t0 : 0) + (quarter > 1 ? t1 : 0) + (quarter > 2 ? t2 : 0);
+}
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o));
