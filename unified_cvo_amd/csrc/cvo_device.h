@@ -291,17 +291,18 @@ struct PairDesc {
   int* dense_rel;         // [N] by position (overflow rows only)
   int* ovf_wsum;          // [words] entries the overflow rows of a 64-row word need
   int* word_base;         // [words + 1]
-  int* dense_off;         // [N] by position: where k_assoc_dense put the row THIS iteration (entry index into the upper part),
-                          // -1 = slot-major; valid for rows whose nnz_row carries NNZ_DENSE_FLAG
+  int* dense_off;         // [N] by position: where k_assoc_dense put the row THIS iteration (index of the run's first entry),
+                          // -1 = slot-major; valid for rows whose nnz_row carries NNZ_DENSE_FLAG.  In the dense regime every
+                          // row is evaluated there and the whole matrix is row-major: row pos at pos * K_max
 };
 
 // nnz_row[pos] of a row the wave-per-row kernels evaluated carries this flag (its entries may live row-major, dense_off)
 constexpr unsigned NNZ_DENSE_FLAG = 0x80000000u;
 __host__ __device__ inline unsigned nnz_count(unsigned v) { return v & ~NNZ_DENSE_FLAG; }
 constexpr int ELL_LOWER_SLOTS = 64;  // slots of the slot-major matrix the thread-per-row kernels can reach (ASSOC_CAP16)
-// index of entry `s` of the row at position `pos`: in its row-major run (off >= 0) or in the slot-major matrix
+// index of entry `s` of the row at position `pos`: in its row-major run (off >= 0: the run's first entry) or in the slot-major matrix
 __host__ __device__ inline size_t ell_index(int N, int s, int pos, int off) {
-  return off >= 0 ? (size_t)ELL_LOWER_SLOTS * (size_t)N + (size_t)off + (size_t)s : (size_t)s * (size_t)N + (size_t)pos;
+  return off >= 0 ? (size_t)off + (size_t)s : (size_t)s * (size_t)N + (size_t)pos;
 }
 __host__ __device__ inline size_t ell_upper_capacity(int N, int K_max) {
   return K_max > ELL_LOWER_SLOTS ? (size_t)(K_max - ELL_LOWER_SLOTS) * (size_t)N : 0;

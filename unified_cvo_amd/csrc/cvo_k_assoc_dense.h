@@ -136,8 +136,15 @@ __global__ __launch_bounds__(64 * DENSE_WAVES, (!WIDE && FEAT == FEAT_GEO) ? CVO
     // The row's run in the row-major part of the ELL, laid out by k_list at the last rebuild (PairDesc::dense_rel /
     // word_base).  All rows of the pair or none: the runs' total has to fit the part (the demo pair, all of its 523 rows on a
     // cap of 256 of 256, stays slot-major); not in the dense regime, whose rows k_list does not list.
-    const bool use_runs = !all_dense && (size_t)D->word_base[(N + 63) >> 6] <= ell_upper_capacity(N, P.K_max);
-    auto run_of = [&](int pos) { return use_runs ? D->word_base[pos >> 6] + D->dense_rel[pos] : -1; };
+    // In the dense regime (every row is evaluated here, the thread-per-row kernels store nothing) the whole matrix is
+    // row-major, K_max entries per row.
+    const size_t upper_cap = ell_upper_capacity(N, P.K_max);
+    const bool small = (size_t)N * (size_t)P.K_max < 0x7fffffffull;  // (run indices are ints)
+    const bool use_runs = small && (all_dense || (size_t)D->word_base[(N + 63) >> 6] <= upper_cap);
+    auto run_of = [&](int pos) {
+      if (!use_runs) return -1;
+      return all_dense ? pos * P.K_max : ELL_LOWER_SLOTS * N + D->word_base[pos >> 6] + D->dense_rel[pos];
+    };
     for (int q = blockIdx.x * DENSE_WAVES + wave; q < n_ovf; q += (int)gridDim.x * DENSE_WAVES) {
       // a position of k_list's ordering (all per-row outputs are stored by position); dense regime: every row
       const int r_sorted = all_dense ? q : D->ovf_rows[q];
