@@ -249,4 +249,13 @@ def test_clustered_pairs_batch_equals_solo():
     for k in range(3):
         r = g2.align(g2.upload(pairs[k][1]), g2.upload(pairs[k][2]), pairs[k][3], max_iterations=220)
         assert np.array_equal(r.transform, solo[k].transform)
+    # ... and with the chip full of pairs, where the row classes, the dense kernels' grid AND their work split change
+    # (rows of up to 64 candidates stay in the thread-per-row kernels; k_coeff_dense takes eight rows per wave): the three
+    # pairs above inside a batch of 36 clustered pairs
+    more = [cases.scene(n=1200 + 90 * p, pair_id=10 + p) for p in range(33)]
+    src2 = src + [gpu.upload(p[1]) for p in more]
+    tgt2 = tgt + [gpu.upload(p[2]) for p in more]
+    big = gpu.align_batch(src2, tgt2, [p[3] for p in pairs + more], max_iterations=220)
+    for a, b in zip(solo, big[:3]):
+        assert a.iterations == b.iterations == 220 and np.array_equal(a.transform, b.transform)
 
