@@ -10,7 +10,7 @@ opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
 for NP in sizes:
     pairs = [cases.scene(n=10000, pair_id=p) for p in range(NP)]
     P = pairs[0][0]
-    gpu = CvoGPU(params=P)
+    gpu = CvoGPU(params=P, library=os.environ.get("CVO_LIB") or None)
     for k, v in opts.items():
         gpu.set_option(k, v)
     both = gpu.upload_many([a[1] for a in pairs] + [a[2] for a in pairs])
