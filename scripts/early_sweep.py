@@ -11,7 +11,7 @@ NP = int(os.environ.get("SWEEP_PAIRS", "64"))
 builder = {"config2": cases.config2, "config3": cases.config3, "config4": cases.config4, "scene": cases.scene}[os.environ.get("SWEEP_CASE", "config2")]
 pairs = [builder(n=10000, pair_id=p) for p in range(NP)]
 P = pairs[0][0]
-gpu = CvoGPU(params=P)
+gpu = CvoGPU(params=P, library=os.environ.get("CVO_LIB") or None)
 both = gpu.upload_many([a[1] for a in pairs] + [a[2] for a in pairs])
 inits = [a[3] for a in pairs]
 ref = None

@@ -61,6 +61,10 @@ extern "C" int cvo_process_hint_hw_queues(void) {
   return q ? atoi(q) : 4;
 }
 
+#ifndef CVO_COEFF_DENSE_MULTI_FROM
+#define CVO_COEFF_DENSE_MULTI_FROM 8  // pairs per launch from which k_coeff_dense takes eight rows per wave
+#endif
+
 struct cvo_cloud {
   cvo_ctx* ctx = nullptr;  // identity check only: never dereferenced after upload (the context may be gone)
   int device = 0;
@@ -632,7 +636,7 @@ void launch_core(cvo_ctx* c, const LaunchGeom& g, bool lean, int flags, bool den
     // (7 waves per SIMD against k_assoc_dense's 4: twice the blocks, so that a lone pair's rows get a wave each - the kernel
     // then lasts as long as its longest row, not as two)
     hipLaunchKernelGGL((k_coeff_dense<4>), dim3(g.n_pairs <= 4 ? std::min(2 * g.dense_blocks, (int)DENSE_BLOCKS_MAX) : g.dense_blocks, g.n_pairs), dim3(256), 0, g.stream, descs,
-                       c->d_params, c->d_states + g.p0, g.n_pairs >= 8 ? 8 : 1);
+                       c->d_params, c->d_states + g.p0, g.n_pairs >= CVO_COEFF_DENSE_MULTI_FROM ? 8 : 1);
   launch_coeff(g.stream, g.instr, g.nba, g.csplit, g.n_pairs, descs, c->d_params, c->d_states + g.p0, g.arena,
                flags | (lean ? 1 : 0) | (lean_dense ? 32 : 0) | (g.idx16 ? 0 : 64));
 }
