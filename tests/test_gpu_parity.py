@@ -556,6 +556,29 @@ def test_overlap_kernel_equals_the_list_chain():
     assert np.diff(A[0]).max() == 6  # (rows sit on the cap)
 
 
+def test_association_export_reads_row_major_runs(oracle):
+    """Rows beyond their lists keep their ELL entries row-major (PairDesc::dense_off, laid out by k_list); the exports have to
+    find them there.  A clustered scene, rows of several hundred entries: compute_association_gpu against the oracle's
+    matrix (columns exact, values to an ulp), its sum against inner_product_gpu through the list chain, and the last
+    iteration's matrix of an align() against its own nonzero count."""
+    P, src, tgt, init = cases.scene(n=2500)
+    gpu = CvoGPU(params=P)
+    da, db = gpu.upload(src), gpu.upload(tgt)
+    ell = 0.8
+    rp, col, val = gpu.compute_association_gpu(da, db, init, ell)[:3]
+    counts = np.diff(rp)
+    assert counts.max() > 200 and (counts > 64).sum() > 100          # (rows that live in the row-major part)
+    orp, ocol, oval = oracle.association(oracle.params_from(P), _ocloud(oracle, src), _ocloud(oracle, tgt), init, ell)
+    assert np.array_equal(rp, orp) and np.array_equal(col, ocol)
+    assert np.allclose(val, oval, rtol=2e-7, atol=0)
+    gpu.set_option("IP_CHAIN", "1")
+    assert float(np.sum(val.astype(np.float64))) == pytest.approx(gpu.inner_product_gpu(da, db, init, ell), rel=1e-6)
+    gpu.set_option("IP_CHAIN", None)
+    g = gpu.align(da, db, init, max_iterations=30, trace_capacity=30, trace_dense=30)
+    rp2, col2, val2 = gpu.align_association(src.num_points())[:3]
+    assert len(col2) == g.trace[-1].nnz and np.diff(rp2).max() > 64 and np.all(val2 > 0)
+
+
 def test_context_options_are_validated():
     gpu = CvoGPU(params=CvoParams())
     gpu.set_option("CVO_VERBOSE", None)      # with or without the prefix; None clears
