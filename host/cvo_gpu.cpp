@@ -328,10 +328,16 @@ std::vector<int> CvoGPU::align_stream(const ResidentClouds& sources, const Resid
     n_min = std::min(n_min, ns);
     m_max = std::max(m_max, nt);
   }
-  cvo_batch_queue* q = nullptr;
-  check(ctx, cvo_batch_open(ctx, &params, std::max(1, std::min(slots, n)), n_max, m_max, n_min, nullptr, &q), "cvo_batch_open");
+  std::vector<cvo_batch_result_t> buf((size_t)n);  // (before the queue opens: nothing below may throw while it is open ...)
+  struct QueueGuard {  // (... and if something does, the queue is closed on the way out: an open queue locks the context)
+    cvo_batch_queue* q = nullptr;
+    ~QueueGuard() {
+      if (q) cvo_batch_close(q);
+    }
+  } guard;
+  check(ctx, cvo_batch_open(ctx, &params, std::max(1, std::min(slots, n)), n_max, m_max, n_min, nullptr, &guard.q), "cvo_batch_open");
+  cvo_batch_queue* const q = guard.q;
   const auto t0 = std::chrono::steady_clock::now();
-  std::vector<cvo_batch_result_t> buf((size_t)n);
   int got = 0, rc = CVO_OK;
   for (int k = 0; k < n && rc == CVO_OK; k++) {
     rc = cvo_batch_submit(q, sources.handles[pairs[k].first], targets.handles[pairs[k].second], inits[k].data(),
@@ -347,6 +353,7 @@ std::vector<int> CvoGPU::align_stream(const ResidentClouds& sources, const Resid
     if (rc == CVO_OK && m == 0 && cvo_batch_pending(q) == 0) break;
   }
   cvo_batch_close(q);
+  guard.q = nullptr;
   check(ctx, rc, "cvo_batch_submit / cvo_batch_poll");
   if (got != n) throw std::runtime_error("align_stream: the queue delivered fewer results than pairs were submitted");
   for (int k = 0; k < n; k++) {  // (delivered in submission order: buf[k].ticket == k)

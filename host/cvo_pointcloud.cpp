@@ -1,4 +1,5 @@
 // cvo::CvoPointCloud accessor subset (see include/UnifiedCvo/utils/CvoPointCloud.hpp).
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>

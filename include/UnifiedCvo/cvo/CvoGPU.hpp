@@ -73,7 +73,10 @@ class CvoGPU {
   // full however different the pairs' iteration counts are - upstream's own use is a frame stream with warm starts
   // (main_cvo_gpu_align_raw_image.cpp:100-170).  pairs[k] = {index into sources, index into targets}; max_iterations[k]
   // (optional) = that pair's own iteration limit.  Transforms / return values in submission order, every pose
-  // bit-identical to a solo align().
+  // bit-identical to a solo align().  Memory: the workspace is sized up front for min(slots, pairs) pairs of the LARGEST
+  // source x target sizes of the call - ~139 MB per slot at 10k x 10k with nearest_neighbors_max = 512 (17 GB for the
+  // default 128 slots), N * M / 8 bytes of candidate bitmap per slot beyond that; a request that does not fit fails with
+  // a sized CVO_E_NOMEM message (cvo_last_error).  The queue is closed on every way out, exceptions included.
   std::vector<int> align_stream(const ResidentClouds& sources, const ResidentClouds& targets,
                                 const std::vector<std::pair<int, int>>& pairs, const std::vector<Mat4f>& inits,
                                 std::vector<Mat4f>& transforms, int slots = 128, const std::vector<int>* max_iterations = nullptr,

@@ -3,6 +3,7 @@
 //   cvo::Mat4f  <-> Eigen::Matrix4f        (both 16 floats, column-major: the conversion is a memcpy)
 //   cvo::Mat3f  <-> Eigen::Matrix3f
 //   cvo::Vec3f  <-> Eigen::Vector3f
+//   cvo::Vec2f  <-> Eigen::Vector2f,  cvo::VecXf <-> Eigen::VectorXf   (CvoPointCloud::geometry_type_at / label_at / feature_at)
 //   cvo::SparseRowMat -> Eigen::SparseMatrix<float, Eigen::RowMajor>   (Association::pairs, upstream Association.hpp:9)
 #pragma once
 #include "utils/data_type.hpp"
@@ -39,6 +40,19 @@ inline Mat3f from_eigen(const Eigen::Matrix3f& e) {
 }
 inline Eigen::Vector3f to_eigen(const Vec3f& v) { return Eigen::Vector3f(v[0], v[1], v[2]); }
 inline Vec3f from_eigen(const Eigen::Vector3f& e) { return Vec3f{{e[0], e[1], e[2]}}; }
+
+inline Eigen::Vector2f to_eigen(const Vec2f& v) { return Eigen::Vector2f(v[0], v[1]); }
+inline Vec2f from_eigen(const Eigen::Vector2f& e) { return Vec2f{{e[0], e[1]}}; }
+inline Eigen::VectorXf to_eigen(const VecXf& v) {
+  Eigen::VectorXf e(v.size());
+  for (int i = 0; i < v.size(); i++) e[i] = v[i];
+  return e;
+}
+inline VecXf from_eigen(const Eigen::VectorXf& e) {
+  VecXf v((int)e.size());
+  for (int i = 0; i < v.size(); i++) v[i] = e[i];
+  return v;
+}
 
 inline Eigen::SparseMatrix<float, Eigen::RowMajor> to_eigen(const SparseRowMat& s) {
   std::vector<Eigen::Triplet<float>> t;

@@ -44,6 +44,13 @@ class CvoPointCloud {
   const std::vector<Vec3f>& positions() const { return positions_; }
   Vec3f at(unsigned int index) const { return positions_[index]; }
   const MatXf& labels() const { return labels_; }
+  // upstream CvoPointCloud.hpp:141-143 (CvoPointCloud.cpp:1282-1286): one point's class distribution / feature row /
+  // (edge, surface) pair by value
+  VecXf label_at(unsigned int index) const { return labels_.row((int)index); }
+  VecXf feature_at(unsigned int index) const { return features_.row((int)index); }
+  Vec2f geometry_type_at(unsigned int index) const {
+    return Vec2f{{geometric_types_[(size_t)index * 2], geometric_types_[(size_t)index * 2 + 1]}};
+  }
   const MatXf& semantics() const { return labels_; }
   const MatXf& features() const { return features_; }
   const std::vector<float>& geometric_types() const { return geometric_types_; }

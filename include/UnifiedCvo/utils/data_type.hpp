@@ -17,6 +17,34 @@ struct Vec3f {
   float operator[](int i) const { return v[i]; }
 };
 
+// 2-vector of floats, same layout as Eigen::Vector2f (CvoPointCloud::geometry_type_at).
+struct Vec2f {
+  float v[2];
+  float& operator()(int i) { return v[i]; }
+  float operator()(int i) const { return v[i]; }
+  float& operator[](int i) { return v[i]; }
+  float operator[](int i) const { return v[i]; }
+};
+
+// Dynamic float vector in the role of Eigen::VectorXf (CvoPointCloud::label_at / feature_at return one row of the
+// N x C / N x F matrices by value).
+class VecXf {
+ public:
+  VecXf() = default;
+  explicit VecXf(int n) : d_((size_t)n, 0.f) {}
+  int size() const { return (int)d_.size(); }
+  int rows() const { return (int)d_.size(); }
+  float& operator()(int i) { return d_[(size_t)i]; }
+  float operator()(int i) const { return d_[(size_t)i]; }
+  float& operator[](int i) { return d_[(size_t)i]; }
+  float operator[](int i) const { return d_[(size_t)i]; }
+  const float* data() const { return d_.data(); }
+  float* data() { return d_.data(); }
+
+ private:
+  std::vector<float> d_;
+};
+
 // 4x4 float matrix, COLUMN-major like Eigen::Matrix4f: element (r, c) is m[4*c + r].
 struct Mat4f {
   float m[16];
@@ -61,6 +89,11 @@ class MatXf {
   float& operator()(int r, int c) { return d_[(size_t)c * rows_ + r]; }
   float operator()(int r, int c) const { return d_[(size_t)c * rows_ + r]; }
   const float* data() const { return d_.data(); }
+  VecXf row(int r) const {  // (Eigen: `VectorXf v = m.row(r)`)
+    VecXf out(cols_);
+    for (int c = 0; c < cols_; c++) out(c) = (*this)(r, c);
+    return out;
+  }
 
  private:
   int rows_ = 0, cols_ = 0;

@@ -233,7 +233,10 @@ int cvo_batch_poses_to_device(cvo_ctx* ctx, void* dst_device, int n_pairs);
  *                     1: until at least one result can be delivered (or nothing is pending); 2: until everything
  *                     submitted so far has finished (or `capacity` results are ready).
  *   cvo_batch_pending submitted pairs not yet delivered.  cvo_batch_close waits for the device and releases the queue
- *                     (undelivered results are dropped). */
+ *                     (undelivered results are dropped).
+ *   While a queue is open the context refuses cvo_align* / inner products / cvo_ctx_set_option (CVO_E_INVALID).
+ *   cvo_ctx_destroy on a context with an open queue drains the queue's streams, releases its device side and ORPHANS the
+ *   handle: every later call on it returns CVO_E_INVALID, cvo_batch_close then only frees the host object. */
 typedef struct cvo_batch_queue cvo_batch_queue;
 typedef struct cvo_batch_result_t {
   long long ticket;

@@ -106,3 +106,44 @@ def test_queue_random_mix_equals_solo():
     for r, (kind, lim) in zip(got, jobs):
         assert _same(r, solo[(kind, lim)]), (r.ticket, kind, lim)
 
+
+
+def test_queue_lifetime_edges():
+    """a context destroyed under an open queue releases the queue's device side and orphans the handle (later
+    calls fail cleanly, close() only frees the host object); options cannot change under an open queue; a queue dropped
+    without close() unlocks its context; a with-block closes on the way out; an empty stream is an empty result."""
+    P, a, b, init = cases.config2(n=1200)
+    gpu = CvoGPU(params=P)
+    da, db = gpu.upload(a), gpu.upload(b)
+    solo = gpu.align(da, db, init, max_iterations=60)
+    assert gpu.align_stream([], [], []) == []
+    with gpu.open_queue(2, 1200, 1200, max_iterations=60) as q:
+        with pytest.raises(CvoError):
+            gpu.set_option("SKIN", "0.5")      # graphs with chunks in flight would be destroyed
+        q.submit(da, db, init)
+        assert _same(q.poll(wait=2)[0], solo)
+    assert _same(gpu.align(da, db, init, max_iterations=60), solo)   # closed by the with-block
+    gpu.set_option("SKIN", None)
+    q = gpu.open_queue(2, 1200, 1200, max_iterations=60)
+    q.submit(da, db, init)
+    del q                                      # dropped without close(): __del__ closes it
+    import gc
+    gc.collect()
+    assert _same(gpu.align(da, db, init, max_iterations=60), solo)
+    # context destroyed under an open queue with work in flight
+    gpu2 = CvoGPU(params=P)
+    ea, eb = gpu2.upload(a), gpu2.upload(b)
+    q2 = gpu2.open_queue(2, 1200, 1200, max_iterations=400)
+    q2.submit(ea, eb, init)
+    L, h = gpu2.L, q2.handle
+    L.cvo_ctx_destroy(gpu2.ctx)                # the raw C-ABI call, behind the wrapper's back
+    gpu2.ctx = None
+    import ctypes as C
+    n = C.c_int()
+    from unified_cvo_amd import _capi
+    buf = (_capi.cvo_batch_result_t * 1)()
+    assert L.cvo_batch_poll(h, 2, 1, buf, C.byref(n)) != 0 and n.value == 0
+    assert L.cvo_batch_pending(h) == 0
+    q2.close()                                 # frees the orphaned host object only
+    ea.free()                                  # (clouds outlive their context: cvo_cloud_free only needs the device ordinal)
+    eb.free()

@@ -125,6 +125,16 @@ class CvoPointCloud:
 
     semantics = labels
 
+    # label_at / feature_at / geometry_type_at (CvoPointCloud.hpp:141-143, CvoPointCloud.cpp:1282-1286): rows by value
+    def label_at(self, index):
+        return np.array(self.labels_[index], dtype=np.float32)
+
+    def feature_at(self, index):
+        return np.array(self.features_[index], dtype=np.float32)
+
+    def geometry_type_at(self, index):
+        return np.array(self.geometric_types_.reshape(-1)[2 * index:2 * index + 2], dtype=np.float32)
+
     def geometric_types(self):
         return self.geometric_types_.reshape(-1)
 
@@ -267,6 +277,7 @@ class BatchQueue:
     """cvo_batch_open / _submit / _poll / _close: a stream of frame pairs through a fixed number of in-flight slots."""
 
     def __init__(self, gpu, slots, max_source_points, max_target_points, min_source_points=0, max_iterations=0):
+        self.handle = None  # (set before anything can raise: close() / __del__ then have something to look at)
         self.gpu = gpu
         self.slots = slots
         o = _capi.cvo_align_opts_t()
@@ -277,6 +288,7 @@ class BatchQueue:
                                         C.byref(o), C.byref(h)))
         self.handle = h
         self._keep = {}
+        gpu._queues.append(self)
 
     def submit(self, source, target, init, max_iterations=0):
         src, tgt = self.gpu._dev(source), self.gpu._dev(target)
@@ -287,8 +299,8 @@ class BatchQueue:
         return t.value
 
     def poll(self, wait=1, capacity=None):
-        """Finished pairs in submission order as (ticket, AlignResult); wait: 0 = just make progress, 1 = until one is
-        ready, 2 = until everything submitted has finished."""
+        """Finished pairs in submission order as AlignResult objects whose `.ticket` is the submission's ticket; wait:
+        0 = just make progress, 1 = until one is ready, 2 = until everything submitted has finished."""
         cap = capacity or max(self.pending(), 1)
         buf = (_capi.cvo_batch_result_t * cap)()
         n = C.c_int()
@@ -315,6 +327,22 @@ class BatchQueue:
         if self.handle:
             self.gpu.L.cvo_batch_close(self.handle)
             self.handle = None
+            self._keep = {}
+            if self in self.gpu._queues:
+                self.gpu._queues.remove(self)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class CvoGPU:
@@ -333,8 +361,11 @@ class CvoGPU:
         if rc != 0:
             raise CvoError(f"cvo_ctx_create(device={device}) failed with {rc}: is a HIP GPU visible?")
         self.ctx = ctx
+        self._queues = []  # live BatchQueue objects (closed before the context goes)
 
     def close(self):
+        for q in list(getattr(self, "_queues", [])):
+            q.close()
         if getattr(self, "ctx", None):
             self.L.cvo_ctx_destroy(self.ctx)
             self.ctx = None
@@ -482,6 +513,8 @@ class CvoGPU:
         (limits: per-pair iteration limits)."""
         src = [self._dev(s) for s in sources]
         tgt = [self._dev(t) for t in targets]
+        if not src:  # (the C++ veneer returns an empty result likewise)
+            return []
         q = self.open_queue(slots, max(s.n for s in src), max(t.n for t in tgt), min(s.n for s in src), max_iterations)
         try:
             for k, (s, t, T) in enumerate(zip(src, tgt, inits)):

@@ -178,6 +178,7 @@ struct cvo_ctx {
   DevParams last_params{};
   int last_gx = 0, last_gy = 0, last_csplit = 1;
   bool queue_open = false;  // a cvo_batch_queue owns the workspace: the other align / evaluation calls are refused meanwhile
+  cvo_batch_queue* queue = nullptr;  // ... that queue (cvo_ctx_destroy releases its device side, see queue_release)
   double clock_ms_per_tick = 0.0;  // s_memrealtime, calibrated on first use (cvo_debug_kernel_clock)
   unsigned last_stride256 = 0;
   int last_Npad = 0;
@@ -213,7 +214,8 @@ int fail(cvo_ctx* ctx, int code, const std::string& msg) {
   } while (0)
 
 // A cloud that lacks an attribute array the kernels of a call dereference gets a zeroed one (once).
-int ensure_attributes(cvo_ctx* ctx, const cvo_cloud* c, bool need_feat, bool need_label, bool need_geo) {
+// *created (optional) is set when this call allocated the slab: its zero fill is in flight on ctx->stream.
+int ensure_attributes(cvo_ctx* ctx, const cvo_cloud* c, bool need_feat, bool need_label, bool need_geo, bool* created = nullptr) {
   if ((!need_feat || c->feat) && (!need_label || c->label) && (!need_geo || c->geo)) return CVO_OK;
   cvo_cloud* m = const_cast<cvo_cloud*>(c);
   const size_t nn = (size_t)std::max(c->n, 1);
@@ -229,6 +231,7 @@ int ensure_attributes(cvo_ctx* ctx, const cvo_cloud* c, bool need_feat, bool nee
       m->zero_slab = nullptr;
       return fail(ctx, CVO_E_HIP, std::string("cloud hipMemsetAsync: ") + hipGetErrorString(e));
     }
+    if (created) *created = true;
   }
   if (!m->feat) m->feat = (float4*)(m->zero_slab + o_feat);
   if (!m->label) m->label = (float4*)(m->zero_slab + o_label);
@@ -1395,9 +1398,14 @@ int cvo_ctx_create(int device, cvo_ctx** out) {
   return CVO_OK;
 }
 
+static void queue_release(cvo_batch_queue* q);
+
 void cvo_ctx_destroy(cvo_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  // an open batch queue goes first: its streams are drained, its pinned block freed and the handle orphaned - the host
+  // object stays until its owner calls cvo_batch_close, every other call on it returns CVO_E_INVALID
+  if (c->queue) queue_release(c->queue);
   // every stream of the set must be idle before the workspace goes (work queued by a call that returned early on an
   // error would otherwise run against freed memory) - and a set whose streams cannot be drained is not pooled
   bool drained = true;
@@ -1454,6 +1462,8 @@ int cvo_ctx_set_option(cvo_ctx* ctx, const char* name, const char* value) {
   bool known = false;
   for (const char* k : kOptionNames) known = known || std::strcmp(k, name) == 0;
   if (!known) return fail(ctx, CVO_E_INVALID, std::string("cvo_ctx_set_option: unknown option ") + name);
+  // (an open queue has chunks in flight on graphs that bake the switches in, and re-captures from its own copy of them)
+  if (ctx->queue_open) return fail(ctx, CVO_E_INVALID, "cvo_ctx_set_option: a batch queue is open on this context (cvo_batch_close it first)");
   if (value)
     ctx->opt[name] = value;
   else
@@ -2497,13 +2507,14 @@ int cvo_batch_open(cvo_ctx* ctx, const cvo_params_t* params, int slots, int max_
     return fail(ctx, CVO_E_HIP, std::string("cvo_batch_open: ") + hipGetErrorString(e));
   }
   ctx->queue_open = true;
+  ctx->queue = q;
   *out = q;
   return CVO_OK;
 }
 
 int cvo_batch_submit(cvo_batch_queue* q, const cvo_cloud* source, const cvo_cloud* target, const float init_T[16],
                      int max_iterations, long long* ticket) {
-  if (!q) return CVO_E_INVALID;
+  if (!q || !q->ctx) return CVO_E_INVALID;  // (ctx == nullptr: the context was destroyed under the queue)
   cvo_ctx* ctx = q->ctx;
   if (!source || !target || !init_T) return fail(ctx, CVO_E_INVALID, "cvo_batch_submit: null argument");
   if (source->ctx != ctx || target->ctx != ctx) return fail(ctx, CVO_E_INVALID, "cloud belongs to another context");
@@ -2516,10 +2527,14 @@ int cvo_batch_submit(cvo_batch_queue* q, const cvo_cloud* source, const cvo_clou
   {
     const bool nf = q->params.is_using_intensity != 0, nl = q->params.is_using_semantics != 0, ng = q->params.is_using_geometric_type != 0;
     if (nf || nl || ng) {
-      int rc0 = ensure_attributes(ctx, source, nf, nl, ng);
-      if (rc0 == CVO_OK) rc0 = ensure_attributes(ctx, target, nf, nl, ng);
+      bool created = false;
+      int rc0 = ensure_attributes(ctx, source, nf, nl, ng, &created);
+      if (rc0 == CVO_OK) rc0 = ensure_attributes(ctx, target, nf, nl, ng, &created);
       if (rc0 != CVO_OK) return rc0;
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (a zero slab is filled on the context's stream; the sub-batch streams read it)
+      // a zero slab is filled on the context's stream (= sub-batch 0's) and read on every sub-batch stream: wait for the
+      // fill - only when this call made one (the stream carries sub-batch 0's chunks: a wait per submission serialised the
+      // host with the device)
+      if (created) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
   }
   cvo_batch_queue::Job job;
@@ -2549,8 +2564,9 @@ int cvo_batch_submit(cvo_batch_queue* q, const cvo_cloud* source, const cvo_clou
 
 int cvo_batch_poll(cvo_batch_queue* q, int wait, int capacity, cvo_batch_result_t* results, int* n_results) {
   if (!q || !n_results || (capacity > 0 && !results)) return CVO_E_INVALID;
-  cvo_ctx* ctx = q->ctx;
   *n_results = 0;
+  if (!q->ctx) return CVO_E_INVALID;
+  cvo_ctx* ctx = q->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   auto deliverable = [&] { return q->done.count(q->next_deliver) != 0; };
   for (;;) {
@@ -2581,7 +2597,7 @@ int cvo_batch_poll(cvo_batch_queue* q, int wait, int capacity, cvo_batch_result_
   return CVO_OK;
 }
 
-int cvo_batch_pending(const cvo_batch_queue* q) { return q ? queue_pending(q) : 0; }
+int cvo_batch_pending(const cvo_batch_queue* q) { return (q && q->ctx) ? queue_pending(q) : 0; }
 
 int cvo_batch_stats(const cvo_batch_queue* q, unsigned long long* chunks, unsigned long long* full_chunks, unsigned long long* refills) {
   if (!q) return CVO_E_INVALID;
@@ -2591,13 +2607,25 @@ int cvo_batch_stats(const cvo_batch_queue* q, unsigned long long* chunks, unsign
   return CVO_OK;
 }
 
-void cvo_batch_close(cvo_batch_queue* q) {
-  if (!q) return;
+// The device side of a queue: streams drained, pinned block freed, the context unlocked and the handle orphaned.
+static void queue_release(cvo_batch_queue* q) {
   cvo_ctx* ctx = q->ctx;
+  if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (int g = 0; g < q->G; g++) (void)hipStreamSynchronize(q->geom[g].stream);
   if (q->pinned) (void)hipHostFree(q->pinned);
+  q->pinned = nullptr;
+  q->h_out = nullptr;
+  q->h_desc_stage = nullptr;
+  q->h_state_stage = nullptr;
   ctx->queue_open = false;
+  ctx->queue = nullptr;
+  q->ctx = nullptr;
+}
+
+void cvo_batch_close(cvo_batch_queue* q) {
+  if (!q) return;
+  queue_release(q);  // (a no-op when cvo_ctx_destroy already ran it)
   delete q;
 }
 
