@@ -8,6 +8,7 @@
   * argument validation of the public override fields.
 """
 import collections
+import os
 
 import numpy as np
 import pytest
@@ -235,6 +236,79 @@ def test_device_step_selection_vs_numpy(op):
         near_rule = any(abs(abs(z.imag) - 1e-5) < 1e-7 or abs(z.real) < 1e-12 for z in r)
         assert near_rule, (it, s, ref32, r)
     assert n_short > 50
+
+
+def _step_shortcut_items(rs, n_random):
+    """Coefficient sets (B, C, D, E, min_step, max_step) around everything the certified Newton shortcut has to get right or
+    refuse: the real loop's shapes (golden traces), small first roots with the other two far / near / almost equal, complex
+    pairs in front of the first real root whose imaginary part straddles the 1e-5 rule, roots on the clamps and on float
+    rounding boundaries, decreasing and increasing starts, both signs of B."""
+    import json
+    items = []
+    d = json.load(open(os.path.join(cases.ROOT, "tests", "golden", "oracle_traces.json")))
+    for c in d["cases"]:
+        for t in c["trace"]:
+            for mn, mx in ((1e-4, 0.8), (1e-6, 0.01), (1e-7, 0.01), (2e-5, 0.8)):
+                items.append([t["B"], t["C"], t["D"], t["E"], mn, mx])
+
+    def from_roots(roots, lead, mn, mx):
+        c = np.real(np.poly(roots)) * lead          # 4E, 3D, 2C, B
+        items.append([c[3], c[2] / 2, c[1] / 3, c[0] / 4, mn, mx])
+
+    for _ in range(n_random):
+        r0 = 10.0 ** rs.uniform(-7, 0)
+        lead = rs.choice([-1, 1]) * 10.0 ** rs.uniform(0, 9)
+        kind = rs.integers(0, 8)
+        mn, mx = [(1e-4, 0.8), (1e-6, 0.01), (1e-7, 0.01)][rs.integers(0, 3)]
+        if kind == 0:    # the other roots far away, either side
+            from_roots([r0, rs.choice([-1, 1]) * r0 * 10 ** rs.uniform(0.3, 4), rs.choice([-1, 1]) * r0 * 10 ** rs.uniform(0.3, 4)], lead, mn, mx)
+        elif kind == 1:  # a second root right behind the first (near-double root)
+            from_roots([r0, r0 * (1 + 10.0 ** rs.uniform(-12, -1)), -rs.uniform(0.1, 3)], lead, mn, mx)
+        elif kind == 2:  # complex pair in front of the first real root, |imag| around the 1e-5 rule
+            u = r0 * rs.uniform(0.05, 0.95)
+            from_roots([r0, complex(u, 10.0 ** rs.uniform(-7, -3)), complex(u, -(10.0 ** rs.uniform(-7, -3)))], lead, mn, mx)
+            v = 10.0 ** rs.uniform(-7, -3)
+            from_roots([r0, complex(u, v), complex(u, -v)], lead, mn, mx)
+        elif kind == 3:  # complex pair of the size of the root (the first iterations of the BASELINE shapes)
+            from_roots([r0, complex(-r0 * rs.uniform(0.5, 2), r0 * rs.uniform(0.5, 2)), 0], lead, mn, mx)
+            items.pop()
+            z = complex(-r0 * rs.uniform(0.5, 2), r0 * rs.uniform(0.5, 2))
+            from_roots([r0, z, z.conjugate()], lead, mn, mx)
+        elif kind == 4:  # the first root on a clamp or on a float rounding boundary, give or take a few ulps
+            base = float(rs.choice([mn, mx, np.float32(r0)]))
+            f = np.float32(base)
+            mid = (float(f) + float(np.nextafter(f, np.float32(np.inf)))) / 2
+            r = rs.choice([base, mid]) * (1 + rs.integers(-4, 5) * 2.0 ** -rs.integers(36, 53))
+            from_roots([r, -rs.uniform(0.01, 3), rs.uniform(0.5, 30) + r], lead, mn, mx)
+        elif kind == 5:  # no positive root / only roots beyond max_step
+            from_roots([-r0, -rs.uniform(0.1, 3), rs.choice([-1.0, 1.0]) * (mx * rs.uniform(1.0, 50))], lead, mn, mx)
+        elif kind == 6:  # increasing start: the first positive root lies behind a local maximum
+            from_roots([-r0 * rs.uniform(0.1, 10), r0, r0 * rs.uniform(1.5, 100)], lead, mn, mx)
+        else:            # anything
+            B, Cc, D, E = rs.normal(size=4) * 10.0 ** rs.uniform(-2, 6, 4)
+            items.append([B, Cc, D, E, mn, mx])
+    return np.array(items)
+
+
+def test_certified_newton_step_equals_the_full_solve_bit_for_bit():
+    """select_step's shortcut for unclamped iterations (step_newton_certified, cvo_device.h) against the full bracketing solve
+    on the device, on real-loop coefficients and on shapes built to sit on every edge of its certificate: identical floats,
+    and the shortcut actually answers most real-loop cases (reference CvoGPU.cu:1136-1158,
+    LieGroup.cpp:309-325)."""
+    rs = np.random.default_rng(101)
+    items = _step_shortcut_items(rs, 40000)
+    gpu = CvoGPU()
+    fast = gpu.debug_scalar_math(3, items)
+    full = gpu.debug_scalar_math(13, items)[:, 0]
+    diff = np.nonzero(fast[:, 0].view(np.uint64) != full.view(np.uint64))[0]
+    assert diff.size == 0, [(items[i].tolist(), fast[i, 0], full[i]) for i in diff[:5]]
+    path = fast[:, 1]
+    n_real = sum(len(c["trace"]) for c in __import__("json").load(open(os.path.join(cases.ROOT, "tests", "golden", "oracle_traces.json")))["cases"]) * 4
+    taken_real = np.count_nonzero(path[:n_real])
+    unclamped_real = np.count_nonzero(fast[:n_real, 0] != items[:n_real, 4].astype(np.float32))
+    # (the end-game shortcut answers the clamped cases first; of the rest the Newton shortcut must take nearly all)
+    assert taken_real >= 0.9 * unclamped_real, (taken_real, unclamped_real, n_real)
+    assert np.count_nonzero(path == 1) > 5000 and np.count_nonzero(path == 2) > 500 and np.count_nonzero(path == 0) > 500
 
 
 def test_device_exp_sek3_vs_scipy():

@@ -5,6 +5,7 @@ This is the harness used by tests/ and bench.py; the C++ veneer with the same na
 include/UnifiedCvo/.  All compute happens in libcvo_hip.so on the GPU.
 """
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -288,7 +289,7 @@ class BatchQueue:
                                         C.byref(o), C.byref(h)))
         self.handle = h
         self._keep = {}
-        gpu._queues.append(self)
+        gpu._queues.append(weakref.ref(self))  # (weak: a queue dropped without close() must still be collected)
 
     def submit(self, source, target, init, max_iterations=0):
         src, tgt = self.gpu._dev(source), self.gpu._dev(target)
@@ -328,8 +329,7 @@ class BatchQueue:
             self.gpu.L.cvo_batch_close(self.handle)
             self.handle = None
             self._keep = {}
-            if self in self.gpu._queues:
-                self.gpu._queues.remove(self)
+            self.gpu._queues[:] = [w for w in self.gpu._queues if w() is not None and w() is not self]
 
     def __enter__(self):
         return self
@@ -361,11 +361,13 @@ class CvoGPU:
         if rc != 0:
             raise CvoError(f"cvo_ctx_create(device={device}) failed with {rc}: is a HIP GPU visible?")
         self.ctx = ctx
-        self._queues = []  # live BatchQueue objects (closed before the context goes)
+        self._queues = []  # weak references to the live BatchQueue objects (closed before the context goes)
 
     def close(self):
-        for q in list(getattr(self, "_queues", [])):
-            q.close()
+        for w in list(getattr(self, "_queues", [])):
+            q = w()
+            if q is not None:
+                q.close()
         if getattr(self, "ctx", None):
             self.L.cvo_ctx_destroy(self.ctx)
             self.ctx = None

@@ -38,11 +38,15 @@ def _hipcc():
 
 
 def sources():
+    """The translation units hipcc is given: ONE (cvo_hip.hip includes its sections - cvo_ctx.hip, cvo_sched.hip ... - see
+    the note at its top)."""
     return [os.path.join(CSRC, f) for f in ("cvo_hip.hip",)]
 
 
 def headers():
-    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))  # cvo_device.h, cvo_kernels.h and its parts
+    """Everything else a build depends on: the kernel headers, cvo_internal.h, the sections of cvo_hip.hip, the C-ABI."""
+    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                if f.endswith(".h") or (f.endswith(".hip") and f != "cvo_hip.hip"))
     hs.append(os.path.join(ROOT, "include", "cvo_hip.h"))
     hs.append(os.path.join(ROOT, "include", "cvo_hip_debug.h"))
     return hs

@@ -784,9 +784,98 @@ __device__ inline void cubic_roots_wave(const double coef[4], double re[3], doub
   }
 }
 
-// compute_step_size host half (CvoGPU.cu:1122-1158), overwrite quirk included.
-template <bool WAVE>
-__device__ inline float select_step(double B, double C, double D, double E, float min_step, float max_step) {
+// Exact shortcut for the iterations whose step is NOT clamped at min_step (the first ~hundred of every BASELINE shape,
+// every iteration of a warm-started tracking solve or of the demo pair): the bracketing solve below costs ~7 000 cycles
+// of one wave on the pair's serial tail, and all that survives of it is ONE float - the smallest admissible root, clamped
+// and rounded (CvoGPU.cu:1136-1158).  Here: g = sign(B) p, so g(0) > 0; Newton from 0 (an approximate reciprocal is
+// enough: the iteration corrects itself) finds the first root r where g decreases through zero, and a CERTIFICATE in
+// exact-arithmetic terms says that whatever cubic_roots returns selects the same float:
+//   * g(r (1 - d)) > noise and g(r (1 + d)) < -noise with d = 2^-38 and noise = 1e-14 x the magnitude sum of the Horner
+//     evaluation (45 eps): a simple root of the real polynomial lies in that interval, and every x where the MONIC
+//     polynomial cubic_roots works with can evaluate to zero or change sign does too;
+//   * g' < 0 on [0, r (1 + d)] - at both ends and, where the parabola g' opens downwards, at its vertex if that lies in
+//     between - hence no other real root below r, and |g'| >= 4e-10 |g3| on it, hence no complex pair u +- iv with
+//     0 < u < r and |v| < 1e-5 either (g'(u) = g3 v^2 for such a pair): the reference's `fabs(im) < 1e-5` rule (1142)
+//     cannot admit anything smaller;
+//   * both ends of the interval round to the same float and fall on the same side of min_step and max_step.
+// "No root up to max_step" is certified the same way (g > noise at max_step (1 + d), g' < 0 up to there) and returns
+// max_step, as does temp_step = DBL_MAX upstream.  Anything else - an increasing start, a sign the noise could flip, a root
+// within 2^-38 of a float boundary (1e-4 of the iterations), leading coefficients cubic_roots would turn into NaN - returns
+// false and the caller runs the full solve.  `path` (tests): 1 = root, 2 = max_step, 0 = not taken.
+__device__ inline bool step_newton_certified(const double p[4], float min_step, float max_step, float* step_out, int* path) {
+  if (path) *path = 0;
+  const double a0 = fabs(p[0]), a1 = fabs(p[1]), a2 = fabs(p[2]), a3 = fabs(p[3]);
+  if (!(min_step > 0.f && min_step <= max_step && max_step <= 100.f && a0 >= 1e-200 && a0 <= 1e100 && a1 <= 1e100 && a2 <= 1e100 &&
+        a3 <= 1e100 && a3 > 0.0))
+    return false;
+  const double sg = p[3] > 0.0 ? 1.0 : -1.0;
+  const double g3 = sg * p[0], g2 = sg * p[1], g1 = sg * p[2], g0 = a3;
+  if (!(g1 < 0.0)) return false;  // (g has to leave 0 downwards)
+  auto g = [&](double x) { return __builtin_fma(__builtin_fma(__builtin_fma(g3, x, g2), x, g1), x, g0); };
+  auto dg = [&](double x) { return __builtin_fma(__builtin_fma(3.0 * g3, x, 2.0 * g2), x, g1); };
+  auto noise = [&](double x) { return 1e-14 * __builtin_fma(__builtin_fma(__builtin_fma(a0, x, a1), x, a2), x, a3); };
+  const double DELTA = 0x1p-38;
+  const double dmin = 4e-10 * a0;  // |g'| below this could hide a complex pair with |imag| < 1e-5
+  // g' < 0 on [0, x1], clear of dmin (see above)
+  // (g' is a parabola: over an interval it is largest at an end or - when it opens downwards, g3 < 0 - at its vertex
+  // -g2 / (3 g3) if that lies inside; g' is flat there, so the rounding of the vertex does not matter)
+  auto decreasing_up_to = [&](double x1) {
+    if (!(g1 < -dmin) || !(dg(x1) < -dmin)) return false;
+    if (g3 < 0.0) {
+      const double xv = -g2 / (3.0 * g3);
+      if (xv > 0.0 && xv < x1 && !(dg(xv) < -dmin)) return false;
+    }
+    return true;
+  };
+  const double xcap = (double)max_step * (1.0 + 0x1p-30);
+  double x = 0.0;
+  bool conv = false;
+  for (int it = 0; it < 40; it++) {
+    const double f = g(x), d = dg(x);
+    if (!(d < 0.0)) return false;
+    const double dx = f * __builtin_amdgcn_rcp(d);
+    double xn = x - dx;
+    if (!(xn == xn) || !(xn > 0.0)) return false;
+    if (xn > xcap) {
+      const double gc = g(xcap);
+      if (gc > noise(xcap)) {  // no root up to max_step?
+        if (!decreasing_up_to(xcap)) return false;
+        *step_out = max_step;
+        if (path) *path = 2;
+        return true;
+      }
+      if (x == xcap) return false;  // (already restarted from there once)
+      x = xcap;                     // the root is inside: come back from the right end
+      continue;
+    }
+    conv = fabs(dx) <= 0x1p-42 * xn;
+    x = xn;
+    if (conv) break;
+  }
+  if (!conv) return false;
+  const double lo = x * (1.0 - DELTA), hi = x * (1.0 + DELTA);
+  if (!(g(lo) > noise(lo)) || !(g(hi) < -noise(hi)) || !decreasing_up_to(hi)) return false;
+  const float flo = (float)lo, fhi = (float)hi;
+  if (flo != fhi) return false;
+  const double mn = (double)min_step, mx = (double)max_step;
+  float st;
+  if (lo > mx)
+    st = max_step;
+  else if (hi < mn)
+    st = min_step;
+  else if (lo >= mn && hi <= mx)
+    st = flo;
+  else
+    return false;
+  *step_out = st;
+  if (path) *path = 1;
+  return true;
+}
+
+// compute_step_size host half (CvoGPU.cu:1122-1158), overwrite quirk included.  FAST = false: without the certified
+// Newton shortcut (cvo_debug_scalar_math runs both and the tests compare the bits).
+template <bool WAVE, bool FAST = true>
+__device__ inline float select_step(double B, double C, double D, double E, float min_step, float max_step, int* path = nullptr) {
   const double DMAX = 1.7976931348623157e308;
   double p_coef[4] = {4.0 * E, 3.0 * D, 2.0 * C, B};
   {
@@ -802,6 +891,10 @@ __device__ inline float select_step(double B, double C, double D, double E, floa
       const double noise = 3.6e-15 * (((a0 * ms + a1) * ms + a2) * ms + a3);  // 16 eps times the magnitude sum
       if ((p_coef[3] > 0.0 && fm < -noise) || (p_coef[3] < 0.0 && fm > noise)) return min_step;
     }
+  }
+  if (FAST) {
+    float st;
+    if (step_newton_certified(p_coef, min_step, max_step, &st, path)) return st;
   }
   double re[3], im[3];
   if (WAVE)

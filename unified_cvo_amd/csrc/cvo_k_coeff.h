@@ -27,6 +27,21 @@ __device__ __forceinline__ void coeff_terms(const XiMats& M, const float4 x, flo
   const V3 xi3z{t.x + M.m2v.x, t.y + M.m2v.y, t.z + M.m2v.z};
   t = matvec_dev(M.m4, yy);
   const V3 xi4z{t.x + M.m3v.x, t.y + M.m3v.y, t.z + M.m3v.z};
+#ifdef CVO_EXP_BC_ONLY
+  // EXPERIMENT (timing only, results differ): what k_coeff would cost if only B and C were summed - an upper bound on what a
+  // "step is clamped anyway" certificate from B, C and magnitude bounds on D, E could save (ROUND_LOG round 6)
+  {
+    const float nx2 = dot3_dev(xiz.x, xiz.y, xiz.z, xiz.x, xiz.y, xiz.z);
+    const float ddx = x.x - yy.x, ddy = x.y - yy.y, ddz = x.z - yy.z;
+    const float be = (float)(-2.0 * temp_coef * (double)dot3_dev(xiz.x, xiz.y, xiz.z, ddx, ddy, ddz));
+    const float ga = (-temp_coef) * (nx2 + dot3_dev(2.0f * xi2z.x, 2.0f * xi2z.y, 2.0f * xi2z.z, ddx, ddy, ddz));
+    tq[0] = (double)(A_ij * be);
+    tq[1] = (double)A_ij * ((double)ga + (double)(be * be) / 2.0);
+    tq[2] = 0.0;
+    tq[3] = tq[1] * 1e-30;
+    return;
+  }
+#endif
   const float normxiz2 = dot3_dev(xiz.x, xiz.y, xiz.z, xiz.x, xiz.y, xiz.z);
   const float xiz_dot_xi2z = -dot3_dev(xiz.x, xiz.y, xiz.z, xi2z.x, xi2z.y, xi2z.z);
   const float epsil_const = __builtin_fmaf(2.0f, dot3_dev(xiz.x, xiz.y, xiz.z, xi3z.x, xi3z.y, xi3z.z),

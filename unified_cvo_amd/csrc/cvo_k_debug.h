@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void k_verify(const PairDesc* __restrict__ des
 //   op 0  cubic_roots            in: p0..p3                      out: re[3], im[3]
 //   op 1  cubic_roots_wave       (the three-lane search used by the update)  same layout
 //   op 2  select_step<false>     in: B, C, D, E, min_step, max_step          out: step
-//   op 3  select_step<true>      same
+//   op 3  select_step<true>      same; out[1] = 1 / 2 when the certified Newton shortcut answered, 0 for the full solve
+//   op 13 select_step<true, false>  the full solve alone (the shortcut's answers must equal it bit for bit)
 //   op 4  exp_sek3               in: xi[6], dt                   out: 3x4 row-major
 //   op 5  se3_log_norm           in: R[9] row-major, t[3]        out: norm
 //   op 6  update_tf              in: R[9], T[3]                  out: Rinv[9], Tinv[3]
@@ -156,8 +157,15 @@ __global__ __launch_bounds__(64) void k_scalar_math(int op, int n, const double*
         o[3 + q] = im[q];
       }
   } else if (op == 2 || op == 3) {
-    const float st = op == 2 ? select_step<false>(a[0], a[1], a[2], a[3], (float)a[4], (float)a[5])
-                             : select_step<true>(a[0], a[1], a[2], a[3], (float)a[4], (float)a[5]);
+    int path = 0;
+    const float st = op == 2 ? select_step<false>(a[0], a[1], a[2], a[3], (float)a[4], (float)a[5], &path)
+                             : select_step<true>(a[0], a[1], a[2], a[3], (float)a[4], (float)a[5], &path);
+    if (lane == 0) {
+      o[0] = (double)st;
+      o[1] = (double)path;  // 1 / 2: the certified Newton shortcut answered (root / max_step), 0: the full solve
+    }
+  } else if (op == 13) {  // the full solve alone, to compare bits with op 3
+    const float st = select_step<true, false>(a[0], a[1], a[2], a[3], (float)a[4], (float)a[5]);
     if (lane == 0) o[0] = (double)st;
   } else if (op == 4) {
     float xi[6], dt = (float)a[6], res[12];
