@@ -511,6 +511,8 @@ def main():
         # ... and 64 clustered pairs (NOT a BASELINE shape: tests/synth.scene_pair - ground, facades, small dense objects, local
         # density varying by more than 100x; 13 x the pair tests of the uniform slab, most of them in the wave-per-row kernels)
         batch_clustered = feature_batch(cases.scene, "clustered street scene (10k x 10k xyz, not a BASELINE shape)", 100) if extra else None
+        # ... the same scene with colour features (what "KITTI-stereo-shaped" means for density AND appearance)
+        batch_clustered_colour = feature_batch(cases.scene_colour, "clustered street scene + 5-channel colour (not a BASELINE shape)", 100) if extra else None
 
         # ---- batch queue (cvo_batch_open / _submit / _poll): the 8-GPU headline's whole work list - 512 pairs - on ONE GPU
         # through 128 in-flight slots, and a mixed queue (three pairs in four stop after 300 iterations, like warm-started
@@ -602,7 +604,7 @@ def main():
                                            "advice": gpu.advice()}},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "single_pair": single_pair,
             "overlap_queries": overlap_queries, "pcie_inclusive": pcie_inclusive,
-            "early_phase": early_phase, "shapes_20k": shapes_20k, "batch_colour": batch_colour, "batch_semantic": batch_semantic, "batch_clustered": batch_clustered,
+            "early_phase": early_phase, "shapes_20k": shapes_20k, "batch_colour": batch_colour, "batch_semantic": batch_semantic, "batch_clustered": batch_clustered, "batch_clustered_colour": batch_clustered_colour,
             "batch_queue": batch_queue,
         }
         h2d_rate = (2 * n * 16 * 1.0) * B / max(t_h2d, 1e-9) / 1e9

@@ -51,6 +51,9 @@ if __name__ == "__main__":
         run("config4_n2000", cases.config4, n=2000),
         # not a BASELINE config: a clustered street scene (rows on the lists, beyond them and on the K cap at once)
         run("scene_n2500", cases.scene, n=2500),
+        # ... and at the size of the BASELINE shapes: 10k x 10k, every one of its first 300 iterations (thousands of rows
+        # beyond their lists, hundreds on the K cap, list rebuilds, the row-class switches of round 5)
+        run("scene_n10000_k300", cases.scene, dense=300, every=100, max_iterations=300, n=10000),
     ]
     path = os.path.join(ROOT, "tests", "golden", "oracle_traces.json")
     with open(path, "w") as f:

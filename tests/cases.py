@@ -33,6 +33,16 @@ def scene(n=10000, pair_id=0):
     return p, CvoPointCloud.from_xyz(src), CvoPointCloud.from_xyz(tgt), np.eye(4, dtype=np.float32)
 
 
+def scene_colour(n=10000, pair_id=0):
+    """The clustered street scene with colour features (synth.scene_colour_pair), cvo_intensity_params_gpu.yaml, identity
+    init.  Not a BASELINE.json config: clustered density through the colour instantiations of the kernels."""
+    p = load_params("intensity_gpu")
+    src, fsrc, tgt, ftgt = synth.scene_colour_pair(n, pair_id)
+    geo = np.tile(np.array([[0.0, 1.0]], np.float32), (n, 1))
+    return (p, CvoPointCloud.from_arrays(src, fsrc, None, geo), CvoPointCloud.from_arrays(tgt, ftgt, None, geo),
+            np.eye(4, dtype=np.float32))
+
+
 def config3(n=10000, pair_id=0):
     """Colour clouds, cvo_intensity_params_gpu.yaml (HEAD side + documented overrides), identity init."""
     p = load_params("intensity_gpu")

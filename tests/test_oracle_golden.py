@@ -11,18 +11,21 @@ with open(os.path.join(cases.GOLDEN, "oracle_traces.json")) as f:
     GOLD = {c["name"]: c for c in json.load(f)["cases"]}
 
 BUILDERS = {"config1_demo_geometric_k1000": cases.config1, "config2_n2000": cases.config2,
-            "config3_n2000": cases.config3, "config4_n2000": cases.config4, "scene_n2500": cases.scene}
+            "config3_n2000": cases.config3, "config4_n2000": cases.config4, "scene_n2500": cases.scene,
+            "scene_n10000_k300": cases.scene}
 
 
 @pytest.mark.parametrize("name", ["config1_demo_geometric_k1000", "config2_n2000", "config3_n2000", "config4_n2000",
-                                  "scene_n2500"])
+                                  "scene_n2500", "scene_n10000_k300"])
 def test_oracle_reproduces_golden(oracle, name):
     g = GOLD[name]
     P, src, tgt, init = BUILDERS[name](**g["kwargs"])
     op = oracle.params_from(P)
     x, y = oracle.Cloud.from_pointcloud(src), oracle.Cloud.from_pointcloud(tgt)
     cap = min(300, g["iterations"]) if name != "config4_n2000" else 0
-    r = oracle.align(op, x, y, init, trace_capacity=400, trace_dense=50, trace_every=100,
+    if name == "scene_n10000_k300":
+        cap = 60   # (10k x 10k with thousands of dense rows: a prefix keeps the CPU suite short; the GPU test walks all 300)
+    r = oracle.align(op, x, y, init, trace_capacity=400, trace_dense=50 if name != "scene_n10000_k300" else 300, trace_every=100,
                      max_iterations=cap if cap else g["max_iterations"])
     rows = [t for t in g["trace"] if (not cap or t["k"] < cap)]
     got = {t.k: t for t in r["trace"]}

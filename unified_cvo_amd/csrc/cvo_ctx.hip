@@ -92,9 +92,10 @@ PairLayout make_layout(int N, int M, int Kmax, int trace_capacity, bool long_lis
   L.rowres = take(sizeof(RowRes) * (size_t)N);
   // (rows x the pair's own coefficient split, coeff_split(): one slice above 4096 points, at most 32768 / rows below)
   L.rowcoef = take(sizeof(double) * 4 * (size_t)std::max(N, 32768));
-  L.flow_part = take(sizeof(double) * 8 * (size_t)nba);
+  L.flow_part = take(sizeof(unsigned long long) * FLOW_GRANULES * (size_t)nba);
   L.cnt_part = take(sizeof(unsigned long long) * 4 * (size_t)nba);
-  L.coef_part = take(sizeof(double) * 4 * (size_t)nbc * COEFF_SPLIT_MAX);
+  L.coef_part = take(sizeof(unsigned long long) * COEF_GRANULES * (size_t)nbc * COEFF_SPLIT_MAX);
+  L.shadow = take(sizeof(unsigned long long) * SHADOW_WORDS);
   L.trace = take(sizeof(cvo_trace_t) * (size_t)std::max(trace_capacity, 0));
   L.total = off;
   d->Mpad = Mpad;

@@ -110,6 +110,11 @@ struct PairState {
   // get a thin skin; only the farthest rows pay for the whole motion bound.
   float skin_rot, skin_tr;
   int n_builds;
+  int n_adopted;  // iterations whose scalar tail was adopted from the speculative run (update_speculate; statistics)
+  // sticky: a data-tagged partial of another block of the launch did not arrive within PARTIAL_POLL_LIMIT polls (1 = flow
+  // gate, 2 = update; cvo_wave.h).  Never seen in practice - every block issues its partial before its arrival counter -:
+  // it ends the pair and turns what would be a hung device into CVO_E_HIP.
+  int sync_err;
   int want_full, n_stalls;  // host hint (want_level / want_encode, cvo_kernels.h): 2 = a rebuild opportunity in every iteration,
                             // 1 = the short lean graph (one every lean_U2 iterations), 0 = the lean graph, -1 = calm (one per
                             // chunk); 4 = 2 with k_assoc_dense, 8 / 9 / 10 = -1 / 0 / 1 with it
@@ -219,9 +224,10 @@ struct PairDesc {
   double* rowcoef;            // [N x csplit][4] by position and slice: (B, C, D, E) of the rows k_coeff_dense evaluated - summed
                               // slot by slot in the order a thread of k_coeff would have - picked up by k_coeff
   RowRes* rowres;             // [N] by position: results of the rows k_assoc_dense evaluated, picked up by k_assoc
-  double* flow_part;          // [nblk_assoc][8]: omega(3), v(3), sum a, pad - one partial per row block of k_assoc
+  unsigned long long* flow_part;  // [nblk_assoc][FLOW_GRANULES]: omega(3), v(3), sum a as data-tagged granules (cvo_wave.h), two per value - one partial per row block of k_assoc
   unsigned long long* cnt_part;  // [nblk_assoc][4]: nnz, max, candidates, overflow rows
-  double* coef_part;          // [nblk_assoc * COEFF_SPLIT_MAX][4]: B C D E
+  unsigned long long* shadow;     // [SHADOW_WORDS]: the state a speculative run of the update left for this launch (update_speculate), data-tagged granules
+  unsigned long long* coef_part;  // [nblk_assoc * COEFF_SPLIT_MAX][COEF_GRANULES]: B C D E as data-tagged granules
   int* done;        // [1] k_coeff: blocks that stored their partials (monotonic; the last one runs the update)
   int csplit;                // k_coeff: blocks per row block; block q of a row block takes the ELL slots s = q (mod csplit).
                              // (small clouds; a function of the pair's own size, so that batch == solo)

@@ -55,7 +55,7 @@ namespace {
 
 struct PairLayout {  // byte offsets of one pair's workspace inside the arena
   size_t ycull, xcull, gbox, cellbox, sbox, masks, rowbits, row_cnt, tile_count, ovf_rows, ovf_bits, gate, gate_flow, dense_off, dense_rel, ovf_wsum, word_base, done, cand_cnt, rowperm, iorig, long_j, long_stamp, xp4, ip, cand_j, rowres, rowcoef, ell, ell_j, nnz_row, flow_part, cnt_part,
-      coef_part, trace, total;
+      coef_part, shadow, trace, total;
 };
 
 static const char* const kGraphNames[8] = {"full", "lean", "short", "full-nodense", "calm", "lean+dense", "short+dense", "calm+dense"};

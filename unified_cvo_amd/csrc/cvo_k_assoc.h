@@ -14,24 +14,40 @@ namespace cvo_dev {
 // scalar loads in its first burst (they used to be reduced again by every one of its blocks: ~3 us of
 // dependent round trips in front of each row loop and a hot spot of 150 readers per cache line).
 static_assert(sizeof(XiMats) <= 48 * sizeof(float), "PairState::xi holds an XiMats");
-template <bool COH>
-__device__ __forceinline__ double coeff_twist_load(const PairDesc* __restrict__ D, int nparts) {
+// (the partials are data-tagged granules, cvo_wave.h: a granule that has not landed yet carries an older tag and the
+// round is read again - the elected block no longer waits for anybody's store acknowledgement)
+__device__ __forceinline__ double coeff_twist_load(const PairDesc* __restrict__ D, int nparts, unsigned tag) {
   const int lane = threadIdx.x & 63;
-  const double* __restrict__ src = D->flow_part + (lane & 7);
+  const CVO_GLOBAL unsigned long long* src = as_global(D->flow_part) + 2 * (lane & 7);
   double acc = 0;
-  // sixteen loads per round, all issued before the first addition (79 row blocks = one round); slots past the
-  // end re-read the last one and add zero
-  for (int b = lane >> 3; b < nparts; b += 128) {
-    double p[16];
+  // eight blocks per lane and round (64 row blocks = one round), all sixteen granule loads issued before the first
+  // addition; slots past the end re-read the last block and add zero
+  for (int b = lane >> 3; b < nparts; b += 64) {
+    TaggedF64 p[8];
+    // (component 7 is padding nobody writes: its lanes read it - the sum is never used - without looking at tags.  The
+    // poll is bounded: a partial that has not shown up after ~0.5 s never will - the pair is latched as failed,
+    // PairState::sync_err, and the call returns CVO_E_HIP instead of hanging the device)
+    const bool pad = (lane & 7) == 7;
+    for (int polls = 0;; polls++) {
 #pragma unroll
-    for (int u = 0; u < 16; u++) p[u] = ld_x<COH>(src + (size_t)min(b + 8 * u, nparts - 1) * 8);
+      for (int u = 0; u < 8; u++) p[u] = ld_tagged<true>(src + (size_t)min(b + 8 * u, nparts - 1) * FLOW_GRANULES);
+      bool ok = true;
 #pragma unroll
-    for (int u = 0; u < 16; u++) acc += (b + 8 * u < nparts) ? p[u] : 0.0;
+      for (int u = 0; u < 8; u++) ok = ok && (pad || p[u].carries(tag));
+      if (__ballot(!ok) == 0ull) break;
+      if (polls > PARTIAL_POLL_LIMIT) {
+        if (lane == 0) D->st->sync_err = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc += (b + 8 * u < nparts) ? p[u].value() : 0.0;
   }
   return acc;
 }
-__device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, int nparts) {
-  double acc = coeff_twist_load<true>(D, nparts);
+__device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, int nparts, unsigned tag) {
+  double acc = coeff_twist_load(D, nparts, tag);
   acc += dpp_f64<0x128>(acc);  // row_ror:8 : groups g and g ^ 1
   acc = xor16_sum(acc);
   acc = xor32_sum(acc);
@@ -61,12 +77,10 @@ __device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, i
 }
 // The flow partial of this block is stored; the block that finds it was the last one of its pair reduces them.
 // Every thread of the block calls this.
-__device__ __forceinline__ bool flow_gate(const PairDesc* __restrict__ D, int nblocks, int nparts) {
+__device__ __forceinline__ bool flow_gate(const PairDesc* __restrict__ D, int nblocks, int nparts, unsigned tag) {
   __shared__ int s_flow_last;
-  // this block's partial must have reached the L2 before its counter increment can be seen: the barrier alone only
-  // orders LDS traffic (the compiler emits no vmcnt wait for it), and a store and an atomic of one wave to
-  // different addresses are not ordered on their way to memory
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (no wait for this block's partial: a store and an atomic of one wave to different addresses are not ordered on their
+  // way to memory, so the counter says who reduces, the granules' tags say when a partial has arrived - cvo_wave.h)
   __syncthreads();
   if (threadIdx.x == 0) {
     const int done = __hip_atomic_fetch_add(D->gate_flow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -74,7 +88,7 @@ __device__ __forceinline__ bool flow_gate(const PairDesc* __restrict__ D, int nb
     if (done == nblocks - 1) __hip_atomic_store(D->gate_flow, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (s_flow_last && threadIdx.x < 64) twist_finalize(D, nparts);
+  if (s_flow_last && threadIdx.x < 64) twist_finalize(D, nparts, tag);
   return s_flow_last != 0;
 }
 
@@ -94,8 +108,8 @@ __device__ __forceinline__ void asum_gate(const PairDesc* __restrict__ D, int nb
   __syncthreads();
   if (!s_asum_last) return;
   double s = 0;
-  if (threadIdx.x < 16)
-    for (int b = (int)threadIdx.x; b < nblk; b += 16) s += ld_x<true>(D->flow_part + (size_t)b * 8 + 6);
+  if (threadIdx.x < 16)  // (this gate waits for the stores; the tags are not needed)
+    for (int b = (int)threadIdx.x; b < nblk; b += 16) s += ld_tagged<true>(as_global(D->flow_part) + (size_t)b * FLOW_GRANULES + 12).value();
   s += dpp_f64<DPP_XOR1>(s);
   s += dpp_f64<DPP_XOR2>(s);
   s += dpp_f64<DPP_HALF_MIRROR>(s);
@@ -186,7 +200,7 @@ struct AssocShared {
 
 template <typename IdxT, int ASSOC_CAP, int FEAT, bool INSTR>
 __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* __restrict__ D, const IterView& iv,
-                                            AssocShared& S, const int bx, const AssocRowHead& head) {
+                                            AssocShared& S, const int bx, const AssocRowHead& head, const unsigned tag) {
   const int N = D->N;
   const int pos = bx * ASSOC_THREADS + threadIdx.x;  // position in k_list's count-ordered row windows
   const int K = iv.K;
@@ -307,7 +321,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
   __syncthreads();  // (the staging columns share their LDS with the reduction: every thread has drained its own)
   const double tot = block_reduce_lds<7>(S.red, red);  // (its barrier also covers S.cnt)
   if (threadIdx.x < 56 && (threadIdx.x & 7) == 0) {
-    st_x<true>(D->flow_part + (size_t)bx * 8 + (threadIdx.x >> 3), tot);  // read by another block of this launch (flow_gate)
+    st_tagged(D->flow_part + (size_t)bx * FLOW_GRANULES + 2 * (threadIdx.x >> 3), tot, tag);  // read by another block of this launch (flow_gate)
   } else if (threadIdx.x == 57) {
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
@@ -377,7 +391,9 @@ __global__ __launch_bounds__(ASSOC_THREADS, FEAT != FEAT_GEO ? 1 : CVO_ASSOC_WAV
   if ((lean & 1) && (rebuild_v || (n_ovf_v > 0 && !(lean & 4)))) return;  // (bit 2: k_assoc_dense follows in this graph)
   pair_clock_begin(INSTR && P.kernel_clock && (lean & 3) == 1 && pb.bx == 0, const_cast<PairState*>(st), 0);
   __shared__ AssocShared S;
-  assoc_phase<IdxT, ASSOC_CAP, FEAT, INSTR>(P, D, load_iter_view(st), S, pb.bx, head);
+  // tag of this launch's partials (cvo_wave.h): the call's serial and the pair's iteration count
+  const unsigned tag = partial_tag(D->call_serial, (unsigned)st->k);
+  assoc_phase<IdxT, ASSOC_CAP, FEAT, INSTR>(P, D, load_iter_view(st), S, pb.bx, head, tag);
   // Everything from here on - the block's partial is on its way, the last-block counter, possibly the twist - is the
   // first wave's business.  The other waves retire now instead of sitting on their registers through a store
   // acknowledgement and an atomic round trip (~2 us of a ~7 us wave life; with thousands of waves queued behind them
@@ -387,7 +403,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, FEAT != FEAT_GEO ? 1 : CVO_ASSOC_WAV
   // the block that stores its partial last finishes the twist of the iteration
   if (P.mode == 0) {
     const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && (lean & 3) == 1, st, 0);
-    const bool last = flow_gate(D, nblk, nblk);
+    const bool last = flow_gate(D, nblk, nblk, tag);
     if (last && threadIdx.x == 0 && clk0) D->st->clk_last_assoc = pair_clock_ticks(clk0);  // added up by the update
   } else if (lean & 8) {  // single evaluation that only wants A_sum (inner_product_gpu)
     asum_gate(D, nblk);

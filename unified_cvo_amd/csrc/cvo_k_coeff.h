@@ -27,21 +27,6 @@ __device__ __forceinline__ void coeff_terms(const XiMats& M, const float4 x, flo
   const V3 xi3z{t.x + M.m2v.x, t.y + M.m2v.y, t.z + M.m2v.z};
   t = matvec_dev(M.m4, yy);
   const V3 xi4z{t.x + M.m3v.x, t.y + M.m3v.y, t.z + M.m3v.z};
-#ifdef CVO_EXP_BC_ONLY
-  // EXPERIMENT (timing only, results differ): what k_coeff would cost if only B and C were summed - an upper bound on what a
-  // "step is clamped anyway" certificate from B, C and magnitude bounds on D, E could save (ROUND_LOG round 6)
-  {
-    const float nx2 = dot3_dev(xiz.x, xiz.y, xiz.z, xiz.x, xiz.y, xiz.z);
-    const float ddx = x.x - yy.x, ddy = x.y - yy.y, ddz = x.z - yy.z;
-    const float be = (float)(-2.0 * temp_coef * (double)dot3_dev(xiz.x, xiz.y, xiz.z, ddx, ddy, ddz));
-    const float ga = (-temp_coef) * (nx2 + dot3_dev(2.0f * xi2z.x, 2.0f * xi2z.y, 2.0f * xi2z.z, ddx, ddy, ddz));
-    tq[0] = (double)(A_ij * be);
-    tq[1] = (double)A_ij * ((double)ga + (double)(be * be) / 2.0);
-    tq[2] = 0.0;
-    tq[3] = tq[1] * 1e-30;
-    return;
-  }
-#endif
   const float normxiz2 = dot3_dev(xiz.x, xiz.y, xiz.z, xiz.x, xiz.y, xiz.z);
   const float xiz_dot_xi2z = -dot3_dev(xiz.x, xiz.y, xiz.z, xi2z.x, xi2z.y, xi2z.z);
   const float epsil_const = __builtin_fmaf(2.0f, dot3_dev(xiz.x, xiz.y, xiz.z, xi3z.x, xi3z.y, xi3z.z),
@@ -85,7 +70,7 @@ struct CoeffRowHead {
 template <bool COH>
 __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* __restrict__ D, const float ell,
                                            const float coef_ell, CoeffShared& S, const XiMats& Mu, const CoeffRowHead& h, const int bx,
-                                           const int q, const int nsplit, const Pose& pose) {
+                                           const int q, const int nsplit, const Pose& pose, const unsigned tag) {
   const int N = D->N;
   const int i = bx * ASSOC_THREADS + threadIdx.x;
   double Bi = 0, Ci = 0, Di = 0, Ei = 0;
@@ -142,7 +127,9 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
   }
   const double red[4] = {Bi, Ci, Di, Ei};
   const double tot = block_reduce_lds<4>(S.red, red);
-  if (threadIdx.x < 32 && (threadIdx.x & 7) == 0) st_x<COH>(D->coef_part + ((size_t)bx * nsplit + q) * 4 + (threadIdx.x >> 3), tot);
+  // (data-tagged granules, cvo_wave.h: read by the pair's updating block without anybody waiting for a store to be acknowledged)
+  if (threadIdx.x < 32 && (threadIdx.x & 7) == 0)
+    st_tagged(D->coef_part + ((size_t)bx * nsplit + q) * COEF_GRANULES + 2 * (threadIdx.x >> 3), tot, tag);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -160,9 +147,27 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   // grid: per pair nblk row blocks x launch_split slices of the ELL slots; a pair uses csplit <= launch_split of them
   const int nblk = nblk_split_pairs & 0x3fff, launch_split = (nblk_split_pairs >> 14) & 0x3f,
             n_pairs = (int)((unsigned)nblk_split_pairs >> 20);
+  // (+ 1: the pair's speculative block, update_speculate)
   PairBlock pb;
-  if (!pair_block(nblk * launch_split, n_pairs, pb)) return;
+  if (!pair_block(nblk * launch_split + 1, n_pairs, pb)) return;
   const PairDesc* __restrict__ D = descs + pb.pair;
+  __shared__ union {
+    CoeffShared c;
+    UpdateShared u;
+  } S;
+  if (pb.bx == nblk * launch_split) {
+    // The speculative block: everything of the update that follows the step, on the predicted step, while the row blocks
+    // work.  Not in the instrumented kernels, timing replays, traced calls (the record needs B..E) or single evaluations;
+    // a waiting pair (lean graph) has nothing to advance.
+    if (INSTR || threadIdx.x >= 64 || (flags & (8 | 16))) return;
+    const PairState* __restrict__ sh = states + pb.pair;
+    const int status_h = sh->status, rebuild_h = sh->rebuild, ovf_h = sh->n_ovf, epoch_h = sh->epoch;
+    const DevParams Ph = *Pp;
+    if (status_h != 0 || Ph.mode != 0 || Ph.trace_capacity != 0) return;
+    if ((flags & 1) && (rebuild_h || (ovf_h > 0 && !(flags & 32)))) return;
+    update_speculate(D, states + pb.pair, Ph, flags | 4, S.u, partial_tag(D->call_serial, 0x80000000u | (unsigned)epoch_h));
+    return;
+  }
   const int cq = pb.bx % launch_split;
   pb.bx /= launch_split;
   // head of the row loop, from kernel-argument addresses (row_off_*): count, coordinates and the first ELL entry
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     // (everything the kernel will branch on or start its row loop with - the slice count, the parameters and the twist
     // matrices included - requested before the first wait: each dependent round of scalar loads is ~0.3-0.5 us here)
     const int n = D->N, nb = D->nblk_assoc, ep = st_in->epoch;
-    const double* a0 = D->flow_part;
+    const unsigned long long* a0 = D->flow_part;
     const unsigned* a1 = D->nnz_row;
     const float4* a2 = D->xp4;
     const EllEntry* a3 = D->ell;
@@ -233,10 +238,6 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   if (P.mode != 0) return;
   pair_clock_begin(INSTR && P.kernel_clock && !replay && pb.bx == 0 && cq == 0, st, 1);
   const int epoch = st_in->epoch;  // launches of this kernel the pair has completed (bumped by the updating block)
-  __shared__ union {
-    CoeffShared c;
-    UpdateShared u;
-  } S;
   __shared__ int s_last;
   const int N_ = D->N, pos_ = pb.bx * ASSOC_THREADS + threadIdx.x;
   if (pos_ >= N_) head.nnz = 0;
@@ -254,7 +255,10 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
 #else
   const Pose pose{};
 #endif
-  coeff_rows<true>(P, D, st_in->ell, st_in->temp_coef, S.c, Mu, head, pb.bx, cq, csplit, pose);
+  // tag of this launch's partials: the call's serial and the pair's launch generation (a timing replay re-uses the tag of the
+  // launch it replays: same values, nothing is written back)
+  const unsigned tag = partial_tag(D->call_serial, 0x80000000u | (unsigned)epoch);
+  coeff_rows<true>(P, D, st_in->ell, st_in->temp_coef, S.c, Mu, head, pb.bx, cq, csplit, pose, tag);
   const unsigned long long tt2 = INSTR ? __builtin_readcyclecounter() : 0ull;
   if (threadIdx.x >= 64) return;  // the counter and (in one block of the pair) the update are the first wave's, see k_assoc
   // the scalar state, for whichever block turns out to be the last one: in flight while the counter round trip runs
@@ -268,8 +272,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
   upd.nblk_coeff = nblk * csplit;
   const int n_flow_upd = D->nblk_assoc;  // (requested now, not after the counter's round trip on the pair's serial tail)
   asm volatile("" ::"s"(n_flow_upd));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partial stores before the counter, see flow_gate
-  __syncthreads();
+  __syncthreads();  // (no wait for the partial's store: its granules carry the launch's tag, see flow_gate)
   if (threadIdx.x == 0) {
     // the counter advances by nblk * COEFF_SPLIT_MAX per iteration whatever the split of the iteration is (splits are
     // powers of two): each of the nblk * csplit blocks that store a partial adds its share
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     g_phase_ticks[1][blockIdx.x & 4095][3] = tt3;
   }
   if (!s_last || (flags & 16)) return;  // (bit 4: cost breakdown of cvo_debug_time_kernels, coefficient phase only)
-  update_body<false, true>(upd, P, flags | 4, n_flow_upd, S.u, twist, hot_regs, clk0);
+  update_body<false, true>(upd, P, flags | 4, n_flow_upd, S.u, twist, hot_regs, clk0, tag, !INSTR);
   if (INSTR && P.phase_ticks && threadIdx.x == 0) {
     g_phase_ticks[1][4096 + pb.pair][0] = tt0;
     g_phase_ticks[1][4096 + pb.pair][1] = tt3;

@@ -100,10 +100,10 @@ void launch_coeff(hipStream_t s, bool instr, int nblk, int split, int n_pairs, c
                   PairState* st, const ArenaArg& A, int flags) {
   const int packed = nblk | (split << 14) | (int)((unsigned)n_pairs << 20);  // 14 + 6 + 12 bits
   if (instr)
-    hipLaunchKernelGGL(k_coeff<true>, row_grid(nblk * split, n_pairs), dim3(ASSOC_THREADS), 0, s, descs, dp, st, A.base, flags,
+    hipLaunchKernelGGL(k_coeff<true>, row_grid(nblk * split + 1, n_pairs), dim3(ASSOC_THREADS), 0, s, descs, dp, st, A.base, flags,
                        packed, A.stride256, A.Npad);
-  else
-    hipLaunchKernelGGL(k_coeff<false>, row_grid(nblk * split, n_pairs), dim3(ASSOC_THREADS), 0, s, descs, dp, st, A.base, flags,
+  else  // (+ 1 block per pair: the speculative run of the update, update_speculate)
+    hipLaunchKernelGGL(k_coeff<false>, row_grid(nblk * split + 1, n_pairs), dim3(ASSOC_THREADS), 0, s, descs, dp, st, A.base, flags,
                        packed, A.stride256, A.Npad);
 }
 

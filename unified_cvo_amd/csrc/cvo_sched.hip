@@ -154,9 +154,10 @@ void fill_pair(cvo_ctx* ctx, const BatchSetup* S, const cvo_params_t* params, co
     D.nnz_row = (unsigned*)(base + S->L.nnz_row);
     D.rowres = (RowRes*)(base + S->L.rowres);
     D.rowcoef = (double*)(base + S->L.rowcoef);
-    D.flow_part = (double*)(base + S->L.flow_part);
+    D.flow_part = (unsigned long long*)(base + S->L.flow_part);
     D.cnt_part = (unsigned long long*)(base + S->L.cnt_part);
-    D.coef_part = (double*)(base + S->L.coef_part);
+    D.coef_part = (unsigned long long*)(base + S->L.coef_part);
+    D.shadow = (unsigned long long*)(base + S->L.shadow);
     D.st = ctx->d_states + p;
     D.trace = trace_cap > 0 ? (cvo_trace_t*)(base + S->L.trace) : nullptr;
     {
@@ -679,6 +680,9 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
             std::chrono::duration<double, std::milli>(t_host2 - t_host1).count());
   for (int p = 0; p < n_pairs; p++) {  // CVO_VERIFY_LISTS: a row of the list path differed from the literal scan
     const PairState& st = ctx->h_states[p];
+    if (st.sync_err)
+      return fail(ctx, CVO_E_HIP, st.sync_err == 1 ? "a block partial of k_assoc never arrived at the flow gate (tagged-partial poll limit)"
+                                                    : "a block partial of k_coeff never arrived at the update (tagged-partial poll limit)");
     if (st.verify_err) {
       char msg[256];
       snprintf(msg, sizeof msg,
@@ -689,8 +693,9 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     }
   }
   if (ctx_opt(ctx, "VERBOSE")) {
-    long builds = 0, stalls = 0, its = 0;
+    long builds = 0, stalls = 0, its = 0, adopted = 0;
     for (int p = 0; p < n_pairs; p++) {
+      adopted += ctx->h_states[p].n_adopted;
       builds += ctx->h_states[p].n_builds;
       stalls += ctx->h_states[p].n_stalls;
       its += ctx->h_states[p].status ? ctx->h_states[p].iterations : ctx->h_states[p].k;
@@ -700,8 +705,8 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
         fprintf(stderr, "[cvo]   pair %d: k %d, list allowance used %.3f, per iteration %.5f, want %d, builds %d, ell %.4f (built at %.4f)\n", p,
                 ctx->h_states[p].k, ctx->h_states[p].last_used, ctx->h_states[p].last_rate, ctx->h_states[p].want_full,
                 ctx->h_states[p].n_builds, ctx->h_states[p].ell, ctx->h_states[p].ell_build);
-    fprintf(stderr, "[cvo] %d pairs, %d groups: %d chunks (%d full + %d lean group launches), iterations %ld, list builds %ld, waits %ld, %.3f ms\n",
-            n_pairs, G, ctx->last_chunks, ctx->last_full_launches, ctx->last_lean_launches, its, builds, stalls, ms);
+    fprintf(stderr, "[cvo] %d pairs, %d groups: %d chunks (%d full + %d lean group launches), iterations %ld (%ld with the speculative update adopted), list builds %ld, waits %ld, %.3f ms\n",
+            n_pairs, G, ctx->last_chunks, ctx->last_full_launches, ctx->last_lean_launches, its, adopted, builds, stalls, ms);
   }
   for (int p = 0; p < n_pairs; p++) {
     const PairState& st = ctx->h_states[p];

@@ -173,4 +173,46 @@ __device__ __forceinline__ T ld_x(const T* p) {
   return *p;
 }
 
+// ---- data-tagged partials (round 6) ------------------------------------------------------------------------------
+// A block partial that another block of the SAME launch reads (k_assoc's flow sums -> the flow gate, k_coeff's
+// coefficient sums -> the update) used to be: coherent store, s_waitcnt vmcnt(0) for its acknowledgement from the memory
+// side, then the arrival counter - a store and an atomic of one wave to different addresses are not ordered on their way
+// to memory -, then the elected block's coherent loads: three dependent trips to the memory side per kernel on every
+// pair's serial chain.  Now every double travels as two 8-byte granules {tag : 32 | half of the value : 32}, each
+// written and read by ONE 64-bit relaxed agent-scope atomic (indivisible by construction), and the store is NOT waited
+// for: store and counter are in flight together, the elected block reads the granules and checks that every one of them
+// carries the tag of THIS launch of THIS pair of THIS call (partial_tag: a 32-bit mix of the call's serial - unique per
+// call / queue submission - and the pair's iteration / launch count); a granule that has not landed yet still carries an
+// older tag and is read again.  Two trips instead of three.  (The same form the XCD-resident experiment of round 3 used
+// for its broadcasts.)  The VALUES and the order they are added in are what they were.
+__device__ __forceinline__ unsigned partial_tag(unsigned long long serial, unsigned n) {
+  unsigned h = (unsigned)serial * 0x9E3779B1u + (unsigned)(serial >> 32) * 0x7FEB352Du + (n + 1u) * 0x85EBCA6Bu;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 12;
+  return h;
+}
+__device__ __forceinline__ void st_tagged(unsigned long long* g, double v, unsigned tag) {  // g: two granules
+  const unsigned long long t = (unsigned long long)tag << 32;
+  __hip_atomic_store(g, t | (unsigned long long)(unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(g + 1, t | (unsigned long long)(unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct TaggedF64 {
+  unsigned long long lo, hi;
+  __device__ __forceinline__ bool carries(unsigned tag) const { return (unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag; }
+  __device__ __forceinline__ double value() const { return __hiloint2double((int)(unsigned)hi, (int)(unsigned)lo); }
+};
+// COH = false: the producer was an earlier kernel (plain loads; the tags are not looked at)
+template <bool COH>
+__device__ __forceinline__ TaggedF64 ld_tagged(const CVO_GLOBAL unsigned long long* g) {
+  TaggedF64 t;
+  t.lo = ld_g<COH>(g);
+  t.hi = ld_g<COH>(g + 1);
+  return t;
+}
+// granules per row block: k_assoc's partial (7 doubles, padded to one 128-byte line), k_coeff's (4 doubles)
+constexpr int FLOW_GRANULES = 16, COEF_GRANULES = 8;
+// polls (one memory-side round trip + s_sleep each, ~1-2 us) after which the elected block gives a missing partial up
+constexpr int PARTIAL_POLL_LIMIT = 400000;
+
 }  // namespace cvo_dev

@@ -117,6 +117,16 @@ def colour_pair(n, pair_id=0):
             ftgt[perm].astype(np.float32), pts, perm)
 
 
+def scene_colour_pair(n, pair_id=0):
+    """The clustered street scene of scene_pair with the 5-channel colour features of config 3 on it (what a stereo camera
+    frame looks like to the colour kernel: dense near objects AND per-point appearance).  Not a BASELINE.json config."""
+    src, tgt, perm = scene_pair(n, pair_id)
+    fsrc = colour_features(src, np.random.default_rng(8000 + pair_id))
+    # the target's features: the source point's (same surface point seen again) + sensor noise, in the target's order
+    ftgt = np.clip(fsrc + np.random.default_rng(9000 + pair_id).normal(0, 0.01, fsrc.shape), 0, 1)[perm]
+    return src, fsrc.astype(np.float32), tgt, ftgt.astype(np.float32)
+
+
 def checkerboard_labels(xyz, cell=2.0, flip=0.0, rng=None):
     """19-class one-hot labels from a 3-D checkerboard of `cell` m cells hashed to a class."""
     c = np.floor(xyz.astype(np.float64) / cell).astype(np.int64)
