@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--pairs-per-gpu", type=int, default=64)
     ap.add_argument("--max-iterations", type=int, default=0, help="debug only: cap the optimiser loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-one-device", action="store_true",
+                    help="REHEARSAL of the N>1 branch on a 1-GPU box: every rank solves its shard on device 0 and the poses are "
+                         "gathered with the gloo backend (RCCL refuses two ranks on one device); not a measurement")
     ap.add_argument("--cpu-iters", type=int, default=0, help="0 = one whole align() on the CPU (about 3 s)")
     ap.add_argument("--no-single-pair", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the PCIe-inclusive pipeline leg")
@@ -109,8 +112,12 @@ def main():
             sys.exit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    rehearse = args.rehearse_one_device
+    if rehearse:
+        local_rank = 0  # (every rank on the one device of the box)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = torch.device("cpu") if rehearse else dev  # where the collectives' buffers live (gloo: host)
     # host threads this rank may use (uploads, CPU baseline): the box's usable CPUs are shared by the local ranks
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     n_threads = max(1, available_cpus() // local_world)
@@ -142,20 +149,26 @@ def main():
             os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     use_dist = True
     try:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     except Exception as e:  # noqa: BLE001
         if world > 1:
             raise
         use_dist = False
         log(f"[bench] one-rank RCCL process group failed to initialise ({e}): the step runs without the all-gather")
-    pose_buf = torch.zeros(hi - lo, 16, dtype=torch.float32, device=dev)
+    pose_buf = torch.zeros(hi - lo, 16, dtype=torch.float32, device=coll_dev)
     kw = dict(max_iterations=args.max_iterations) if args.max_iterations > 0 else {}
 
     def step(clocked=False):
         # (cvo_align_opts_t.kernel_clock: the library keeps the graphs of both kernel instantiations)
         res = gpu.align_batch(src, tgt, inits, kernel_clock=clocked, **kw)
-        gpu.poses_to_device(pose_buf.data_ptr(), hi - lo)
-        status = torch.tensor([r.ret for r in res], dtype=torch.int32, device=dev)
+        if rehearse:  # (host buffers for gloo; column-major 4 x 4 like cvo_batch_poses_to_device writes them)
+            pose_buf[:] = torch.from_numpy(np.stack([np.ascontiguousarray(r.transform.T).reshape(16) for r in res]))
+        else:
+            gpu.poses_to_device(pose_buf.data_ptr(), hi - lo)
+        status = torch.tensor([r.ret for r in res], dtype=torch.int32, device=coll_dev)
         poses, stat = sharding.gather_poses(pose_buf, status, total_pairs, world, rank)
         return res, poses, stat
 
@@ -176,7 +189,7 @@ def main():
         res, poses, stat = step()
     fence()
     elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, dev)
+    elapsed = sharding.max_over_ranks(elapsed, coll_dev)
     if CLOCK_EXTRA_STEP:  # outside the timed region: the instrumented kernels (device clock per launch)
         step(clocked=True)
         step(clocked=True)
@@ -595,7 +608,9 @@ def main():
                                    f"(seeds 1000+p / 2000+p), cvo_geometric_params_gpu.yaml, identity init, "
                                    f"{mean_iters:.0f} optimiser iterations per align()",
                        "pairs_per_gpu": B, "points": n, "iterations_per_align": mean_iters,
-                       "parallelism": (f"pairs sharded {B}/GPU over {world} GPU(s); one RCCL all-gather of poses per step "
+                       "parallelism": (f"REHEARSAL, not a measurement: {world} ranks on ONE device, pairs sharded {B}/rank, poses gathered "
+                                       f"with gloo (RCCL refuses two ranks on one device)" if rehearse else
+                                       f"pairs sharded {B}/GPU over {world} GPU(s); one RCCL all-gather of poses per step "
                                        f"(process group of {world} rank(s))" if use_dist else
                                        f"{B} pairs on 1 GPU; NO collective ran (the one-rank process group failed to initialise)"),
                        "timed_steps": f"{args.steps} steps, production kernels (the instrumented step behind roofline.avg_launch_ms runs after the timed region)",
@@ -607,6 +622,16 @@ def main():
             "early_phase": early_phase, "shapes_20k": shapes_20k, "batch_colour": batch_colour, "batch_semantic": batch_semantic, "batch_clustered": batch_clustered, "batch_clustered_colour": batch_clustered_colour,
             "batch_queue": batch_queue,
         }
+        if rehearse:
+            # the gathered table against this rank's own results and against a solo solve of the LAST pair (another rank's)
+            mine = np.stack([np.ascontiguousarray(r.transform.T).reshape(16) for r in res])
+            pl = cases.config2(n=n, pair_id=total_pairs - 1)
+            solo = gpu.align(pl[1], pl[2], pl[3], **kw)
+            out["rehearsal"] = {"backend": "gloo", "ranks": world, "device_of_every_rank": 0,
+                                "gathered_rows": int(poses.shape[0]),
+                                "own_shard_in_place": bool(np.array_equal(poses[lo:hi].cpu().numpy(), mine)),
+                                "last_pair_of_last_rank_equals_solo_solve": bool(np.array_equal(
+                                    poses[total_pairs - 1].cpu().numpy(), np.ascontiguousarray(solo.transform.T).reshape(16)))}
         h2d_rate = (2 * n * 16 * 1.0) * B / max(t_h2d, 1e-9) / 1e9
         log(f"[bench] inputs: generated in {t_gen:.2f}s, uploaded in {t_h2d:.3f}s ({h2d_rate:.2f} GB/s incl. host-side k-d ordering on {n_threads} threads); "
             f"PCIe-inclusive rate = {aligns / (elapsed + args.steps * t_h2d):.2f} align/s")

@@ -165,8 +165,8 @@ const char* cvo_ctx_advice(const cvo_ctx* ctx);
 /* Destroys the HIP streams pooled from destroyed contexts (they are kept across contexts so that a later context finds
  * its sub-batch streams on the hardware queues the first one was given).  Optional, e.g. before unloading the library. */
 void cvo_shutdown(void);
-/* Tuning / diagnostic switches of a context (none changes a result; the list is in unified_cvo_amd/csrc/cvo_hip.hip,
- * kOptionNames, and DESIGN.md).  A context reads CVO_<NAME> from the environment ONCE, in cvo_ctx_create; afterwards
+/* Tuning / diagnostic switches of a context (none changes a result; the list is in unified_cvo_amd/csrc/cvo_internal.h,
+ * kOptionNames, and INTEGRATION.md).  A context reads CVO_<NAME> from the environment ONCE, in cvo_ctx_create; afterwards
  * only this call changes them (value NULL = unset), so no library call depends on the process environment while it
  * runs.  `name` with or without the CVO_ prefix.  Unknown names: CVO_E_INVALID. */
 int cvo_ctx_set_option(cvo_ctx* ctx, const char* name, const char* value);

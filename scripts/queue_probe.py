@@ -13,7 +13,7 @@ out = {}
 NQ = int(os.environ.get("QUEUE_PAIRS", "512"))
 P = cases.load_params("geometric_gpu")
 pairs = [cases.config2(n=10000, pair_id=p) for p in range(64)]
-gpu = CvoGPU(params=P)
+gpu = CvoGPU(params=P, library=os.environ.get("CVO_LIB") or None)
 both = gpu.upload_many([a[1] for a in pairs] + [a[2] for a in pairs])
 src, tgt, inits = both[:64], both[64:], [a[3] for a in pairs]
 ref = gpu.align_batch(src, tgt, inits)
@@ -49,7 +49,7 @@ gpu.close()
 
 # ---- mixed queue: the geometric configuration, three pairs in four stop after 300 iterations (warm-started tracking
 # frames), the fourth runs its 2000 (a cold start)
-g = CvoGPU(params=P)
+g = CvoGPU(params=P, library=os.environ.get("CVO_LIB") or None)
 pm = cases.config2(n=10000, pair_id=3)
 da, db, cold = g.upload(pm[1]), g.upload(pm[2]), pm[3]
 warm = cold

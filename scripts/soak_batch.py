@@ -34,11 +34,11 @@ for trial in range(seed0, seed0 + trials):
     if verify:
         os.environ["CVO_VERIFY_LISTS"] = "1"
     try:
-        gpu = CvoGPU(params=P)
+        gpu = CvoGPU(params=P, library=os.environ.get("CVO_LIB") or None)
         res = gpu.align_batch([p[0] for p in pairs], [p[1] for p in pairs], [p[2] for p in pairs], max_iterations=n_it)
     finally:
         os.environ.pop("CVO_VERIFY_LISTS", None)
-    solo = CvoGPU(params=P)
+    solo = CvoGPU(params=P, library=os.environ.get("CVO_LIB") or None)
     diff = []
     for q, (p, r) in enumerate(zip(pairs, res)):
         one = solo.align(p[0], p[1], p[2], max_iterations=n_it)

@@ -287,3 +287,40 @@ def test_clustered_pairs_batch_equals_solo():
     for a, b in zip(solo, big[:3]):
         assert a.iterations == b.iterations == 220 and np.array_equal(a.transform, b.transform)
 
+
+
+def test_speculative_update_survives_a_late_block():
+    """Round 6: the speculative run of the update (update_speculate, an extra block per pair of k_coeff) is the last block of
+    its pair to be dispatched.  On a full chip - a ragged 16-pair batch of small clouds in the dense regime with k_verify's
+    blocks queued in front of every k_coeff: soak trial 136 - it can start after its launch's update has run; before the
+    twist carried the (generation, iteration) stamp it then published the NEXT state advanced with THIS twist under the next
+    launch's tag, and one batch in three ended 2e-4 away from the solo poses.  Five batches == the solo calls, bit for bit."""
+    from unified_cvo_amd import synth
+    trial = 136
+    rs = np.random.default_rng(5000 + trial)
+    P = cases.load_params("geometric_gpu")
+    P.ell_init = float(rs.choice([0.3, 0.6, 0.95, 1.4]))
+    P.nearest_neighbors_max = int(rs.choice([40, 200, 512]))
+    P.ell_decay_start = int(rs.choice([5, 30]))
+    n_pairs = int(rs.integers(2, 25))
+    big = rs.integers(0, 4) == 0
+    pairs = []
+    for q in range(n_pairs):
+        n = int(rs.integers(300, 9000 if big else 3500))
+        m = int(rs.integers(300, 9000 if big else 3500))
+        s, t, _ = (synth.scene_pair if rs.integers(0, 2) else synth.geometric_pair)(n, 100 * trial + q, m=m)
+        init = (synth.gt_motion() @ synth.warm_start_delta()).astype(np.float32) if rs.integers(0, 2) else np.eye(4, dtype=np.float32)
+        pairs.append((CvoPointCloud.from_xyz(s), CvoPointCloud.from_xyz(t), init))
+    n_it = int(rs.choice([40, 150, 400, 0])) if not big else int(rs.choice([40, 150]))
+    assert (n_pairs, n_it) == (16, 150)
+    solo_gpu = CvoGPU(params=P)
+    solo = [solo_gpu.align(p[0], p[1], p[2], max_iterations=n_it) for p in pairs]
+    os.environ["CVO_VERIFY_LISTS"] = "1"
+    try:
+        gpu = CvoGPU(params=P)
+    finally:
+        os.environ.pop("CVO_VERIFY_LISTS", None)
+    for _ in range(5):
+        res = gpu.align_batch([p[0] for p in pairs], [p[1] for p in pairs], [p[2] for p in pairs], max_iterations=n_it)
+        for q, (a, b) in enumerate(zip(res, solo)):
+            assert np.array_equal(a.transform, b.transform) and a.iterations == b.iterations, q

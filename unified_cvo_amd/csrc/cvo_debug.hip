@@ -86,7 +86,7 @@ int cvo_debug_time_kernels(cvo_ctx* ctx, int reps, float* ms_assoc, float* ms_co
                        2);
         else
           launch_coeff(ctx->stream, instr, nba, ctx->last_csplit, p1 - p0, ctx->d_descs + p0, ctx->d_params, ctx->d_states + p0,
-                       A, 8 | 2 | (ctx_opt(ctx, "COEFF_NO_UPDATE") ? 16 : 0));
+                       A, 8 | 2);
       }
     };
     sweep();  // warm-up
@@ -221,8 +221,7 @@ int cvo_debug_time_scan(cvo_ctx* ctx, int reps, float* ms) {
   // the same launches the optimiser loop issues: one k_scan per sub-batch, here back to back on one stream
   const int n_pairs = ctx->last_pairs, G = ctx->last_groups;
   const DevParams& dp = ctx->last_params;
-  int variant = 1;  // CVO_SCAN_DEBUG: 1 = no emission, 2 = no fine tiles (cost breakdown only)
-  if (const char* e = ctx_opt(ctx, "SCAN_DEBUG")) variant |= atoi(e) << 1;
+  const int variant = 1;  // force the scan for pairs whose lists are current (k_scan's `force` bits: 2 = no emission, 4 = no fine tiles)
   auto sweep = [&]() {
     for (int g = 0; g < G; g++) {
       const int p0 = (int)((long)n_pairs * g / G), p1 = (int)((long)n_pairs * (g + 1) / G);

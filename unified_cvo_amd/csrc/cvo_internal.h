@@ -80,9 +80,13 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // is created (CVO_<NAME>), and settable afterwards with cvo_ctx_set_option: no library call reads the process
 // environment while it runs.
 static const char* const kOptionNames[] = {
-    "SKIN", "SKIN_BLEND", "SKIN_MIN", "SKIN_MAX", "LEAN_SKIN", "SHRINK", "SHRINK_ALIGN", "LEAN_U", "LEAN_U2", "NO_LEAN",
-    "NO_DENSE_REGIME", "STREAMS", "SCAN_T", "SCAN_GROUPS", "SCAN_DEBUG", "NO_SORT", "FIXED_CHUNKS", "KEEP_COLUMNS", "VERBOSE",
-    "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "IP_CHAIN", "DEBUG_NO_MOTION_BOUND", "COEFF_NO_UPDATE", "ORDER", "NO_NODENSE", "CALM_U", "HORIZON_MARGIN", "NO_LONG_LISTS", "FIRST_U", "FIRST_CHUNKS", "ROW_MAX", "ROW_MAX_BUSY", "NO_ONEHOT", "QUEUE_U", "QUEUE_ADMIT"};
+    // list reuse / graphs (scripts/skin_sweep.py, early_sweep.py, first_chunk_sweep.sh)
+    "SKIN", "SKIN_MAX", "LEAN_SKIN", "HORIZON_MARGIN", "SHRINK_ALIGN", "LEAN_U", "NO_LEAN", "NO_DENSE_REGIME", "FIXED_CHUNKS", "FIRST_U",
+    "FIRST_CHUNKS", "STREAMS", "QUEUE_ADMIT",
+    // A/B switches of the tests: every one of them leaves the results bit-identical
+    "NO_SORT", "ORDER", "NO_LONG_LISTS", "ROW_MAX", "NO_ONEHOT", "IP_CHAIN", "KEEP_COLUMNS",
+    // diagnostics
+    "VERBOSE", "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND"};
 
 struct cvo_ctx {
   int device = 0;

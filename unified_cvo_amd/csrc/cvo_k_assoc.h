@@ -13,7 +13,7 @@ namespace cvo_dev {
 // groups meet through DPP / ds_swizzle; the order of the additions is fixed.  k_coeff reads the 42 floats with
 // scalar loads in its first burst (they used to be reduced again by every one of its blocks: ~3 us of
 // dependent round trips in front of each row loop and a hot spot of 150 readers per cache line).
-static_assert(sizeof(XiMats) <= 48 * sizeof(float), "PairState::xi holds an XiMats");
+static_assert(sizeof(XiMats) <= 46 * sizeof(float), "PairState::xi holds an XiMats and the two words of its stamp");
 // (the partials are data-tagged granules, cvo_wave.h: a granule that has not landed yet carries an older tag and the
 // round is read again - the elected block no longer waits for anybody's store acknowledgement)
 __device__ __forceinline__ double coeff_twist_load(const PairDesc* __restrict__ D, int nparts, unsigned tag) {
@@ -46,7 +46,10 @@ __device__ __forceinline__ double coeff_twist_load(const PairDesc* __restrict__ 
   }
   return acc;
 }
-__device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, int nparts, unsigned tag) {
+// stamp_epoch / stamp_k: the pair's launch generation and iteration count as this launch of k_assoc found them, left next to
+// the matrices (xi[46], xi[47]): whoever reads the twist can tell which iteration it belongs to (update_speculate must - a
+// speculative block that starts after its launch's update has run would otherwise combine the NEXT state with THIS twist)
+__device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, int nparts, unsigned tag, int stamp_epoch, int stamp_k) {
   double acc = coeff_twist_load(D, nparts, tag);
   acc += dpp_f64<0x128>(acc);  // row_ror:8 : groups g and g ^ 1
   acc = xor16_sum(acc);
@@ -73,11 +76,13 @@ __device__ __forceinline__ void twist_finalize(const PairDesc* __restrict__ D, i
     float* dst = D->st->xi;
 #pragma unroll
     for (int q = 0; q < (int)(sizeof(XiMats) / sizeof(float)); q++) dst[q] = mv[q];
+    dst[46] = __int_as_float(stamp_epoch);
+    dst[47] = __int_as_float(stamp_k);
   }
 }
 // The flow partial of this block is stored; the block that finds it was the last one of its pair reduces them.
 // Every thread of the block calls this.
-__device__ __forceinline__ bool flow_gate(const PairDesc* __restrict__ D, int nblocks, int nparts, unsigned tag) {
+__device__ __forceinline__ bool flow_gate(const PairDesc* __restrict__ D, int nblocks, int nparts, unsigned tag, int stamp_epoch, int stamp_k) {
   __shared__ int s_flow_last;
   // (no wait for this block's partial: a store and an atomic of one wave to different addresses are not ordered on their
   // way to memory, so the counter says who reduces, the granules' tags say when a partial has arrived - cvo_wave.h)
@@ -88,7 +93,7 @@ __device__ __forceinline__ bool flow_gate(const PairDesc* __restrict__ D, int nb
     if (done == nblocks - 1) __hip_atomic_store(D->gate_flow, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (s_flow_last && threadIdx.x < 64) twist_finalize(D, nparts, tag);
+  if (s_flow_last && threadIdx.x < 64) twist_finalize(D, nparts, tag, stamp_epoch, stamp_k);
   return s_flow_last != 0;
 }
 
@@ -392,7 +397,8 @@ __global__ __launch_bounds__(ASSOC_THREADS, FEAT != FEAT_GEO ? 1 : CVO_ASSOC_WAV
   pair_clock_begin(INSTR && P.kernel_clock && (lean & 3) == 1 && pb.bx == 0, const_cast<PairState*>(st), 0);
   __shared__ AssocShared S;
   // tag of this launch's partials (cvo_wave.h): the call's serial and the pair's iteration count
-  const unsigned tag = partial_tag(D->call_serial, (unsigned)st->k);
+  const int stamp_epoch = st->epoch, stamp_k = st->k;
+  const unsigned tag = partial_tag(D->call_serial, (unsigned)stamp_k);
   assoc_phase<IdxT, ASSOC_CAP, FEAT, INSTR>(P, D, load_iter_view(st), S, pb.bx, head, tag);
   // Everything from here on - the block's partial is on its way, the last-block counter, possibly the twist - is the
   // first wave's business.  The other waves retire now instead of sitting on their registers through a store
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(ASSOC_THREADS, FEAT != FEAT_GEO ? 1 : CVO_ASSOC_WAV
   // the block that stores its partial last finishes the twist of the iteration
   if (P.mode == 0) {
     const unsigned long long clk0 = pair_clock_peek(INSTR && P.kernel_clock && (lean & 3) == 1, st, 0);
-    const bool last = flow_gate(D, nblk, nblk, tag);
+    const bool last = flow_gate(D, nblk, nblk, tag, stamp_epoch, stamp_k);
     if (last && threadIdx.x == 0 && clk0) D->st->clk_last_assoc = pair_clock_ticks(clk0);  // added up by the update
   } else if (lean & 8) {  // single evaluation that only wants A_sum (inner_product_gpu)
     asum_gate(D, nblk);

@@ -161,11 +161,11 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     // a waiting pair (lean graph) has nothing to advance.
     if (INSTR || threadIdx.x >= 64 || (flags & (8 | 16))) return;
     const PairState* __restrict__ sh = states + pb.pair;
-    const int status_h = sh->status, rebuild_h = sh->rebuild, ovf_h = sh->n_ovf, epoch_h = sh->epoch;
+    const int status_h = sh->status, rebuild_h = sh->rebuild, ovf_h = sh->n_ovf;
     const DevParams Ph = *Pp;
     if (status_h != 0 || Ph.mode != 0 || Ph.trace_capacity != 0) return;
     if ((flags & 1) && (rebuild_h || (ovf_h > 0 && !(flags & 32)))) return;
-    update_speculate(D, states + pb.pair, Ph, flags | 4, S.u, partial_tag(D->call_serial, 0x80000000u | (unsigned)epoch_h));
+    update_speculate(D, states + pb.pair, Ph, flags | 4, S.u, D->call_serial);
     return;
   }
   const int cq = pb.bx % launch_split;

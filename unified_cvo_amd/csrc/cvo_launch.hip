@@ -8,12 +8,7 @@
 namespace {
 
 void choose_scan_config(const cvo_ctx* ctx, int n_pairs, int NG, int Mpad, int* T_out, int* gpb_out) {
-  int T = 2;
-  const char* eT = ctx_opt(ctx, "SCAN_T");
-  if (eT) {
-    int v = atoi(eT);
-    if (v == 1 || v == 2 || v == 4 || v == 8) T = v;
-  }
+  const int T = 2;  // (1 / 4 / 8 were swept in round 2: the k_scan<T> instantiations remain)
   // Measured on MI355X (64 x 10k x 10k, T = 2): one row segment per wave (5120 waves) beats 128-group
   // blocks by 1.4x; a single pair needs the row range split to fill the chip.  Rule: the fewest
   // segments that still give ~4096 waves.
@@ -24,11 +19,6 @@ void choose_scan_config(const cvo_ctx* ctx, int n_pairs, int NG, int Mpad, int* 
     const long waves = slices * ((ngr + gpb - 1) / gpb) * n_pairs;
     if (waves >= 4096) break;
     gpb = (int)align_up((size_t)gpb / 2, 64);
-  }
-  const char* eG = ctx_opt(ctx, "SCAN_GROUPS");
-  if (eG) {
-    int v = atoi(eG);
-    if (v >= 64 && v % 64 == 0) gpb = v;
   }
   *T_out = T;
   *gpb_out = gpb;

@@ -220,13 +220,12 @@ int cvo_batch_open(cvo_ctx* ctx, const cvo_params_t* params, int slots, int max_
     q->geom[g].stream = ctx->gstream[g];
   }
   // Iterations per chunk: a finished pair idles until the chunk after next (the host learns of it one chunk behind), so a
-  // queue of short solves wants short chunks; a boundary costs a stream ~10 us.  QUEUE_U (default 16 for the fast graphs,
-  // twice that for the lean ones, as cvo_align_batch).
+  // queue of short solves wants short chunks; a boundary costs a stream ~10 us.  16 iterations for the fast graphs,
+  // twice that for the lean ones, as cvo_align_batch.
   int U = 16;
-  if (const char* e = ctx_opt(ctx, "QUEUE_U")) U = std::max(2, std::min(atoi(e), 64));
   q->cfg = LoopCfg{U, 2 * U, std::max(1, std::min(q->dp.lean_U, U)), std::max(0, std::min(q->dp.lean_U2, U)), q->S.geom.instr ? 8 : 0};
   q->allow_lean = ctx_opt(ctx, "NO_LEAN") == nullptr;
-  q->start_nodense = q->allow_lean && q->S.N > 4096 && ctx_opt(ctx, "NO_NODENSE") == nullptr;
+  q->start_nodense = q->allow_lean && q->S.N > 4096;
   q->allow_calm = q->dp.calm_U > 0;
   q->slot.assign((size_t)slots, cvo_batch_queue::Slot());
   const size_t per = align_up(sizeof(PairState), 256) * 2 + align_up(sizeof(PairDesc), 256);

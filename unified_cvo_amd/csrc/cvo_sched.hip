@@ -50,10 +50,8 @@ DevParams make_dev_params(const cvo_ctx* ctx, const cvo_params_t& p) {
   d.lean_skin = 0.5f;
   d.dense_regime = ctx_opt(ctx, "NO_DENSE_REGIME") ? 0 : 1;
   d.skin_blend = 0.25f;
-  if (const char* e = ctx_opt(ctx, "SKIN_BLEND")) d.skin_blend = std::min(1.f, std::max(0.f, (float)atof(e)));
   d.skin_min = 0.05f;
   d.skin_max = 0.25f;
-  if (const char* e = ctx_opt(ctx, "SKIN_MIN")) d.skin_min = std::max(0.f, (float)atof(e));
   if (const char* e = ctx_opt(ctx, "SKIN_MAX")) d.skin_max = std::max(d.skin_min, (float)atof(e));
   if (const char* e = ctx_opt(ctx, "LEAN_SKIN")) d.lean_skin = std::max(0.1f, (float)atof(e));
   d.horizon_margin = 0.3f;
@@ -64,7 +62,6 @@ DevParams make_dev_params(const cvo_ctx* ctx, const cvo_params_t& p) {
   d.kernel_clock = ctx_opt_on(ctx, "KERNEL_CLOCK") ? 1 : 0;
   d.verify_lists = ctx_opt_on(ctx, "VERIFY_LISTS") ? 1 : 0;
   d.debug_no_motion_bound = ctx_opt(ctx, "DEBUG_NO_MOTION_BOUND") ? 1 : 0;
-  if (const char* e = ctx_opt(ctx, "SHRINK")) d.rebuild_shrink = std::min(0.99f, std::max(0.f, (float)atof(e)));
   return d;
 }
 
@@ -342,7 +339,6 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   // are all rows, not in steps of 128 candidate slots per row)
   dp.row_max_busy = n_pairs <= 4 ? 8 : (n_pairs <= 16 ? 24 : (int)ASSOC_CAP16);
   if (const char* e = ctx_opt(ctx, "ROW_MAX")) dp.row_max_cap = std::max(1, std::min(atoi(e), (int)ASSOC_CAP16));
-  if (const char* e = ctx_opt(ctx, "ROW_MAX_BUSY")) dp.row_max_busy = std::max(1, std::min(atoi(e), (int)ASSOC_CAP16));
   dp.lean_U = 8;
   if (const char* e = ctx_opt(ctx, "LEAN_U")) dp.lean_U = std::max(1, atoi(e));
   // Calm pairs (see PairState::want_full).  In the end game the pose jitters around its optimum: the motion PER ITERATION
@@ -350,9 +346,7 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   // iterations (CVO_VERBOSE=2 prints both), so a linear "outlives the next 64 iterations" test never fires.  Four
   // iterations of linear margin it is: 62.3 -> 61.4 ms per headline step, single pairs -1.5 ... -2.5 %, no additional waits.
   dp.calm_U = 4;
-  if (const char* e = ctx_opt(ctx, "CALM_U")) dp.calm_U = std::max(0, atoi(e));
   dp.lean_U2 = 2;
-  if (const char* e = ctx_opt(ctx, "LEAN_U2")) dp.lean_U2 = std::max(0, atoi(e));  // 0 = no short lean graph
   if (dp.lean_U2 >= dp.lean_U) dp.lean_U2 = 0;
   dp.shrink_align = n_pairs >= 8 ? 63 : 0;
   if (const char* e = ctx_opt(ctx, "SHRINK_ALIGN")) dp.shrink_align = std::max(0, atoi(e));
@@ -585,7 +579,7 @@ int cvo_align_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const
     int graph_next[cvo_ctx::MAX_GROUPS];  // 0 = full, 1 = lean, 2 = short lean, 3 = full without the dense kernel
     // the first iterations move fast: full graph - for large clouds without the dense kernel (rows that overflow their
     // lists are a small-cloud / huge-lengthscale matter; a pair that has some waits two chunks for the real full graph)
-    const bool start_nodense = allow_lean && S.N > 4096 && ctx_opt(ctx, "NO_NODENSE") == nullptr;
+    const bool start_nodense = allow_lean && S.N > 4096;
     const bool allow_calm = dp.calm_U > 0;
     for (int g = 0; g < G; g++) graph_next[g] = start_nodense ? 3 : 0;
     bool all_done = false;

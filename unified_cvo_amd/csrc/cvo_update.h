@@ -490,7 +490,7 @@ __device__ __forceinline__ void reduce_counts(const unsigned long long* cnt_part
 // the state a pair ends an iteration with does not depend on who computed it.  (The indicator FIFO entries the run pushes
 // are the ones update_advance would push whatever the step: written twice with the same value when the run is not adopted.)
 __device__ __forceinline__ void update_speculate(const PairDesc* __restrict__ Dp, PairState* const gst, const DevParams& P, int flags,
-                                                 UpdateShared& U, unsigned tag) {
+                                                 UpdateShared& U, unsigned long long call_serial) {
   const int tid = threadIdx.x;  // < 64
   // (gst == D.st from the kernel's state array: the state is requested next to the descriptor, not behind it - this run
   // has the row blocks' time and no more)
@@ -506,6 +506,17 @@ __device__ __forceinline__ void update_speculate(const PairDesc* __restrict__ Dp
   PairState* const st = reinterpret_cast<PairState*>(s_hot);
   const float pred = st->step;
   if (!step_is_clamp(P, pred)) return;
+  // Is this the state the launch STARTED with?  The block is the last of its pair to be dispatched; on a full chip it can
+  // start after the pair's row blocks have finished and the update has run - the state it stages is then the NEXT
+  // iteration's, the twist and counts still this one's, and the tag it would publish under the next launch's.  The flow gate
+  // stamped the twist with the (launch generation, iteration) k_assoc saw: anything else in the state means "late" (or a
+  // state caught in the middle of the update's write-back) and the run is abandoned before it touches anything.
+  {
+    const int xe = __float_as_int(gst->xi[46]), xk = __float_as_int(gst->xi[47]);
+    if (xe != st->epoch || xk != st->k || st->status != 0) return;
+  }
+  // (the tag of this launch's partials, from the VALIDATED generation: k_coeff's row blocks form the same one)
+  const unsigned tag = partial_tag(call_serial, 0x80000000u | (unsigned)st->epoch);
   reduce_counts(D.cnt_part, Dp->nblk_assoc, tid, U.n);
   __builtin_amdgcn_wave_barrier();
   if (tid == 0) {
