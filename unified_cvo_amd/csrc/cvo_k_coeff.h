@@ -155,7 +155,14 @@ __global__ __launch_bounds__(ASSOC_THREADS, CVO_COEFF_WAVES) void k_coeff(const 
     CoeffShared c;
     UpdateShared u;
   } S;
+#ifndef CVO_SPEC_BLOCK_LAST
+  // (the pair's FIRST block: workgroups are dispatched in index order, and this run has the row blocks' time and no more -
+  // as the last block of its pair it started late on a full chip and was adopted less often)
+  pb.bx -= 1;
+  if (pb.bx < 0) {
+#else
   if (pb.bx == nblk * launch_split) {
+#endif
     // The speculative block: everything of the update that follows the step, on the predicted step, while the row blocks
     // work.  Not in the instrumented kernels, timing replays, traced calls (the record needs B..E) or single evaluations;
     // a waiting pair (lean graph) has nothing to advance.
