@@ -494,6 +494,26 @@ def test_verify_lists_catches_a_broken_skin(monkeypatch):
         CvoGPU(params=P).align(src, tgt, init, max_iterations=60)
 
 
+@pytest.mark.parametrize("which", [1, 2])
+def test_a_partial_that_never_arrives_ends_the_call_instead_of_hanging(monkeypatch, which):
+    """Round 6: block partials cross blocks as data-tagged granules and the elected block POLLS for tags (cvo_wave.h).  The
+    poll is bounded: with CVO_DEBUG_DROP_PARTIAL row block 1 of k_assoc (1) / k_coeff (2) never publishes, the flow gate /
+    the update give up after PARTIAL_POLL_LIMIT polls, latch PairState::sync_err and the call returns CVO_E_HIP - within
+    seconds, with the device alive (the next call on a fresh context is bit-identical to an undisturbed one)."""
+    import time
+    P, src, tgt, init = cases.config2(n=3000)
+    good = CvoGPU(params=P).align(src, tgt, init, max_iterations=40)
+    monkeypatch.setenv("CVO_DEBUG_DROP_PARTIAL", str(which))
+    bad = CvoGPU(params=P)
+    monkeypatch.delenv("CVO_DEBUG_DROP_PARTIAL")
+    t0 = time.time()
+    with pytest.raises(CvoError, match="never arrived"):
+        bad.align(src, tgt, init, max_iterations=40)
+    assert time.time() - t0 < 30.0
+    again = CvoGPU(params=P).align(src, tgt, init, max_iterations=40)
+    assert np.array_equal(again.transform, good.transform) and again.iterations == good.iterations
+
+
 def test_verify_lists_batch(monkeypatch):
     monkeypatch.setenv("CVO_VERIFY_LISTS", "1")
     pairs = [cases.config2(n=3000, pair_id=p) for p in range(6)] + [cases.config2(n=1200, pair_id=9, m=2100)]

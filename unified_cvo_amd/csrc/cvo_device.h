@@ -70,6 +70,8 @@ struct DevParams {
                      // then): 24 in a batch, 8 when at most four pairs are in flight (scripts/rowmax_probe.py: a clustered
                      // 3000-point pair 42.8 -> 34.4 us per iteration, 10k 92.5 -> 85.5)
   int long_lists;  // overflow rows keep a cached sorted candidate list of up to LONG_CAP entries (PairDesc::long_j)
+  int debug_drop_partial;     // CVO_DEBUG_DROP_PARTIAL (tests only): 1 / 2 = row block 1 of k_assoc / k_coeff never publishes its partial:
+                              // the elected block's bounded poll must end the pair (PairState::sync_err), not hang the device
   int debug_no_motion_bound;  // CVO_DEBUG_NO_MOTION_BOUND (tests only): the update pretends no target ever moves, so
                               // lists outlive their validity - what CVO_VERIFY_LISTS exists to catch
 };

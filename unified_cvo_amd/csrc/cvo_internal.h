@@ -86,7 +86,7 @@ static const char* const kOptionNames[] = {
     // A/B switches of the tests: every one of them leaves the results bit-identical
     "NO_SORT", "ORDER", "NO_LONG_LISTS", "ROW_MAX", "NO_ONEHOT", "IP_CHAIN", "KEEP_COLUMNS",
     // diagnostics
-    "VERBOSE", "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND"};
+    "VERBOSE", "KERNEL_CLOCK", "PHASE_TICKS", "VERIFY_LISTS", "DEBUG_NO_MOTION_BOUND", "DEBUG_DROP_PARTIAL"};
 
 struct cvo_ctx {
   int device = 0;

@@ -325,7 +325,7 @@ __device__ __forceinline__ void assoc_phase(const DevParams& P, const PairDesc* 
   }
   __syncthreads();  // (the staging columns share their LDS with the reduction: every thread has drained its own)
   const double tot = block_reduce_lds<7>(S.red, red);  // (its barrier also covers S.cnt)
-  if (threadIdx.x < 56 && (threadIdx.x & 7) == 0) {
+  if (threadIdx.x < 56 && (threadIdx.x & 7) == 0 && !(P.debug_drop_partial == 1 && bx == 1)) {
     st_tagged(D->flow_part + (size_t)bx * FLOW_GRANULES + 2 * (threadIdx.x >> 3), tot, tag);  // read by another block of this launch (flow_gate)
   } else if (threadIdx.x == 57) {
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;

@@ -128,7 +128,7 @@ __device__ __forceinline__ void coeff_rows(const DevParams& P, const PairDesc* _
   const double red[4] = {Bi, Ci, Di, Ei};
   const double tot = block_reduce_lds<4>(S.red, red);
   // (data-tagged granules, cvo_wave.h: read by the pair's updating block without anybody waiting for a store to be acknowledged)
-  if (threadIdx.x < 32 && (threadIdx.x & 7) == 0)
+  if (threadIdx.x < 32 && (threadIdx.x & 7) == 0 && !(P.debug_drop_partial == 2 && bx == 1))
     st_tagged(D->coef_part + ((size_t)bx * nsplit + q) * COEF_GRANULES + 2 * (threadIdx.x >> 3), tot, tag);
 }
 

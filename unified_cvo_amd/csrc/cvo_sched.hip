@@ -62,6 +62,7 @@ DevParams make_dev_params(const cvo_ctx* ctx, const cvo_params_t& p) {
   d.kernel_clock = ctx_opt_on(ctx, "KERNEL_CLOCK") ? 1 : 0;
   d.verify_lists = ctx_opt_on(ctx, "VERIFY_LISTS") ? 1 : 0;
   d.debug_no_motion_bound = ctx_opt(ctx, "DEBUG_NO_MOTION_BOUND") ? 1 : 0;
+  d.debug_drop_partial = ctx_opt(ctx, "DEBUG_DROP_PARTIAL") ? atoi(ctx_opt(ctx, "DEBUG_DROP_PARTIAL")) : 0;
   return d;
 }
 
