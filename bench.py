@@ -306,7 +306,9 @@ def main():
             # whose kernels wait on memory - 16 extra bytes per row cost 3 % although they saved 35 VALU instructions per row,
             # halving the ELL stream gains 3 % only at 128 pairs in flight.  "hbm" is the closer of the two roofs this field
             # can name; the honest description is "memory-side latency and bytes, far from either roof".
-            "binds": "memory-side latency and bytes per dependent launch (measured: profiles/r5/ell8_experiment.txt), not VALU issue",
+            "binds": ("the 64-pair step sits on the knee between a chain's latency (dependent launches, memory-side round trips: "
+                      "profiles/r5/ell8_experiment.txt, profiles/r6/scale_probe.txt) and the chip's throughput, where VALU issue is ~80 % of "
+                      "the time (profiles/r6/pmc_summary.txt); far from the HBM roof either way"),
             "pairs_per_launch": ppl, "sub_batches": n_groups, "timed_at_iteration": mid_iters,
             "step_traffic_gbs": step_traffic_gbs,
             "other_kernels": [other, kernel_entry("cvo_dev::k_scan", scan_ms, round(builds / max(iters_total, 1), 5))],
