@@ -122,7 +122,7 @@ typedef struct cvo_trace_t {
 /* Per-call outputs beyond the transform. */
 typedef struct cvo_align_info_t {
   int iterations;        /* value of k when the loop ended ("cvo # of iterations", CvoGPU.cu:1545) */
-  int ret;               /* 0 or -1, as CvoGPU::align returns */
+  int ret;               /* 0 or -1, as CvoGPU::align returns (batch queue results: CVO_E_HIP if the pair was ended by a device-side synchronisation time-out) */
   float final_ell;
   int final_num_neighbors;
   double seconds;        /* registration_seconds: hipEvent time of the loop (CvoGPU.cu:1534-1560) */

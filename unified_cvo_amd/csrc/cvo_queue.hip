@@ -111,7 +111,7 @@ int queue_step(cvo_batch_queue* q, int g, bool block, bool* progressed) {
         r.ticket = ro[k].ticket;
         std::memcpy(r.transform, ps.out_T, sizeof(float) * 16);
         r.info.iterations = ps.status ? ps.iterations : ps.k;
-        r.info.ret = ps.ret;
+        r.info.ret = ps.sync_err ? CVO_E_HIP : ps.ret;  // (a block partial never arrived: cvo_wave.h; never seen in practice)
         r.info.final_ell = ps.ell;
         r.info.final_num_neighbors = ps.K;
         r.info.seconds = ro[k].seconds;
