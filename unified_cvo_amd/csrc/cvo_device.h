@@ -50,7 +50,7 @@ struct DevParams {
   int calm_U;            // a pair whose list outlives this many more iterations at its current speed reports itself calm
                          // (want = -1): the host may give it one rebuild opportunity per chunk (0 = never)
   int shrink_align;      // optional (ell-shrink) rebuilds wait for an iteration count with (k & shrink_align) == 0:
-                         // 63 when several pairs share a sub-batch (their rebuilds then share a pass), 0 otherwise
+                         // 0 = at the next opportunity (the default since round 6; 63 was round 4's choice for batches)
   float skin_min, skin_max;  // clamp of the skin (fractions of the cut-off radius) before skin_frac
   float skin_blend;          // share of the pooled motion budget both the rotation and the translation allowance get on top of their own
   int dense_regime;      // 0: never switch a pair to the all-rows-dense regime (CVO_NO_DENSE_REGIME)

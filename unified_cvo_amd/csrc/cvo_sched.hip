@@ -56,7 +56,10 @@ DevParams make_dev_params(const cvo_ctx* ctx, const cvo_params_t& p) {
   if (const char* e = ctx_opt(ctx, "LEAN_SKIN")) d.lean_skin = std::max(0.1f, (float)atof(e));
   d.horizon_margin = 0.3f;
   if (const char* e = ctx_opt(ctx, "HORIZON_MARGIN")) d.horizon_margin = std::max(0.f, (float)atof(e));
-  d.rebuild_shrink = 0.9f;
+#ifndef CVO_REBUILD_SHRINK
+#define CVO_REBUILD_SHRINK 0.9f
+#endif
+  d.rebuild_shrink = CVO_REBUILD_SHRINK;
   if (const char* e = ctx_opt(ctx, "SKIN")) d.skin_frac = std::max(0.f, (float)atof(e));
   d.phase_ticks = ctx_opt(ctx, "PHASE_TICKS") ? 1 : 0;
   d.kernel_clock = ctx_opt_on(ctx, "KERNEL_CLOCK") ? 1 : 0;
@@ -349,7 +352,12 @@ int setup_batch(cvo_ctx* ctx, const cvo_params_t* params, int n_pairs, const cvo
   dp.calm_U = 4;
   dp.lean_U2 = 2;
   if (dp.lean_U2 >= dp.lean_U) dp.lean_U2 = 0;
-  dp.shrink_align = n_pairs >= 8 ? 63 : 0;
+  // (Round 4 made the optional shrink rebuilds of a batch wait for iteration counts that are multiples of 64 so that the pairs
+  // of a sub-batch share a pass of the rebuild kernels: -1.7 % then.  Re-measured in round 6, with cheaper rebuild kernels and
+  // a shorter serial tail: the stale lists' extra candidates cost more than the shared passes save - 64 x 10k geometric 56.55 ->
+  // 55.67 ms, 64 x config 3 163.5 -> 158.1, 64 clustered scenes 793 -> 779, 16 / 32 pairs 0 / -1.6 % (profiles/r6/shrink_align.txt).
+  // The mask stays as a switch.)
+  dp.shrink_align = 0;
   if (const char* e = ctx_opt(ctx, "SHRINK_ALIGN")) dp.shrink_align = std::max(0, atoi(e));
   if (opts && opts->max_iterations > 0) dp.max_iter = std::min(dp.max_iter, opts->max_iterations);
   if (opts && opts->kernel_clock) dp.kernel_clock = 1;

@@ -301,9 +301,9 @@ __device__ __forceinline__ void update_advance(const UpdDesc& D, const DevParams
     // the list is unusable for the coming iteration ...
     // (A list built for a larger ell stays a superset: rebuilding it after ell has shrunk only sheds candidates.  That
     // rebuild is optional, so it waits for a rebuild opportunity - flagged in the middle of a lean period it would
-    // stall the pair until the next one - and, in a batch, for an iteration count that is a multiple of 64: the pairs
-    // of a sub-batch decay in step, their shrink rebuilds then share one pass of the rebuild kernels instead of
-    // putting real work into a different one each.)
+    // stall the pair until the next one - and, when P.shrink_align is set (CVO_SHRINK_ALIGN; off since round 6), for an
+    // iteration count with (k & shrink_align) == 0: the pairs of a sub-batch decay in step, their shrink rebuilds then
+    // share one pass of the rebuild kernels instead of putting real work into a different one each.)
     const bool shrink_due = ell_next < P.rebuild_shrink * st->ell_build;
     const bool shrink_now = shrink_due && trio_follows &&
                             ((st->k & P.shrink_align) == 0 || ell_next < 0.85f * P.rebuild_shrink * st->ell_build);
