@@ -51,7 +51,8 @@ DevParams make_dev_params(const cvo_ctx* ctx, const cvo_params_t& p) {
   d.dense_regime = ctx_opt(ctx, "NO_DENSE_REGIME") ? 0 : 1;
   d.skin_blend = 0.25f;
   d.skin_min = 0.05f;
-  d.skin_max = 0.25f;
+  d.skin_max = 0.35f;  // (0.25 until round 6; re-swept on the un-aligned shrink rebuilds: 0.25 / 0.3 / 0.35 / 0.4 / 0.5 -> 55.55 / 55.22 / 55.06 / 55.19 /
+                       // 55.25 ms for the 64-pair step, 16 pairs -1.3 %, config 3 batch +0.3 %, single pairs unchanged: profiles/r6/shrink_align.txt)
   if (const char* e = ctx_opt(ctx, "SKIN_MAX")) d.skin_max = std::max(d.skin_min, (float)atof(e));
   if (const char* e = ctx_opt(ctx, "LEAN_SKIN")) d.lean_skin = std::max(0.1f, (float)atof(e));
   d.horizon_margin = 0.3f;
