@@ -1,5 +1,6 @@
 # Round 6, VERDICT item 6 + 9: the queue at 64 ... 192 slots with the product library and the 8-byte-ELL experiment build,
 # admission shares of the mixed queue, the A/B at 64 pairs, the early phase, and the one-device rehearsal of bench.py's N>1 branch.
+# (the experiment build first, here: python -c "from unified_cvo_amd import build; build.build_variant(\"ell8\", [\"-DCVO_ELL8\"])")
 mkdir -p gpurun_out/r6
 O=gpurun_out/r6/queue_probe.txt
 echo "== product library" > $O
